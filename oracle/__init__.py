@@ -1,0 +1,361 @@
+"""CPU oracle for the ntLink `pair` hot path -- TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this
+package.  The product package ``ntlink_amd`` never does.
+
+Two layers:
+
+* ``ntl_oracle.c`` (built by ``oracle/Makefile`` into ``libntl_oracle.so``): sketch, contig index
+  and per-read mapping, each function citing the reference lines it restates.
+* this module: ctypes bindings plus small pure-Python restatements of the host-side tail of
+  ``bin/ntlink_pair.py`` (pair tally, filters, ``.pairs.tsv`` / ``.scaffold.dot`` / verbose / PAF text),
+  used to pin the oracle against the reference's golden files.
+
+Parity status: pinned -- see ``tests/test_oracle_*.py``.
+"""
+import ctypes as C
+import gzip
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libntl_oracle.so")
+_lib = None
+
+
+def build(force=False):
+    """Compile libntl_oracle.so with the committed Makefile (gcc only)."""
+    src = os.path.join(_HERE, "ntl_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libntl_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+class Params(C.Structure):
+    _fields_ = [("k", C.c_int32), ("z", C.c_int32), ("x", C.c_double),
+                ("sensitive", C.c_int32), ("repeat_filter", C.c_int32)]
+
+
+MAPPING_DT = np.dtype([("read", "<u4"), ("ctg", "<u4"), ("n_hits", "<u4"), ("pad", "<u4"), ("hit_off", "<u8")])
+HIT_DT = np.dtype([("ctg_pos", "<u4"), ("read_pos", "<u4"), ("ctg_strand", "u1"), ("read_strand", "u1"),
+                   ("pad", "u1", (2,))])
+PAF_DT = np.dtype([("read", "<u4"), ("ctg", "<u4"), ("q_start", "<u4"), ("q_end", "<u4"),
+                   ("t_start", "<u4"), ("t_end", "<u4"), ("n_hits", "<u4"), ("strand", "<u4")])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        u64p, u32p, u8p = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)
+        L.orc_sketch_seq.restype = C.c_uint64
+        L.orc_sketch_seq.argtypes = [C.c_char_p, C.c_uint64, C.c_uint, C.c_uint, u64p, u32p, u8p, C.c_uint64]
+        L.orc_hash_seq.restype = C.c_uint64
+        L.orc_hash_seq.argtypes = [C.c_char_p, C.c_uint64, C.c_uint, u64p, u64p, u32p, u8p]
+        L.orc_sketch_batch.restype = C.c_int
+        L.orc_sketch_batch.argtypes = [C.c_void_p, u64p, C.c_uint64, C.c_uint, C.c_uint, u64p, u64p,
+                                       u64p, u32p, u8p, C.c_int]
+        L.orc_index_build.restype = C.c_void_p
+        L.orc_index_build.argtypes = [u64p, u32p, u32p, u8p, C.c_uint64]
+        L.orc_index_free.argtypes = [C.c_void_p]
+        L.orc_index_size.restype = C.c_uint64
+        L.orc_index_size.argtypes = [C.c_void_p]
+        L.orc_index_lookup.restype = C.c_int
+        L.orc_index_lookup.argtypes = [C.c_void_p, C.c_uint64, u32p, u32p, u8p]
+        L.orc_map_reads.restype = C.c_void_p
+        L.orc_map_reads.argtypes = [C.c_void_p, u32p, C.c_uint32, C.POINTER(Params), C.c_uint64, u64p, u32p,
+                                    u64p, u32p, u8p, C.c_int]
+        L.orc_result_free.argtypes = [C.c_void_p]
+        for nm in ("maps", "hits", "pafs"):
+            getattr(L, "orc_result_n_" + nm).restype = C.c_uint64
+            getattr(L, "orc_result_n_" + nm).argtypes = [C.c_void_p]
+            getattr(L, "orc_result_" + nm).restype = C.c_void_p
+            getattr(L, "orc_result_" + nm).argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+# ---------------------------------------------------------------- sequence input (a0)
+
+def read_fastx(path):
+    """FASTA/FASTQ(.gz) records as (name, sequence-bytes).  name = header up to the first whitespace;
+    multi-line FASTA joined; FASTQ qualities skipped (behaviour of bin/read_fasta.py:6-46)."""
+    opener = gzip.open if path.endswith(".gz") else open
+    with opener(path, "rb") as f:
+        data = f.read()
+    lines = data.split(b"\n")
+    i, n = 0, len(lines)
+    while i < n:
+        ln = lines[i]
+        if not ln or ln[:1] not in (b">", b"@"):
+            i += 1
+            continue
+        name = ln[1:].split(None, 1)[0] if ln[1:].split(None, 1) else b""
+        i += 1
+        seqs = []
+        while i < n and lines[i][:1] not in (b">", b"@", b"+"):
+            seqs.append(lines[i].rstrip(b"\r"))
+            i += 1
+        seq = b"".join(seqs)
+        if i < n and lines[i][:1] == b"+":  # fastq: skip as many quality bytes as there are bases
+            i += 1
+            got = 0
+            while i < n and got < len(seq):
+                got += len(lines[i])
+                i += 1
+        yield name.decode(), seq
+
+
+# ---------------------------------------------------------------- sketch (a1-a3)
+
+def sketch_seq(seq, k, w):
+    """Minimizers of one sequence: (hash u64, pos u32, strand u8 [1 = '+'])."""
+    L = lib()
+    n = L.orc_sketch_seq(seq, len(seq), k, w, None, None, None, 0)
+    h = np.empty(n, np.uint64); p = np.empty(n, np.uint32); s = np.empty(n, np.uint8)
+    if n:
+        L.orc_sketch_seq(seq, len(seq), k, w, _p(h, C.c_uint64), _p(p, C.c_uint32), _p(s, C.c_uint8), n)
+    return h, p, s
+
+
+def hash_seq(seq, k):
+    """All valid k-mers: (h0, h1, pos, forward)."""
+    L = lib()
+    cap = max(len(seq) - k + 1, 0)
+    h0 = np.empty(cap, np.uint64); h1 = np.empty(cap, np.uint64)
+    p = np.empty(cap, np.uint32); s = np.empty(cap, np.uint8)
+    n = L.orc_hash_seq(seq, len(seq), k, _p(h0, C.c_uint64), _p(h1, C.c_uint64), _p(p, C.c_uint32),
+                       _p(s, C.c_uint8)) if cap else 0
+    return h0[:n], h1[:n], p[:n], s[:n]
+
+
+def sketch_batch(seq_bytes, offsets, k, w, threads=0):
+    """Sketch concatenated sequences.  Returns (mx_off u64[n+1], hash, pos, strand)."""
+    L = lib()
+    buf = np.frombuffer(seq_bytes, np.uint8) if not isinstance(seq_bytes, np.ndarray) else seq_bytes
+    off = np.ascontiguousarray(offsets, np.uint64)
+    n = len(off) - 1
+    counts = np.zeros(n, np.uint64)
+    rc = L.orc_sketch_batch(buf.ctypes.data, _p(off, C.c_uint64), n, k, w, _p(counts, C.c_uint64), None,
+                            None, None, None, threads)
+    assert rc == 0
+    mx_off = np.zeros(n + 1, np.uint64)
+    np.cumsum(counts, out=mx_off[1:])
+    tot = int(mx_off[-1])
+    h = np.empty(tot, np.uint64); p = np.empty(tot, np.uint32); s = np.empty(tot, np.uint8)
+    if tot:
+        rc = L.orc_sketch_batch(buf.ctypes.data, _p(off, C.c_uint64), n, k, w, _p(counts, C.c_uint64),
+                                _p(mx_off, C.c_uint64), _p(h, C.c_uint64), _p(p, C.c_uint32),
+                                _p(s, C.c_uint8), threads)
+        assert rc == 0
+    return mx_off, h, p, s
+
+
+def format_indexlr(records, with_len=False):
+    """Text of `indexlr --long --pos --strand [--len]` (ntLink:199,223): records =
+    [(name, length, hash[], pos[], strand[])]."""
+    out = []
+    for name, length, h, p, s in records:
+        toks = " ".join(f"{int(a)}:{int(b)}:{'+' if c else '-'}" for a, b, c in zip(h, p, s))
+        if with_len:
+            out.append(f"{name}\t{length}\t{toks}\n")
+        else:
+            out.append(f"{name}\t{toks}\n")
+    return "".join(out)
+
+
+# ---------------------------------------------------------------- index + map (a4-a9)
+
+class Index:
+    """Contig minimizer index with global duplicate removal (bin/ntlink_pair.py:189-211)."""
+
+    def __init__(self, mx_hash, ctg, pos, strand):
+        L = lib()
+        self._h = np.ascontiguousarray(mx_hash, np.uint64)
+        self._c = np.ascontiguousarray(ctg, np.uint32)
+        self._p = np.ascontiguousarray(pos, np.uint32)
+        self._s = np.ascontiguousarray(strand, np.uint8)
+        self.ptr = L.orc_index_build(_p(self._h, C.c_uint64), _p(self._c, C.c_uint32), _p(self._p, C.c_uint32),
+                                     _p(self._s, C.c_uint8), len(self._h))
+
+    def __len__(self):
+        return int(lib().orc_index_size(self.ptr))
+
+    def lookup(self, key):
+        c, p, s = C.c_uint32(), C.c_uint32(), C.c_uint8()
+        if lib().orc_index_lookup(self.ptr, int(key), C.byref(c), C.byref(p), C.byref(s)):
+            return c.value, p.value, s.value
+        return None
+
+    def __del__(self):
+        try:
+            lib().orc_index_free(self.ptr)
+        except Exception:
+            pass
+
+
+def map_reads(index, ctg_len, mx_off, read_len, mh, mp, ms, k, z=1000, x=0.0, sensitive=False,
+              repeat_filter=False, threads=1):
+    """Per-read mapping.  Returns dict(maps=, hits=, pafs=) of structured arrays, read order."""
+    L = lib()
+    ctg_len = np.ascontiguousarray(ctg_len, np.uint32)
+    mx_off = np.ascontiguousarray(mx_off, np.uint64)
+    read_len = np.ascontiguousarray(read_len, np.uint32)
+    mh = np.ascontiguousarray(mh, np.uint64); mp = np.ascontiguousarray(mp, np.uint32)
+    ms = np.ascontiguousarray(ms, np.uint8)
+    P = Params(int(k), int(z), float(x), int(bool(sensitive)), int(bool(repeat_filter)))
+    r = L.orc_map_reads(index.ptr, _p(ctg_len, C.c_uint32), len(ctg_len), C.byref(P), len(read_len),
+                        _p(mx_off, C.c_uint64), _p(read_len, C.c_uint32), _p(mh, C.c_uint64),
+                        _p(mp, C.c_uint32), _p(ms, C.c_uint8), threads)
+    out = {}
+    for nm, dt in (("maps", MAPPING_DT), ("hits", HIT_DT), ("pafs", PAF_DT)):
+        n = getattr(L, "orc_result_n_" + nm)(r)
+        ptr = getattr(L, "orc_result_" + nm)(r)
+        if n:
+            buf = (C.c_char * (n * dt.itemsize)).from_address(ptr)
+            out[nm] = np.frombuffer(buf, dt).copy()
+        else:
+            out[nm] = np.empty(0, dt)
+    L.orc_result_free(r)
+    return out
+
+
+# ---------------------------------------------------------------- text + pair tally (a8, a10, a11)
+
+def format_verbose(res, read_names, ctg_names):
+    """<prefix>.verbose_mapping.tsv (bin/ntlink_pair.py:308-313,382-388)."""
+    out = []
+    hits = res["hits"]
+    for m in res["maps"]:
+        hs = hits[int(m["hit_off"]):int(m["hit_off"]) + int(m["n_hits"])]
+        toks = " ".join(f"{int(h['ctg_pos'])}:{'+' if h['ctg_strand'] else '-'}_"
+                        f"{int(h['read_pos'])}:{'+' if h['read_strand'] else '-'}" for h in hs)
+        out.append(f"{read_names[m['read']]}\t{ctg_names[m['ctg']]}\t{int(m['n_hits'])}\t{toks}\n")
+    return "".join(out)
+
+
+def format_paf(res, read_names, read_len, ctg_names, ctg_len):
+    """<prefix>.paf (bin/ntlink_paf_output.py:131-135)."""
+    out = []
+    for p in res["pafs"]:
+        r, c = int(p["read"]), int(p["ctg"])
+        out.append(f"{read_names[r]}\t{int(read_len[r])}\t{int(p['q_start'])}\t{int(p['q_end'])}\t"
+                   f"{'+' if p['strand'] else '-'}\t{ctg_names[c]}\t{int(ctg_len[c])}\t{int(p['t_start'])}\t"
+                   f"{int(p['t_end'])}\t{int(p['n_hits'])}\t{int(p['t_end']) - int(p['t_start'])}\t255\n")
+    return "".join(out)
+
+
+def _flip(o):
+    return "-" if o == "+" else "+"
+
+
+def tally_pairs(res, read_len, ctg_names, ctg_len, k, f=10):
+    """tally_pairs_from_mappings / add_pair / calculate_pair_info / calculate_gap_size /
+    normalize_pair (bin/ntlink_pair.py:416-435,315-334,222-239,157-187,213-219).
+    Returns an insertion-ordered dict (src, src_ori, tgt, tgt_ori) -> [gap list, anchor]."""
+    pairs = {}
+    maps, hits = res["maps"], res["hits"]
+    n = len(maps)
+    i = 0
+    while i < n:
+        j = i
+        while j < n and maps[j]["read"] == maps[i]["read"]:
+            j += 1
+        runs = maps[i:j]
+        rl = int(read_len[int(maps[i]["read"])])
+
+        def add(a, b, check=None):
+            ma, mb = runs[a], runs[b]
+            ha = hits[int(ma["hit_off"]) + int(ma["n_hits"]) - 1]  # terminal hit of the source contig
+            hb = hits[int(mb["hit_off"])]                            # first hit of the target contig
+            assert int(ha["read_pos"]) < int(hb["read_pos"])
+            s_ori = "+" if ha["read_strand"] == ha["ctg_strand"] else "-"
+            t_ori = "+" if hb["read_strand"] == hb["ctg_strand"] else "-"
+            ca, cb = int(ma["ctg"]), int(mb["ctg"])
+            aa = int(ctg_len[ca]) - int(ha["ctg_pos"]) - k if s_ori == "+" else int(ha["ctg_pos"])
+            bb = int(hb["ctg_pos"]) if t_ori == "+" else int(ctg_len[cb]) - int(hb["ctg_pos"]) - k
+            assert aa >= 0 and bb >= 0
+            gap = int(hb["read_pos"]) - int(ha["read_pos"]) - aa - bb
+            na, nb = ctg_names[ca], ctg_names[cb]
+            key = (na, s_ori, nb, t_ori) if na < nb else (nb, _flip(t_ori), na, _flip(s_ori))
+            if abs(gap) > rl:
+                return None
+            if check is not None and key in check:
+                return None
+            e = pairs.setdefault(key, [[], 0])
+            e[0].append(gap)
+            if int(ma["n_hits"]) > 1 and int(mb["n_hits"]) > 1:
+                e[1] += 1
+            return key
+
+        m = len(runs)
+        if m <= f:
+            for a in range(m):
+                for b in range(a + 1, m):
+                    add(a, b)
+        else:
+            added = set()
+            for a in range(m - 1):
+                added.add(add(a, a + 1))
+            strong = [a for a in range(m) if int(runs[a]["n_hits"]) > 1]
+            for a, b in zip(strong, strong[1:]):
+                add(a, b, check=added)
+        i = j
+    return pairs
+
+
+def gap_estimate(gaps):
+    """int(np.median(list)) (bin/ntlink_pair.py:70-74): truncation toward zero."""
+    return int(np.median(gaps))
+
+
+def filter_pairs(pairs, ctg_len_by_name, a=1):
+    """filter_pairs_distances then filter_weak_anchor_pairs (bin/ntlink_pair.py:241-255)."""
+    out = {}
+    for key, (gaps, anchor) in pairs.items():
+        g = gap_estimate(gaps)
+        if g <= -ctg_len_by_name[key[0]] or g <= -ctg_len_by_name[key[2]]:
+            continue
+        if anchor < a:
+            continue
+        out[key] = [gaps, anchor]
+    return out
+
+
+def format_pairs(pairs):
+    """<prefix>.pairs.tsv (bin/ntlink_pair.py:80-83,490-496)."""
+    return "".join(f"{s}{so}\t{t}{to}\tn={len(g)}, gap_estimates={g}, anchor={a}\n"
+                   for (s, so, t, to), (g, a) in pairs.items())
+
+
+def format_dot(pairs, ctg_len_by_name, n=1):
+    """<prefix>.n<N>.scaffold.dot (bin/ntlink_pair.py:133-155,263-305,498-506).  Returns
+    (header lines, node-line set, edge lines): node order in the reference is Python-set order."""
+    import re
+    edges = {}
+    vertices = []
+    for (s, so, t, to), (gaps, _a) in pairs.items():
+        fwd = (s + so, t + to)
+        rc = (t + _flip(to), s + _flip(so))
+        for v in (fwd[0], fwd[1], rc[0], rc[1]):
+            if v not in vertices:
+                vertices.append(v)
+        for a, b in (fwd, rc):
+            edges.setdefault(a, {})[b] = (gap_estimate(gaps), len(gaps))
+    largest = None
+    for name in ctg_len_by_name:
+        mm = re.search(r"^ntLink_(\d+)$", name)
+        if mm and (largest is None or int(mm.group(1)) > largest):
+            largest = int(mm.group(1))
+    head = ["digraph G {\n", f"graph [scaf_num={largest}]\n"]
+    nodes = {f"\"{v}\" [l={ctg_len_by_name[v[:-1]]}]\n" for v in vertices}
+    elines = [f"\"{a}\" -> \"{b}\" [d={d} e=100 n={cnt}]\n"
+              for a in edges for b, (d, cnt) in edges[a].items() if cnt >= n]
+    return head, nodes, elines
