@@ -1,0 +1,160 @@
+/*
+ * ntlink_amd.h -- C ABI of the MI355X implementation of the ntLink `pair` hot path.
+ *
+ * The reference (bcgsc/ntLink v1.3.11) has no FFI for this path: its boundary is two
+ * executables joined by a pipe (ntLink:221-225).  Each group of entry points below replaces
+ * one of them; INTEGRATION.md shows the ctypes stub a reference maintainer would add.
+ *
+ *   ntl_batch_*   sequence hand-over                <- btllib SeqReader inside `indexlr`
+ *                                                      (ntLink:199,223; id/seq semantics of
+ *                                                      bin/read_fasta.py:6-46)
+ *   ntl_sketch_*  (k,w) minimizer sketch            <- `indexlr --long --pos --strand [--len]
+ *                                                      -k K -w W` (ntLink:199,223) and
+ *                                                      btllib.Indexlr(path,k,w,LONG_MODE,t)
+ *                                                      (bin/ntlink_patch_gaps.py:417-441)
+ *   ntl_index_*   contig minimizer index            <- NtLink.read_minimizers
+ *                                                      (bin/ntlink_pair.py:189-211)
+ *   ntl_map_*     per-read lookup, hit filtering,   <- NtLink.find_scaffold_pairs body
+ *                 accepted contigs, PAF blocks         (bin/ntlink_pair.py:352-408),
+ *                                                      get_accepted_anchor_contigs
+ *                                                      (bin/ntlink_utils.py:200-294),
+ *                                                      print_paf (bin/ntlink_paf_output.py:103-135)
+ *
+ * Conventions: every call returns 0 on success or a negative NTL_E* code; the message is
+ * available from ntl_last_error().  All pointers in signatures are HOST pointers unless the
+ * name says otherwise; buffers are caller-owned; counts are obtained first, then filled.
+ * Handles are opaque; one context per device; calls on one context are not thread-safe.
+ * Strands are encoded 1 = '+', 0 = '-'.  Results are in input order (reads, then minimizers in
+ * position order), exactly as the reference emits them.
+ */
+#ifndef NTLINK_AMD_H
+#define NTLINK_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NTL_OK 0
+#define NTL_EINVAL (-1)   /* bad argument */
+#define NTL_EDEVICE (-2)  /* no usable gfx950 device / HIP runtime error */
+#define NTL_ENOMEM (-3)
+#define NTL_EINTERNAL (-4) /* an internal invariant failed (reported, never silently ignored) */
+
+typedef struct ntl_ctx ntl_ctx;
+typedef struct ntl_batch ntl_batch;
+typedef struct ntl_sketch ntl_sketch;
+typedef struct ntl_index ntl_index;
+typedef struct ntl_mapres ntl_mapres;
+
+/* ---- context ------------------------------------------------------------------------- */
+
+/* Opens device `device` (a HIP ordinal).  Fails with NTL_EDEVICE if there is no GPU: there is
+ * no CPU fallback. */
+int ntl_ctx_create(int device, ntl_ctx **out);
+void ntl_ctx_destroy(ntl_ctx *ctx);
+const char *ntl_last_error(const ntl_ctx *ctx);
+/* Human-readable device description ("AMD Instinct MI355X gfx950 256 CUs"). */
+const char *ntl_ctx_device_name(const ntl_ctx *ctx);
+/* Blocks until all work queued on the context's stream has finished. */
+int ntl_ctx_sync(ntl_ctx *ctx);
+
+/* Kernel timing with HIP events on the context's stream.  When enabled, every launch of the
+ * named kernel groups is bracketed by events; ntl_prof_get returns the accumulated time and
+ * launch count since the last ntl_prof_reset.  Names: "sketch_mask", "sketch_emit", "index",
+ * "probe", "map", "compact". */
+int ntl_prof_enable(ntl_ctx *ctx, int on);
+int ntl_prof_reset(ntl_ctx *ctx);
+int ntl_prof_get(ntl_ctx *ctx, const char *name, double *total_ms, uint64_t *launches);
+
+/* ---- sequences ------------------------------------------------------------------------ */
+
+/* Hands nseq sequences over: sequence i is the ASCII bytes seqs[offsets[i] .. offsets[i+1]).
+ * They are packed to 2 bits/base plus a table of non-ACGT runs and copied to the device, where
+ * they stay until ntl_batch_destroy.  Replaces: SeqReader -> NtHash input (ntLink:199,223). */
+int ntl_batch_create(ntl_ctx *ctx, const char *seqs, const uint64_t *offsets, uint64_t nseq,
+                     ntl_batch **out);
+void ntl_batch_destroy(ntl_batch *b);
+uint64_t ntl_batch_nseq(const ntl_batch *b);
+uint64_t ntl_batch_bases(const ntl_batch *b);
+
+/* ---- sketch ---------------------------------------------------------------------------- */
+
+/* Computes the (k,w) minimizers of every sequence of the batch on the device; the result stays
+ * in device memory.  Replaces `indexlr --long --pos --strand -k K -w W` (ntLink:199,223):
+ * ntHash canonical hash for the window minimum, second hash as the emitted value, window over
+ * valid k-mers, rightmost minimum on ties. */
+int ntl_sketch_run(ntl_ctx *ctx, const ntl_batch *b, int k, int w, ntl_sketch **out);
+void ntl_sketch_destroy(ntl_sketch *s);
+uint64_t ntl_sketch_nseq(const ntl_sketch *s);
+/* Total number of minimizers. */
+uint64_t ntl_sketch_count(const ntl_sketch *s);
+/* mx_off[nseq+1]: minimizers of sequence i are [mx_off[i], mx_off[i+1]); hash/pos/strand hold
+ * ntl_sketch_count() entries (the three fields `indexlr` prints as H:pos:strand). */
+int ntl_sketch_download(const ntl_sketch *s, uint64_t *mx_off, uint64_t *hash, uint32_t *pos,
+                        uint8_t *strand);
+/* Builds a device-resident sketch from host arrays (the text TSV path of the reference:
+ * `ntlink_pair.py -m contigs.tsv FILES`, bin/ntlink_pair.py:195-207,355-378). */
+int ntl_sketch_from_host(ntl_ctx *ctx, uint64_t nseq, const uint64_t *mx_off, const uint64_t *hash,
+                         const uint32_t *pos, const uint8_t *strand, ntl_sketch **out);
+
+/* ---- contig index ---------------------------------------------------------------------- */
+
+/* Builds the minimizer -> (contig, position, strand) table from the contig sketch; a hash that
+ * occurs more than once anywhere is dropped entirely (bin/ntlink_pair.py:204-209).
+ * ctg_len[n_ctg] are the contig lengths (bin/ntlink_utils.py:65-73), n_ctg == sketch nseq. */
+int ntl_index_build(ntl_ctx *ctx, const ntl_sketch *contigs, const uint32_t *ctg_len, uint32_t n_ctg,
+                    ntl_index **out);
+void ntl_index_destroy(ntl_index *ix);
+/* Number of minimizers kept (unique hashes). */
+uint64_t ntl_index_size(const ntl_index *ix);
+
+/* ---- mapping ---------------------------------------------------------------------------- */
+
+typedef struct {
+    int32_t k;             /* -k */
+    int32_t z;             /* -z minimum contig length (ntLink passes 1000) */
+    double x;              /* -x fudge factor; 0 = compare with the read length only */
+    int32_t sensitive;     /* --sensitive */
+    int32_t repeat_filter; /* --repeat-filter */
+} ntl_map_params;
+
+/* One accepted (read, contig) mapping = one line of <prefix>.verbose_mapping.tsv
+ * (bin/ntlink_pair.py:382-388); its hits are hits[hit_off .. hit_off + n_hits) in read order. */
+typedef struct {
+    uint32_t read, ctg, n_hits, pad;
+    uint64_t hit_off;
+} ntl_mapping;
+
+/* ctg_pos:ctg_strand_read_pos:read_strand (bin/ntlink_pair.py:308-313) */
+typedef struct {
+    uint32_t ctg_pos, read_pos;
+    uint8_t ctg_strand, read_strand, pad[2];
+} ntl_hit;
+
+/* One line of <prefix>.paf (bin/ntlink_paf_output.py:123-135); col 11 = t_end - t_start. */
+typedef struct {
+    uint32_t read, ctg;
+    uint32_t q_start, q_end, t_start, t_end;
+    uint32_t n_hits;
+    uint32_t strand;
+} ntl_paf;
+
+/* Maps every read of the read sketch: index lookup, optional repeat filter, contig length and
+ * span filters, run grouping, subsumption, accepted contigs, PAF blocks.  read_len[nreads] is
+ * the `--len` column.  Results stay on the device until downloaded. */
+int ntl_map_run(ntl_ctx *ctx, const ntl_index *ix, const ntl_sketch *reads, const uint32_t *read_len,
+                const ntl_map_params *params, ntl_mapres **out);
+void ntl_mapres_destroy(ntl_mapres *r);
+uint64_t ntl_mapres_n_mappings(const ntl_mapres *r);
+uint64_t ntl_mapres_n_hits(const ntl_mapres *r);
+uint64_t ntl_mapres_n_pafs(const ntl_mapres *r);
+/* Number of read minimizers found in the index (before any filter): the hit fraction h. */
+uint64_t ntl_mapres_n_index_hits(const ntl_mapres *r);
+int ntl_mapres_download(const ntl_mapres *r, ntl_mapping *maps, ntl_hit *hits, ntl_paf *pafs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

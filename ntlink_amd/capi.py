@@ -1,0 +1,282 @@
+"""ctypes binding of the C ABI in include/ntlink_amd.h (libntlink_hip.so).
+
+The library is the hipcc-built HIP extension that sits next to this file.  There is no CPU
+fallback: importing works anywhere (so that CLIs can print --help), but opening a Device without
+the library or without a GPU raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "libntlink_hip.so")
+
+# every symbol include/ntlink_amd.h declares
+SYMBOLS = [
+    "ntl_ctx_create", "ntl_ctx_destroy", "ntl_last_error", "ntl_ctx_device_name", "ntl_ctx_sync",
+    "ntl_prof_enable", "ntl_prof_reset", "ntl_prof_get",
+    "ntl_batch_create", "ntl_batch_destroy", "ntl_batch_nseq", "ntl_batch_bases",
+    "ntl_sketch_run", "ntl_sketch_destroy", "ntl_sketch_nseq", "ntl_sketch_count", "ntl_sketch_download",
+    "ntl_sketch_from_host",
+    "ntl_index_build", "ntl_index_destroy", "ntl_index_size",
+    "ntl_map_run", "ntl_mapres_destroy", "ntl_mapres_n_mappings", "ntl_mapres_n_hits", "ntl_mapres_n_pafs",
+    "ntl_mapres_n_index_hits", "ntl_mapres_download",
+]
+
+MAPPING_DT = np.dtype([("read", "<u4"), ("ctg", "<u4"), ("n_hits", "<u4"), ("pad", "<u4"), ("hit_off", "<u8")])
+HIT_DT = np.dtype([("ctg_pos", "<u4"), ("read_pos", "<u4"), ("ctg_strand", "u1"), ("read_strand", "u1"),
+                   ("pad", "u1", (2,))])
+PAF_DT = np.dtype([("read", "<u4"), ("ctg", "<u4"), ("q_start", "<u4"), ("q_end", "<u4"),
+                   ("t_start", "<u4"), ("t_end", "<u4"), ("n_hits", "<u4"), ("strand", "<u4")])
+
+
+class MapParams(C.Structure):
+    _fields_ = [("k", C.c_int32), ("z", C.c_int32), ("x", C.c_double),
+                ("sensitive", C.c_int32), ("repeat_filter", C.c_int32)]
+
+
+class NtlError(RuntimeError):
+    pass
+
+
+_libs = {}
+
+
+def load(path=None):
+    """dlopen the C-ABI library and declare its prototypes."""
+    path = path or DEFAULT_LIB
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        raise NtlError(f"HIP extension not built: {path} is missing (run __graft_entry__.build())")
+    L = C.CDLL(path)
+    vp, u64p, u32p, u8p = C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)
+    L.ntl_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.ntl_ctx_destroy.argtypes = [vp]
+    L.ntl_ctx_destroy.restype = None
+    L.ntl_last_error.argtypes = [vp]
+    L.ntl_last_error.restype = C.c_char_p
+    L.ntl_ctx_device_name.argtypes = [vp]
+    L.ntl_ctx_device_name.restype = C.c_char_p
+    L.ntl_ctx_sync.argtypes = [vp]
+    L.ntl_prof_enable.argtypes = [vp, C.c_int]
+    L.ntl_prof_reset.argtypes = [vp]
+    L.ntl_prof_get.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), u64p]
+    L.ntl_batch_create.argtypes = [vp, vp, u64p, C.c_uint64, C.POINTER(vp)]
+    L.ntl_batch_destroy.argtypes = [vp]
+    L.ntl_batch_destroy.restype = None
+    L.ntl_batch_nseq.argtypes = [vp]
+    L.ntl_batch_nseq.restype = C.c_uint64
+    L.ntl_batch_bases.argtypes = [vp]
+    L.ntl_batch_bases.restype = C.c_uint64
+    L.ntl_sketch_run.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]
+    L.ntl_sketch_destroy.argtypes = [vp]
+    L.ntl_sketch_destroy.restype = None
+    L.ntl_sketch_nseq.argtypes = [vp]
+    L.ntl_sketch_nseq.restype = C.c_uint64
+    L.ntl_sketch_count.argtypes = [vp]
+    L.ntl_sketch_count.restype = C.c_uint64
+    L.ntl_sketch_download.argtypes = [vp, u64p, u64p, u32p, u8p]
+    L.ntl_sketch_from_host.argtypes = [vp, C.c_uint64, u64p, u64p, u32p, u8p, C.POINTER(vp)]
+    L.ntl_index_build.argtypes = [vp, vp, u32p, C.c_uint32, C.POINTER(vp)]
+    L.ntl_index_destroy.argtypes = [vp]
+    L.ntl_index_destroy.restype = None
+    L.ntl_index_size.argtypes = [vp]
+    L.ntl_index_size.restype = C.c_uint64
+    L.ntl_map_run.argtypes = [vp, vp, vp, u32p, C.POINTER(MapParams), C.POINTER(vp)]
+    L.ntl_mapres_destroy.argtypes = [vp]
+    L.ntl_mapres_destroy.restype = None
+    for nm in ("n_mappings", "n_hits", "n_pafs", "n_index_hits"):
+        f = getattr(L, "ntl_mapres_" + nm)
+        f.argtypes = [vp]
+        f.restype = C.c_uint64
+    L.ntl_mapres_download.argtypes = [vp, vp, vp, vp]
+    _libs[path] = L
+    return L
+
+
+def _ptr(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+class _Handle:
+    _destroy = None
+
+    def __init__(self, dev, ptr):
+        self.dev, self.ptr = dev, ptr
+
+    def close(self):
+        if self.ptr:
+            getattr(self.dev.L, self._destroy)(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+class Batch(_Handle):
+    """Sequences resident in HBM as packed 2-bit bases + ACGT-run table."""
+    _destroy = "ntl_batch_destroy"
+
+    @property
+    def nseq(self):
+        return int(self.dev.L.ntl_batch_nseq(self.ptr))
+
+    @property
+    def bases(self):
+        return int(self.dev.L.ntl_batch_bases(self.ptr))
+
+
+class Sketch(_Handle):
+    """Device-resident minimizer lists (the output of `indexlr --long --pos --strand`)."""
+    _destroy = "ntl_sketch_destroy"
+
+    @property
+    def nseq(self):
+        return int(self.dev.L.ntl_sketch_nseq(self.ptr))
+
+    @property
+    def count(self):
+        return int(self.dev.L.ntl_sketch_count(self.ptr))
+
+    def download(self):
+        """(mx_off u64[nseq+1], hash u64, pos u32, strand u8 [1 = '+'])."""
+        n, ns = self.count, self.nseq
+        off = np.zeros(ns + 1, np.uint64)
+        h = np.empty(n, np.uint64); p = np.empty(n, np.uint32); s = np.empty(n, np.uint8)
+        self.dev._chk(self.dev.L.ntl_sketch_download(self.ptr, _ptr(off, C.c_uint64), _ptr(h, C.c_uint64),
+                                                     _ptr(p, C.c_uint32), _ptr(s, C.c_uint8)))
+        return off, h, p, s
+
+
+class Index(_Handle):
+    """Contig minimizer -> (contig, position, strand), duplicates removed."""
+    _destroy = "ntl_index_destroy"
+
+    def __len__(self):
+        return int(self.dev.L.ntl_index_size(self.ptr))
+
+
+class MapResult(_Handle):
+    _destroy = "ntl_mapres_destroy"
+
+    @property
+    def n_index_hits(self):
+        return int(self.dev.L.ntl_mapres_n_index_hits(self.ptr))
+
+    def counts(self):
+        L = self.dev.L
+        return (int(L.ntl_mapres_n_mappings(self.ptr)), int(L.ntl_mapres_n_hits(self.ptr)),
+                int(L.ntl_mapres_n_pafs(self.ptr)))
+
+    def download(self):
+        """dict(maps=, hits=, pafs=) of structured arrays, read order."""
+        nm, nh, npf = self.counts()
+        maps = np.empty(nm, MAPPING_DT); hits = np.empty(nh, HIT_DT); pafs = np.empty(npf, PAF_DT)
+        self.dev._chk(self.dev.L.ntl_mapres_download(self.ptr, maps.ctypes.data, hits.ctypes.data, pafs.ctypes.data))
+        return {"maps": maps, "hits": hits, "pafs": pafs}
+
+
+class Device:
+    """One MI355X: context + stream.  Raises NtlError when there is no GPU or no HIP extension."""
+
+    def __init__(self, device=0, lib_path=None):
+        self.L = load(lib_path)
+        p = C.c_void_p()
+        rc = self.L.ntl_ctx_create(int(device), C.byref(p))
+        if rc != 0:
+            raise NtlError(f"ntl_ctx_create(device={device}) failed with {rc}: no usable GPU "
+                           f"(this package has no CPU path)")
+        self.ptr = p
+
+    def close(self):
+        if self.ptr:
+            self.L.ntl_ctx_destroy(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise NtlError(f"error {rc}: {self.L.ntl_last_error(self.ptr).decode()}")
+
+    @property
+    def name(self):
+        return self.L.ntl_ctx_device_name(self.ptr).decode()
+
+    def sync(self):
+        self._chk(self.L.ntl_ctx_sync(self.ptr))
+
+    # ---- profiling (HIP events on the context's stream)
+    def prof_enable(self, on=True):
+        self._chk(self.L.ntl_prof_enable(self.ptr, int(on)))
+
+    def prof_reset(self):
+        self._chk(self.L.ntl_prof_reset(self.ptr))
+
+    def prof_get(self, name):
+        ms, n = C.c_double(), C.c_uint64()
+        self._chk(self.L.ntl_prof_get(self.ptr, name.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, int(n.value)
+
+    # ---- the path
+    def batch(self, seqs, offsets=None):
+        """seqs: list of bytes, or one contiguous bytes/uint8 buffer with offsets[n+1]."""
+        if offsets is None:
+            lens = np.fromiter((len(s) for s in seqs), np.uint64, len(seqs))
+            offsets = np.zeros(len(seqs) + 1, np.uint64)
+            np.cumsum(lens, out=offsets[1:])
+            buf = np.frombuffer(b"".join(seqs), np.uint8)
+        else:
+            buf = seqs if isinstance(seqs, np.ndarray) else np.frombuffer(seqs, np.uint8)
+            offsets = np.ascontiguousarray(offsets, np.uint64)
+        if len(buf) == 0:
+            buf = np.zeros(1, np.uint8)
+        p = C.c_void_p()
+        self._chk(self.L.ntl_batch_create(self.ptr, buf.ctypes.data, _ptr(offsets, C.c_uint64), len(offsets) - 1,
+                                          C.byref(p)))
+        return Batch(self, p)
+
+    def sketch(self, batch, k, w):
+        p = C.c_void_p()
+        self._chk(self.L.ntl_sketch_run(self.ptr, batch.ptr, int(k), int(w), C.byref(p)))
+        return Sketch(self, p)
+
+    def sketch_from_arrays(self, mx_off, mx_hash, pos, strand):
+        mx_off = np.ascontiguousarray(mx_off, np.uint64)
+        h = np.ascontiguousarray(mx_hash, np.uint64); q = np.ascontiguousarray(pos, np.uint32)
+        s = np.ascontiguousarray(strand, np.uint8)
+        p = C.c_void_p()
+        self._chk(self.L.ntl_sketch_from_host(self.ptr, len(mx_off) - 1, _ptr(mx_off, C.c_uint64), _ptr(h, C.c_uint64),
+                                              _ptr(q, C.c_uint32), _ptr(s, C.c_uint8), C.byref(p)))
+        return Sketch(self, p)
+
+    def index(self, contig_sketch, ctg_len):
+        cl = np.ascontiguousarray(ctg_len, np.uint32)
+        p = C.c_void_p()
+        self._chk(self.L.ntl_index_build(self.ptr, contig_sketch.ptr, _ptr(cl, C.c_uint32), len(cl), C.byref(p)))
+        return Index(self, p)
+
+    def map(self, index, read_sketch, read_len, k, z=1000, x=0.0, sensitive=False, repeat_filter=False):
+        rl = np.ascontiguousarray(read_len, np.uint32)
+        if len(rl) != read_sketch.nseq:
+            raise ValueError("read_len must have one entry per sketched read")
+        P = MapParams(int(k), int(z), float(x), int(bool(sensitive)), int(bool(repeat_filter)))
+        p = C.c_void_p()
+        self._chk(self.L.ntl_map_run(self.ptr, index.ptr, read_sketch.ptr, _ptr(rl, C.c_uint32), C.byref(P),
+                                     C.byref(p)))
+        return MapResult(self, p)

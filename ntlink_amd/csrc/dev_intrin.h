@@ -1,0 +1,24 @@
+/* gfx950 instruction wrappers used by the kernels (the SIMT mock under tests/sim supplies its
+ * own file of the same name with portable bodies). */
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+/* ({hi,lo} >> sh)[31:0], sh in 0..31 : v_alignbit_b32 */
+__device__ __forceinline__ uint32_t ntl_alignbit(uint32_t hi, uint32_t lo, uint32_t sh)
+{
+    return __builtin_amdgcn_alignbit(hi, lo, sh);
+}
+
+/* number of set bits of `mask` below this lane: v_mbcnt_lo/hi */
+__device__ __forceinline__ uint32_t ntl_mbcnt(unsigned long long mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+/* x*d + k in IEEE double with two roundings (no FMA contraction): the reference computes
+ * `args.x * abs(...) + args.k` in Python floats (bin/ntlink_utils.py:230-231). */
+__device__ __forceinline__ double ntl_mul_add_rn(double x, double d, double k)
+{
+    return __dadd_rn(__dmul_rn(x, d), k);
+}

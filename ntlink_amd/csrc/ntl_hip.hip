@@ -1,0 +1,724 @@
+/*
+ * Host side of libntlink_hip.so: the C ABI of include/ntlink_amd.h over the HIP kernels.
+ * One context = one device + one stream; all launches are asynchronous on that stream and the
+ * host only synchronises where a size has to come back (totals of the offset scans).
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <map>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/ntlink_amd.h"
+#include "dev_common.h"
+#include "scan_kernels.h"
+#include "sketch_kernels.h"
+#include "map_kernels.h"
+
+#define NTL_END_PAD 4096u /* bases of padding behind the last sequence (rolling over-reads) */
+#define SK_NT 256
+
+/* ------------------------------------------------------------------ context ------------- */
+
+struct ProfEntry {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> spans;
+    double done_ms = 0;
+    uint64_t launches = 0;
+};
+
+struct ntl_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::string devname;
+    bool prof = false;
+    std::map<std::string, ProfEntry> profs;
+    std::vector<hipEvent_t> ev_free;
+    std::multimap<size_t, void *> pool; /* cached device blocks by size */
+    size_t pool_bytes = 0;
+};
+
+static int fail(ntl_ctx *c, int code, const std::string &msg)
+{
+    if (c) c->err = msg;
+    return code;
+}
+
+#define HIPCHK(ctx, expr)                                                                         \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(ctx, NTL_EDEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+    } while (0)
+
+static int dev_alloc(ntl_ctx *c, size_t bytes, void **out)
+{
+    hipError_t e = hipMalloc(out, bytes);
+    if (e != hipSuccess) {
+        /* drop the cache and retry once */
+        for (auto &kv : c->pool) hipFree(kv.second);
+        c->pool.clear();
+        c->pool_bytes = 0;
+        e = hipMalloc(out, bytes);
+        if (e != hipSuccess) return fail(c, NTL_ENOMEM, "hipMalloc failed");
+    }
+    return NTL_OK;
+}
+
+/* a device buffer that returns to the context's cache */
+struct DevBuf {
+    ntl_ctx *c = nullptr;
+    void *p = nullptr;
+    size_t bytes = 0;
+    DevBuf() {}
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    int alloc(ntl_ctx *ctx, size_t n)
+    {
+        release();
+        c = ctx;
+        size_t want = n ? n : 256;
+        want = (want + 255) & ~(size_t)255;
+        /* look for a cached block; its true size is the map key */
+        auto it = c->pool.lower_bound(want);
+        if (it != c->pool.end() && it->first <= want + want / 4 + (1 << 20)) {
+            p = it->second; bytes = it->first;
+            c->pool_bytes -= it->first;
+            c->pool.erase(it);
+            return NTL_OK;
+        }
+        int rc = dev_alloc(c, want, &p);
+        if (rc) { p = nullptr; return rc; }
+        bytes = want;
+        return NTL_OK;
+    }
+    void release()
+    {
+        if (p && c) { c->pool.insert({bytes, p}); c->pool_bytes += bytes; }
+        p = nullptr; bytes = 0;
+    }
+    ~DevBuf() { release(); }
+    template <typename T> T *as() const { return (T *)p; }
+};
+
+struct ProfSpan {
+    ntl_ctx *c;
+    const char *name;
+    hipEvent_t a = nullptr, b = nullptr;
+    ProfSpan(ntl_ctx *ctx, const char *nm) : c(ctx), name(nm)
+    {
+        if (!c->prof) return;
+        auto get = [&](hipEvent_t &e) {
+            if (!c->ev_free.empty()) { e = c->ev_free.back(); c->ev_free.pop_back(); }
+            else if (hipEventCreate(&e) != hipSuccess) e = nullptr;
+        };
+        get(a); get(b);
+        if (a) hipEventRecord(a, c->stream);
+    }
+    ~ProfSpan()
+    {
+        if (!c->prof || !a || !b) return;
+        hipEventRecord(b, c->stream);
+        ProfEntry &P = c->profs[name];
+        P.spans.push_back({a, b});
+        P.launches++;
+    }
+};
+
+extern "C" int ntl_ctx_create(int device, ntl_ctx **out)
+{
+    if (!out) return NTL_EINVAL;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return NTL_EDEVICE;
+    ntl_ctx *c = new ntl_ctx();
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
+        delete c;
+        return NTL_EDEVICE;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+        char buf[256];
+        snprintf(buf, sizeof buf, "%s %s %d CUs %.0f GiB", prop.name, prop.gcnArchName, prop.multiProcessorCount,
+                 (double)prop.totalGlobalMem / (1024.0 * 1024.0 * 1024.0));
+        c->devname = buf;
+    }
+    *out = c;
+    return NTL_OK;
+}
+
+extern "C" void ntl_ctx_destroy(ntl_ctx *c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    for (auto &kv : c->pool) hipFree(kv.second);
+    for (auto &kv : c->profs)
+        for (auto &sp : kv.second.spans) { hipEventDestroy(sp.first); hipEventDestroy(sp.second); }
+    for (auto e : c->ev_free) hipEventDestroy(e);
+    hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" const char *ntl_last_error(const ntl_ctx *c) { return c ? c->err.c_str() : "no context"; }
+extern "C" const char *ntl_ctx_device_name(const ntl_ctx *c) { return c ? c->devname.c_str() : ""; }
+
+extern "C" int ntl_ctx_sync(ntl_ctx *c)
+{
+    if (!c) return NTL_EINVAL;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return NTL_OK;
+}
+
+extern "C" int ntl_prof_enable(ntl_ctx *c, int on)
+{
+    if (!c) return NTL_EINVAL;
+    c->prof = on != 0;
+    return NTL_OK;
+}
+
+static void prof_collect(ntl_ctx *c)
+{
+    hipStreamSynchronize(c->stream);
+    for (auto &kv : c->profs) {
+        for (auto &sp : kv.second.spans) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, sp.first, sp.second) == hipSuccess) kv.second.done_ms += ms;
+            c->ev_free.push_back(sp.first);
+            c->ev_free.push_back(sp.second);
+        }
+        kv.second.spans.clear();
+    }
+}
+
+extern "C" int ntl_prof_reset(ntl_ctx *c)
+{
+    if (!c) return NTL_EINVAL;
+    prof_collect(c);
+    for (auto &kv : c->profs) { kv.second.done_ms = 0; kv.second.launches = 0; }
+    return NTL_OK;
+}
+
+extern "C" int ntl_prof_get(ntl_ctx *c, const char *name, double *total_ms, uint64_t *launches)
+{
+    if (!c || !name) return NTL_EINVAL;
+    prof_collect(c);
+    auto it = c->profs.find(name);
+    if (total_ms) *total_ms = it == c->profs.end() ? 0.0 : it->second.done_ms;
+    if (launches) *launches = it == c->profs.end() ? 0 : it->second.launches;
+    return NTL_OK;
+}
+
+/* ------------------------------------------------------------------ scan helper ---------- */
+
+/* out[0..n) = exclusive scan of in[0..n); *total = sum (host).  in may equal out. */
+static int device_scan(ntl_ctx *c, const uint32_t *in, uint32_t *out, uint64_t n, uint32_t *total_host)
+{
+    uint64_t tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    if (tiles == 0) tiles = 1;
+    DevBuf tile, tot;
+    int rc;
+    if ((rc = tile.alloc(c, tiles * 4))) return rc;
+    if ((rc = tot.alloc(c, 4))) return rc;
+    hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)tiles), dim3(SCAN_NT), 0, c->stream, in, n, tile.as<uint32_t>());
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(SCAN_NT), 0, c->stream, tile.as<uint32_t>(), tiles, tot.as<uint32_t>());
+    hipLaunchKernelGGL(scan_down_kernel, dim3((unsigned)tiles), dim3(SCAN_NT), 0, c->stream, in, out, n,
+                       (const uint32_t *)tile.as<uint32_t>());
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(total_host, tot.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return NTL_OK;
+}
+
+/* ------------------------------------------------------------------ batch ---------------- */
+
+struct ntl_batch {
+    ntl_ctx *c;
+    uint64_t nseq = 0, bases = 0, nruns = 0, total_gpos = 0, nwords_packed = 0;
+    bool any_multi = false; /* some sequence has more than one ACGT run */
+    DevBuf packed, seq_base, seq_run_first, run_start, run_len;
+    std::vector<uint32_t> seq_len;
+};
+
+static const uint8_t *base_lut()
+{
+    static uint8_t lut[256];
+    static bool init = false;
+    if (!init) {
+        memset(lut, 4, sizeof lut);
+        lut[(int)'A'] = lut[(int)'a'] = 0; lut[(int)'C'] = lut[(int)'c'] = 1;
+        lut[(int)'G'] = lut[(int)'g'] = 2; lut[(int)'T'] = lut[(int)'t'] = 3;
+        init = true;
+    }
+    return lut;
+}
+
+extern "C" int ntl_batch_create(ntl_ctx *c, const char *seqs, const uint64_t *off, uint64_t nseq, ntl_batch **out)
+{
+    if (!c || !out || (!seqs && nseq) || !off) return NTL_EINVAL;
+    *out = nullptr;
+    if (nseq >= ((uint64_t)1 << 31)) return fail(c, NTL_EINVAL, "too many sequences in one batch");
+    for (uint64_t i = 0; i < nseq; i++) {
+        if (off[i + 1] < off[i]) return fail(c, NTL_EINVAL, "offsets must be non-decreasing");
+        if (off[i + 1] - off[i] >= 0xFFFFFFF0ull) return fail(c, NTL_EINVAL, "sequence longer than 2^32 bases");
+    }
+    const uint8_t *lut = base_lut();
+    const uint64_t o0 = nseq ? off[0] : 0;
+    const uint64_t total = nseq ? off[nseq] - o0 : 0;
+    ntl_batch *b = new ntl_batch();
+    b->c = c;
+    b->nseq = nseq;
+    b->bases = total;
+    b->total_gpos = NTL_LEAD_PAD + total;
+    const uint64_t nwords = (NTL_LEAD_PAD + total + NTL_END_PAD + 15) / 16 + 2;
+    b->nwords_packed = nwords;
+    std::vector<uint32_t> packed(nwords, 0u);
+    std::vector<uint64_t> seq_base(nseq + 1);
+    b->seq_len.resize(nseq);
+    for (uint64_t i = 0; i <= nseq; i++) seq_base[i] = NTL_LEAD_PAD + ((i < nseq ? off[i] : off[nseq]) - o0);
+    for (uint64_t i = 0; i < nseq; i++) b->seq_len[i] = (uint32_t)(off[i + 1] - off[i]);
+
+    unsigned nthr = std::thread::hardware_concurrency();
+    if (nthr == 0) nthr = 1;
+    if (nthr > 16) nthr = 16;
+    if (total < (1u << 20)) nthr = 1;
+    /* pass 1: pack, split by word ranges so that no word is shared */
+    {
+        const uint64_t data_words = (total + NTL_LEAD_PAD + 15) / 16;
+        auto work = [&](uint64_t w0, uint64_t w1) {
+            const unsigned char *src = (const unsigned char *)seqs + o0;
+            for (uint64_t w = w0; w < w1; w++) {
+                uint32_t v = 0;
+                for (int j = 0; j < 16; j++) {
+                    const uint64_t g = w * 16 + j;
+                    if (g < NTL_LEAD_PAD || g >= NTL_LEAD_PAD + total) continue;
+                    const uint8_t cde = lut[src[g - NTL_LEAD_PAD]];
+                    v |= (uint32_t)(cde & 3u) << (2 * j);
+                }
+                packed[w] = v;
+            }
+        };
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nthr; t++) {
+            uint64_t w0 = data_words * t / nthr, w1 = data_words * (t + 1) / nthr;
+            if (nthr == 1) work(w0, w1); else th.emplace_back(work, w0, w1);
+        }
+        for (auto &x : th) x.join();
+    }
+    /* pass 2: maximal ACGT runs per sequence */
+    std::vector<uint32_t> seq_run_first(nseq + 1, 0);
+    std::vector<uint32_t> run_start, run_len;
+    {
+        std::vector<std::vector<uint32_t>> rs(nthr), rl(nthr);
+        std::vector<std::vector<uint32_t>> cnt(nthr);
+        std::vector<uint64_t> lo(nthr + 1);
+        /* split sequences so that threads get about equal bases */
+        lo[0] = 0;
+        for (unsigned t = 1; t <= nthr; t++) {
+            const uint64_t target = o0 + total * t / nthr;
+            lo[t] = std::lower_bound(off, off + nseq, target) - off;
+            if (lo[t] < lo[t - 1]) lo[t] = lo[t - 1];
+        }
+        lo[nthr] = nseq;
+        auto work = [&](unsigned t) {
+            for (uint64_t i = lo[t]; i < lo[t + 1]; i++) {
+                const unsigned char *s = (const unsigned char *)seqs + off[i];
+                const uint64_t len = off[i + 1] - off[i];
+                uint32_t nr = 0;
+                uint64_t p = 0;
+                while (p < len) {
+                    while (p < len && lut[s[p]] == 4) p++;
+                    if (p >= len) break;
+                    uint64_t q = p;
+                    while (q < len && lut[s[q]] != 4) q++;
+                    rs[t].push_back((uint32_t)p);
+                    rl[t].push_back((uint32_t)(q - p));
+                    nr++;
+                    p = q;
+                }
+                cnt[t].push_back(nr);
+            }
+        };
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nthr; t++) {
+            if (nthr == 1) work(t); else th.emplace_back(work, t);
+        }
+        for (auto &x : th) x.join();
+        uint64_t nr_total = 0;
+        for (unsigned t = 0; t < nthr; t++) nr_total += rs[t].size();
+        if (nr_total >= 0xFFFFFFF0ull) { delete b; return fail(c, NTL_EINVAL, "too many ACGT runs in one batch"); }
+        run_start.reserve(nr_total); run_len.reserve(nr_total);
+        uint32_t acc = 0;
+        for (unsigned t = 0; t < nthr; t++) {
+            run_start.insert(run_start.end(), rs[t].begin(), rs[t].end());
+            run_len.insert(run_len.end(), rl[t].begin(), rl[t].end());
+            for (uint64_t j = 0; j < cnt[t].size(); j++) {
+                seq_run_first[lo[t] + j] = acc;
+                acc += cnt[t][j];
+                if (cnt[t][j] > 1) b->any_multi = true;
+            }
+        }
+        seq_run_first[nseq] = acc;
+        b->nruns = nr_total;
+    }
+    int rc;
+    hipSetDevice(c->device);
+    if ((rc = b->packed.alloc(c, nwords * 4)) || (rc = b->seq_base.alloc(c, (nseq + 1) * 8)) ||
+        (rc = b->seq_run_first.alloc(c, (nseq + 1) * 4)) || (rc = b->run_start.alloc(c, (b->nruns + 1) * 4)) ||
+        (rc = b->run_len.alloc(c, (b->nruns + 1) * 4))) {
+        delete b;
+        return rc;
+    }
+    auto up = [&](DevBuf &d, const void *src, size_t n) -> hipError_t {
+        return n ? hipMemcpyAsync(d.p, src, n, hipMemcpyHostToDevice, c->stream) : hipSuccess;
+    };
+    hipError_t e = up(b->packed, packed.data(), nwords * 4);
+    if (e == hipSuccess) e = up(b->seq_base, seq_base.data(), (nseq + 1) * 8);
+    if (e == hipSuccess) e = up(b->seq_run_first, seq_run_first.data(), (nseq + 1) * 4);
+    if (e == hipSuccess) e = up(b->run_start, run_start.data(), b->nruns * 4);
+    if (e == hipSuccess) e = up(b->run_len, run_len.data(), b->nruns * 4);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream); /* host vectors die here */
+    if (e != hipSuccess) { delete b; return fail(c, NTL_EDEVICE, std::string("upload: ") + hipGetErrorString(e)); }
+    *out = b;
+    return NTL_OK;
+}
+
+extern "C" void ntl_batch_destroy(ntl_batch *b) { delete b; }
+extern "C" uint64_t ntl_batch_nseq(const ntl_batch *b) { return b ? b->nseq : 0; }
+extern "C" uint64_t ntl_batch_bases(const ntl_batch *b) { return b ? b->bases : 0; }
+
+/* ------------------------------------------------------------------ sketch --------------- */
+
+struct ntl_sketch {
+    ntl_ctx *c;
+    uint64_t nseq = 0, count = 0;
+    DevBuf records; /* MxRecord[count] */
+    DevBuf mx_off;  /* u32[nseq+1] */
+};
+
+static uint64_t h_srol1(uint64_t x)
+{
+    uint64_t m = ((x & 0x8000000000000000ull) >> 30) | ((x & 0x100000000ull) >> 32);
+    return ((x << 1) & 0xFFFFFFFDFFFFFFFFull) | m;
+}
+
+static void make_tables(int k, uint64_t roll[16][2], uint64_t seed[4][2])
+{
+    const uint64_t S[4] = {0x3c8bfbb395c60474ull, 0x3193c18562a02b4cull, 0x20323ed082572324ull, 0x295549f54be24456ull};
+    uint64_t sk[4], sck[4];
+    for (int c = 0; c < 4; c++) {
+        uint64_t a = S[c], b = S[3 - c];
+        for (int i = 0; i < k; i++) { a = h_srol1(a); b = h_srol1(b); }
+        sk[c] = a; sck[c] = b;
+        seed[c][0] = S[c]; seed[c][1] = S[3 - c];
+    }
+    for (int in = 0; in < 4; in++)
+        for (int o = 0; o < 4; o++) {
+            roll[in << 2 | o][0] = S[in] ^ sk[o];
+            roll[in << 2 | o][1] = sck[in] ^ S[3 - o];
+        }
+}
+
+template <int C>
+static void launch_mask(ntl_ctx *c, const SketchArgs &A, unsigned strips, bool multi)
+{
+    hipLaunchKernelGGL((sketch_mask_kernel<C, SK_NT, false>), dim3(strips), dim3(SK_NT), 0, c->stream, A);
+    if (multi) hipLaunchKernelGGL((sketch_mask_kernel<C, SK_NT, true>), dim3(strips), dim3(SK_NT), 0, c->stream, A);
+}
+
+extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_sketch **out)
+{
+    if (!c || !b || !out) return NTL_EINVAL;
+    *out = nullptr;
+    if (k < 1 || k > 4096 || w < 1) return fail(c, NTL_EINVAL, "k must be in 1..4096 and w >= 1");
+    hipSetDevice(c->device);
+    const int C = w >= 16 ? 16 : (w >= 4 ? 4 : 1);
+    SketchGeom G;
+    G.k = k; G.w = w;
+    G.a = (w - C) / C; G.r0 = (w - C) % C;
+    G.LW = SK_NT - (G.a + 2);
+    G.NWO = G.LW * C - 1;
+    if (G.LW < 2 || G.NWO < 1) return fail(c, NTL_EINVAL, "window size too large for this build (w <= ~4000)");
+    const uint64_t nseq = b->nseq;
+    ntl_sketch *s = new ntl_sketch();
+    s->c = c; s->nseq = nseq;
+    int rc;
+    DevBuf run_n, run_ord, seq_M, nstrips, strip_first, mask, tile, tot, word_rank;
+    const uint64_t nmask = (b->total_gpos + 31) / 32 + 1;
+    if ((rc = run_n.alloc(c, (b->nruns + 1) * 4)) || (rc = run_ord.alloc(c, (b->nruns + 1) * 4)) ||
+        (rc = seq_M.alloc(c, (nseq + 1) * 4)) || (rc = nstrips.alloc(c, (nseq + 1) * 4)) ||
+        (rc = strip_first.alloc(c, (nseq + 2) * 4)) || (rc = mask.alloc(c, nmask * 4)) ||
+        (rc = s->mx_off.alloc(c, (nseq + 1) * 4))) {
+        delete s;
+        return rc;
+    }
+    SeqTables T;
+    T.packed = b->packed.as<uint32_t>(); T.seq_base = b->seq_base.as<uint64_t>();
+    T.seq_run_first = b->seq_run_first.as<uint32_t>(); T.run_start = b->run_start.as<uint32_t>();
+    T.run_len = b->run_len.as<uint32_t>(); T.nseq = (uint32_t)nseq;
+    uint32_t total_strips = 0, total_mx = 0;
+    {
+        ProfSpan sp(c, "sketch_meta");
+        HIPCHK(c, hipMemsetAsync(mask.p, 0, nmask * 4, c->stream));
+        if (nseq) {
+            KTables K;
+            K.run_n = run_n.as<uint32_t>(); K.run_ord = run_ord.as<uint32_t>();
+            K.seq_M = seq_M.as<uint32_t>(); K.seq_nstrips = nstrips.as<uint32_t>();
+            hipLaunchKernelGGL(seq_meta_kernel, dim3((unsigned)((nseq + 255) / 256)), dim3(256), 0, c->stream, T, K, k, w, G.NWO);
+            HIPCHK(c, hipGetLastError());
+            if ((rc = device_scan(c, nstrips.as<uint32_t>(), strip_first.as<uint32_t>(), nseq, &total_strips))) { delete s; return rc; }
+            HIPCHK(c, hipMemcpyAsync(strip_first.as<uint32_t>() + nseq, &total_strips, 4, hipMemcpyHostToDevice, c->stream));
+        }
+    }
+    if (total_strips) {
+        SketchArgs A;
+        A.T = T;
+        A.run_n = run_n.as<uint32_t>(); A.run_ord = run_ord.as<uint32_t>(); A.seq_M = seq_M.as<uint32_t>();
+        A.strip_first = strip_first.as<uint32_t>(); A.mask = mask.as<uint32_t>(); A.G = G;
+        make_tables(k, A.roll_tab, A.seed_tab);
+        ProfSpan sp(c, "sketch_mask");
+        if (C == 16) launch_mask<16>(c, A, total_strips, b->any_multi);
+        else if (C == 4) launch_mask<4>(c, A, total_strips, b->any_multi);
+        else launch_mask<1>(c, A, total_strips, b->any_multi);
+        HIPCHK(c, hipGetLastError());
+    }
+    {
+        ProfSpan sp(c, "sketch_emit");
+        const uint64_t tiles = (nmask + EMIT_TILE - 1) / EMIT_TILE;
+        if ((rc = tile.alloc(c, tiles * 4)) || (rc = tot.alloc(c, 4)) || (rc = word_rank.alloc(c, nmask * 4))) { delete s; return rc; }
+        hipLaunchKernelGGL(mask_count_kernel, dim3((unsigned)tiles), dim3(EMIT_NT), 0, c->stream,
+                           (const uint32_t *)mask.as<uint32_t>(), nmask, tile.as<uint32_t>());
+        hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(SCAN_NT), 0, c->stream, tile.as<uint32_t>(), tiles, tot.as<uint32_t>());
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(&total_mx, tot.p, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        s->count = total_mx;
+        if ((rc = s->records.alloc(c, (uint64_t)total_mx * sizeof(MxRecord)))) { delete s; return rc; }
+        EmitArgs E;
+        E.packed = T.packed; E.seq_base = T.seq_base; E.nseq = (uint32_t)nseq; E.mask = mask.as<uint32_t>();
+        E.nwords = nmask; E.tile_off = tile.as<uint32_t>(); E.word_rank = word_rank.as<uint32_t>();
+        E.out = s->records.as<MxRecord>(); E.k = k; E.mult = 1ull ^ ((uint64_t)k * 0x90b45d39fb6da1faull);
+        uint64_t roll[16][2];
+        make_tables(k, roll, E.seed_tab);
+        hipLaunchKernelGGL(emit_kernel, dim3((unsigned)tiles), dim3(EMIT_NT), 0, c->stream, E);
+        hipLaunchKernelGGL(mx_offsets_kernel, dim3((unsigned)((nseq + 1 + 255) / 256)), dim3(256), 0, c->stream,
+                           T.seq_base, (uint32_t)nseq, (const uint32_t *)mask.as<uint32_t>(),
+                           (const uint32_t *)word_rank.as<uint32_t>(), nmask, total_mx, s->mx_off.as<uint32_t>());
+        HIPCHK(c, hipGetLastError());
+    }
+    /* temporaries go back to the cache only after the stream has consumed them */
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *out = s;
+    return NTL_OK;
+}
+
+extern "C" void ntl_sketch_destroy(ntl_sketch *s) { delete s; }
+extern "C" uint64_t ntl_sketch_nseq(const ntl_sketch *s) { return s ? s->nseq : 0; }
+extern "C" uint64_t ntl_sketch_count(const ntl_sketch *s) { return s ? s->count : 0; }
+
+extern "C" int ntl_sketch_download(const ntl_sketch *s, uint64_t *mx_off, uint64_t *hash, uint32_t *pos, uint8_t *strand)
+{
+    if (!s) return NTL_EINVAL;
+    ntl_ctx *c = s->c;
+    hipSetDevice(c->device);
+    std::vector<uint32_t> off(s->nseq + 1);
+    std::vector<MxRecord> rec(s->count);
+    HIPCHK(c, hipMemcpyAsync(off.data(), s->mx_off.p, (s->nseq + 1) * 4, hipMemcpyDeviceToHost, c->stream));
+    if (s->count) HIPCHK(c, hipMemcpyAsync(rec.data(), s->records.p, s->count * sizeof(MxRecord), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (mx_off) for (uint64_t i = 0; i <= s->nseq; i++) mx_off[i] = off[i];
+    for (uint64_t i = 0; i < s->count; i++) {
+        if (hash) hash[i] = rec[i].hash;
+        if (pos) pos[i] = rec[i].pos;
+        if (strand) strand[i] = (uint8_t)(rec[i].meta & 1u);
+    }
+    return NTL_OK;
+}
+
+extern "C" int ntl_sketch_from_host(ntl_ctx *c, uint64_t nseq, const uint64_t *mx_off, const uint64_t *hash,
+                                    const uint32_t *pos, const uint8_t *strand, ntl_sketch **out)
+{
+    if (!c || !out || !mx_off) return NTL_EINVAL;
+    *out = nullptr;
+    const uint64_t n = mx_off[nseq];
+    if (n >= 0xFFFFFFF0ull || nseq >= ((uint64_t)1 << 31)) return fail(c, NTL_EINVAL, "sketch too large for one batch");
+    if (n && (!hash || !pos || !strand)) return NTL_EINVAL;
+    hipSetDevice(c->device);
+    std::vector<MxRecord> rec(n);
+    std::vector<uint32_t> off(nseq + 1);
+    for (uint64_t i = 0; i <= nseq; i++) {
+        if (i && mx_off[i] < mx_off[i - 1]) return fail(c, NTL_EINVAL, "mx_off must be non-decreasing");
+        off[i] = (uint32_t)mx_off[i];
+    }
+    for (uint64_t s = 0; s < nseq; s++)
+        for (uint64_t i = mx_off[s]; i < mx_off[s + 1]; i++) {
+            rec[i].hash = hash[i]; rec[i].pos = pos[i];
+            rec[i].meta = ((uint32_t)s << 1) | (strand[i] ? 1u : 0u);
+        }
+    ntl_sketch *sk = new ntl_sketch();
+    sk->c = c; sk->nseq = nseq; sk->count = n;
+    int rc;
+    if ((rc = sk->records.alloc(c, n * sizeof(MxRecord))) || (rc = sk->mx_off.alloc(c, (nseq + 1) * 4))) { delete sk; return rc; }
+    hipError_t e = hipSuccess;
+    if (n) e = hipMemcpyAsync(sk->records.p, rec.data(), n * sizeof(MxRecord), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(sk->mx_off.p, off.data(), (nseq + 1) * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { delete sk; return fail(c, NTL_EDEVICE, hipGetErrorString(e)); }
+    *out = sk;
+    return NTL_OK;
+}
+
+/* ------------------------------------------------------------------ index ---------------- */
+
+struct ntl_index {
+    ntl_ctx *c;
+    int bits = 0;
+    uint64_t nslots = 0, size = 0;
+    uint32_t n_ctg = 0;
+    DevBuf slots, special, ctg_len;
+};
+
+extern "C" int ntl_index_build(ntl_ctx *c, const ntl_sketch *ctg, const uint32_t *ctg_len, uint32_t n_ctg, ntl_index **out)
+{
+    if (!c || !ctg || !out || (!ctg_len && n_ctg)) return NTL_EINVAL;
+    *out = nullptr;
+    if ((uint64_t)n_ctg != ctg->nseq) return fail(c, NTL_EINVAL, "n_ctg must equal the number of sketched contigs");
+    if (n_ctg >= (1u << 30)) return fail(c, NTL_EINVAL, "too many contigs");
+    hipSetDevice(c->device);
+    ntl_index *ix = new ntl_index();
+    ix->c = c; ix->n_ctg = n_ctg;
+    int bits = 10;
+    while (((uint64_t)1 << bits) < 2 * ctg->count + 2) bits++;
+    ix->bits = bits;
+    ix->nslots = (uint64_t)1 << bits;
+    int rc;
+    DevBuf cnt;
+    if ((rc = ix->slots.alloc(c, ix->nslots * sizeof(IndexSlot))) || (rc = ix->special.alloc(c, sizeof(IndexSpecial))) ||
+        (rc = ix->ctg_len.alloc(c, ((uint64_t)n_ctg + 1) * 4)) || (rc = cnt.alloc(c, 8))) { delete ix; return rc; }
+    unsigned long long size = 0;
+    {
+        ProfSpan sp(c, "index");
+        if (n_ctg) HIPCHK(c, hipMemcpyAsync(ix->ctg_len.p, ctg_len, (uint64_t)n_ctg * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemsetAsync(ix->special.p, 0, sizeof(IndexSpecial), c->stream));
+        HIPCHK(c, hipMemsetAsync(cnt.p, 0, 8, c->stream));
+        hipLaunchKernelGGL(index_clear_kernel, dim3((unsigned)((ix->nslots + 255) / 256)), dim3(256), 0, c->stream,
+                           ix->slots.as<IndexSlot>(), ix->nslots);
+        if (ctg->count)
+            hipLaunchKernelGGL(index_insert_kernel, dim3((unsigned)((ctg->count + 255) / 256)), dim3(256), 0, c->stream,
+                               (const MxRecord *)ctg->records.as<MxRecord>(), ctg->count, ix->slots.as<IndexSlot>(), bits,
+                               ix->special.as<IndexSpecial>());
+        hipLaunchKernelGGL(index_count_kernel, dim3((unsigned)((ix->nslots + 255) / 256)), dim3(256), 0, c->stream,
+                           (const IndexSlot *)ix->slots.as<IndexSlot>(), ix->nslots,
+                           (const IndexSpecial *)ix->special.as<IndexSpecial>(), cnt.as<unsigned long long>());
+        HIPCHK(c, hipGetLastError());
+    }
+    HIPCHK(c, hipMemcpyAsync(&size, cnt.p, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    ix->size = size;
+    *out = ix;
+    return NTL_OK;
+}
+
+extern "C" void ntl_index_destroy(ntl_index *ix) { delete ix; }
+extern "C" uint64_t ntl_index_size(const ntl_index *ix) { return ix ? ix->size : 0; }
+
+/* ------------------------------------------------------------------ map ------------------ */
+
+struct ntl_mapres {
+    ntl_ctx *c;
+    uint64_t n_maps = 0, n_hits = 0, n_pafs = 0, n_index_hits = 0;
+    DevBuf maps, hits, pafs;
+};
+
+extern "C" int ntl_map_run(ntl_ctx *c, const ntl_index *ix, const ntl_sketch *reads, const uint32_t *read_len,
+                           const ntl_map_params *params, ntl_mapres **out)
+{
+    if (!c || !ix || !reads || !params || !out || (!read_len && reads->nseq)) return NTL_EINVAL;
+    *out = nullptr;
+    hipSetDevice(c->device);
+    const uint64_t nreads = reads->nseq, nmx = reads->count;
+    ntl_mapres *R = new ntl_mapres();
+    R->c = c;
+    int rc;
+    DevBuf cand, rlen, smaps, shits, spafs, n3, off3, scr, nfound, err;
+    const uint64_t cap = nmx ? nmx : 1;
+    if ((rc = cand.alloc(c, cap * sizeof(Cand))) || (rc = rlen.alloc(c, (nreads + 1) * 4)) ||
+        (rc = smaps.alloc(c, cap * sizeof(MapRec))) || (rc = shits.alloc(c, cap * sizeof(HitRec))) ||
+        (rc = spafs.alloc(c, cap * sizeof(PafRec))) || (rc = n3.alloc(c, 3 * (nreads + 1) * 4)) ||
+        (rc = off3.alloc(c, 3 * (nreads + 1) * 4)) || (rc = scr.alloc(c, (uint64_t)(MAP_NHA + MAP_NRA) * cap * 4)) ||
+        (rc = nfound.alloc(c, 8)) || (rc = err.alloc(c, 4))) { delete R; return rc; }
+    if (nreads) HIPCHK(c, hipMemcpyAsync(rlen.p, read_len, nreads * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(nfound.p, 0, 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(err.p, 0, 4, c->stream));
+    {
+        ProfSpan sp(c, "probe");
+        if (nmx)
+            hipLaunchKernelGGL(probe_kernel, dim3((unsigned)((nmx + 255) / 256)), dim3(256), 0, c->stream,
+                               (const MxRecord *)reads->records.as<MxRecord>(), nmx, (const IndexSlot *)ix->slots.as<IndexSlot>(),
+                               ix->bits, (const IndexSpecial *)ix->special.as<IndexSpecial>(), cand.as<Cand>(),
+                               nfound.as<unsigned long long>());
+        HIPCHK(c, hipGetLastError());
+    }
+    MapArgs A;
+    A.mx = reads->records.as<MxRecord>(); A.mx_off = reads->mx_off.as<uint32_t>(); A.cand = cand.as<Cand>();
+    A.read_len = rlen.as<uint32_t>(); A.ctg_len = ix->ctg_len.as<uint32_t>(); A.nreads = (uint32_t)nreads;
+    A.P.k = params->k; A.P.z = params->z; A.P.x = params->x; A.P.sensitive = params->sensitive;
+    A.P.repeat_filter = params->repeat_filter;
+    A.maps = smaps.as<MapRec>(); A.hits = shits.as<HitRec>(); A.pafs = spafs.as<PafRec>();
+    A.n_maps = n3.as<uint32_t>(); A.n_hits = A.n_maps + (nreads + 1); A.n_pafs = A.n_hits + (nreads + 1);
+    A.scr = scr.as<uint32_t>(); A.scr_stride = cap; A.err = err.as<uint32_t>();
+    uint32_t tot[3] = {0, 0, 0};
+    if (nreads) {
+        {
+            ProfSpan sp(c, "map");
+            hipLaunchKernelGGL(map_kernel, dim3((unsigned)nreads), dim3(MAP_NT), 0, c->stream, A);
+            HIPCHK(c, hipGetLastError());
+        }
+        ProfSpan sp(c, "compact");
+        uint32_t *o = off3.as<uint32_t>();
+        for (int i = 0; i < 3; i++)
+            if ((rc = device_scan(c, n3.as<uint32_t>() + i * (nreads + 1), o + i * (nreads + 1), nreads, &tot[i]))) { delete R; return rc; }
+        R->n_maps = tot[0]; R->n_hits = tot[1]; R->n_pafs = tot[2];
+        if ((rc = R->maps.alloc(c, (uint64_t)tot[0] * sizeof(MapRec))) || (rc = R->hits.alloc(c, (uint64_t)tot[1] * sizeof(HitRec))) ||
+            (rc = R->pafs.alloc(c, (uint64_t)tot[2] * sizeof(PafRec)))) { delete R; return rc; }
+        hipLaunchKernelGGL(map_gather_kernel, dim3((unsigned)nreads), dim3(64), 0, c->stream, A, (const uint32_t *)o,
+                           (const uint32_t *)(o + (nreads + 1)), (const uint32_t *)(o + 2 * (nreads + 1)),
+                           R->maps.as<MapRec>(), R->hits.as<HitRec>(), R->pafs.as<PafRec>());
+        HIPCHK(c, hipGetLastError());
+    }
+    unsigned long long nf = 0;
+    uint32_t errflag = 0;
+    HIPCHK(c, hipMemcpyAsync(&nf, nfound.p, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&errflag, err.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    R->n_index_hits = nf;
+    if (errflag) { delete R; return fail(c, NTL_EINTERNAL, "an accepted contig appeared twice in one read (bin/ntlink_utils.py:262-266)"); }
+    *out = R;
+    return NTL_OK;
+}
+
+extern "C" void ntl_mapres_destroy(ntl_mapres *r) { delete r; }
+extern "C" uint64_t ntl_mapres_n_mappings(const ntl_mapres *r) { return r ? r->n_maps : 0; }
+extern "C" uint64_t ntl_mapres_n_hits(const ntl_mapres *r) { return r ? r->n_hits : 0; }
+extern "C" uint64_t ntl_mapres_n_pafs(const ntl_mapres *r) { return r ? r->n_pafs : 0; }
+extern "C" uint64_t ntl_mapres_n_index_hits(const ntl_mapres *r) { return r ? r->n_index_hits : 0; }
+
+extern "C" int ntl_mapres_download(const ntl_mapres *r, ntl_mapping *maps, ntl_hit *hits, ntl_paf *pafs)
+{
+    if (!r) return NTL_EINVAL;
+    ntl_ctx *c = r->c;
+    hipSetDevice(c->device);
+    static_assert(sizeof(ntl_mapping) == sizeof(MapRec) && sizeof(ntl_hit) == sizeof(HitRec) && sizeof(ntl_paf) == sizeof(PafRec),
+                  "ABI records must match the device records");
+    if (maps && r->n_maps) HIPCHK(c, hipMemcpyAsync(maps, r->maps.p, r->n_maps * sizeof(MapRec), hipMemcpyDeviceToHost, c->stream));
+    if (hits && r->n_hits) HIPCHK(c, hipMemcpyAsync(hits, r->hits.p, r->n_hits * sizeof(HitRec), hipMemcpyDeviceToHost, c->stream));
+    if (pafs && r->n_pafs) HIPCHK(c, hipMemcpyAsync(pafs, r->pafs.p, r->n_pafs * sizeof(PafRec), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return NTL_OK;
+}

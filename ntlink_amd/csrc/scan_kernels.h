@@ -1,0 +1,75 @@
+/*
+ * Exclusive prefix sums of u32 arrays (offsets of variable-length per-sequence / per-read
+ * outputs, so that results land in input order without atomics -- the reference emits
+ * everything in read order, ntLink:222, bin/ntlink_pair.py:352-408).
+ *
+ *   scan_reduce_kernel   per tile of SCAN_TILE items: sum -> tile_cnt
+ *   scan_tiles_kernel    one workgroup: exclusive scan of tile_cnt in place, grand total
+ *   scan_down_kernel     per tile: exclusive scan of the items + tile offset -> out
+ */
+#pragma once
+#include "dev_common.h"
+
+#define SCAN_NT 256
+#define SCAN_IPT 8
+#define SCAN_TILE (SCAN_NT * SCAN_IPT)
+
+__global__ __launch_bounds__(SCAN_NT) void scan_reduce_kernel(const uint32_t *in, uint64_t n, uint32_t *tile_cnt)
+{
+    __shared__ uint32_t s_tmp[SCAN_NT];
+    const uint64_t i0 = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_IPT;
+    uint32_t c = 0;
+    for (int i = 0; i < SCAN_IPT; i++)
+        if (i0 + i < n) c += in[i0 + i];
+    uint32_t total;
+    block_excl_scan<SCAN_NT>(c, s_tmp, total);
+    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = total;
+}
+
+/* single workgroup; data[0..n) becomes its exclusive scan, *total the sum */
+__global__ __launch_bounds__(SCAN_NT) void scan_tiles_kernel(uint32_t *data, uint64_t n, uint32_t *total_out)
+{
+    __shared__ uint32_t s_tmp[SCAN_NT];
+    uint32_t carry = 0;
+    for (uint64_t base = 0; base < n; base += SCAN_TILE) {
+        const uint64_t i0 = base + (uint64_t)threadIdx.x * SCAN_IPT;
+        uint32_t v[SCAN_IPT];
+        uint32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < SCAN_IPT; i++) {
+            v[i] = i0 + i < n ? data[i0 + i] : 0u;
+            c += v[i];
+        }
+        uint32_t total;
+        uint32_t r = carry + block_excl_scan<SCAN_NT>(c, s_tmp, total);
+#pragma unroll
+        for (int i = 0; i < SCAN_IPT; i++) {
+            if (i0 + i < n) data[i0 + i] = r;
+            r += v[i];
+        }
+        carry += total;
+    }
+    if (threadIdx.x == 0) *total_out = carry;
+}
+
+/* out may alias in; out[n] is not written */
+__global__ __launch_bounds__(SCAN_NT) void scan_down_kernel(const uint32_t *in, uint32_t *out, uint64_t n,
+                                                            const uint32_t *tile_off)
+{
+    __shared__ uint32_t s_tmp[SCAN_NT];
+    const uint64_t i0 = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_IPT;
+    uint32_t v[SCAN_IPT];
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_IPT; i++) {
+        v[i] = i0 + i < n ? in[i0 + i] : 0u;
+        c += v[i];
+    }
+    uint32_t total;
+    uint32_t r = tile_off[blockIdx.x] + block_excl_scan<SCAN_NT>(c, s_tmp, total);
+#pragma unroll
+    for (int i = 0; i < SCAN_IPT; i++) {
+        if (i0 + i < n) out[i0 + i] = r;
+        r += v[i];
+    }
+}

@@ -1,0 +1,421 @@
+/*
+ * Sketch kernels: packed 2-bit sequence -> (k,w) minimizers.
+ *
+ * Replaces btllib `indexlr --long --pos --strand` (ntLink:199,223) = NtHash(seq,2,k) +
+ * Indexlr::minimize.  Semantics reproduced bit for bit:
+ *   - only k-mers made of ACGT are hashed; the sliding window runs over the ORDINAL of valid
+ *     k-mers (an N run does not consume window slots);
+ *   - the window minimum is taken on h0 = fwd + rev; ties -> the rightmost k-mer;
+ *   - a minimizer is emitted when the window minimum moves to a new k-mer (the sequence of
+ *     rightmost minima is monotone, so "position > last emitted" == "argmin changed");
+ *   - h0 == 2^64-1 is never emitted.
+ *
+ * Decomposition (DESIGN.md "sketch"):
+ *   seq_meta_kernel   per sequence: valid-k-mer ordinals of its ACGT runs, window count, strips
+ *   sketch_mask_kernel  one workgroup = one STRIP of NT*C consecutive valid k-mers of one
+ *                     sequence.  Lane L owns C consecutive k-mers ("block" L): rolls their hashes
+ *                     in registers, stages them in LDS (transposed [t][L], conflict-free), then
+ *                     evaluates every window that starts in its block as
+ *                         argmin( suffix of own block | whole blocks between | prefix of a later block )
+ *                     and sets one bit per emitted minimizer in a global bitmask (1 bit / base).
+ *   emit_kernel       bitmask -> 16-byte records {h1, pos, strand|seq}: ranks the set bits
+ *                     (scan), rehashes only the emitted k-mers (2/(w+1) of all) and applies the
+ *                     64x64 multiply of the second hash there.
+ */
+#pragma once
+#include "dev_common.h"
+
+struct SeqTables {
+    const uint32_t *packed;        /* 2-bit bases, 16 per word, NTL_LEAD_PAD bases of front padding */
+    const uint64_t *seq_base;      /* [nseq+1] global base index of each sequence start */
+    const uint32_t *seq_run_first; /* [nseq+1] first ACGT run of each sequence */
+    const uint32_t *run_start;     /* [nruns] start of the run inside its sequence */
+    const uint32_t *run_len;       /* [nruns] bases */
+    uint32_t nseq;
+};
+
+/* k-dependent tables, produced by seq_meta_kernel */
+struct KTables {
+    uint32_t *run_n;       /* [nruns] valid k-mers of the run = max(0, len-k+1) */
+    uint32_t *run_ord;     /* [nruns] ordinal of its first k-mer within the sequence */
+    uint32_t *seq_M;       /* [nseq] valid k-mers of the sequence */
+    uint32_t *seq_nstrips; /* [nseq] */
+};
+
+struct SketchGeom {
+    int k, w;
+    int a;   /* (w - C) / C : whole blocks always covered by a window besides its own */
+    int r0;  /* (w - C) % C */
+    int LW;  /* lanes that own windows (the others only supply data) */
+    int NWO; /* windows owned per strip = LW*C - 1 */
+};
+
+__global__ void seq_meta_kernel(SeqTables T, KTables K, int k, int w, int NWO)
+{
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= T.nseq) return;
+    uint32_t ord = 0;
+    for (uint32_t g = T.seq_run_first[s]; g < T.seq_run_first[s + 1]; g++) {
+        uint32_t len = T.run_len[g];
+        uint32_t n = len >= (uint32_t)k ? len - (uint32_t)k + 1u : 0u;
+        K.run_n[g] = n;
+        K.run_ord[g] = ord;
+        ord += n;
+    }
+    K.seq_M[s] = ord;
+    uint32_t nwin = ord >= (uint32_t)w ? ord - (uint32_t)w + 1u : 0u;
+    K.seq_nstrips[s] = (nwin + (uint32_t)NWO - 1u) / (uint32_t)NWO;
+}
+
+struct SketchArgs {
+    SeqTables T;
+    const uint32_t *run_n, *run_ord, *seq_M;
+    const uint32_t *strip_first; /* [nseq+1] exclusive scan of seq_nstrips */
+    uint32_t *mask;              /* 1 bit per global base index: k-mer starting there is a minimizer */
+    SketchGeom G;
+    uint64_t roll_tab[16][2];    /* [in<<2|out] = {seed[in]^srol^k(seed[out]), srol^k(seedc[in])^seedc[out]} */
+    uint64_t seed_tab[4][2];     /* [c] = {seed[c], seed[3-c]} */
+};
+
+struct StripInfo {
+    uint32_t seq;
+    int32_t E0;      /* ordinal of the strip's first element (may be -1) */
+    uint32_t M;      /* valid k-mers of the sequence */
+    uint32_t run;    /* run containing the first real element */
+    int32_t multi;   /* strip spans more than one ACGT run */
+    int64_t P0;      /* single-run strips: position (in the sequence) of element E0 */
+    uint64_t base;   /* seq_base */
+};
+
+/*
+ * MULTI = false: strips whose k-mers lie in one ACGT run (positions contiguous): register rolling.
+ * MULTI = true : strips that cross non-ACGT runs: per-lane walk over the run table, positions
+ *                staged in LDS.  Both instantiations are launched over all strips; each returns
+ *                immediately on strips of the other kind.
+ */
+template <int C, int NT, bool MULTI>
+__global__ __launch_bounds__(NT) void sketch_mask_kernel(SketchArgs A)
+{
+    __shared__ uint64_t s_h[C * NT];  /* element (L,t) at [t*NT + L] */
+    __shared__ uint32_t s_pos[MULTI ? C * NT : 1];
+    __shared__ uint64_t s_bm_h[NT], s_pr_h[NT];
+    __shared__ uint32_t s_bm_i[NT], s_pr_i[NT], s_last[NT];
+    __shared__ uint64_t s_roll[16][2], s_seed[4][2];
+    __shared__ StripInfo s_info;
+
+    const int L = threadIdx.x;
+    const SketchGeom G = A.G;
+
+    if (L == 0) {
+        /* strip -> sequence: largest s with strip_first[s] <= blockIdx.x */
+        uint32_t lo = 0, hi = A.T.nseq;
+        const uint32_t b = blockIdx.x;
+        while (hi - lo > 1) {
+            uint32_t mid = (lo + hi) >> 1;
+            if (A.strip_first[mid] <= b) lo = mid; else hi = mid;
+        }
+        const uint32_t s = lo;
+        const uint32_t i = b - A.strip_first[s];
+        StripInfo I;
+        I.seq = s;
+        I.E0 = (int32_t)(i * (uint32_t)G.NWO) - 1;
+        I.M = A.seq_M[s];
+        I.base = A.T.seq_base[s];
+        const uint32_t e_lo = I.E0 < 0 ? 0u : (uint32_t)I.E0;
+        uint32_t e_hi = (uint32_t)(I.E0 + C * NT);
+        if (e_hi > I.M) e_hi = I.M;
+        /* run containing e_lo: last run with run_ord <= e_lo and run_n > 0 */
+        uint32_t g0 = A.T.seq_run_first[s], g1 = A.T.seq_run_first[s + 1];
+        uint32_t rl = g0, rh = g1;
+        while (rh - rl > 1) {
+            uint32_t mid = (rl + rh) >> 1;
+            if (A.run_ord[mid] <= e_lo) rl = mid; else rh = mid;
+        }
+        /* runs with zero k-mers share the ordinal of their successor: step back over them */
+        while (rl > g0 && A.run_n[rl] == 0) rl--;
+        while (rl + 1 < g1 && e_lo >= A.run_ord[rl] + A.run_n[rl]) rl++;
+        I.run = rl;
+        I.multi = (e_hi > A.run_ord[rl] + A.run_n[rl]) ? 1 : 0;
+        I.P0 = (int64_t)A.T.run_start[rl] - (int64_t)A.run_ord[rl] + (int64_t)I.E0;
+        s_info = I;
+    }
+    if (L < 16) { s_roll[L][0] = A.roll_tab[L][0]; s_roll[L][1] = A.roll_tab[L][1]; }
+    if (L < 4) { s_seed[L][0] = A.seed_tab[L][0]; s_seed[L][1] = A.seed_tab[L][1]; }
+    __syncthreads();
+    const StripInfo I = s_info;
+    if ((I.multi != 0) != MULTI) return;
+
+    const int64_t e_lane = (int64_t)I.E0 + (int64_t)L * C; /* ordinal of this lane's element t = 0 */
+    uint64_t h[C];
+
+    /* ---- phase 1: h0 of the lane's C k-mers ------------------------------------------- */
+    if (!MULTI) {
+#pragma unroll
+        for (int t = 0; t < C; t++) h[t] = NTL_INF;
+        if (e_lane < (int64_t)I.M) {
+            /* element -1 of the first strip is virtual: it is hashed like a real k-mer (the bases
+               in front of the sequence are padding or the previous sequence) so that rolling out
+               of it is exact, then voided. */
+            const uint64_t gp = (uint64_t)((int64_t)I.base + I.P0 + (int64_t)L * C);
+            uint64_t fwd, rev;
+            hash_init(A.T.packed, gp, G.k, s_seed, fwd, rev);
+            h[0] = fwd + rev;
+            const uint32_t so = load_bases16(A.T.packed, gp);
+            const uint32_t si = load_bases16(A.T.packed, gp + (uint64_t)G.k);
+#pragma unroll
+            for (int t = 1; t < C; t++) {
+                const uint32_t idx = (((si >> (2 * (t - 1))) & 3u) << 2) | ((so >> (2 * (t - 1))) & 3u);
+                fwd = srol1(fwd) ^ s_roll[idx][0];
+                rev = sror1(rev ^ s_roll[idx][1]);
+                h[t] = fwd + rev;
+            }
+#pragma unroll
+            for (int t = 0; t < C; t++) {
+                const int64_t e = e_lane + t;
+                if (e < 0 || e >= (int64_t)I.M) h[t] = NTL_INF;
+            }
+        }
+    } else {
+        /* walk the run table; re-initialise the hash at every run crossing */
+        uint32_t g = I.run;
+        const uint32_t g1 = A.T.seq_run_first[I.seq + 1];
+        uint64_t fwd = 0, rev = 0, gp = 0;
+        uint32_t run_end = 0; /* ordinal one past the current run */
+        bool have = false;
+        for (int t = 0; t < C; t++) {
+            const int64_t e = e_lane + t;
+            uint64_t hv = NTL_INF;
+            uint32_t pv = 0;
+            if (e >= 0 && e < (int64_t)I.M) {
+                const uint32_t eo = (uint32_t)e;
+                if (!have || eo >= run_end) {
+                    while (g + 1 < g1 && (A.run_n[g] == 0 || eo >= A.run_ord[g] + A.run_n[g])) g++;
+                    run_end = A.run_ord[g] + A.run_n[g];
+                    pv = A.T.run_start[g] + (eo - A.run_ord[g]);
+                    gp = I.base + pv;
+                    hash_init(A.T.packed, gp, G.k, s_seed, fwd, rev);
+                    have = true;
+                } else {
+                    const uint32_t cin = load_base(A.T.packed, gp + (uint64_t)G.k);
+                    const uint32_t cout = load_base(A.T.packed, gp);
+                    const uint32_t idx = (cin << 2) | cout;
+                    fwd = srol1(fwd) ^ s_roll[idx][0];
+                    rev = sror1(rev ^ s_roll[idx][1]);
+                    gp++;
+                    pv = (uint32_t)(gp - I.base);
+                }
+                hv = fwd + rev;
+            }
+            s_h[t * NT + L] = hv;
+            s_pos[t * NT + L] = pv;
+        }
+#pragma unroll
+        for (int t = 0; t < C; t++) h[t] = s_h[t * NT + L];
+    }
+
+    /* ---- phase 2: suffix minima of the own block, block minimum, prefix of length r0 --- */
+    uint64_t S_h[C];
+    uint32_t S_i[C];
+    {
+        uint64_t rh = NTL_INF;
+        uint32_t ri = NTL_NONE;
+#pragma unroll
+        for (int j = C - 1; j >= 0; j--) {
+            if (h[j] < rh) { rh = h[j]; ri = (uint32_t)(L * C + j); } /* ties keep the right one */
+            S_h[j] = rh;
+            S_i[j] = ri;
+        }
+        s_bm_h[L] = rh;
+        s_bm_i[L] = ri;
+        uint64_t ph = NTL_INF;
+        uint32_t pi = NTL_NONE;
+#pragma unroll
+        for (int t = 0; t < C; t++) {
+            if (t < G.r0 && h[t] <= ph) { ph = h[t]; pi = (uint32_t)(L * C + t); }
+        }
+        s_pr_h[L] = ph;
+        s_pr_i[L] = pi;
+        if (!MULTI) {
+#pragma unroll
+            for (int t = 0; t < C; t++) s_h[t * NT + L] = h[t];
+        }
+    }
+    __syncthreads();
+
+    /* ---- phase 3: minimum over the whole blocks L+1..L+a and L+1..L+a+1 ---------------- */
+    const bool own = L < G.LW;
+    uint64_t fa_h = NTL_INF, fb_h;
+    uint32_t fa_i = NTL_NONE, fb_i;
+    if (own) {
+        for (int d = 1; d <= G.a; d++) {
+            const uint64_t hh = s_bm_h[L + d];
+            if (hh <= fa_h) { fa_h = hh; fa_i = s_bm_i[L + d]; }
+        }
+        fb_h = fa_h; fb_i = fa_i;
+        const uint64_t hh = s_bm_h[L + G.a + 1];
+        if (hh <= fb_h) { fb_h = hh; fb_i = s_bm_i[L + G.a + 1]; }
+    } else {
+        fb_h = NTL_INF; fb_i = NTL_NONE;
+    }
+
+    /* ---- phase 4: every window starting in the own block -------------------------------- */
+    uint32_t prev_i = NTL_NONE, A0_i = NTL_NONE;
+    uint64_t A0_h = NTL_INF;
+    auto emit = [&](uint32_t idx) {
+        uint64_t g;
+        if (!MULTI) g = (uint64_t)((int64_t)I.base + I.P0 + (int64_t)idx);
+        else g = I.base + s_pos[(idx % C) * NT + (idx / C)];
+        atomicOr(&A.mask[g >> 5], 1u << ((uint32_t)g & 31u));
+    };
+    if (own) {
+        int Lr = L + G.a + 1;
+        uint64_t P_h = s_pr_h[Lr];
+        uint32_t P_i = s_pr_i[Lr];
+#pragma unroll
+        for (int j = 0; j < C; j++) {
+            const int rt = G.r0 + j;
+            if (j > 0) {
+                if (rt == C) { Lr++; P_h = NTL_INF; P_i = NTL_NONE; }
+                else {
+                    const int tp = rt - 1 < C ? rt - 1 : rt - 1 - C;
+                    const uint64_t hh = s_h[tp * NT + Lr];
+                    if (hh <= P_h) { P_h = hh; P_i = (uint32_t)(Lr * C + tp); }
+                }
+            }
+            uint64_t x_h = S_h[j];
+            uint32_t x_i = S_i[j];
+            const uint64_t F_h = rt < C ? fa_h : fb_h;
+            const uint32_t F_i = rt < C ? fa_i : fb_i;
+            if (F_h <= x_h) { x_h = F_h; x_i = F_i; }
+            if (P_h <= x_h) { x_h = P_h; x_i = P_i; }
+            const int64_t s = e_lane + j; /* window = ordinals [s, s+w) */
+            const bool valid = s >= 0 && s + G.w <= (int64_t)I.M;
+            const uint32_t a_i = valid ? x_i : NTL_NONE;
+            if (j == 0) { A0_i = a_i; A0_h = x_h; }
+            else if (valid && a_i != prev_i && x_h != NTL_INF) emit(a_i);
+            prev_i = a_i;
+        }
+    }
+    s_last[L] = prev_i;
+    __syncthreads();
+    /* window (L,0) compares with the last window of lane L-1; (0,0) belongs to the previous strip */
+    if (own && L > 0 && A0_i != NTL_NONE && A0_i != s_last[L - 1] && A0_h != NTL_INF) emit(A0_i);
+}
+
+/* ---------------------------------------------------------------------------- emit -------- */
+
+struct MxRecord {
+    uint64_t hash; /* h1: the value indexlr prints and ntlink_pair looks up */
+    uint32_t pos;  /* k-mer start within its sequence */
+    uint32_t meta; /* bit 0: strand (1 = '+'), bits 1..31: sequence index */
+};
+
+#define EMIT_NT 256
+#define EMIT_WPT 8                       /* mask words per thread */
+#define EMIT_TILE (EMIT_NT * EMIT_WPT)   /* mask words per workgroup */
+#define EMIT_CAP 4096                    /* positions staged in LDS per round */
+
+/* pass 1 of the rank scan: set bits per tile */
+__global__ __launch_bounds__(EMIT_NT) void mask_count_kernel(const uint32_t *mask, uint64_t nwords,
+                                                             uint32_t *tile_cnt)
+{
+    __shared__ uint32_t s_tmp[EMIT_NT];
+    const uint64_t w0 = (uint64_t)blockIdx.x * EMIT_TILE + (uint64_t)threadIdx.x * EMIT_WPT;
+    uint32_t c = 0;
+    for (int i = 0; i < EMIT_WPT; i++)
+        if (w0 + i < nwords) c += (uint32_t)__popc(mask[w0 + i]);
+    uint32_t total;
+    block_excl_scan<EMIT_NT>(c, s_tmp, total);
+    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = total;
+}
+
+struct EmitArgs {
+    const uint32_t *packed;
+    const uint64_t *seq_base; /* [nseq+1] */
+    uint32_t nseq;
+    const uint32_t *mask;
+    uint64_t nwords;
+    const uint32_t *tile_off; /* exclusive scan of tile_cnt */
+    uint32_t *word_rank;      /* [nwords] set bits before each word */
+    MxRecord *out;
+    int k;
+    uint64_t mult;            /* 1 ^ (k * MULTISEED) */
+    uint64_t seed_tab[4][2];
+};
+
+__global__ __launch_bounds__(EMIT_NT) void emit_kernel(EmitArgs A)
+{
+    __shared__ uint32_t s_tmp[EMIT_NT];
+    __shared__ uint32_t s_list[EMIT_CAP];
+    __shared__ uint64_t s_seed[4][2];
+    const int t = threadIdx.x;
+    if (t < 4) { s_seed[t][0] = A.seed_tab[t][0]; s_seed[t][1] = A.seed_tab[t][1]; }
+    const uint64_t tile_w0 = (uint64_t)blockIdx.x * EMIT_TILE;
+    const uint64_t w0 = tile_w0 + (uint64_t)t * EMIT_WPT;
+    uint32_t words[EMIT_WPT];
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < EMIT_WPT; i++) {
+        words[i] = w0 + i < A.nwords ? A.mask[w0 + i] : 0u;
+        c += (uint32_t)__popc(words[i]);
+    }
+    uint32_t total;
+    const uint32_t excl = block_excl_scan<EMIT_NT>(c, s_tmp, total);
+    const uint32_t tile_base = A.tile_off[blockIdx.x];
+    {
+        uint32_t r = tile_base + excl;
+#pragma unroll
+        for (int i = 0; i < EMIT_WPT; i++) {
+            if (w0 + i < A.nwords) A.word_rank[w0 + i] = r;
+            r += (uint32_t)__popc(words[i]);
+        }
+    }
+    for (uint32_t r0 = 0; r0 < total; r0 += EMIT_CAP) {
+        uint32_t r = excl;
+#pragma unroll
+        for (int i = 0; i < EMIT_WPT; i++) {
+            uint32_t m = words[i];
+            while (m) {
+                const int b = __ffs(m) - 1;
+                m &= m - 1;
+                if (r >= r0 && r < r0 + EMIT_CAP) s_list[r - r0] = (uint32_t)((t * EMIT_WPT + i) * 32 + b);
+                r++;
+            }
+        }
+        __syncthreads();
+        const uint32_t n = total - r0 < EMIT_CAP ? total - r0 : EMIT_CAP;
+        for (uint32_t i = t; i < n; i += EMIT_NT) {
+            const uint64_t gp = tile_w0 * 32 + s_list[i];
+            uint32_t lo = 0, hi = A.nseq; /* largest s with seq_base[s] <= gp */
+            while (hi - lo > 1) {
+                uint32_t mid = (lo + hi) >> 1;
+                if (A.seq_base[mid] <= gp) lo = mid; else hi = mid;
+            }
+            uint64_t fwd, rev;
+            hash_init(A.packed, gp, A.k, s_seed, fwd, rev);
+            uint64_t tt = (fwd + rev) * A.mult;
+            tt ^= tt >> 27;
+            MxRecord R;
+            R.hash = tt;
+            R.pos = (uint32_t)(gp - A.seq_base[lo]);
+            R.meta = (lo << 1) | (fwd <= rev ? 1u : 0u);
+            A.out[tile_base + r0 + i] = R;
+        }
+        __syncthreads();
+    }
+}
+
+/* minimizers before each sequence start = offsets of the per-sequence lists */
+__global__ void mx_offsets_kernel(const uint64_t *seq_base, uint32_t nseq, const uint32_t *mask,
+                                  const uint32_t *word_rank, uint64_t nwords, uint32_t total,
+                                  uint32_t *mx_off)
+{
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s > nseq) return;
+    if (s == nseq) { mx_off[s] = total; return; }
+    const uint64_t g = seq_base[s];
+    const uint64_t wi = g >> 5;
+    if (wi >= nwords) { mx_off[s] = total; return; }
+    const uint32_t b = (uint32_t)g & 31u;
+    mx_off[s] = word_rank[wi] + (uint32_t)__popc(mask[wi] & ((1u << b) - 1u));
+}

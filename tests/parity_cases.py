@@ -1,0 +1,108 @@
+"""Parity checks shared by the GPU tests (real library, through the C ABI) and the SIMT-mock tests.
+Every check compares the product's records with the oracle's on the same inputs, bit for bit."""
+import os
+
+import numpy as np
+
+import oracle
+from helpers import REF, contig_ids, load_scenario, parse_indexlr
+
+
+def offsets_of(seqs):
+    off = np.zeros(len(seqs) + 1, np.uint64)
+    np.cumsum([len(s) for s in seqs], out=off[1:])
+    return off
+
+
+def check_sketch(dev, seqs, k, w, threads=0):
+    """Device sketch == oracle sketch (offsets, hashes, positions, strands)."""
+    with dev.batch(seqs) as b, dev.sketch(b, k, w) as sk:
+        off, h, p, s = sk.download()
+    ooff, oh, op, os_ = oracle.sketch_batch(b"".join(seqs), offsets_of(seqs), k, w, threads=threads)
+    assert np.array_equal(off, ooff), "per-sequence minimizer counts differ"
+    assert np.array_equal(p, op), "positions differ"
+    assert np.array_equal(h, oh), "hashes differ"
+    assert np.array_equal(s, os_), "strands differ"
+    return len(h)
+
+
+def assert_same_records(got, exp):
+    for nm in ("maps", "hits", "pafs"):
+        a, b = got[nm], exp[nm]
+        assert len(a) == len(b), f"{nm}: {len(a)} records, oracle has {len(b)}"
+        if a.tobytes() != b.tobytes():
+            av = a.view(np.uint8).reshape(len(a), -1)
+            bv = b.view(np.uint8).reshape(len(b), -1)
+            i = int(np.flatnonzero((av != bv).any(axis=1))[0])
+            raise AssertionError(f"{nm}[{i}]: {a[i]} != oracle {b[i]}")
+
+
+def check_pair_arrays(dev, coff, ch, cp, cs, ctg_len, roff, rlen, rh, rp, rs, **kw):
+    """index + map on given sketches (device) == oracle."""
+    with dev.sketch_from_arrays(coff, ch, cp, cs) as csk, dev.index(csk, ctg_len) as ix, \
+            dev.sketch_from_arrays(roff, rh, rp, rs) as rsk, dev.map(ix, rsk, rlen, **kw) as res:
+        got = res.download()
+        nix = len(ix)
+        nhit = res.n_index_hits
+    cid = contig_ids(coff) if len(ch) else np.empty(0, np.uint32)
+    oix = oracle.Index(ch, cid, cp, cs)
+    exp = oracle.map_reads(oix, ctg_len, roff, rlen, rh, rp, rs, threads=0, **kw)
+    assert nix == len(oix), "index size differs"
+    assert_same_records(got, exp)
+    return got, nhit
+
+
+def scenario_arrays(name):
+    meta, ctext, rtext, exp = load_scenario(name)
+    p, k = meta["params"], meta["k"]
+    cn, _, coff, ch, cp, cs = parse_indexlr(ctext, False)
+    ids = [meta["ctg_names"].index(n) for n in cn]
+    nctg = len(meta["ctg_names"])
+    cnt = np.zeros(nctg, np.uint64)
+    cnt[ids] = np.diff(coff)
+    full_off = np.zeros(nctg + 1, np.uint64)
+    np.cumsum(cnt, out=full_off[1:])
+    rn, rlen, roff, rh, rp, rs = parse_indexlr(rtext, True)
+    kw = dict(k=k, z=p.get("z", 1000), x=p.get("x", 0.0), sensitive=p.get("sensitive", False),
+              repeat_filter=p.get("repeat_filter", False))
+    return meta, exp, (full_off, ch, cp, cs, np.array(meta["ctg_len"], np.uint32), roff, rlen, rh, rp, rs), kw, rn
+
+
+def check_scenario(dev, name):
+    _, _, arrs, kw, _ = scenario_arrays(name)
+    return check_pair_arrays(dev, *arrs, **kw)
+
+
+def check_full_pipeline(dev, contigs, reads, k, w, **kw):
+    """FASTA-level: device sketch of contigs and reads -> index -> map, everything against the oracle."""
+    ctg_len = np.array([len(s) for s in contigs], np.uint32)
+    rlen = np.array([len(s) for s in reads], np.uint32)
+    with dev.batch(contigs) as cb, dev.sketch(cb, k, w) as csk, dev.index(csk, ctg_len) as ix, \
+            dev.batch(reads) as rb, dev.sketch(rb, k, w) as rsk, dev.map(ix, rsk, rlen, k=k, **kw) as res:
+        got = res.download()
+        coff, ch, cp, cs = csk.download()
+        roff, rh, rp, rs = rsk.download()
+        nix = len(ix)
+    ooff, oh, op, os_ = oracle.sketch_batch(b"".join(contigs), offsets_of(contigs), k, w)
+    assert np.array_equal(coff, ooff) and np.array_equal(ch, oh) and np.array_equal(cp, op) and np.array_equal(cs, os_)
+    qoff, qh, qp, qs = oracle.sketch_batch(b"".join(reads), offsets_of(reads), k, w)
+    assert np.array_equal(roff, qoff) and np.array_equal(rh, qh) and np.array_equal(rp, qp) and np.array_equal(rs, qs)
+    oix = oracle.Index(oh, contig_ids(ooff), op, os_)
+    exp = oracle.map_reads(oix, ctg_len, qoff, rlen, qh, qp, qs, k=k, threads=0, **kw)
+    assert nix == len(oix)
+    assert_same_records(got, exp)
+    return got
+
+
+def fixture_seqs(fname):
+    return [s for _, s in oracle.read_fastx(os.path.join(REF, fname))]
+
+
+def edge_sequences(seed=5):
+    rng = np.random.default_rng(seed)
+
+    def rnd(n):
+        return bytes(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n)])
+    return [b"", b"ACGT", rnd(50), b"A" * 3000, b"AC" * 2000, rnd(31), rnd(32), rnd(131), rnd(132), b"N" * 500,
+            rnd(700) + b"N" * 40 + rnd(800) + b"n" + rnd(33) + b"NN" + rnd(5000) + b"RYK" + rnd(20),
+            b"N" + rnd(4500), rnd(4500) + b"N", rnd(4085), rnd(4086), rnd(4087), rnd(8200)]

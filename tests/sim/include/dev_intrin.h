@@ -1,0 +1,21 @@
+/* Portable bodies of the gfx950 instruction wrappers, for the SIMT mock (tests/sim). */
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+inline uint32_t ntl_alignbit(uint32_t hi, uint32_t lo, uint32_t sh)
+{
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> (sh & 31));
+}
+
+inline uint32_t ntl_mbcnt(unsigned long long mask)
+{
+    unsigned l = sim::tid & 63;
+    return (uint32_t)__builtin_popcountll(mask & ((1ull << l) - 1));
+}
+
+inline double ntl_mul_add_rn(double x, double d, double k)
+{
+    volatile double m = x * d; /* built with -ffp-contract=off; volatile keeps the two roundings */
+    return m + k;
+}

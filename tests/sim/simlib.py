@@ -1,0 +1,32 @@
+"""Builds and opens the SIMT-mock build of the product's kernels (test tool, see include/hip/hip_runtime.h)."""
+import os
+import subprocess
+
+from ntlink_amd import capi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+SIM_LIB = os.path.join(HERE, "build", "libntlink_sim.so")
+SRC = [os.path.join(ROOT, "ntlink_amd", "csrc", f) for f in
+       ("ntl_hip.hip", "dev_common.h", "scan_kernels.h", "sketch_kernels.h", "map_kernels.h")] + \
+      [os.path.join(HERE, "sim_runtime.cpp"), os.path.join(HERE, "include", "hip", "hip_runtime.h"),
+       os.path.join(HERE, "include", "dev_intrin.h")]
+
+
+def build(sanitize=False):
+    out = SIM_LIB if not sanitize else SIM_LIB.replace(".so", "_asan.so")
+    if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(s) for s in SRC):
+        return out
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    cmd = ["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-pthread", "-ffp-contract=off", "-Wall",
+           "-Wno-unused-function", "-Wno-unknown-pragmas", "-x", "c++",
+           "-I", os.path.join(HERE, "include"), "-I", os.path.join(ROOT, "ntlink_amd", "csrc"),
+           SRC[0], os.path.join(HERE, "sim_runtime.cpp"), "-o", out]
+    if sanitize:
+        cmd[1:1] = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer"]
+    subprocess.check_call(cmd)
+    return out
+
+
+def device():
+    return capi.Device(0, lib_path=build())

@@ -1,0 +1,41 @@
+"""The product's kernel source executed under the SIMT mock (tests/sim: one pthread per lane), checked
+against the oracle.  This is a CPU debugging aid for the kernels' logic and for sanitizers -- the parity
+tests proper are tests/test_gpu_parity.py on a real MI355X."""
+import pytest
+
+import parity_cases as pc
+from sim import simlib
+
+
+@pytest.fixture(scope="module")
+def dev():
+    d = simlib.device()
+    yield d
+    d.close()
+
+
+@pytest.mark.parametrize("fa,k,w", [("scaffolds_2.fa", 32, 100), ("scaffolds_4.fa", 40, 100), ("scaffolds_1.fa", 32, 250)])
+def test_sim_sketch_fixtures(dev, fa, k, w):
+    assert pc.check_sketch(dev, pc.fixture_seqs(fa), k, w) > 0
+
+
+@pytest.mark.parametrize("k,w", [(32, 100), (8, 4), (5, 17), (3, 1), (32, 250)])
+def test_sim_sketch_edges(dev, k, w):
+    pc.check_sketch(dev, pc.edge_sequences(), k, w)
+
+
+def test_sim_sketch_reads_small_w(dev):
+    reads = pc.fixture_seqs("long_reads_4_top5.fa")
+    pc.check_sketch(dev, reads[:2], 15, 5)
+    pc.check_sketch(dev, reads, 40, 100)
+
+
+@pytest.mark.parametrize("name", ["syn_default", "syn_sensitive", "syn_sens_repeat", "syn_x03", "syn_many_ctg"])
+def test_sim_map_scenarios(dev, name):
+    pc.check_scenario(dev, name)
+
+
+def test_sim_full_pipeline_top5(dev):
+    got = pc.check_full_pipeline(dev, pc.fixture_seqs("scaffolds_4.fa"), pc.fixture_seqs("long_reads_4_top5.fa"),
+                                 40, 100, z=1000)
+    assert len(got["pafs"]) == 6
