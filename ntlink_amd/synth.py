@@ -46,40 +46,49 @@ def make_assembly(seed, n_chrom, contigs_per_chrom, contig_len, gap_lo=100, gap_
 
 def make_reads(seed, chroms, total_bases, mean_len, sub=0.02, ins=0.015, dele=0.015, lognormal_sigma=0.0,
                min_len=1000, max_len=100000):
-    """Returns (read buffer uint8, offsets u64[n+1], names)."""
+    """Returns (read buffer uint8, offsets u64[n+1], names).  Error-free reads are sliced from the
+    chromosomes, then sparse error events (binomially many, uniformly placed) are applied to the whole buffer."""
     rng = np.random.default_rng(seed)
     clen = np.array([len(c) for c in chroms], np.int64)
     cprob = clen / clen.sum()
-    parts, made = [], 0
-    while made < total_bases:
-        if lognormal_sigma > 0:
-            ln = int(np.clip(rng.lognormal(np.log(mean_len) - lognormal_sigma ** 2 / 2, lognormal_sigma), min_len, max_len))
-        else:
-            ln = int(mean_len)
-        c = int(rng.choice(len(chroms), p=cprob))
-        ln = min(ln, int(clen[c]))
-        s = int(rng.integers(0, clen[c] - ln + 1))
-        r = chroms[c][s:s + ln].copy()
-        n = len(r)
-        if sub > 0:
-            m = rng.random(n) < sub
-            k = int(m.sum())
-            if k:  # a different base
-                r[m] = _ACGT[(np.searchsorted(_ACGT, r[m]) + rng.integers(1, 4, k)) % 4]
-        if dele > 0:
-            r = r[rng.random(len(r)) >= dele]
-        if ins > 0:
-            m = np.flatnonzero(rng.random(len(r)) < ins)
-            if len(m):
-                r = np.insert(r, m, random_bases(rng, len(m)))
-        if rng.random() < 0.5:
-            r = _COMP[r[::-1]]
-        parts.append(r)
-        made += len(r)
-    off = np.zeros(len(parts) + 1, np.uint64)
-    np.cumsum([len(p) for p in parts], out=off[1:])
-    names = [f"read{i}" for i in range(len(parts))]
-    return np.concatenate(parts), off, names
+    n = max(1, int(np.ceil(total_bases / mean_len)))
+    if lognormal_sigma > 0:
+        ln = np.clip(rng.lognormal(np.log(mean_len) - lognormal_sigma ** 2 / 2, lognormal_sigma, n),
+                     min_len, max_len).astype(np.int64)
+    else:
+        ln = np.full(n, int(mean_len), np.int64)
+    c = rng.choice(len(chroms), size=n, p=cprob) if len(chroms) > 1 else np.zeros(n, np.int64)
+    ln = np.minimum(ln, clen[c])
+    st = (rng.random(n) * (clen[c] - ln + 1)).astype(np.int64)
+    rev = rng.random(n) < 0.5
+    off = np.zeros(n + 1, np.int64)
+    np.cumsum(ln, out=off[1:])
+    r = np.empty(int(off[-1]), np.uint8)
+    for i in range(n):
+        piece = chroms[c[i]][st[i]:st[i] + ln[i]]
+        r[off[i]:off[i + 1]] = _COMP[piece[::-1]] if rev[i] else piece
+    tot = len(r)
+    lens = ln.copy()
+    if sub > 0 and tot:
+        pos = rng.integers(0, tot, rng.binomial(tot, sub))
+        r[pos] = _ACGT[(np.searchsorted(_ACGT, r[pos]) + rng.integers(1, 4, len(pos))) % 4]
+    if dele > 0 and tot:
+        pos = np.unique(rng.integers(0, tot, rng.binomial(tot, dele)))
+        keep = np.ones(tot, bool)
+        keep[pos] = False
+        lens -= np.bincount(np.searchsorted(off, pos, side="right") - 1, minlength=n)
+        r = r[keep]
+        np.cumsum(lens, out=off[1:])
+        tot = len(r)
+    if ins > 0 and tot:
+        pos = np.unique(rng.integers(0, tot, rng.binomial(tot, ins)))
+        lens += np.bincount(np.searchsorted(off, pos, side="right") - 1, minlength=n)
+        r = np.insert(r, pos, random_bases(rng, len(pos)))
+    o = np.zeros(n + 1, np.uint64)
+    np.cumsum(lens, out=o[1:])
+    assert int(o[-1]) == len(r)
+    names = [f"read{i}" for i in range(n)]
+    return r, o, names
 
 
 def workload(name, scale=1.0):

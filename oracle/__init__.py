@@ -58,6 +58,14 @@ def lib():
         L.orc_sketch_batch.restype = C.c_int
         L.orc_sketch_batch.argtypes = [C.c_void_p, u64p, C.c_uint64, C.c_uint, C.c_uint, u64p, u64p,
                                        u64p, u32p, u8p, C.c_int]
+        L.orc_sketch_batch_1p.restype = C.c_void_p
+        L.orc_sketch_batch_1p.argtypes = [C.c_void_p, u64p, C.c_uint64, C.c_uint, C.c_uint, C.c_int]
+        L.orc_sketch_free.argtypes = [C.c_void_p]
+        L.orc_sketch_total.restype = C.c_uint64
+        L.orc_sketch_total.argtypes = [C.c_void_p]
+        for nm in ("off", "hash", "pos", "strand"):
+            getattr(L, "orc_sketch_" + nm).restype = C.c_void_p
+            getattr(L, "orc_sketch_" + nm).argtypes = [C.c_void_p]
         L.orc_index_build.restype = C.c_void_p
         L.orc_index_build.argtypes = [u64p, u32p, u32p, u8p, C.c_uint64]
         L.orc_index_free.argtypes = [C.c_void_p]
@@ -136,8 +144,31 @@ def hash_seq(seq, k):
     return h0[:n], h1[:n], p[:n], s[:n]
 
 
+def _copy(ptr, n, dt):
+    if n == 0:
+        return np.empty(0, dt)
+    return np.frombuffer((C.c_char * (n * np.dtype(dt).itemsize)).from_address(ptr), dt).copy()
+
+
 def sketch_batch(seq_bytes, offsets, k, w, threads=0):
-    """Sketch concatenated sequences.  Returns (mx_off u64[n+1], hash, pos, strand)."""
+    """Sketch concatenated sequences in one pass (threads = indexlr -t).  Returns
+    (mx_off u64[n+1], hash, pos, strand)."""
+    L = lib()
+    buf = np.frombuffer(seq_bytes, np.uint8) if not isinstance(seq_bytes, np.ndarray) else seq_bytes
+    off = np.ascontiguousarray(offsets, np.uint64)
+    n = len(off) - 1
+    if len(buf) == 0:
+        buf = np.zeros(1, np.uint8)
+    r = L.orc_sketch_batch_1p(buf.ctypes.data, _p(off, C.c_uint64), n, k, w, threads)
+    tot = int(L.orc_sketch_total(r))
+    out = (_copy(L.orc_sketch_off(r), n + 1, np.uint64), _copy(L.orc_sketch_hash(r), tot, np.uint64),
+           _copy(L.orc_sketch_pos(r), tot, np.uint32), _copy(L.orc_sketch_strand(r), tot, np.uint8))
+    L.orc_sketch_free(r)
+    return out
+
+
+def sketch_batch_2p(seq_bytes, offsets, k, w, threads=0):
+    """Two-call form (count, then fill) of the batch sketch."""
     L = lib()
     buf = np.frombuffer(seq_bytes, np.uint8) if not isinstance(seq_bytes, np.ndarray) else seq_bytes
     off = np.ascontiguousarray(offsets, np.uint64)

@@ -1,0 +1,131 @@
+"""Parity tests proper: the hipcc-built library on a real MI355X, called through the C ABI
+(ntlink_amd.capi -> libntlink_hip.so), against the oracle and the committed golden fixtures."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+import parity_cases as pc
+from helpers import FIXTURES, GEN, REF, SCENARIOS, TEST7_PAF, read_text
+from ntlink_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    d = capi.Device(0)          # raises if the HIP extension or the GPU is missing: no fallback
+    assert "gfx950" in d.name, d.name
+    yield d
+    d.close()
+
+
+@pytest.mark.parametrize("tag,target,reads,k,w,gold", [f for f in FIXTURES if f[5]])
+def test_contig_sketch_equals_reference_golden_tsv(dev, tag, target, reads, k, w, gold):
+    recs = list(oracle.read_fastx(os.path.join(REF, target)))
+    with dev.batch([s for _, s in recs]) as b, dev.sketch(b, k, w) as sk:
+        off, h, p, s = sk.download()
+    text = oracle.format_indexlr([(n, len(q), h[int(off[i]):int(off[i + 1])], p[int(off[i]):int(off[i + 1])],
+                                   s[int(off[i]):int(off[i + 1])]) for i, (n, q) in enumerate(recs)])
+    assert text == read_text(os.path.join(REF, "expected_outputs", gold + ".tsv"))
+
+
+@pytest.mark.parametrize("tag,target,reads,k,w,gold", FIXTURES)
+def test_read_sketch_md5(dev, tag, target, reads, k, w, gold):
+    recs = list(oracle.read_fastx(os.path.join(REF, reads)))
+    with dev.batch([s for _, s in recs]) as b, dev.sketch(b, k, w) as sk:
+        off, h, p, s = sk.download()
+    text = oracle.format_indexlr([(n, len(q), h[int(off[i]):int(off[i + 1])], p[int(off[i]):int(off[i + 1])],
+                                   s[int(off[i]):int(off[i + 1])]) for i, (n, q) in enumerate(recs)], with_len=True)
+    summ = json.load(open(os.path.join(GEN, "fixtures", "summary.json")))[tag]
+    assert hashlib.md5(text.encode()).hexdigest() == summ["read_tsv_md5"]
+
+
+@pytest.mark.parametrize("k,w", [(32, 100), (32, 250), (24, 100), (40, 100), (15, 5), (20, 10), (8, 4), (5, 17), (3, 1), (64, 1000)])
+def test_sketch_edge_cases(dev, k, w):
+    pc.check_sketch(dev, pc.edge_sequences(), k, w)
+
+
+def test_sketch_empty_batch(dev):
+    with dev.batch([]) as b, dev.sketch(b, 32, 100) as sk:
+        assert sk.count == 0
+    with dev.batch([b"", b"", b"ACGT"]) as b, dev.sketch(b, 32, 100) as sk:
+        off, h, p, s = sk.download()
+        assert sk.count == 0 and list(off) == [0, 0, 0, 0]
+
+
+@pytest.mark.parametrize("flags", [{}, {"sensitive": True}, {"repeat_filter": True}], ids=["default", "sensitive", "repeat"])
+@pytest.mark.parametrize("tag,target,reads,k,w,gold", FIXTURES)
+def test_fixture_pair_outputs(dev, tag, target, reads, k, w, gold, flags):
+    """FASTA in -> verbose/PAF/pairs text identical to the vectors made by the imported reference."""
+    crecs = list(oracle.read_fastx(os.path.join(REF, target)))
+    rrecs = list(oracle.read_fastx(os.path.join(REF, reads)))
+    got = pc.check_full_pipeline(dev, [s for _, s in crecs], [s for _, s in rrecs], k, w, z=1000, **flags)
+    cn, rn = [n for n, _ in crecs], [n for n, _ in rrecs]
+    cl = np.array([len(s) for _, s in crecs], np.uint32)
+    rl = np.array([len(s) for _, s in rrecs], np.uint32)
+    full = tag + "".join("." + f for f in flags)
+    d = os.path.join(GEN, "fixtures")
+    assert oracle.format_verbose(got, rn, cn) == read_text(os.path.join(d, full + ".verbose_mapping.tsv"))
+    paf = oracle.format_paf(got, rn, rl, cn, cl)
+    assert paf == read_text(os.path.join(d, full + ".paf"))
+    pairs = oracle.filter_pairs(oracle.tally_pairs(got, rl, cn, cl, k, 10), dict(zip(cn, map(int, cl))), 1)
+    assert oracle.format_pairs(pairs) == read_text(os.path.join(d, full + ".pairs.tsv"))
+    if tag.startswith("t7") and not flags:
+        assert set(paf.splitlines()) == TEST7_PAF
+
+
+@pytest.mark.parametrize("name", SCENARIOS)
+def test_synthetic_scenarios(dev, name):
+    """Branches the fixtures never reach (x != 0, z, noisy contigs, subsumption, PAF filter/break)."""
+    meta, exp, arrs, kw, rn = pc.scenario_arrays(name)
+    got, _ = pc.check_pair_arrays(dev, *arrs, **kw)
+    assert oracle.format_verbose(got, rn, meta["ctg_names"]) == exp[".verbose_mapping.tsv"]
+    assert oracle.format_paf(got, rn, arrs[6], meta["ctg_names"], arrs[4]) == exp[".paf"]
+
+
+@pytest.mark.parametrize("cfg", [dict(k=32, w=100, rl=10000, sens=False, err=(0.02, 0.015, 0.015)),
+                                 dict(k=32, w=250, rl=15000, sens=False, err=(0.02, 0.015, 0.015)),
+                                 dict(k=24, w=100, rl=20000, sens=True, err=(0.001, 0.0005, 0.0005))],
+                         ids=["C2like", "C3like", "C5like"])
+def test_synthetic_workloads_vs_oracle(dev, cfg):
+    """Scaled-down BASELINE configs (genome 3 Mbp, ~6 Mbases of reads), full pipeline, bit-exact."""
+    chroms, cbuf, coff, names, _ = synth.make_assembly(1, 1, 12, 250_000, n_run_every=5)
+    rbuf, roff, _ = synth.make_reads(2, chroms, 6_000_000, cfg["rl"], *cfg["err"], lognormal_sigma=0.4)
+    contigs = [cbuf[int(coff[i]):int(coff[i + 1])].tobytes() for i in range(len(coff) - 1)]
+    reads = [rbuf[int(roff[i]):int(roff[i + 1])].tobytes() for i in range(len(roff) - 1)]
+    got = pc.check_full_pipeline(dev, contigs, reads, cfg["k"], cfg["w"], z=1000, sensitive=cfg["sens"])
+    assert len(got["maps"]) > 0.5 * len(reads)
+
+
+def test_long_read_uses_global_scratch(dev):
+    """A read with far more than 512 hits and 128 runs (LDS capacities of the map kernel)."""
+    rng = np.random.default_rng(3)
+    contigs = [bytes(synth.random_bases(rng, 3000)) for _ in range(400)]
+    order = rng.permutation(400)
+    read = b"".join(contigs[i] for i in order[:300])
+    reads = [read, contigs[5] + contigs[5], b"ACGT"]
+    pc.check_full_pipeline(dev, contigs, reads, 24, 20, z=1000)
+    pc.check_full_pipeline(dev, contigs, reads, 24, 20, z=1000, sensitive=True)
+
+
+def test_full_size_properties(dev):
+    """BASELINE-size properties that need no oracle: per-sequence positions strictly increase,
+    density ~ 2/(w+1), sketch of a batch == sketches of its halves, mapping is independent of batching."""
+    chroms, cbuf, coff, names, _ = synth.make_assembly(7, 1, 20, 500_000)
+    k, w = 32, 100
+    with dev.batch(cbuf, coff) as b, dev.sketch(b, k, w) as sk:
+        off, h, p, s = sk.download()
+    n = len(h)
+    dens = n / float(coff[-1])
+    assert abs(dens - 2.0 / (w + 1)) < 0.002
+    for i in range(len(off) - 1):
+        q = p[int(off[i]):int(off[i + 1])].astype(np.int64)
+        assert np.all(np.diff(q) > 0)
+    half = len(coff) // 2
+    with dev.batch(cbuf[:int(coff[half])], coff[:half + 1]) as b1, dev.sketch(b1, k, w) as s1:
+        o1, h1, p1, st1 = s1.download()
+    assert np.array_equal(h[:len(h1)], h1) and np.array_equal(p[:len(p1)], p1) and np.array_equal(s[:len(st1)], st1)
