@@ -1,0 +1,127 @@
+"""Command-line surfaces of the pair stage, argument-compatible with the reference's executables.
+
+  indexlr_main      `indexlr --long --pos --strand [--len] -k K -w W [-t T] FILE|-`   (ntLink:199,223)
+  ntlink_pair_main  `ntlink_pair.py ...` with the reference's argparse               (bin/ntlink_pair.py:509-536)
+  ntlink_main       `ntLink pair target= reads= [k= w= ...]` make-style key=value    (ntLink:8-89,165)
+"""
+import argparse
+import sys
+
+VERSION = "ntLink v1.3.11 pair stage, MI355X build 0.1.0"
+
+
+def _device(ordinal=0):
+    from . import capi
+    return capi.Device(ordinal)
+
+
+def indexlr_main(argv=None):
+    ap = argparse.ArgumentParser(prog="indexlr", description="(k,w) minimizer sketch on MI355X; output format of btllib indexlr")
+    ap.add_argument("-k", type=int, required=True)
+    ap.add_argument("-w", type=int, required=True)
+    ap.add_argument("-t", type=int, default=1, help="accepted for compatibility (the GPU does the work)")
+    ap.add_argument("--long", action="store_true", help="accepted: long mode is the only mode")
+    ap.add_argument("--pos", action="store_true")
+    ap.add_argument("--strand", action="store_true")
+    ap.add_argument("--len", action="store_true", dest="with_len")
+    ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("files", nargs="+")
+    a = ap.parse_args(argv)
+    if not (a.pos and a.strand):
+        ap.error("only the `--pos --strand` output of the pair stage is implemented")
+    from . import pipeline
+    dev = _device(a.device)
+    try:
+        pipeline.run_indexlr(dev, a.files, a.k, a.w, sys.stdout, a.with_len)
+    finally:
+        dev.close()
+    return 0
+
+
+def ntlink_pair_parser():
+    p = argparse.ArgumentParser(description="ntLink: Scaffolding genome assemblies using long reads (pair stage on MI355X)")
+    p.add_argument("FILES", nargs="+", help="Long read minimizer TSV files")
+    p.add_argument("-s", help="Target scaffolds fasta file", required=True)
+    p.add_argument("-m", help="Target scaffolds minimizer TSV file", required=True)
+    p.add_argument("-p", help="Output prefix [out]", default="out", type=str)
+    p.add_argument("-n", help="Minimum edge weight [1]", default=1, type=int)
+    p.add_argument("-k", help="Kmer size used for minimizer step", required=True, type=int)
+    p.add_argument("-z", help="Minimum size of contig to scaffold", default=500, type=int)
+    p.add_argument("-a", help="Minimum number of anchoring long reads for an edge", type=int, default=1)
+    p.add_argument("-f", help="Maximum number of contigs in a run for full transitive edge addition", default=10, type=int)
+    p.add_argument("-x", help="Fudge factor allowed between mapping block lengths on read and assembly. "
+                              "Set to 0 to allow mapping block to be up to read length", type=float, default=0)
+    p.add_argument("-c", "--checkpoint", help="Mappings checkpoint file")
+    p.add_argument("--pairs", help="Output pairs TSV file", action="store_true")
+    p.add_argument("--paf", help="Output mappings in PAF-like format", action="store_true")
+    p.add_argument("--sensitive", help="Run more sensitive read mapping", action="store_true")
+    p.add_argument("--repeat-filter", help="Remove repetitive minimizers within a long read's sketch", action="store_true")
+    p.add_argument("-v", "--version", action="version", version=VERSION)
+    p.add_argument("--verbose", help="Verbose output logging", action="store_true")
+    p.add_argument("--device", type=int, default=0, help="GPU ordinal")
+    return p
+
+
+class NtlinkPairError(Exception):
+    "ntLink pair exception"
+
+
+def ntlink_pair_main(argv=None):
+    a = ntlink_pair_parser().parse_args(argv)
+    print("Running pairing stage of ntLink ...\n")
+    from . import pipeline
+    try:
+        dev = _device(a.device)
+        try:
+            pipeline.run_ntlink_pair(dev, a)
+        finally:
+            dev.close()
+    except Exception as exc:
+        raise NtlinkPairError("ntLink pairing stage encountered an error..") from exc
+    return 0
+
+
+_DEFAULTS = dict(target="None", reads="None", w="100", k="32", t="4", z="1000", n="1", a="1", f="10", x="0",
+                 sensitive="False", repeats="False", verbose="True", ntlink_pairs_tsv="False", paf="False", v="0",
+                 prefix=None, device="0")
+
+
+def ntlink_main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    targets, kv = [], dict(_DEFAULTS)
+    for tok in argv:
+        if tok.startswith("-"):
+            continue  # make flags such as -B
+        if "=" in tok:
+            key, val = tok.split("=", 1)
+            kv[key] = val
+        else:
+            targets.append(tok)
+    if not targets or "help" in targets:
+        print("Usage: ntLink pair target=<target scaffolds> reads='List of long read files' [k= w= z= n= a= f= x= "
+              "paf= verbose= sensitive= repeats= ntlink_pairs_tsv= prefix= device=]\n"
+              "Only the `pair` stage (minimizer sketch + read-to-contig mapping) runs on the GPU; "
+              "scaffold/gap_fill stay with the reference pipeline.")
+        return 0
+    if "version" in targets:
+        print(VERSION)
+        return 0
+    if targets != ["pair"]:
+        print(f"ERROR: target(s) {targets} are outside the GPU pair stage; run them with the reference ntLink", file=sys.stderr)
+        return 2
+    if kv["reads"] == "None":
+        print("ERROR: Must set reads", file=sys.stderr)
+        return 2
+    if kv["target"] == "None":
+        print("ERROR: Must set target", file=sys.stderr)
+        return 2
+    from . import pipeline
+    dev = _device(int(kv["device"]))
+    try:
+        pipeline.run_pair(dev, kv["target"], kv["reads"], prefix=kv["prefix"], k=int(kv["k"]), w=int(kv["w"]), n=int(kv["n"]),
+                          a=int(kv["a"]), z=int(kv["z"]), f=int(kv["f"]), x=float(kv["x"]), paf=kv["paf"] == "True",
+                          verbose=kv["verbose"] == "True", sensitive=kv["sensitive"] == "True", repeats=kv["repeats"] == "True",
+                          pairs_tsv=kv["ntlink_pairs_tsv"] == "True")
+    finally:
+        dev.close()
+    return 0

@@ -70,18 +70,27 @@ __global__ void index_insert_kernel(const MxRecord *mx, uint64_t n, IndexSlot *s
     }
 }
 
+/* one atomic per workgroup: sum of per-thread counts (all threads must call) */
+__device__ __forceinline__ void block_count_add(unsigned long long mine, unsigned long long *counter)
+{
+    __shared__ unsigned long long s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    if (mine) atomicAdd(&s_cnt, mine);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_cnt) atomicAdd(counter, s_cnt);
+}
+
+/* grid-stride: launch a bounded number of workgroups */
 __global__ void index_count_kernel(const IndexSlot *slots, uint64_t nslots, const IndexSpecial *special,
                                    unsigned long long *count)
 {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int u = i < nslots && slots[i].key != NTL_INF && !(slots[i].meta & 1u);
-    if (i == 0 && special->cnt == 1) u++;
-    unsigned long long b = __ballot(u == 1);
-    unsigned long long b2 = __ballot(u == 2);
-    if ((threadIdx.x & 63) == 0) {
-        unsigned long long c = (unsigned long long)__popcll(b) + 2ull * (unsigned long long)__popcll(b2);
-        if (c) atomicAdd(count, c);
-    }
+    unsigned long long u = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nslots; i += stride)
+        u += (slots[i].key != NTL_INF && !(slots[i].meta & 1u)) ? 1u : 0u;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && special->cnt == 1) u++;
+    block_count_add(u, count);
 }
 
 struct Cand {
@@ -92,15 +101,16 @@ struct Cand {
 __global__ void probe_kernel(const MxRecord *mx, uint64_t n, const IndexSlot *slots, int bits,
                              const IndexSpecial *special, Cand *cand, unsigned long long *nfound)
 {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    Cand c;
-    c.cpos = 0; c.meta = 0;
-    if (i < n) {
+    unsigned long long found = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t mask = ((uint64_t)1 << bits) - 1;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        Cand c;
+        c.cpos = 0; c.meta = 0;
         const uint64_t key = mx[i].hash;
         if (key == NTL_INF) {
             if (special->cnt == 1) { c.cpos = special->pos; c.meta = (special->meta & ~1u) | 1u; }
         } else {
-            const uint64_t mask = ((uint64_t)1 << bits) - 1;
             uint64_t s = index_home(key, bits);
             for (;;) {
                 const IndexSlot e = slots[s];
@@ -113,9 +123,9 @@ __global__ void probe_kernel(const MxRecord *mx, uint64_t n, const IndexSlot *sl
             }
         }
         cand[i] = c;
+        found += c.meta & 1u;
     }
-    unsigned long long b = __ballot(c.meta & 1u);
-    if ((threadIdx.x & 63) == 0 && b) atomicAdd(nfound, (unsigned long long)__popcll(b));
+    block_count_add(found, nfound);
 }
 
 /* -------------------------------------------------------------------------------- map ---- */

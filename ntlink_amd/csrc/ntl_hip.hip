@@ -613,7 +613,7 @@ extern "C" int ntl_index_build(ntl_ctx *c, const ntl_sketch *ctg, const uint32_t
             hipLaunchKernelGGL(index_insert_kernel, dim3((unsigned)((ctg->count + 255) / 256)), dim3(256), 0, c->stream,
                                (const MxRecord *)ctg->records.as<MxRecord>(), ctg->count, ix->slots.as<IndexSlot>(), bits,
                                ix->special.as<IndexSpecial>());
-        hipLaunchKernelGGL(index_count_kernel, dim3((unsigned)((ix->nslots + 255) / 256)), dim3(256), 0, c->stream,
+        hipLaunchKernelGGL(index_count_kernel, dim3((unsigned)std::min<uint64_t>((ix->nslots + 255) / 256, 2048)), dim3(256), 0, c->stream,
                            (const IndexSlot *)ix->slots.as<IndexSlot>(), ix->nslots,
                            (const IndexSpecial *)ix->special.as<IndexSpecial>(), cnt.as<unsigned long long>());
         HIPCHK(c, hipGetLastError());
@@ -659,7 +659,7 @@ extern "C" int ntl_map_run(ntl_ctx *c, const ntl_index *ix, const ntl_sketch *re
     {
         ProfSpan sp(c, "probe");
         if (nmx)
-            hipLaunchKernelGGL(probe_kernel, dim3((unsigned)((nmx + 255) / 256)), dim3(256), 0, c->stream,
+            hipLaunchKernelGGL(probe_kernel, dim3((unsigned)std::min<uint64_t>((nmx + 255) / 256, 4096)), dim3(256), 0, c->stream,
                                (const MxRecord *)reads->records.as<MxRecord>(), nmx, (const IndexSlot *)ix->slots.as<IndexSlot>(),
                                ix->bits, (const IndexSpecial *)ix->special.as<IndexSpecial>(), cand.as<Cand>(),
                                nfound.as<unsigned long long>());

@@ -1,0 +1,86 @@
+"""Text formats at the boundary of the pair stage (byte-for-byte those of the reference).
+
+* indexlr TSV     `id\\t[len\\t]H:pos:strand H:pos:strand ...`   (ntLink:199,223; parsers
+                  bin/ntlink_pair.py:197-207,355-378)
+* verbose mapping `read\\tcontig\\tn\\tctgpos:ctgstrand_readpos:readstrand ...`
+                  (bin/ntlink_pair.py:308-313,382-388)
+* PAF-like        12 columns (bin/ntlink_paf_output.py:131-135)
+"""
+import numpy as np
+
+_STRAND = ("-", "+")
+
+
+def write_indexlr(fh, names, lengths, mx_off, mx_hash, pos, strand, with_len):
+    """Every record prints its id even without minimizers (such lines are skipped by the consumers,
+    bin/ntlink_pair.py:200,357)."""
+    hs = mx_hash.tolist()
+    ps = pos.tolist()
+    ss = strand.tolist()
+    off = [int(v) for v in mx_off]
+    for i, name in enumerate(names):
+        a, b = off[i], off[i + 1]
+        toks = " ".join(f"{hs[j]}:{ps[j]}:{_STRAND[ss[j]]}" for j in range(a, b))
+        if with_len:
+            fh.write(f"{name}\t{int(lengths[i])}\t{toks}\n")
+        else:
+            fh.write(f"{name}\t{toks}\n")
+
+
+def parse_indexlr(fh, with_len):
+    """-> (names, lengths u32 or None, mx_off u64[n+1], hash u64, pos u32, strand u8).  Lines keep their
+    place even when they carry no minimizers."""
+    names, lens, off, hs, ps, ss = [], [], [0], [], [], []
+    col = 2 if with_len else 1
+    for line in fh:
+        f = line.strip().split("\t")
+        if not f or f == [""]:
+            continue
+        names.append(f[0])
+        if with_len:
+            lens.append(int(f[1]) if len(f) > 1 else 0)
+        if len(f) > col and f[col]:
+            for tok in f[col].split(" "):
+                a, b, c = tok.split(":")
+                hs.append(int(a)); ps.append(int(b)); ss.append(1 if c == "+" else 0)
+        off.append(len(hs))
+    return (names, np.array(lens, np.uint32) if with_len else None, np.array(off, np.uint64),
+            np.array(hs, np.uint64), np.array(ps, np.uint32), np.array(ss, np.uint8))
+
+
+def write_verbose(fh, res, read_names, ctg_names, read_base=0):
+    maps, hits = res["maps"], res["hits"]
+    cp = hits["ctg_pos"].tolist(); rp = hits["read_pos"].tolist()
+    cs = hits["ctg_strand"].tolist(); rs = hits["read_strand"].tolist()
+    for r, c, n, o in zip(maps["read"].tolist(), maps["ctg"].tolist(), maps["n_hits"].tolist(), maps["hit_off"].tolist()):
+        toks = " ".join(f"{cp[j]}:{_STRAND[cs[j]]}_{rp[j]}:{_STRAND[rs[j]]}" for j in range(o, o + n))
+        fh.write(f"{read_names[r + read_base]}\t{ctg_names[c]}\t{n}\t{toks}\n")
+
+
+def write_paf(fh, res, read_names, read_len, ctg_names, ctg_len, read_base=0):
+    p = res["pafs"]
+    for r, c, qs, qe, ts, te, n, st in zip(p["read"].tolist(), p["ctg"].tolist(), p["q_start"].tolist(), p["q_end"].tolist(),
+                                            p["t_start"].tolist(), p["t_end"].tolist(), p["n_hits"].tolist(), p["strand"].tolist()):
+        fh.write(f"{read_names[r + read_base]}\t{int(read_len[r + read_base])}\t{qs}\t{qe}\t{_STRAND[st]}\t"
+                 f"{ctg_names[c]}\t{int(ctg_len[c])}\t{ts}\t{te}\t{n}\t{te - ts}\t255\n")
+
+
+def parse_verbose(fh):
+    """Checkpoint reader (bin/ntlink_pair.py:437-488, bin/ntlink_utils.py:296-305): yields
+    (read_id, [(contig, [(ctg_pos, ctg_strand, read_pos, read_strand), ...]), ...]) per read."""
+    cur, entries = None, []
+    for line in fh:
+        read_id, contig, _n, mx = line.strip().split("\t")
+        hl = []
+        for tok in mx.split(" "):
+            c, r = tok.split("_")
+            cpos, cst = c.split(":")
+            rpos, rst = r.split(":")
+            hl.append((int(cpos), 1 if cst == "+" else 0, int(rpos), 1 if rst == "+" else 0))
+        if read_id != cur:
+            if cur is not None:
+                yield cur, entries
+            cur, entries = read_id, []
+        entries.append((contig, hl))
+    if cur is not None:
+        yield cur, entries

@@ -1,0 +1,181 @@
+"""The pair stage on MI355X: drivers that mirror the reference's two operators and the fused path.
+
+  run_indexlr(...)      = `indexlr --long --pos --strand [--len] -k K -w W`        (ntLink:199,223)
+  run_ntlink_pair(...)  = `ntlink_pair.py -p P -n N -m contigs.tsv -s target.fa -k K -a A -z Z -f F
+                           -x X [--verbose --pairs --sensitive --repeat-filter --paf] FILES`
+                                                                    (bin/ntlink_pair.py:509-613)
+  run_pair(...)         = `ntLink pair target= reads= ...` without the text TSV between the two
+                          (ntLink:165,198-199,221-225); still leaves <target>.kK.wW.tsv behind.
+
+Compute is on the GPU through ntlink_amd.capi (C ABI -> HIP kernels); this module only moves
+records between files and the device and runs the small CPU tail (pairing.py).
+"""
+import datetime
+import os
+import sys
+
+import numpy as np
+
+from . import capi, formats, pairing, seqio
+
+DEFAULT_BATCH_BASES = 2_000_000_000  # read bases per device batch (packed: 0.5 GB)
+
+
+def _log(*a):
+    print(datetime.datetime.today(), ":", *a, file=sys.stdout, flush=True)
+
+
+class PairOutputs:
+    """<prefix>.verbose_mapping.tsv / .paf writers + the pair tally, fed batch by batch in read order."""
+
+    def __init__(self, prefix, ctg_names, ctg_len, k, f, verbose, paf):
+        self.prefix = prefix
+        self.ctg_names, self.ctg_len = ctg_names, ctg_len
+        self.verbose_fh = open(prefix + ".verbose_mapping.tsv", "w") if verbose else None
+        self.paf_fh = open(prefix + ".paf", "w") if paf else None
+        self.tally = pairing.PairTally(ctg_names, ctg_len, k, f)
+
+    def add(self, res, read_names, read_len):
+        if self.verbose_fh:
+            formats.write_verbose(self.verbose_fh, res, read_names, self.ctg_names)
+        if self.paf_fh:
+            formats.write_paf(self.paf_fh, res, read_names, read_len, self.ctg_names, self.ctg_len)
+        self.tally.add_batch(res, read_len)
+
+    def close(self):
+        for fh in (self.verbose_fh, self.paf_fh):
+            if fh:
+                fh.close()
+
+    def remove_partial(self):
+        """Error convention of the reference: partial outputs are deleted (bin/ntlink_pair.py:608-613)."""
+        self.close()
+        for ext, on in ((".verbose_mapping.tsv", self.verbose_fh), (".paf", self.paf_fh)):
+            if on and os.path.exists(self.prefix + ext):
+                os.remove(self.prefix + ext)
+
+
+def finish_pairs(tally, prefix, n, a, write_pairs_tsv):
+    pairs = tally.filtered(a)
+    if write_pairs_tsv:
+        with open(prefix + ".pairs.tsv", "w") as fh:
+            pairing.write_pairs(fh, pairs)
+    dot = f"{prefix}.n{n}.scaffold.dot"
+    _log("Printing graph", dot)
+    with open(dot, "w") as fh:
+        pairing.write_dot(fh, pairs, tally.names, tally.ctg_len, int(n))
+    return pairs
+
+
+def run_indexlr(dev, paths, k, w, out, with_len, batch_bases=DEFAULT_BATCH_BASES):
+    """Sketch FASTA/FASTQ files on the device and print indexlr's TSV."""
+    for ss in seqio.load(paths, max_bases=batch_bases):
+        if not len(ss):
+            continue
+        with dev.batch(ss.buf, ss.offsets) as b, dev.sketch(b, k, w) as sk:
+            off, h, p, s = sk.download()
+        formats.write_indexlr(out, ss.names, ss.lengths, off, h, p, s, with_len)
+
+
+def _contig_lengths(fasta):
+    names, lens = [], []
+    for name, seq in seqio.read_fastx(fasta):
+        names.append(name)
+        lens.append(len(seq))
+    return names, np.array(lens, np.uint32)
+
+
+def run_ntlink_pair(dev, args):
+    """args: the namespace of the reference's argparse (FILES s m p n k z a f x checkpoint pairs paf
+    sensitive repeat_filter verbose)."""
+    ckpt = args.checkpoint
+    if os.path.isfile(args.p + ".verbose_mapping.tsv"):
+        ckpt = args.p + ".verbose_mapping.tsv"  # bin/ntlink_pair.py:565-567
+    _log("Reading fasta file", args.s)
+    names, ctg_len = _contig_lengths(args.s)
+    index_of = {n: i for i, n in enumerate(names)}
+    if len(index_of) != len(names):
+        # the reference keeps the LAST record of a repeated id (dict overwrite, bin/ntlink_utils.py:71)
+        for i, n in enumerate(names):
+            ctg_len[index_of[n]] = ctg_len[i]
+    if ckpt:
+        print("Found checkpoint file, bypassing read mapping...\n")
+        if args.paf:
+            print("Warning: --paf specified, but not compatible with checkpoint")
+        tally = pairing.PairTally(names, ctg_len, args.k, args.f)
+        _log("Finding pairs")
+        with open(ckpt) as fh:
+            for _read, entries in formats.parse_verbose(fh):
+                tally.add_checkpoint_read(entries, index_of)
+        finish_pairs(tally, args.p, args.n, args.a, args.pairs)
+        _log("DONE!")
+        return
+    _log("Reading minimizers", args.s)
+    with (sys.stdin if args.m == "-" else open(args.m)) as fh:
+        cn, _, coff, ch, cp, cs = formats.parse_indexlr(fh, False)
+    # contig-id order = order of the FASTA; TSV lines may be any subset in any order
+    nctg = len(names)
+    ids = np.array([index_of[n] for n in cn], np.int64)
+    cid = np.repeat(ids, np.diff(coff).astype(np.int64)) if len(ids) else np.zeros(0, np.int64)
+    order = np.argsort(cid, kind="stable")
+    cnt = np.bincount(cid, minlength=nctg).astype(np.uint64)
+    full_off = np.zeros(nctg + 1, np.uint64)
+    np.cumsum(cnt, out=full_off[1:])
+    out = PairOutputs(args.p, names, ctg_len, args.k, args.f, args.verbose, args.paf)
+    try:
+        with dev.sketch_from_arrays(full_off, ch[order], cp[order], cs[order]) as csk, dev.index(csk, ctg_len) as ix:
+            _log("Finding pairs")
+            for path in args.FILES:
+                with (sys.stdin if path == "-" else open(path)) as fh:
+                    rn, rlen, roff, rh, rp, rs = formats.parse_indexlr(fh, True)
+                with dev.sketch_from_arrays(roff, rh, rp, rs) as rsk, \
+                        dev.map(ix, rsk, rlen, k=args.k, z=args.z, x=args.x, sensitive=args.sensitive,
+                                repeat_filter=args.repeat_filter) as res:
+                    out.add(res.download(), rn, rlen)
+        out.close()
+        finish_pairs(out.tally, args.p, args.n, args.a, args.pairs)
+        _log("DONE!")
+    except BaseException:
+        out.remove_partial()
+        raise
+
+
+def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=10, x=0.0, paf=False, verbose=True,
+             sensitive=False, repeats=False, pairs_tsv=False, batch_bases=DEFAULT_BATCH_BASES, write_contig_tsv=True):
+    """`ntLink pair target=T reads='R1 R2' k= w= ...`: the fused device path."""
+    prefix = prefix or f"{target}.k{k}.w{w}.z{z}"
+    if os.path.isfile(prefix + ".verbose_mapping.tsv"):
+        # same silent switch as the reference
+        import argparse
+        return run_ntlink_pair(dev, argparse.Namespace(FILES=[], s=target, m=None, p=prefix, n=n, k=k, z=z, a=a, f=f, x=x,
+                                                       checkpoint=None, pairs=pairs_tsv, paf=paf, sensitive=sensitive,
+                                                       repeat_filter=repeats, verbose=verbose))
+    ctg = seqio.load_all([target])
+    ctg_len = ctg.lengths
+    out = PairOutputs(prefix, ctg.names, ctg_len, k, f, verbose, paf)
+    stats = dict(read_bases=0, reads=0, read_minimizers=0, index_hits=0)
+    try:
+        with dev.batch(ctg.buf, ctg.offsets) as cb, dev.sketch(cb, k, w) as csk:
+            if write_contig_tsv:
+                off, h, p, s = csk.download()
+                with open(f"{target}.k{k}.w{w}.tsv", "w") as fh:
+                    formats.write_indexlr(fh, ctg.names, ctg_len, off, h, p, s, False)
+            with dev.index(csk, ctg_len) as ix:
+                stats["index_size"] = len(ix)
+                for rs_ in seqio.load(reads.split() if isinstance(reads, str) else list(reads), max_bases=batch_bases):
+                    if not len(rs_):
+                        continue
+                    rl = rs_.lengths
+                    with dev.batch(rs_.buf, rs_.offsets) as rb, dev.sketch(rb, k, w) as rsk, \
+                            dev.map(ix, rsk, rl, k=k, z=z, x=x, sensitive=sensitive, repeat_filter=repeats) as res:
+                        out.add(res.download(), rs_.names, rl)
+                        stats["read_bases"] += rs_.bases
+                        stats["reads"] += len(rs_)
+                        stats["read_minimizers"] += rsk.count
+                        stats["index_hits"] += res.n_index_hits
+        out.close()
+        finish_pairs(out.tally, prefix, n, a, pairs_tsv)
+    except BaseException:
+        out.remove_partial()
+        raise
+    return stats

@@ -1,0 +1,95 @@
+"""End-to-end drop-in tests on a real MI355X: the reference's command lines, run through bin/, must
+leave the reference's files byte for byte (cf. tests/ntlink_pytest.py:182-198 of the reference)."""
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+from helpers import FIXTURES, GEN, REF, TEST7_PAF, read_text
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "bin")
+
+
+def _stage(tmp_path, *names):
+    for n in names:
+        shutil.copy(os.path.join(REF, n), tmp_path / n)
+
+
+def _check_outputs(tmp_path, prefix, tag, gold, flags=""):
+    d = os.path.join(GEN, "fixtures")
+    full = tag + flags
+    assert read_text(str(tmp_path / (prefix + ".verbose_mapping.tsv"))) == read_text(os.path.join(d, full + ".verbose_mapping.tsv"))
+    assert read_text(str(tmp_path / (prefix + ".paf"))) == read_text(os.path.join(d, full + ".paf"))
+    assert read_text(str(tmp_path / (prefix + ".pairs.tsv"))) == read_text(os.path.join(d, full + ".pairs.tsv"))
+    if gold and not flags:
+        exp = os.path.join(REF, "expected_outputs", gold + ".z1000")
+        assert read_text(str(tmp_path / (prefix + ".pairs.tsv"))) == read_text(exp + ".pairs.tsv")
+        got = read_text(str(tmp_path / (prefix + ".n1.scaffold.dot"))).splitlines()
+        ref = read_text(exp + ".n1.scaffold.dot").splitlines()
+        assert got[:2] == ref[:2] and got[-1] == "}"
+        assert sorted(l for l in got if "->" not in l) == sorted(l for l in ref if "->" not in l)
+        assert [l for l in got if "->" in l] == [l for l in ref if "->" in l]
+
+
+@pytest.mark.parametrize("tag,target,reads,k,w,gold", FIXTURES)
+def test_ntlink_pair_driver(tmp_path, tag, target, reads, k, w, gold):
+    """`ntLink pair target= reads= k= w= paf=True` (tests/ntlink_pytest.py:184)."""
+    _stage(tmp_path, target, reads)
+    cmd = [sys.executable, os.path.join(BIN, "ntLink"), "pair", "-B", f"target={target}", f"reads={reads}", f"k={k}", f"w={w}",
+           "paf=True", "ntlink_pairs_tsv=True"]
+    assert subprocess.call(cmd, cwd=tmp_path) == 0
+    prefix = f"{target}.k{k}.w{w}.z1000"
+    _check_outputs(tmp_path, prefix, tag, gold)
+    if gold:
+        assert read_text(str(tmp_path / f"{target}.k{k}.w{w}.tsv")) == read_text(os.path.join(REF, "expected_outputs", gold + ".tsv"))
+    if tag.startswith("t7"):
+        assert set(read_text(str(tmp_path / (prefix + ".paf"))).splitlines()) == TEST7_PAF
+
+
+def test_makefile_pipe_two_operators(tmp_path):
+    """The reference's own recipe (ntLink:198-199,221-225) with bin/indexlr and bin/ntlink_pair.py
+    in place of btllib's indexlr and the reference's ntlink_pair.py, reads split over two files."""
+    tag, target, k, w = "t2_k32_w100", "scaffolds_2.fa", 32, 100
+    _stage(tmp_path, target, "long_reads_2.fq.gz")
+    env = dict(os.environ, PATH=BIN + os.pathsep + os.environ["PATH"])
+    sh = (f"indexlr --long --pos --strand -k {k} -w {w} -t 4 {target} > {target}.k{k}.w{w}.tsv && "
+          f"gzip -f -cd long_reads_2.fq.gz | indexlr --long --pos --strand --len -k {k} -w {w} -t 4 - | "
+          f"ntlink_pair.py -p out -n 1 -m {target}.k{k}.w{w}.tsv -s {target} -k {k} -a 1 -z 1000 -f 10 -x 0 "
+          f"--verbose --pairs --paf -")
+    assert subprocess.call(["bash", "-e", "-o", "pipefail", "-c", sh], cwd=tmp_path, env=env) == 0
+    _check_outputs(tmp_path, "out", tag, "scaffolds_2.fa.k32.w100")
+
+
+def test_sensitive_and_repeat_flags(tmp_path):
+    tag, target, reads, k, w = "t3_k24_w250", "scaffolds_3.fa", "long_reads_3.fa.gz", 24, 250
+    _stage(tmp_path, target, reads)
+    for flag, suffix in (("sensitive=True", ".sensitive"), ("repeats=True", ".repeat_filter")):
+        cmd = [sys.executable, os.path.join(BIN, "ntLink"), "pair", f"target={target}", f"reads={reads}", f"k={k}", f"w={w}",
+               "paf=True", "ntlink_pairs_tsv=True", flag, "prefix=run" + suffix]
+        assert subprocess.call(cmd, cwd=tmp_path) == 0
+        _check_outputs(tmp_path, "run" + suffix, tag, None, suffix)
+
+
+def test_checkpoint_file_bypasses_mapping(tmp_path):
+    """bin/ntlink_pair.py:565-575: an existing <prefix>.verbose_mapping.tsv switches to the re-tally."""
+    target, reads = "scaffolds_4.fa", "long_reads_4.fa.gz"
+    _stage(tmp_path, target, reads)
+    prefix = f"{target}.k40.w100.z1000"
+    shutil.copy(os.path.join(GEN, "fixtures", "t4_k40_w100.verbose_mapping.tsv"), tmp_path / (prefix + ".verbose_mapping.tsv"))
+    cmd = [sys.executable, os.path.join(BIN, "ntLink"), "pair", f"target={target}", f"reads={reads}", "k=40", "w=100", "ntlink_pairs_tsv=True"]
+    assert subprocess.call(cmd, cwd=tmp_path) == 0
+    assert read_text(str(tmp_path / (prefix + ".pairs.tsv"))) == read_text(os.path.join(GEN, "fixtures", "t4_k40_w100.checkpoint.pairs.tsv"))
+
+
+def test_error_removes_partial_outputs(tmp_path):
+    """Non-zero exit and no partial verbose/paf files (bin/ntlink_pair.py:608-613)."""
+    _stage(tmp_path, "scaffolds_4.fa")
+    (tmp_path / "bad.tsv").write_text("r1\t100\tnot_a_minimizer\n")
+    (tmp_path / "c.tsv").write_text("scaf1\t123:5:+\n")
+    cmd = [sys.executable, os.path.join(BIN, "ntlink_pair.py"), "-p", "o", "-m", "c.tsv", "-s", "scaffolds_4.fa", "-k", "40", "--verbose", "--paf", "bad.tsv"]
+    assert subprocess.call(cmd, cwd=tmp_path, stderr=subprocess.DEVNULL) != 0
+    assert not (tmp_path / "o.verbose_mapping.tsv").exists() and not (tmp_path / "o.paf").exists()

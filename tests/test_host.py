@@ -1,0 +1,125 @@
+"""Host side of the product (no GPU): sequence input, text formats, pair tally / graph writers, CLI
+argument surfaces.  Records come from the oracle here; the same writers are fed by the GPU in
+tests/test_gpu_cli.py."""
+import io
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from helpers import FIXTURES, GEN, REF, SCENARIOS, contig_ids, load_scenario, parse_indexlr, read_text
+from ntlink_amd import cli, formats, pairing, seqio
+
+
+@pytest.mark.parametrize("fname", ["scaffolds_2.fa", "long_reads_2.fq.gz", "long_reads_3.fa.gz", "long_reads_4_top5.fa"])
+def test_seqio_matches_reference_reader_semantics(fname):
+    a = list(seqio.read_fastx(os.path.join(REF, fname)))
+    b = list(oracle.read_fastx(os.path.join(REF, fname)))
+    assert a == b and len(a) > 0
+    ss = seqio.load_all([os.path.join(REF, fname)])
+    assert ss.names == [n for n, _ in b] and ss.bases == sum(len(s) for _, s in b)
+
+
+def test_seqio_edge_records(tmp_path):
+    p = tmp_path / "x.fa"
+    p.write_text(">a desc here\nACGT\nAC\n>b\n\n>c\tz\nGG\n@q1 x\nACGT\n+\nIIII\n@q2\nAC\nGT\n+q2\nII\nII\n>d\nTT")
+    recs = list(seqio.read_fastx(str(p)))
+    assert recs == [("a", b"ACGTAC"), ("b", b""), ("c", b"GG"), ("q1", b"ACGT"), ("q2", b"ACGT"), ("d", b"TT")]
+    batches = list(seqio.load([str(p)], max_bases=6))
+    assert [len(b) for b in batches] == [1, 3, 2] and sum(b.bases for b in batches) == 18
+
+
+@pytest.mark.parametrize("tag,target,reads,k,w,gold", [f for f in FIXTURES if f[5]])
+def test_indexlr_writer_and_parser(tag, target, reads, k, w, gold):
+    ss = seqio.load_all([os.path.join(REF, target)])
+    off, h, p, s = oracle.sketch_batch(ss.buf, ss.offsets, k, w)
+    buf = io.StringIO()
+    formats.write_indexlr(buf, ss.names, ss.lengths, off, h, p, s, False)
+    text = buf.getvalue()
+    assert text == read_text(os.path.join(REF, "expected_outputs", gold + ".tsv"))
+    n2, _, o2, h2, p2, s2 = formats.parse_indexlr(io.StringIO(text), False)
+    assert n2 == ss.names and np.array_equal(o2, off) and np.array_equal(h2, h) and np.array_equal(p2, p) and np.array_equal(s2, s)
+
+
+def _oracle_records(target, reads, k, w, **kw):
+    cs_, rs_ = seqio.load_all([os.path.join(REF, target)]), seqio.load_all([os.path.join(REF, reads)])
+    coff, ch, cp, cst = oracle.sketch_batch(cs_.buf, cs_.offsets, k, w)
+    roff, rh, rp, rst = oracle.sketch_batch(rs_.buf, rs_.offsets, k, w)
+    ix = oracle.Index(ch, contig_ids(coff), cp, cst)
+    res = oracle.map_reads(ix, cs_.lengths, roff, rs_.lengths, rh, rp, rst, k=k, z=1000, threads=0, **kw)
+    return cs_, rs_, res
+
+
+@pytest.mark.parametrize("tag,target,reads,k,w,gold", FIXTURES)
+def test_writers_and_tally_on_fixtures(tag, target, reads, k, w, gold, tmp_path):
+    cs_, rs_, res = _oracle_records(target, reads, k, w)
+    d = os.path.join(GEN, "fixtures")
+    v, p = io.StringIO(), io.StringIO()
+    formats.write_verbose(v, res, rs_.names, cs_.names)
+    formats.write_paf(p, res, rs_.names, rs_.lengths, cs_.names, cs_.lengths)
+    assert v.getvalue() == read_text(os.path.join(d, tag + ".verbose_mapping.tsv"))
+    assert p.getvalue() == read_text(os.path.join(d, tag + ".paf"))
+    t = pairing.PairTally(cs_.names, cs_.lengths, k, 10)
+    # feed in two batches: the tally is order-sensitive and must not care about batching
+    half = len(rs_) // 2
+    cut = int(np.searchsorted(res["maps"]["read"], half))
+    hcut = int(res["maps"]["hit_off"][cut]) if cut < len(res["maps"]) else len(res["hits"])
+    m1 = res["maps"][:cut]
+    m2 = res["maps"][cut:].copy()
+    m2["hit_off"] -= hcut
+    t.add_batch({"maps": m1, "hits": res["hits"][:hcut]}, rs_.lengths)
+    t.add_batch({"maps": m2, "hits": res["hits"][hcut:]}, rs_.lengths)
+    pairs = t.filtered(1)
+    buf = io.StringIO()
+    pairing.write_pairs(buf, pairs)
+    assert buf.getvalue() == read_text(os.path.join(d, tag + ".pairs.tsv"))
+    if gold:
+        dot = io.StringIO()
+        pairing.write_dot(dot, pairs, cs_.names, cs_.lengths, 1)
+        got = dot.getvalue().splitlines()
+        exp = read_text(os.path.join(REF, "expected_outputs", gold + ".z1000.n1.scaffold.dot")).splitlines()
+        assert got[:2] == exp[:2] and got[-1] == exp[-1] == "}"
+        assert sorted(l for l in got if "->" not in l) == sorted(l for l in exp if "->" not in l)
+        assert [l for l in got if "->" in l] == [l for l in exp if "->" in l]
+
+
+@pytest.mark.parametrize("name", SCENARIOS)
+def test_tally_on_synthetic_scenarios(name):
+    meta, ctext, rtext, exp = load_scenario(name)
+    p = meta["params"]
+    cn, _, coff, ch, cp, cs = parse_indexlr(ctext, False)
+    ids = np.array([meta["ctg_names"].index(n) for n in cn], np.uint32)
+    ix = oracle.Index(ch, ids[contig_ids(coff)], cp, cs)
+    rn, rlen, roff, rh, rp, rs = parse_indexlr(rtext, True)
+    cl = np.array(meta["ctg_len"], np.uint32)
+    res = oracle.map_reads(ix, cl, roff, rlen, rh, rp, rs, k=meta["k"], z=p.get("z", 1000), x=p.get("x", 0.0),
+                           sensitive=p.get("sensitive", False), repeat_filter=p.get("repeat_filter", False))
+    t = pairing.PairTally(meta["ctg_names"], cl, meta["k"], p.get("f", 10))
+    t.add_batch(res, rlen)
+    buf = io.StringIO()
+    pairing.write_pairs(buf, t.filtered(p.get("a", 1)))
+    assert buf.getvalue() == exp[".pairs.tsv"]
+
+
+@pytest.mark.parametrize("tag,target,k", [("t4_k40_w100", "scaffolds_4.fa", 40), ("t3_k24_w250", "scaffolds_3.fa", 24)])
+def test_checkpoint_retally(tag, target, k):
+    """A pre-existing verbose_mapping.tsv bypasses mapping (bin/ntlink_pair.py:565-575, 437-488)."""
+    cs_ = seqio.load_all([os.path.join(REF, target)])
+    t = pairing.PairTally(cs_.names, cs_.lengths, k, 10)
+    index_of = {n: i for i, n in enumerate(cs_.names)}
+    with open(os.path.join(GEN, "fixtures", tag + ".verbose_mapping.tsv")) as fh:
+        for _read, entries in formats.parse_verbose(fh):
+            t.add_checkpoint_read(entries, index_of)
+    buf = io.StringIO()
+    pairing.write_pairs(buf, t.filtered(1))
+    assert buf.getvalue() == read_text(os.path.join(GEN, "fixtures", tag + ".checkpoint.pairs.tsv"))
+
+
+def test_cli_surfaces():
+    a = cli.ntlink_pair_parser().parse_args("-p out -n 1 -m c.tsv -s t.fa -k 32 -a 1 -z 1000 -f 10 -x 0 --verbose --paf -".split())
+    assert (a.FILES, a.z, a.x, a.paf, a.verbose, a.pairs, a.repeat_filter) == (["-"], 1000, 0.0, True, True, False, False)
+    assert cli.ntlink_pair_parser().parse_args("-m c -s t -k 32 r.tsv".split()).z == 500  # argparse default differs from make's
+    assert cli.ntlink_main(["help"]) == 0
+    assert cli.ntlink_main(["scaffold", "target=a", "reads=b"]) == 2
+    assert cli.ntlink_main(["pair", "-B", "target=a"]) == 2

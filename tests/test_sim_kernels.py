@@ -39,3 +39,26 @@ def test_sim_full_pipeline_top5(dev):
     got = pc.check_full_pipeline(dev, pc.fixture_seqs("scaffolds_4.fa"), pc.fixture_seqs("long_reads_4_top5.fa"),
                                  40, 100, z=1000)
     assert len(got["pafs"]) == 6
+
+
+def test_sim_pair_driver_files(dev, tmp_path):
+    """The fused `ntLink pair` driver over the SIMT mock leaves the reference's files (top-5 reads)."""
+    import os
+    import shutil
+    from helpers import GEN, REF, TEST7_PAF, read_text
+    from ntlink_amd import pipeline
+    for n in ("scaffolds_4.fa", "long_reads_4_top5.fa"):
+        shutil.copy(os.path.join(REF, n), tmp_path / n)
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        pipeline.run_pair(dev, "scaffolds_4.fa", "long_reads_4_top5.fa", k=40, w=100, paf=True, pairs_tsv=True)
+    finally:
+        os.chdir(cwd)
+    pre = str(tmp_path / "scaffolds_4.fa.k40.w100.z1000")
+    d = os.path.join(GEN, "fixtures", "t7_top5_k40_w100")
+    assert read_text(pre + ".verbose_mapping.tsv") == read_text(d + ".verbose_mapping.tsv")
+    assert set(read_text(pre + ".paf").splitlines()) == TEST7_PAF
+    assert read_text(pre + ".pairs.tsv") == read_text(d + ".pairs.tsv")
+    assert read_text(str(tmp_path / "scaffolds_4.fa.k40.w100.tsv")) == read_text(os.path.join(REF, "expected_outputs", "scaffolds_4.fa.k40.w100.tsv"))
+    assert os.path.exists(pre + ".n1.scaffold.dot")

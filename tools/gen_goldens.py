@@ -218,6 +218,11 @@ SCENARIOS = [
 ]
 
 
+def _gz_write(path, text):
+    with open(path, "wb") as raw, gzip.GzipFile(filename="", mode="wb", fileobj=raw, mtime=0) as f:
+        f.write(text.encode())
+
+
 def gen_scenarios(tmp):
     d = os.path.join(OUT, "synthetic")
     os.makedirs(d, exist_ok=True)
@@ -232,19 +237,36 @@ def gen_scenarios(tmp):
                 f.write(f">{nm} comment\n{'A' * ln}\n")
         prefix = os.path.join(tmp, name)
         run_reference(ctsv, rtsv, fa, prefix, k, **params)
-        with gzip.open(os.path.join(d, name + ".contigs.tsv.gz"), "wt") as f:
-            f.write(ctext)
-        with gzip.open(os.path.join(d, name + ".reads.tsv.gz"), "wt") as f:
-            f.write(rtext)
+        _gz_write(os.path.join(d, name + ".contigs.tsv.gz"), ctext)
+        _gz_write(os.path.join(d, name + ".reads.tsv.gz"), rtext)
         json.dump({"k": k, "params": params, "ctg_names": names, "ctg_len": ctg_len},
                   open(os.path.join(d, name + ".json"), "w"))
         for ext in (".verbose_mapping.tsv", ".paf", ".pairs.tsv"):
-            with open(prefix + ext) as src, gzip.open(os.path.join(d, name + ext + ".gz"), "wt") as dst:
-                dst.write(src.read())
+            _gz_write(os.path.join(d, name + ext + ".gz"), open(prefix + ext).read())
         nv = sum(1 for _ in open(prefix + ".verbose_mapping.tsv"))
         npaf = sum(1 for _ in open(prefix + ".paf"))
         npairs = sum(1 for _ in open(prefix + ".pairs.tsv"))
         print(f"{name}: verbose={nv} paf={npaf} pairs={npairs}")
+
+
+def gen_checkpoint(tmp):
+    """Checkpoint mode (bin/ntlink_pair.py:437-488): pairs re-derived from a verbose_mapping.tsv."""
+    d = os.path.join(OUT, "fixtures")
+    for tag, target, k in (("t4_k40_w100", "scaffolds_4.fa", 40), ("t3_k24_w250", "scaffolds_3.fa", 24)):
+        prefix = os.path.join(tmp, "ck_" + tag)
+        shutil.copy(os.path.join(d, tag + ".verbose_mapping.tsv"), prefix + ".verbose_mapping.tsv")
+        nt = object.__new__(ntlink_pair.NtLink)
+        nt.args = argparse.Namespace(FILES=["-"], s=os.path.join(REF, target), m=None, p=prefix, n=1, k=k, z=1000, a=1,
+                                     f=10, x=0.0, checkpoint=prefix + ".verbose_mapping.tsv", pairs=True, paf=False,
+                                     sensitive=False, repeat_filter=False, verbose=True)
+        with ntlink_utils.HiddenPrints():
+            ntlink_pair.NtLink.list_mx_info = {}
+            ntlink_pair.NtLink.scaffolds = ntlink_utils.read_fasta_file(nt.args.s)
+            pairs = nt.find_scaffold_pairs_checkpoints()
+            pairs = nt.filter_pairs_distances(pairs)
+            pairs = nt.filter_weak_anchor_pairs(pairs)
+            nt.write_pairs(pairs)
+        shutil.copy(prefix + ".pairs.tsv", os.path.join(d, tag + ".checkpoint.pairs.tsv"))
 
 
 if __name__ == "__main__":
@@ -252,5 +274,6 @@ if __name__ == "__main__":
     try:
         gen_fixtures(tmp)
         gen_scenarios(tmp)
+        gen_checkpoint(tmp)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
