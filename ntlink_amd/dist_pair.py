@@ -1,0 +1,67 @@
+"""`ntLink pair` on N GPUs of one node: one process per GPU, launched by torch.distributed.run.
+
+Reads shard embarrassingly: the contig index is rebuilt on every GPU
+(deterministic, <= 1 GB), each rank maps a contiguous share of each read batch, rank 0 gathers the
+result RECORDS (host objects, gloo) in rank order and writes the files.  No RCCL collective is on
+the data path; RCCL/gloo only carry the barrier and the result gather.
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
+        -m ntlink_amd.dist_pair pair target=asm.fa reads='r1.fq.gz r2.fq.gz' k=32 w=250 paf=True
+"""
+import os
+import sys
+
+
+class DistComm:
+    def __init__(self, backend="gloo"):
+        import torch.distributed as dist
+        self.dist = dist
+        if not dist.is_initialized():
+            dist.init_process_group(backend)
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+
+    def gather(self, obj):
+        out = [None] * self.world if self.rank == 0 else None
+        self.dist.gather_object(obj, out, dst=0)
+        return out
+
+    def barrier(self):
+        self.dist.barrier()
+
+
+def main(argv=None, device_factory=None):
+    from . import cli, pipeline
+    argv = list(sys.argv[1:] if argv is None else argv)
+    kv = dict(cli._DEFAULTS)
+    targets = []
+    for tok in argv:
+        if tok.startswith("-"):
+            continue
+        if "=" in tok:
+            key, val = tok.split("=", 1)
+            kv[key] = val
+        else:
+            targets.append(tok)
+    if targets != ["pair"] or kv["target"] == "None" or kv["reads"] == "None":
+        print("usage: ... -m ntlink_amd.dist_pair pair target=<fa> reads='<files>' [k= w= ...]", file=sys.stderr)
+        return 2
+    comm = DistComm("gloo")  # host objects only; the device work needs no collective
+    local = int(os.environ.get("LOCAL_RANK", comm.rank))
+    if device_factory is None:
+        from . import capi
+        dev = capi.Device(local)
+    else:
+        dev = device_factory(local)
+    try:
+        pipeline.run_pair(dev, kv["target"], kv["reads"], prefix=kv["prefix"], k=int(kv["k"]), w=int(kv["w"]), n=int(kv["n"]),
+                          a=int(kv["a"]), z=int(kv["z"]), f=int(kv["f"]), x=float(kv["x"]), paf=kv["paf"] == "True",
+                          verbose=kv["verbose"] == "True", sensitive=kv["sensitive"] == "True", repeats=kv["repeats"] == "True",
+                          pairs_tsv=kv["ntlink_pairs_tsv"] == "True", comm=comm)
+    finally:
+        dev.close()
+        comm.dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

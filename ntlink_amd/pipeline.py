@@ -140,42 +140,91 @@ def run_ntlink_pair(dev, args):
         raise
 
 
+class LocalComm:
+    """Single process.  The multi-GPU launcher passes a torch.distributed-backed object with the same
+    three members (ntlink_amd/dist_pair.py)."""
+    rank, world = 0, 1
+
+    def gather(self, obj):
+        return [obj]
+
+    def barrier(self):
+        pass
+
+
+def shard_range(offsets, rank, world):
+    """Contiguous read range [lo, hi) of this rank, balanced by bases; concatenating the ranks' ranges
+    in rank order restores the input order."""
+    n = len(offsets) - 1
+    if world == 1:
+        return 0, n
+    total = int(offsets[-1]) - int(offsets[0])
+    cuts = [int(np.searchsorted(offsets, int(offsets[0]) + total * r // world, side="left")) for r in range(world + 1)]
+    cuts[0], cuts[-1] = 0, n
+    cuts = [min(max(c, 0), n) for c in cuts]
+    for i in range(1, world + 1):
+        cuts[i] = max(cuts[i], cuts[i - 1])
+    return cuts[rank], cuts[rank + 1]
+
+
 def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=10, x=0.0, paf=False, verbose=True,
-             sensitive=False, repeats=False, pairs_tsv=False, batch_bases=DEFAULT_BATCH_BASES, write_contig_tsv=True):
-    """`ntLink pair target=T reads='R1 R2' k= w= ...`: the fused device path."""
+             sensitive=False, repeats=False, pairs_tsv=False, batch_bases=DEFAULT_BATCH_BASES, write_contig_tsv=True,
+             comm=None):
+    """`ntLink pair target=T reads='R1 R2' k= w= ...`: the fused device path.
+
+    With a communicator of world > 1 (one process per GPU) every rank builds the same contig index on
+    its own GPU and maps a contiguous share of every read batch; rank 0 gathers the records in rank
+    order -- which is read order -- and does all the writing and the pair tally.  No collective touches
+    the data path on the device."""
+    comm = comm or LocalComm()
+    root = comm.rank == 0
     prefix = prefix or f"{target}.k{k}.w{w}.z{z}"
     if os.path.isfile(prefix + ".verbose_mapping.tsv"):
         # same silent switch as the reference (SURVEY appendix B 19)
-        import argparse
-        return run_ntlink_pair(dev, argparse.Namespace(FILES=[], s=target, m=None, p=prefix, n=n, k=k, z=z, a=a, f=f, x=x,
-                                                       checkpoint=None, pairs=pairs_tsv, paf=paf, sensitive=sensitive,
-                                                       repeat_filter=repeats, verbose=verbose))
+        if root:
+            import argparse
+            run_ntlink_pair(dev, argparse.Namespace(FILES=[], s=target, m=None, p=prefix, n=n, k=k, z=z, a=a, f=f, x=x,
+                                                    checkpoint=None, pairs=pairs_tsv, paf=paf, sensitive=sensitive,
+                                                    repeat_filter=repeats, verbose=verbose))
+        comm.barrier()
+        return None
+    comm.barrier()  # nobody creates the verbose file before everyone has looked for it
     ctg = seqio.load_all([target])
     ctg_len = ctg.lengths
-    out = PairOutputs(prefix, ctg.names, ctg_len, k, f, verbose, paf)
+    out = PairOutputs(prefix, ctg.names, ctg_len, k, f, verbose, paf) if root else None
     stats = dict(read_bases=0, reads=0, read_minimizers=0, index_hits=0)
     try:
         with dev.batch(ctg.buf, ctg.offsets) as cb, dev.sketch(cb, k, w) as csk:
-            if write_contig_tsv:
+            if write_contig_tsv and root:
                 off, h, p, s = csk.download()
                 with open(f"{target}.k{k}.w{w}.tsv", "w") as fh:
                     formats.write_indexlr(fh, ctg.names, ctg_len, off, h, p, s, False)
             with dev.index(csk, ctg_len) as ix:
                 stats["index_size"] = len(ix)
-                for rs_ in seqio.load(reads.split() if isinstance(reads, str) else list(reads), max_bases=batch_bases):
+                for rs_ in seqio.load(reads.split() if isinstance(reads, str) else list(reads), max_bases=batch_bases * comm.world):
                     if not len(rs_):
                         continue
                     rl = rs_.lengths
-                    with dev.batch(rs_.buf, rs_.offsets) as rb, dev.sketch(rb, k, w) as rsk, \
-                            dev.map(ix, rsk, rl, k=k, z=z, x=x, sensitive=sensitive, repeat_filter=repeats) as res:
-                        out.add(res.download(), rs_.names, rl)
+                    lo, hi = shard_range(rs_.offsets, comm.rank, comm.world)
+                    b0 = int(rs_.offsets[lo])
+                    sub_off = rs_.offsets[lo:hi + 1] - np.uint64(b0)
+                    with dev.batch(rs_.buf[b0:int(rs_.offsets[hi])], sub_off) as rb, dev.sketch(rb, k, w) as rsk, \
+                            dev.map(ix, rsk, rl[lo:hi], k=k, z=z, x=x, sensitive=sensitive, repeat_filter=repeats) as res:
+                        mine = (lo, hi, res.download(), rsk.count, res.n_index_hits)
+                    parts = comm.gather(mine)
+                    if root:
+                        for plo, phi, pres, pmx, phits in parts:
+                            out.add(pres, rs_.names[plo:phi], rl[plo:phi])
+                            stats["read_minimizers"] += pmx
+                            stats["index_hits"] += phits
                         stats["read_bases"] += rs_.bases
                         stats["reads"] += len(rs_)
-                        stats["read_minimizers"] += rsk.count
-                        stats["index_hits"] += res.n_index_hits
-        out.close()
-        finish_pairs(out.tally, prefix, n, a, pairs_tsv)
+        if root:
+            out.close()
+            finish_pairs(out.tally, prefix, n, a, pairs_tsv)
+        comm.barrier()
     except BaseException:
-        out.remove_partial()
+        if out:
+            out.remove_partial()
         raise
     return stats
