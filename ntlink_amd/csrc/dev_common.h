@@ -17,16 +17,34 @@
 #define NTL_NONE 0xFFFFFFFFu
 #define NTL_LEAD_PAD 16u /* bases of padding in front of the first sequence of a batch */
 
+/* srol / sror on the two 32-bit halves: 5 VALU ops each (alignbit + bfi) */
 __device__ __forceinline__ uint64_t srol1(uint64_t x)
 {
-    uint64_t m = ((x & 0x8000000000000000ull) >> 30) | ((x & 0x100000000ull) >> 32);
-    return ((x << 1) & 0xFFFFFFFDFFFFFFFFull) | m;
+    const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    const uint32_t nlo = (lo << 1) | (hi & 1u);                 /* bit 32 -> bit 0 */
+    uint32_t nhi = ntl_alignbit(hi, lo, 31);                    /* (hi << 1) | (lo >> 31): bit 31 -> bit 32 */
+    nhi = (nhi & ~2u) | ((hi >> 30) & 2u);                      /* bit 63 -> bit 33 */
+    return ((uint64_t)nhi << 32) | nlo;
 }
 
 __device__ __forceinline__ uint64_t sror1(uint64_t x)
 {
-    uint64_t m = ((x & 0x200000000ull) << 30) | ((x & 1ull) << 32);
-    return ((x >> 1) & 0xFFFFFFFEFFFFFFFFull) | m;
+    const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    const uint32_t nlo = ntl_alignbit(hi, lo, 1);               /* bit 32 -> bit 31 */
+    uint32_t nhi = (hi >> 1) & 0x7FFFFFFEu;                     /* bits 34..63 -> 33..62 */
+    nhi |= lo & 1u;                                             /* bit 0 -> bit 32 */
+    nhi |= (hi << 30) & 0x80000000u;                            /* bit 33 -> bit 63 */
+    return ((uint64_t)nhi << 32) | nlo;
+}
+
+/* rotate the 33-bit ring left by a (0..32) and the 31-bit ring left by b (0..30) */
+__device__ __forceinline__ uint64_t srot(uint64_t x, uint32_t a, uint32_t b)
+{
+    uint64_t r33 = x & 0x1FFFFFFFFull;
+    uint32_t r31 = (uint32_t)(x >> 33);
+    r33 = ((r33 << a) | (r33 >> (33u - a))) & 0x1FFFFFFFFull;
+    r31 = ((r31 << b) | (b ? r31 >> (31u - b) : 0u)) & 0x7FFFFFFFu;
+    return r33 | ((uint64_t)r31 << 33);
 }
 
 /* 16 consecutive bases starting at global base index gp, base j in bits [2j, 2j+2) */
@@ -43,23 +61,37 @@ __device__ __forceinline__ uint32_t load_base(const uint32_t *__restrict__ packe
     return (packed[gp >> 4] >> (2u * ((uint32_t)gp & 15u))) & 3u;
 }
 
-/* seed_tab[c] = {seed[c], seed[3-c]}.  Hash of the k-mer starting at gp, from scratch. */
+/*
+ * Hash of the k-mer starting at gp, from scratch, four bases per step:
+ *   g4[byte] = {XOR_j srol^(3-j)(seed[b_j]), XOR_j sror^(3-j)(seed[3-b_j])},  b_j = (byte >> 2j) & 3
+ *   f = srol^4(f) ^ g4[byte][0]          (Horner form of fwd)
+ *   u = sror^4(u) ^ g4[byte][1]          (u = XOR_j sror^(k-1-j)(seedc_j);  rev = srol^(k-1)(u))
+ * The k % 4 trailing bases take single steps with seed_tab[c] = {seed[c], seed[3-c]}.
+ * g4 (4 KB, k-independent) is read from global memory and lives in L1.
+ */
 __device__ __forceinline__ void hash_init(const uint32_t *__restrict__ packed, uint64_t gp, int k,
-                                          const uint64_t (*seed_tab)[2], uint64_t &fwd, uint64_t &rev)
+                                          const uint64_t (*__restrict__ g4)[2], const uint64_t (*seed_tab)[2],
+                                          uint64_t &fwd, uint64_t &rev)
 {
     uint64_t f = 0, u = 0;
     for (int i = 0; i < k; i += 16) {
-        uint32_t s = load_bases16(packed, gp + (uint64_t)i);
-        int nb = k - i < 16 ? k - i : 16;
-        for (int j = 0; j < nb; j++) {
-            uint32_t c = (s >> (2 * j)) & 3u;
+        const uint32_t s = load_bases16(packed, gp + (uint64_t)i);
+        const int nb = k - i < 16 ? k - i : 16;
+        const int ng = nb >> 2;
+        for (int g = 0; g < ng; g++) {
+            const uint32_t byte = (s >> (8 * g)) & 255u;
+            const uint64_t gf = g4[byte][0], gu = g4[byte][1];
+            f = srot(f, 4, 4) ^ gf;
+            u = srot(u, 29, 27) ^ gu;
+        }
+        for (int j = ng * 4; j < nb; j++) {
+            const uint32_t c = (s >> (2 * j)) & 3u;
             f = srol1(f) ^ seed_tab[c][0];
-            u = sror1(u) ^ seed_tab[c][1]; /* u = XOR_j sror^(k-1-j)(seedc_j) */
+            u = sror1(u) ^ seed_tab[c][1];
         }
     }
-    for (int i = 1; i < k; i++) u = srol1(u); /* rev = srol^(k-1)(u) */
     fwd = f;
-    rev = u;
+    rev = srot(u, (uint32_t)(k - 1) % 33u, (uint32_t)(k - 1) % 31u);
 }
 
 /* Exclusive scan of one value per thread over a workgroup of NT threads; returns the prefix and

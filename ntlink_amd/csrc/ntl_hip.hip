@@ -39,6 +39,7 @@ struct ntl_ctx {
     bool prof = false;
     std::map<std::string, ProfEntry> profs;
     std::vector<hipEvent_t> ev_free;
+    void *g4 = nullptr;                 /* device copy of the four-base init table */
     std::multimap<size_t, void *> pool; /* cached device blocks by size */
     size_t pool_bytes = 0;
 };
@@ -130,6 +131,8 @@ struct ProfSpan {
     }
 };
 
+static void make_g4(uint64_t g4[256][2]);
+
 extern "C" int ntl_ctx_create(int device, ntl_ctx **out)
 {
     if (!out) return NTL_EINVAL;
@@ -141,6 +144,14 @@ extern "C" int ntl_ctx_create(int device, ntl_ctx **out)
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
         delete c;
         return NTL_EDEVICE;
+    }
+    {
+        uint64_t g4[256][2];
+        make_g4(g4);
+        if (hipMalloc(&c->g4, sizeof g4) != hipSuccess || hipMemcpy(c->g4, g4, sizeof g4, hipMemcpyHostToDevice) != hipSuccess) {
+            delete c;
+            return NTL_EDEVICE;
+        }
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
@@ -159,6 +170,7 @@ extern "C" void ntl_ctx_destroy(ntl_ctx *c)
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     for (auto &kv : c->pool) hipFree(kv.second);
+    hipFree(c->g4);
     for (auto &kv : c->profs)
         for (auto &sp : kv.second.spans) { hipEventDestroy(sp.first); hipEventDestroy(sp.second); }
     for (auto e : c->ev_free) hipEventDestroy(e);
@@ -425,6 +437,27 @@ static void make_tables(int k, uint64_t roll[16][2], uint64_t seed[4][2])
         }
 }
 
+static uint64_t h_sror1(uint64_t x)
+{
+    uint64_t m = ((x & 0x200000000ull) << 30) | ((x & 1ull) << 32);
+    return ((x >> 1) & 0xFFFFFFFEFFFFFFFFull) | m;
+}
+
+/* four-base init table (k-independent), see dev_common.h hash_init */
+static void make_g4(uint64_t g4[256][2])
+{
+    const uint64_t S[4] = {0x3c8bfbb395c60474ull, 0x3193c18562a02b4cull, 0x20323ed082572324ull, 0x295549f54be24456ull};
+    for (int b = 0; b < 256; b++) {
+        uint64_t f = 0, u = 0;
+        for (int j = 0; j < 4; j++) {
+            const int c = (b >> (2 * j)) & 3;
+            f = h_srol1(f) ^ S[c];
+            u = h_sror1(u) ^ S[3 - c];
+        }
+        g4[b][0] = f; g4[b][1] = u;
+    }
+}
+
 template <int C>
 static void launch_mask(ntl_ctx *c, const SketchArgs &A, unsigned strips, bool multi)
 {
@@ -482,6 +515,7 @@ extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_
         A.run_n = run_n.as<uint32_t>(); A.run_ord = run_ord.as<uint32_t>(); A.seq_M = seq_M.as<uint32_t>();
         A.strip_first = strip_first.as<uint32_t>(); A.mask = mask.as<uint32_t>(); A.G = G;
         make_tables(k, A.roll_tab, A.seed_tab);
+        A.g4 = (const uint64_t (*)[2])c->g4;
         ProfSpan sp(c, "sketch_mask");
         if (C == 16) launch_mask<16>(c, A, total_strips, b->any_multi);
         else if (C == 4) launch_mask<4>(c, A, total_strips, b->any_multi);
@@ -506,6 +540,7 @@ extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_
         E.out = s->records.as<MxRecord>(); E.k = k; E.mult = 1ull ^ ((uint64_t)k * 0x90b45d39fb6da1faull);
         uint64_t roll[16][2];
         make_tables(k, roll, E.seed_tab);
+        E.g4 = (const uint64_t (*)[2])c->g4;
         hipLaunchKernelGGL(emit_kernel, dim3((unsigned)tiles), dim3(EMIT_NT), 0, c->stream, E);
         hipLaunchKernelGGL(mx_offsets_kernel, dim3((unsigned)((nseq + 1 + 255) / 256)), dim3(256), 0, c->stream,
                            T.seq_base, (uint32_t)nseq, (const uint32_t *)mask.as<uint32_t>(),

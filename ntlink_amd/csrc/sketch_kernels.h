@@ -75,6 +75,7 @@ struct SketchArgs {
     SketchGeom G;
     uint64_t roll_tab[16][2];    /* [in<<2|out] = {seed[in]^srol^k(seed[out]), srol^k(seedc[in])^seedc[out]} */
     uint64_t seed_tab[4][2];     /* [c] = {seed[c], seed[3-c]} */
+    const uint64_t (*g4)[2];     /* [256] four-base init table (dev_common.h hash_init) */
 };
 
 struct StripInfo {
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(NT) void sketch_mask_kernel(SketchArgs A)
                of it is exact, then voided. */
             const uint64_t gp = (uint64_t)((int64_t)I.base + I.P0 + (int64_t)L * C);
             uint64_t fwd, rev;
-            hash_init(A.T.packed, gp, G.k, s_seed, fwd, rev);
+            hash_init(A.T.packed, gp, G.k, A.g4, s_seed, fwd, rev);
             h[0] = fwd + rev;
             const uint32_t so = load_bases16(A.T.packed, gp);
             const uint32_t si = load_bases16(A.T.packed, gp + (uint64_t)G.k);
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(NT) void sketch_mask_kernel(SketchArgs A)
                     run_end = A.run_ord[g] + A.run_n[g];
                     pv = A.T.run_start[g] + (eo - A.run_ord[g]);
                     gp = I.base + pv;
-                    hash_init(A.T.packed, gp, G.k, s_seed, fwd, rev);
+                    hash_init(A.T.packed, gp, G.k, A.g4, s_seed, fwd, rev);
                     have = true;
                 } else {
                     const uint32_t cin = load_base(A.T.packed, gp + (uint64_t)G.k);
@@ -341,6 +342,7 @@ struct EmitArgs {
     int k;
     uint64_t mult;            /* 1 ^ (k * MULTISEED) */
     uint64_t seed_tab[4][2];
+    const uint64_t (*g4)[2];
 };
 
 __global__ __launch_bounds__(EMIT_NT) void emit_kernel(EmitArgs A)
@@ -392,7 +394,7 @@ __global__ __launch_bounds__(EMIT_NT) void emit_kernel(EmitArgs A)
                 if (A.seq_base[mid] <= gp) lo = mid; else hi = mid;
             }
             uint64_t fwd, rev;
-            hash_init(A.packed, gp, A.k, s_seed, fwd, rev);
+            hash_init(A.packed, gp, A.k, A.g4, s_seed, fwd, rev);
             uint64_t tt = (fwd + rev) * A.mult;
             tt ^= tt >> 27;
             MxRecord R;
