@@ -40,12 +40,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
-    if world > 1:
+    torch.cuda.set_device(local_rank)
+    if "RANK" in os.environ:  # launched by torch.distributed.run: one rank per GPU, RCCL for barrier/max only
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
 
     W = synth.workload(args.workload, args.scale)
     if args.workload != "C2":
@@ -120,6 +118,7 @@ def main():
         bytes_per_launch = bytes_per_step / max(launches_per_step, 1)
         achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
         hfrac = stats["index_hits"] / max(stats["read_mx"], 1)
+        traffic, traffic_src = pmc_traffic(args.workload, args.scale)
         out = {
             "metric": "read Gbases/s mapped (ntLink pair, paf=True)",
             "value": round(value, 4), "unit": "Gbases/s",
@@ -135,7 +134,7 @@ def main():
                        "device": dev.name, "gen_s": round(gen_s, 1), "upload_s": round(upload_s, 2),
                        "stage_ms_per_step": {nm: round(v[0] / args.steps, 3) for nm, v in prof.items()}},
             "roofline": {"bound": "hbm", "kernel": "sketch_mask_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "bytes_per_base": round(0.25 + 16.0 * d, 4), "avg_launch_ms": round(avg_launch_ms, 4),
                          "launches": mask_n,
                          "note": "integer/VALU-bound kernel (SURVEY 7): see DESIGN.md for the VALU roofline"},
@@ -148,6 +147,19 @@ def main():
     dev.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def pmc_traffic(workload, scale):
+    """HBM bytes per sketch_mask_kernel launch from the rocprofv3 PMC passes of this same command
+    (FETCH_SIZE and WRITE_SIZE in separate --pmc runs, tools/gpu_round.sh); PMC counters cannot be read
+    from inside the process, so the committed summary of the latest profiled run is quoted."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if scale != 1.0 or not os.path.exists(path):
+        return None, None
+    t = json.load(open(path)).get(workload)
+    if not t:
+        return None, None
+    return t["bytes_per_launch"], t["source"]
 
 
 def cpu_baseline(cbuf, coff, ctg_len, rbuf, roff, read_len, k, w, params, stats):
