@@ -69,9 +69,9 @@ __device__ __forceinline__ uint32_t load_base(const uint32_t *__restrict__ packe
  * The k % 4 trailing bases take single steps with seed_tab[c] = {seed[c], seed[3-c]}.
  * g4 (4 KB, k-independent) is read from global memory and lives in L1.
  */
-__device__ __forceinline__ void hash_init(const uint32_t *__restrict__ packed, uint64_t gp, int k,
-                                          const uint64_t (*__restrict__ g4)[2], const uint64_t (*seed_tab)[2],
-                                          uint64_t &fwd, uint64_t &rev)
+__device__ __forceinline__ void hash_init_loop(const uint32_t *__restrict__ packed, uint64_t gp, int k,
+                                               const uint64_t (*__restrict__ g4)[2], const uint64_t (*seed_tab)[2],
+                                               uint64_t &fwd, uint64_t &rev)
 {
     uint64_t f = 0, u = 0;
     for (int i = 0; i < k; i += 16) {
@@ -89,6 +89,47 @@ __device__ __forceinline__ void hash_init(const uint32_t *__restrict__ packed, u
             f = srol1(f) ^ seed_tab[c][0];
             u = sror1(u) ^ seed_tab[c][1];
         }
+    }
+    fwd = f;
+    rev = srot(u, (uint32_t)(k - 1) % 33u, (uint32_t)(k - 1) % 31u);
+}
+
+/* k <= 64: straight-line form -- the four base words and the (up to) sixteen table entries are all
+ * requested before the first one is used, so one memory latency is paid instead of one per group. */
+__device__ __forceinline__ void hash_init(const uint32_t *__restrict__ packed, uint64_t gp, int k,
+                                          const uint64_t (*__restrict__ g4)[2], const uint64_t (*seed_tab)[2],
+                                          uint64_t &fwd, uint64_t &rev)
+{
+    if (k > 64) { hash_init_loop(packed, gp, k, g4, seed_tab, fwd, rev); return; }
+    const uint64_t wi = gp >> 4;
+    const uint32_t a2 = 2u * ((uint32_t)gp & 15u);
+    uint32_t raw[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) raw[i] = (16 * i < k + 16) ? packed[wi + i] : 0u; /* k + 15 bases at most */
+    uint32_t s[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) s[i] = ntl_alignbit(raw[i + 1], raw[i], a2);
+    const int ng = k >> 2;
+    uint64_t gf[16], gu[16];
+#pragma unroll
+    for (int g = 0; g < 16; g++) {
+        const uint32_t byte = (s[g >> 2] >> (8 * (g & 3))) & 255u;
+        const bool on = g < ng;
+        gf[g] = on ? g4[byte][0] : 0ull;
+        gu[g] = on ? g4[byte][1] : 0ull;
+    }
+    uint64_t f = 0, u = 0;
+#pragma unroll
+    for (int g = 0; g < 16; g++) {
+        if (g < ng) { /* uniform */
+            f = srot(f, 4, 4) ^ gf[g];
+            u = srot(u, 29, 27) ^ gu[g];
+        }
+    }
+    for (int j = ng * 4; j < k; j++) { /* k % 4 trailing bases */
+        const uint32_t c = load_base(packed, gp + (uint64_t)j);
+        f = srol1(f) ^ seed_tab[c][0];
+        u = sror1(u) ^ seed_tab[c][1];
     }
     fwd = f;
     rev = srot(u, (uint32_t)(k - 1) % 33u, (uint32_t)(k - 1) % 31u);

@@ -458,11 +458,21 @@ static void make_g4(uint64_t g4[256][2])
     }
 }
 
+template <int C, int R0>
+static void launch_mask_r0(ntl_ctx *c, const SketchArgs &A, unsigned strips, bool multi)
+{
+    if (A.G.r0 == R0) {
+        hipLaunchKernelGGL((sketch_mask_kernel<C, SK_NT, false, R0>), dim3(strips), dim3(SK_NT), 0, c->stream, A);
+        if (multi) hipLaunchKernelGGL((sketch_mask_kernel<C, SK_NT, true, R0>), dim3(strips), dim3(SK_NT), 0, c->stream, A);
+        return;
+    }
+    if constexpr (R0 + 1 < C) launch_mask_r0<C, R0 + 1>(c, A, strips, multi);
+}
+
 template <int C>
 static void launch_mask(ntl_ctx *c, const SketchArgs &A, unsigned strips, bool multi)
 {
-    hipLaunchKernelGGL((sketch_mask_kernel<C, SK_NT, false>), dim3(strips), dim3(SK_NT), 0, c->stream, A);
-    if (multi) hipLaunchKernelGGL((sketch_mask_kernel<C, SK_NT, true>), dim3(strips), dim3(SK_NT), 0, c->stream, A);
+    launch_mask_r0<C, 0>(c, A, strips, multi);
 }
 
 extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_sketch **out)

@@ -78,6 +78,12 @@ struct SketchArgs {
     const uint64_t (*g4)[2];     /* [256] four-base init table (dev_common.h hash_init) */
 };
 
+/* 16-bit strip-local index back to 32 bits (0xFFFF -> NTL_NONE) */
+__device__ __forceinline__ uint32_t ntl_idx16(uint16_t v) { return v == 0xFFFFu ? NTL_NONE : (uint32_t)v; }
+
+struct NtlTrue { static constexpr bool value = true; };
+struct NtlFalse { static constexpr bool value = false; };
+
 struct StripInfo {
     uint32_t seq;
     int32_t E0;      /* ordinal of the strip's first element (may be -1) */
@@ -93,19 +99,23 @@ struct StripInfo {
  * MULTI = true : strips that cross non-ACGT runs: per-lane walk over the run table, positions
  *                staged in LDS.  Both instantiations are launched over all strips; each returns
  *                immediately on strips of the other kind.
+ * R0 = (w - C) % C is a template parameter so that the window pass unrolls into straight-line code
+ * (which remote block and which whole-block minimum a window uses is then known at compile time).
  */
-template <int C, int NT, bool MULTI>
+template <int C, int NT, bool MULTI, int R0>
 __global__ __launch_bounds__(NT) void sketch_mask_kernel(SketchArgs A)
 {
+    constexpr int NBW = (C * NT + 31) / 32; /* words of the strip-local emission bitmask */
     __shared__ uint64_t s_h[C * NT];  /* element (L,t) at [t*NT + L] */
     __shared__ uint32_t s_pos[MULTI ? C * NT : 1];
     __shared__ uint64_t s_bm_h[NT], s_pr_h[NT];
-    __shared__ uint32_t s_bm_i[NT], s_pr_i[NT], s_last[NT];
+    __shared__ uint16_t s_bm_i[NT], s_pr_i[NT], s_last[NT]; /* strip-local indices < 65535; 0xFFFF = none */
+    __shared__ uint32_t s_bits[NBW + 64]; /* + one dummy word per lane of a wavefront */
     __shared__ uint64_t s_roll[16][2], s_seed[4][2];
     __shared__ StripInfo s_info;
 
     const int L = threadIdx.x;
-    const SketchGeom G = A.G;
+    const SketchGeom G = A.G; /* G.r0 == R0 (the host picks the instantiation) */
 
     if (L == 0) {
         /* strip -> sequence: largest s with strip_first[s] <= blockIdx.x */
@@ -142,6 +152,7 @@ __global__ __launch_bounds__(NT) void sketch_mask_kernel(SketchArgs A)
     }
     if (L < 16) { s_roll[L][0] = A.roll_tab[L][0]; s_roll[L][1] = A.roll_tab[L][1]; }
     if (L < 4) { s_seed[L][0] = A.seed_tab[L][0]; s_seed[L][1] = A.seed_tab[L][1]; }
+    if (L < NBW) s_bits[L] = 0;
     __syncthreads();
     const StripInfo I = s_info;
     if ((I.multi != 0) != MULTI) return;
@@ -170,10 +181,12 @@ __global__ __launch_bounds__(NT) void sketch_mask_kernel(SketchArgs A)
                 rev = sror1(rev ^ s_roll[idx][1]);
                 h[t] = fwd + rev;
             }
+            if (e_lane < 0 || e_lane + C > (int64_t)I.M) { /* strip edges only */
 #pragma unroll
-            for (int t = 0; t < C; t++) {
-                const int64_t e = e_lane + t;
-                if (e < 0 || e >= (int64_t)I.M) h[t] = NTL_INF;
+                for (int t = 0; t < C; t++) {
+                    const int64_t e = e_lane + t;
+                    if (e < 0 || e >= (int64_t)I.M) h[t] = NTL_INF;
+                }
             }
         }
     } else {
@@ -214,7 +227,7 @@ __global__ __launch_bounds__(NT) void sketch_mask_kernel(SketchArgs A)
         for (int t = 0; t < C; t++) h[t] = s_h[t * NT + L];
     }
 
-    /* ---- phase 2: suffix minima of the own block, block minimum, prefix of length r0 --- */
+    /* ---- phase 2: suffix minima of the own block, block minimum, prefix of length R0 --- */
     uint64_t S_h[C];
     uint32_t S_i[C];
     {
@@ -227,15 +240,15 @@ __global__ __launch_bounds__(NT) void sketch_mask_kernel(SketchArgs A)
             S_i[j] = ri;
         }
         s_bm_h[L] = rh;
-        s_bm_i[L] = ri;
+        s_bm_i[L] = (uint16_t)ri;
         uint64_t ph = NTL_INF;
         uint32_t pi = NTL_NONE;
 #pragma unroll
-        for (int t = 0; t < C; t++) {
-            if (t < G.r0 && h[t] <= ph) { ph = h[t]; pi = (uint32_t)(L * C + t); }
+        for (int t = 0; t < R0; t++) {
+            if (h[t] <= ph) { ph = h[t]; pi = (uint32_t)(L * C + t); }
         }
         s_pr_h[L] = ph;
-        s_pr_i[L] = pi;
+        s_pr_i[L] = (uint16_t)pi;
         if (!MULTI) {
 #pragma unroll
             for (int t = 0; t < C; t++) s_h[t * NT + L] = h[t];
@@ -250,11 +263,11 @@ __global__ __launch_bounds__(NT) void sketch_mask_kernel(SketchArgs A)
     if (own) {
         for (int d = 1; d <= G.a; d++) {
             const uint64_t hh = s_bm_h[L + d];
-            if (hh <= fa_h) { fa_h = hh; fa_i = s_bm_i[L + d]; }
+            if (hh <= fa_h) { fa_h = hh; fa_i = ntl_idx16(s_bm_i[L + d]); }
         }
         fb_h = fa_h; fb_i = fa_i;
         const uint64_t hh = s_bm_h[L + G.a + 1];
-        if (hh <= fb_h) { fb_h = hh; fb_i = s_bm_i[L + G.a + 1]; }
+        if (hh <= fb_h) { fb_h = hh; fb_i = ntl_idx16(s_bm_i[L + G.a + 1]); }
     } else {
         fb_h = NTL_INF; fb_i = NTL_NONE;
     }
@@ -262,19 +275,28 @@ __global__ __launch_bounds__(NT) void sketch_mask_kernel(SketchArgs A)
     /* ---- phase 4: every window starting in the own block -------------------------------- */
     uint32_t prev_i = NTL_NONE, A0_i = NTL_NONE;
     uint64_t A0_h = NTL_INF;
-    auto emit = [&](uint32_t idx) {
-        uint64_t g;
-        if (!MULTI) g = (uint64_t)((int64_t)I.base + I.P0 + (int64_t)idx);
-        else g = I.base + s_pos[(idx % C) * NT + (idx / C)];
-        atomicOr(&A.mask[g >> 5], 1u << ((uint32_t)g & 31u));
+    /* emitted minimizers: single-run strips set bits in the strip-local LDS bitmask without a branch
+       (OR of 0 when nothing is emitted); multi-run strips go straight to the global bitmask */
+    auto emit = [&](uint32_t idx, bool flag) {
+        if (!MULTI) {
+            /* lanes with nothing to emit OR a zero into a private dummy word: no same-address serialisation */
+            const uint32_t wi = flag ? ((idx >> 5) & (uint32_t)(NBW - 1)) : (uint32_t)(NBW + (L & 63));
+            atomicOr(&s_bits[wi], flag ? 1u << (idx & 31u) : 0u);
+        } else if (flag) {
+            const uint64_t g = I.base + s_pos[(idx % C) * NT + (idx / C)];
+            atomicOr(&A.mask[g >> 5], 1u << ((uint32_t)g & 31u));
+        }
     };
-    if (own) {
+    /* CHECK = false: every window of every owning lane of this wavefront lies inside the sequence */
+    auto window_pass = [&](auto chk) {
+        constexpr bool CHECK = decltype(chk)::value;
         int Lr = L + G.a + 1;
         uint64_t P_h = s_pr_h[Lr];
-        uint32_t P_i = s_pr_i[Lr];
+        uint32_t P_i = ntl_idx16(s_pr_i[Lr]);
 #pragma unroll
         for (int j = 0; j < C; j++) {
-            const int rt = G.r0 + j;
+            constexpr int dummy = 0; (void)dummy;
+            const int rt = R0 + j; /* compile-time after unrolling */
             if (j > 0) {
                 if (rt == C) { Lr++; P_h = NTL_INF; P_i = NTL_NONE; }
                 else {
@@ -289,18 +311,46 @@ __global__ __launch_bounds__(NT) void sketch_mask_kernel(SketchArgs A)
             const uint32_t F_i = rt < C ? fa_i : fb_i;
             if (F_h <= x_h) { x_h = F_h; x_i = F_i; }
             if (P_h <= x_h) { x_h = P_h; x_i = P_i; }
-            const int64_t s = e_lane + j; /* window = ordinals [s, s+w) */
-            const bool valid = s >= 0 && s + G.w <= (int64_t)I.M;
+            bool valid = true;
+            if (CHECK) {
+                const int64_t s = e_lane + j; /* window = ordinals [s, s+w) */
+                valid = s >= 0 && s + G.w <= (int64_t)I.M;
+            }
             const uint32_t a_i = valid ? x_i : NTL_NONE;
             if (j == 0) { A0_i = a_i; A0_h = x_h; }
-            else if (valid && a_i != prev_i && x_h != NTL_INF) emit(a_i);
+            else emit(a_i, valid && a_i != prev_i && x_h != NTL_INF);
             prev_i = a_i;
         }
+    };
+    {
+        const bool inside = e_lane >= 0 && e_lane + (C - 1) + G.w <= (int64_t)I.M;
+        const bool all_inside = __ballot(own && !inside) == 0ull;
+        if (own) {
+            if (all_inside) window_pass(NtlFalse());
+            else window_pass(NtlTrue());
+        }
     }
-    s_last[L] = prev_i;
+    s_last[L] = (uint16_t)prev_i;
     __syncthreads();
     /* window (L,0) compares with the last window of lane L-1; (0,0) belongs to the previous strip */
-    if (own && L > 0 && A0_i != NTL_NONE && A0_i != s_last[L - 1] && A0_h != NTL_INF) emit(A0_i);
+    {
+        const bool f0 = own && L > 0 && A0_i != NTL_NONE && A0_i != ntl_idx16(s_last[L - 1]) && A0_h != NTL_INF;
+        if (!MULTI) emit(A0_i, f0);
+        else if (f0) emit(A0_i, true);
+    }
+    if (!MULTI) {
+        __syncthreads();
+        /* flush the strip-local bitmask: strip element 32*L.. starts at global bit g0 */
+        if (L < NBW) {
+            const uint32_t word = s_bits[L];
+            if (word) {
+                const uint64_t g0 = (uint64_t)((int64_t)I.base + I.P0 + 32 * (int64_t)L);
+                const uint32_t sh = (uint32_t)g0 & 31u;
+                atomicOr(&A.mask[g0 >> 5], word << sh);
+                if (sh && (word >> (32u - sh))) atomicOr(&A.mask[(g0 >> 5) + 1], word >> (32u - sh));
+            }
+        }
+    }
 }
 
 /* ---------------------------------------------------------------------------- emit -------- */
