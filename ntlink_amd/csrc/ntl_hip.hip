@@ -229,22 +229,25 @@ extern "C" int ntl_prof_get(ntl_ctx *c, const char *name, double *total_ms, uint
 
 /* ------------------------------------------------------------------ scan helper ---------- */
 
-/* out[0..n) = exclusive scan of in[0..n); *total = sum (host).  in may equal out. */
+/* out[0..n) = exclusive scan of in[0..n), out[n] = sum (out must hold n+1 entries; in may equal out when
+ * in also has n+1).  With total_host the sum also comes back to the host (one stream sync); without it
+ * nothing waits. */
 static int device_scan(ntl_ctx *c, const uint32_t *in, uint32_t *out, uint64_t n, uint32_t *total_host)
 {
     uint64_t tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
     if (tiles == 0) tiles = 1;
-    DevBuf tile, tot;
+    DevBuf tile;
     int rc;
     if ((rc = tile.alloc(c, tiles * 4))) return rc;
-    if ((rc = tot.alloc(c, 4))) return rc;
     hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)tiles), dim3(SCAN_NT), 0, c->stream, in, n, tile.as<uint32_t>());
-    hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(SCAN_NT), 0, c->stream, tile.as<uint32_t>(), tiles, tot.as<uint32_t>());
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(SCAN_NT), 0, c->stream, tile.as<uint32_t>(), tiles, out + n);
     hipLaunchKernelGGL(scan_down_kernel, dim3((unsigned)tiles), dim3(SCAN_NT), 0, c->stream, in, out, n,
                        (const uint32_t *)tile.as<uint32_t>());
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(total_host, tot.p, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (total_host) {
+        HIPCHK(c, hipMemcpyAsync(total_host, out + n, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     return NTL_OK;
 }
 
@@ -493,6 +496,7 @@ extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_
     s->c = c; s->nseq = nseq;
     int rc;
     DevBuf run_n, run_ord, seq_M, nstrips, strip_first, mask, tile, tot, word_rank;
+    /* nstrips / strip_first hold nseq+1 entries: the scan leaves the total behind the last one */
     const uint64_t nmask = (b->total_gpos + 31) / 32 + 1;
     if ((rc = run_n.alloc(c, (b->nruns + 1) * 4)) || (rc = run_ord.alloc(c, (b->nruns + 1) * 4)) ||
         (rc = seq_M.alloc(c, (nseq + 1) * 4)) || (rc = nstrips.alloc(c, (nseq + 1) * 4)) ||
@@ -505,31 +509,45 @@ extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_
     T.packed = b->packed.as<uint32_t>(); T.seq_base = b->seq_base.as<uint64_t>();
     T.seq_run_first = b->seq_run_first.as<uint32_t>(); T.run_start = b->run_start.as<uint32_t>();
     T.run_len = b->run_len.as<uint32_t>(); T.nseq = (uint32_t)nseq;
-    uint32_t total_strips = 0, total_mx = 0;
+    uint32_t total_mx = 0;
+    /* upper bound of the number of strips from the host-side lengths (exact for sequences without
+       non-ACGT bytes): the grid is sized without waiting for the device */
+    uint64_t ub_strips = 0;
+    for (uint64_t i = 0; i < nseq; i++) {
+        const uint64_t len = b->seq_len[i];
+        if (len + 2 > (uint64_t)k + (uint64_t)w) ub_strips += (len - k - w + 2 + (uint64_t)G.NWO - 1) / (uint64_t)G.NWO;
+    }
+    if (ub_strips >= 0x7FFFFFFFull) { delete s; return fail(c, NTL_EINVAL, "batch too large: too many strips"); }
+    DevBuf strip_tab;
+    if ((rc = strip_tab.alloc(c, (ub_strips + 1) * sizeof(StripEnt)))) { delete s; return rc; }
     {
         ProfSpan sp(c, "sketch_meta");
         HIPCHK(c, hipMemsetAsync(mask.p, 0, nmask * 4, c->stream));
+        HIPCHK(c, hipMemsetAsync(strip_tab.p, 0xFF, (ub_strips + 1) * sizeof(StripEnt), c->stream));
         if (nseq) {
             KTables K;
             K.run_n = run_n.as<uint32_t>(); K.run_ord = run_ord.as<uint32_t>();
             K.seq_M = seq_M.as<uint32_t>(); K.seq_nstrips = nstrips.as<uint32_t>();
             hipLaunchKernelGGL(seq_meta_kernel, dim3((unsigned)((nseq + 255) / 256)), dim3(256), 0, c->stream, T, K, k, w, G.NWO);
             HIPCHK(c, hipGetLastError());
-            if ((rc = device_scan(c, nstrips.as<uint32_t>(), strip_first.as<uint32_t>(), nseq, &total_strips))) { delete s; return rc; }
-            HIPCHK(c, hipMemcpyAsync(strip_first.as<uint32_t>() + nseq, &total_strips, 4, hipMemcpyHostToDevice, c->stream));
+            if ((rc = device_scan(c, nstrips.as<uint32_t>(), strip_first.as<uint32_t>(), nseq, nullptr))) { delete s; return rc; }
+            hipLaunchKernelGGL(strip_table_kernel, dim3((unsigned)((nseq + 255) / 256)), dim3(256), 0, c->stream,
+                               (const uint32_t *)strip_first.as<uint32_t>(), (uint32_t)nseq, G.NWO, strip_tab.as<StripEnt>(),
+                               (uint32_t)ub_strips);
+            HIPCHK(c, hipGetLastError());
         }
     }
-    if (total_strips) {
+    if (ub_strips) {
         SketchArgs A;
         A.T = T;
         A.run_n = run_n.as<uint32_t>(); A.run_ord = run_ord.as<uint32_t>(); A.seq_M = seq_M.as<uint32_t>();
-        A.strip_first = strip_first.as<uint32_t>(); A.mask = mask.as<uint32_t>(); A.G = G;
+        A.strip_tab = strip_tab.as<StripEnt>(); A.mask = mask.as<uint32_t>(); A.G = G;
         make_tables(k, A.roll_tab, A.seed_tab);
         A.g4 = (const uint64_t (*)[2])c->g4;
         ProfSpan sp(c, "sketch_mask");
-        if (C == 16) launch_mask<16>(c, A, total_strips, b->any_multi);
-        else if (C == 4) launch_mask<4>(c, A, total_strips, b->any_multi);
-        else launch_mask<1>(c, A, total_strips, b->any_multi);
+        if (C == 16) launch_mask<16>(c, A, (unsigned)ub_strips, b->any_multi);
+        else if (C == 4) launch_mask<4>(c, A, (unsigned)ub_strips, b->any_multi);
+        else launch_mask<1>(c, A, (unsigned)ub_strips, b->any_multi);
         HIPCHK(c, hipGetLastError());
     }
     {
@@ -557,8 +575,8 @@ extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_
                            (const uint32_t *)word_rank.as<uint32_t>(), nmask, total_mx, s->mx_off.as<uint32_t>());
         HIPCHK(c, hipGetLastError());
     }
-    /* temporaries go back to the cache only after the stream has consumed them */
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    /* temporaries return to the context's cache here; every later user of those blocks is queued on the
+       same stream behind the kernels above, so no wait is needed */
     *out = s;
     return NTL_OK;
 }
@@ -624,9 +642,11 @@ extern "C" int ntl_sketch_from_host(ntl_ctx *c, uint64_t nseq, const uint64_t *m
 struct ntl_index {
     ntl_ctx *c;
     int bits = 0;
-    uint64_t nslots = 0, size = 0;
+    uint64_t nslots = 0;
+    mutable uint64_t size = 0;
+    mutable bool size_known = false;
     uint32_t n_ctg = 0;
-    DevBuf slots, special, ctg_len;
+    DevBuf slots, special, ctg_len, cnt; /* cnt: device-side count of kept keys, fetched on demand */
 };
 
 extern "C" int ntl_index_build(ntl_ctx *c, const ntl_sketch *ctg, const uint32_t *ctg_len, uint32_t n_ctg, ntl_index **out)
@@ -643,7 +663,7 @@ extern "C" int ntl_index_build(ntl_ctx *c, const ntl_sketch *ctg, const uint32_t
     ix->bits = bits;
     ix->nslots = (uint64_t)1 << bits;
     int rc;
-    DevBuf cnt;
+    DevBuf &cnt = ix->cnt;
     if ((rc = ix->slots.alloc(c, ix->nslots * sizeof(IndexSlot))) || (rc = ix->special.alloc(c, sizeof(IndexSpecial))) ||
         (rc = ix->ctg_len.alloc(c, ((uint64_t)n_ctg + 1) * 4)) || (rc = cnt.alloc(c, 8))) { delete ix; return rc; }
     unsigned long long size = 0;
@@ -663,15 +683,27 @@ extern "C" int ntl_index_build(ntl_ctx *c, const ntl_sketch *ctg, const uint32_t
                            (const IndexSpecial *)ix->special.as<IndexSpecial>(), cnt.as<unsigned long long>());
         HIPCHK(c, hipGetLastError());
     }
-    HIPCHK(c, hipMemcpyAsync(&size, cnt.p, 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    ix->size = size;
+    (void)size;
     *out = ix;
     return NTL_OK;
 }
 
 extern "C" void ntl_index_destroy(ntl_index *ix) { delete ix; }
-extern "C" uint64_t ntl_index_size(const ntl_index *ix) { return ix ? ix->size : 0; }
+
+extern "C" uint64_t ntl_index_size(const ntl_index *ix)
+{
+    if (!ix) return 0;
+    if (!ix->size_known) {
+        unsigned long long v = 0;
+        hipSetDevice(ix->c->device);
+        if (hipMemcpyAsync(&v, ix->cnt.p, 8, hipMemcpyDeviceToHost, ix->c->stream) == hipSuccess &&
+            hipStreamSynchronize(ix->c->stream) == hipSuccess) {
+            ix->size = v;
+            ix->size_known = true;
+        }
+    }
+    return ix->size;
+}
 
 /* ------------------------------------------------------------------ map ------------------ */
 
@@ -719,6 +751,8 @@ extern "C" int ntl_map_run(ntl_ctx *c, const ntl_index *ix, const ntl_sketch *re
     A.n_maps = n3.as<uint32_t>(); A.n_hits = A.n_maps + (nreads + 1); A.n_pafs = A.n_hits + (nreads + 1);
     A.scr = scr.as<uint32_t>(); A.scr_stride = cap; A.err = err.as<uint32_t>();
     uint32_t tot[3] = {0, 0, 0};
+    unsigned long long nf = 0;
+    uint32_t errflag = 0;
     if (nreads) {
         {
             ProfSpan sp(c, "map");
@@ -728,7 +762,13 @@ extern "C" int ntl_map_run(ntl_ctx *c, const ntl_index *ix, const ntl_sketch *re
         ProfSpan sp(c, "compact");
         uint32_t *o = off3.as<uint32_t>();
         for (int i = 0; i < 3; i++)
-            if ((rc = device_scan(c, n3.as<uint32_t>() + i * (nreads + 1), o + i * (nreads + 1), nreads, &tot[i]))) { delete R; return rc; }
+            if ((rc = device_scan(c, n3.as<uint32_t>() + i * (nreads + 1), o + i * (nreads + 1), nreads, nullptr))) { delete R; return rc; }
+        /* the only wait of the call: three totals (to size the dense arrays), hit count, invariant flag */
+        for (int i = 0; i < 3; i++)
+            HIPCHK(c, hipMemcpyAsync(&tot[i], o + i * (nreads + 1) + nreads, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(&nf, nfound.p, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(&errflag, err.p, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
         R->n_maps = tot[0]; R->n_hits = tot[1]; R->n_pafs = tot[2];
         if ((rc = R->maps.alloc(c, (uint64_t)tot[0] * sizeof(MapRec))) || (rc = R->hits.alloc(c, (uint64_t)tot[1] * sizeof(HitRec))) ||
             (rc = R->pafs.alloc(c, (uint64_t)tot[2] * sizeof(PafRec)))) { delete R; return rc; }
@@ -737,11 +777,6 @@ extern "C" int ntl_map_run(ntl_ctx *c, const ntl_index *ix, const ntl_sketch *re
                            R->maps.as<MapRec>(), R->hits.as<HitRec>(), R->pafs.as<PafRec>());
         HIPCHK(c, hipGetLastError());
     }
-    unsigned long long nf = 0;
-    uint32_t errflag = 0;
-    HIPCHK(c, hipMemcpyAsync(&nf, nfound.p, 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(&errflag, err.p, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
     R->n_index_hits = nf;
     if (errflag) { delete R; return fail(c, NTL_EINTERNAL, "an accepted contig appeared twice in one read (bin/ntlink_utils.py:262-266)"); }
     *out = R;

@@ -67,10 +67,29 @@ __global__ void seq_meta_kernel(SeqTables T, KTables K, int k, int w, int NWO)
     K.seq_nstrips[s] = (nwin + (uint32_t)NWO - 1u) / (uint32_t)NWO;
 }
 
+struct StripEnt {
+    uint32_t seq;
+    int32_t E0;
+};
+
+/* strip table: strip_first[s] + i -> (s, i*NWO - 1) */
+__global__ void strip_table_kernel(const uint32_t *strip_first, uint32_t nseq, int NWO, StripEnt *tab, uint32_t cap)
+{
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nseq) return;
+    const uint32_t a = strip_first[s], b = strip_first[s + 1];
+    for (uint32_t i = a; i < b && i < cap; i++) {
+        StripEnt e;
+        e.seq = s;
+        e.E0 = (int32_t)((i - a) * (uint32_t)NWO) - 1;
+        tab[i] = e;
+    }
+}
+
 struct SketchArgs {
     SeqTables T;
     const uint32_t *run_n, *run_ord, *seq_M;
-    const uint32_t *strip_first; /* [nseq+1] exclusive scan of seq_nstrips */
+    const struct StripEnt *strip_tab; /* [grid] strip -> (sequence, first ordinal); seq = NTL_NONE past the last strip */
     uint32_t *mask;              /* 1 bit per global base index: k-mer starting there is a minimizer */
     SketchGeom G;
     uint64_t roll_tab[16][2];    /* [in<<2|out] = {seed[in]^srol^k(seed[out]), srol^k(seedc[in])^seedc[out]} */
@@ -117,19 +136,13 @@ __global__ __launch_bounds__(NT) void sketch_mask_kernel(SketchArgs A)
     const int L = threadIdx.x;
     const SketchGeom G = A.G; /* G.r0 == R0 (the host picks the instantiation) */
 
+    const StripEnt ent = A.strip_tab[blockIdx.x];
+    if (ent.seq == NTL_NONE) return; /* the grid is an upper bound of the number of strips */
     if (L == 0) {
-        /* strip -> sequence: largest s with strip_first[s] <= blockIdx.x */
-        uint32_t lo = 0, hi = A.T.nseq;
-        const uint32_t b = blockIdx.x;
-        while (hi - lo > 1) {
-            uint32_t mid = (lo + hi) >> 1;
-            if (A.strip_first[mid] <= b) lo = mid; else hi = mid;
-        }
-        const uint32_t s = lo;
-        const uint32_t i = b - A.strip_first[s];
+        const uint32_t s = ent.seq;
         StripInfo I;
         I.seq = s;
-        I.E0 = (int32_t)(i * (uint32_t)G.NWO) - 1;
+        I.E0 = ent.E0;
         I.M = A.seq_M[s];
         I.base = A.T.seq_base[s];
         const uint32_t e_lo = I.E0 < 0 ? 0u : (uint32_t)I.E0;
