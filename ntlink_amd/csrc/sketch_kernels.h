@@ -408,14 +408,32 @@ struct EmitArgs {
     const uint64_t (*g4)[2];
 };
 
+#define EMIT_SEQ_CAP 512 /* sequence starts of one tile cached in LDS */
+
+/* largest s in [lo, hi) with base[s] <= gp */
+__device__ __forceinline__ uint32_t seq_of(const uint64_t *base, uint32_t lo, uint32_t hi, uint64_t gp)
+{
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (base[mid] <= gp) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
 __global__ __launch_bounds__(EMIT_NT) void emit_kernel(EmitArgs A)
 {
     __shared__ uint32_t s_tmp[EMIT_NT];
     __shared__ uint32_t s_list[EMIT_CAP];
     __shared__ uint64_t s_seed[4][2];
+    __shared__ uint64_t s_base[EMIT_SEQ_CAP];
+    __shared__ uint32_t s_range[2];
     const int t = threadIdx.x;
     if (t < 4) { s_seed[t][0] = A.seed_tab[t][0]; s_seed[t][1] = A.seed_tab[t][1]; }
     const uint64_t tile_w0 = (uint64_t)blockIdx.x * EMIT_TILE;
+    if (t == 0) { /* sequences that overlap this tile of 65536 base positions */
+        s_range[0] = seq_of(A.seq_base, 0, A.nseq, tile_w0 * 32);
+        s_range[1] = seq_of(A.seq_base, 0, A.nseq, tile_w0 * 32 + (uint64_t)EMIT_TILE * 32 - 1) + 1;
+    }
     const uint64_t w0 = tile_w0 + (uint64_t)t * EMIT_WPT;
     uint32_t words[EMIT_WPT];
     uint32_t c = 0;
@@ -426,6 +444,10 @@ __global__ __launch_bounds__(EMIT_NT) void emit_kernel(EmitArgs A)
     }
     uint32_t total;
     const uint32_t excl = block_excl_scan<EMIT_NT>(c, s_tmp, total);
+    const uint32_t s_lo = s_range[0], s_hi = s_range[1]; /* candidates [s_lo, s_hi) */
+    const bool cached = s_hi - s_lo <= EMIT_SEQ_CAP;
+    if (cached)
+        for (uint32_t i = t; i < s_hi - s_lo; i += EMIT_NT) s_base[i] = A.seq_base[s_lo + i];
     const uint32_t tile_base = A.tile_off[blockIdx.x];
     {
         uint32_t r = tile_base + excl;
@@ -451,19 +473,16 @@ __global__ __launch_bounds__(EMIT_NT) void emit_kernel(EmitArgs A)
         const uint32_t n = total - r0 < EMIT_CAP ? total - r0 : EMIT_CAP;
         for (uint32_t i = t; i < n; i += EMIT_NT) {
             const uint64_t gp = tile_w0 * 32 + s_list[i];
-            uint32_t lo = 0, hi = A.nseq; /* largest s with seq_base[s] <= gp */
-            while (hi - lo > 1) {
-                uint32_t mid = (lo + hi) >> 1;
-                if (A.seq_base[mid] <= gp) lo = mid; else hi = mid;
-            }
+            const uint32_t sq = cached ? s_lo + seq_of(s_base, 0, s_hi - s_lo, gp) : seq_of(A.seq_base, s_lo, s_hi, gp);
+            const uint64_t sb = cached ? s_base[sq - s_lo] : A.seq_base[sq];
             uint64_t fwd, rev;
             hash_init(A.packed, gp, A.k, A.g4, s_seed, fwd, rev);
             uint64_t tt = (fwd + rev) * A.mult;
             tt ^= tt >> 27;
             MxRecord R;
             R.hash = tt;
-            R.pos = (uint32_t)(gp - A.seq_base[lo]);
-            R.meta = (lo << 1) | (fwd <= rev ? 1u : 0u);
+            R.pos = (uint32_t)(gp - sb);
+            R.meta = (sq << 1) | (fwd <= rev ? 1u : 0u);
             A.out[tile_base + r0 + i] = R;
         }
         __syncthreads();
