@@ -238,12 +238,16 @@ __global__ __launch_bounds__(MAP_NT) void map_kernel(MapArgs A)
     const MapParamsDev P = A.P;
     uint32_t R = 0, n = 0, np = 0;
 
-    /* candidates found in the index */
-    uint32_t nc = 0;
-    for (uint32_t c = 0; c < nmx; c += MAP_NT) {
-        const uint32_t i = c + lane;
-        const bool v = i < nmx && (A.cand[m0 + i].meta & 1u);
-        nc += (uint32_t)__popcll(__ballot(v));
+    /* candidates found in the index: counted only when the read could overflow the LDS staging
+       (hits <= minimizers, so short sketches need no counting pass) */
+    uint32_t nc = nmx;
+    if (nmx > MAP_CAPH) {
+        nc = 0;
+        for (uint32_t c = 0; c < nmx; c += MAP_NT) {
+            const uint32_t i = c + lane;
+            const bool v = i < nmx && (A.cand[m0 + i].meta & 1u);
+            nc += (uint32_t)__popcll(__ballot(v));
+        }
     }
     HitArr H;
     if (nc <= MAP_CAPH) {

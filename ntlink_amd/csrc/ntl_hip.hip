@@ -10,6 +10,7 @@
 #include <string.h>
 #include <algorithm>
 #include <map>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -461,21 +462,22 @@ static void make_g4(uint64_t g4[256][2])
     }
 }
 
-template <int C, int R0>
+template <int C, int NT, int R0>
 static void launch_mask_r0(ntl_ctx *c, const SketchArgs &A, unsigned strips, bool multi)
 {
     if (A.G.r0 == R0) {
-        hipLaunchKernelGGL((sketch_mask_kernel<C, SK_NT, false, R0>), dim3(strips), dim3(SK_NT), 0, c->stream, A);
-        if (multi) hipLaunchKernelGGL((sketch_mask_kernel<C, SK_NT, true, R0>), dim3(strips), dim3(SK_NT), 0, c->stream, A);
+        hipLaunchKernelGGL((sketch_mask_kernel<C, NT, false, R0>), dim3(strips), dim3(NT), 0, c->stream, A);
+        if (multi) hipLaunchKernelGGL((sketch_mask_kernel<C, NT, true, R0>), dim3(strips), dim3(NT), 0, c->stream, A);
         return;
     }
-    if constexpr (R0 + 1 < C) launch_mask_r0<C, R0 + 1>(c, A, strips, multi);
+    if constexpr (R0 + 1 < C) launch_mask_r0<C, NT, R0 + 1>(c, A, strips, multi);
 }
 
 template <int C>
-static void launch_mask(ntl_ctx *c, const SketchArgs &A, unsigned strips, bool multi)
+static void launch_mask(ntl_ctx *c, const SketchArgs &A, unsigned strips, bool multi, int nt)
 {
-    launch_mask_r0<C, 0>(c, A, strips, multi);
+    if (C == 16 && nt == 128) launch_mask_r0<C, 128, 0>(c, A, strips, multi);
+    else launch_mask_r0<C, SK_NT, 0>(c, A, strips, multi);
 }
 
 extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_sketch **out)
@@ -492,11 +494,19 @@ extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_
     SketchGeom G;
     G.k = k; G.w = w;
     G.a = (w - C) / C; G.r0 = (w - C) % C;
-    G.LW = SK_NT - (G.a + 2);
+    /* lanes per strip: 128-lane strips waste fewer lanes on the last strip of a ~10 kb read; the halo
+       (a+2 lanes) makes them a loss for large windows (measured: +5 % at w=100, -3 % at w=250) */
+    int nt = (C == 16 && (w - C) / C + 2 <= 10) ? 128 : SK_NT;
+    if (const char *e = getenv("NTL_SKETCH_NT")) { /* tuning knob */
+        const int v = atoi(e);
+        if (v == 256 || (v == 128 && C == 16)) nt = v;
+    }
+    G.LW = nt - (G.a + 2);
     G.NWO = G.LW * C - 1;
     if (G.LW < 2 || G.NWO < 1) return fail(c, NTL_EINVAL, "window size too large for this build (w <= ~4000)");
     const uint64_t nseq = b->nseq;
-    ntl_sketch *s = new ntl_sketch();
+    std::unique_ptr<ntl_sketch> s_guard(new ntl_sketch());
+    ntl_sketch *s = s_guard.get();
     s->c = c; s->nseq = nseq;
     int rc;
     DevBuf run_n, run_ord, seq_M, nstrips, strip_first, mask, tile, tot, word_rank;
@@ -506,7 +516,6 @@ extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_
         (rc = seq_M.alloc(c, (nseq + 1) * 4)) || (rc = nstrips.alloc(c, (nseq + 1) * 4)) ||
         (rc = strip_first.alloc(c, (nseq + 2) * 4)) || (rc = mask.alloc(c, nmask * 4)) ||
         (rc = s->mx_off.alloc(c, (nseq + 1) * 4))) {
-        delete s;
         return rc;
     }
     SeqTables T;
@@ -521,9 +530,9 @@ extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_
         const uint64_t len = b->seq_len[i];
         if (len + 2 > (uint64_t)k + (uint64_t)w) ub_strips += (len - k - w + 2 + (uint64_t)G.NWO - 1) / (uint64_t)G.NWO;
     }
-    if (ub_strips >= 0x7FFFFFFFull) { delete s; return fail(c, NTL_EINVAL, "batch too large: too many strips"); }
+    if (ub_strips >= 0x7FFFFFFFull) return fail(c, NTL_EINVAL, "batch too large: too many strips");
     DevBuf strip_tab;
-    if ((rc = strip_tab.alloc(c, (ub_strips + 1) * sizeof(StripEnt)))) { delete s; return rc; }
+    if ((rc = strip_tab.alloc(c, (ub_strips + 1) * sizeof(StripEnt)))) return rc;
     {
         ProfSpan sp(c, "sketch_meta");
         HIPCHK(c, hipMemsetAsync(mask.p, 0, nmask * 4, c->stream));
@@ -534,7 +543,7 @@ extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_
             K.seq_M = seq_M.as<uint32_t>(); K.seq_nstrips = nstrips.as<uint32_t>();
             hipLaunchKernelGGL(seq_meta_kernel, dim3((unsigned)((nseq + 255) / 256)), dim3(256), 0, c->stream, T, K, k, w, G.NWO);
             HIPCHK(c, hipGetLastError());
-            if ((rc = device_scan(c, nstrips.as<uint32_t>(), strip_first.as<uint32_t>(), nseq, nullptr))) { delete s; return rc; }
+            if ((rc = device_scan(c, nstrips.as<uint32_t>(), strip_first.as<uint32_t>(), nseq, nullptr))) return rc;
             hipLaunchKernelGGL(strip_table_kernel, dim3((unsigned)((nseq + 255) / 256)), dim3(256), 0, c->stream,
                                (const uint32_t *)strip_first.as<uint32_t>(), (uint32_t)nseq, G.NWO, strip_tab.as<StripEnt>(),
                                (uint32_t)ub_strips);
@@ -549,16 +558,16 @@ extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_
         make_tables(k, A.roll_tab, A.seed_tab);
         A.g4 = (const uint64_t (*)[2])c->g4;
         ProfSpan sp(c, "sketch_mask");
-        if (C == 16) launch_mask<16>(c, A, (unsigned)ub_strips, b->any_multi);
-        else if (C == 8) launch_mask<8>(c, A, (unsigned)ub_strips, b->any_multi);
-        else if (C == 4) launch_mask<4>(c, A, (unsigned)ub_strips, b->any_multi);
-        else launch_mask<1>(c, A, (unsigned)ub_strips, b->any_multi);
+        if (C == 16) launch_mask<16>(c, A, (unsigned)ub_strips, b->any_multi, nt);
+        else if (C == 8) launch_mask<8>(c, A, (unsigned)ub_strips, b->any_multi, nt);
+        else if (C == 4) launch_mask<4>(c, A, (unsigned)ub_strips, b->any_multi, nt);
+        else launch_mask<1>(c, A, (unsigned)ub_strips, b->any_multi, nt);
         HIPCHK(c, hipGetLastError());
     }
     {
         ProfSpan sp(c, "sketch_emit");
         const uint64_t tiles = (nmask + EMIT_TILE - 1) / EMIT_TILE;
-        if ((rc = tile.alloc(c, tiles * 4)) || (rc = tot.alloc(c, 4)) || (rc = word_rank.alloc(c, nmask * 4))) { delete s; return rc; }
+        if ((rc = tile.alloc(c, tiles * 4)) || (rc = tot.alloc(c, 4)) || (rc = word_rank.alloc(c, nmask * 4))) return rc;
         hipLaunchKernelGGL(mask_count_kernel, dim3((unsigned)tiles), dim3(EMIT_NT), 0, c->stream,
                            (const uint32_t *)mask.as<uint32_t>(), nmask, tile.as<uint32_t>());
         hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(SCAN_NT), 0, c->stream, tile.as<uint32_t>(), tiles, tot.as<uint32_t>());
@@ -566,7 +575,7 @@ extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_
         HIPCHK(c, hipMemcpyAsync(&total_mx, tot.p, 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         s->count = total_mx;
-        if ((rc = s->records.alloc(c, (uint64_t)total_mx * sizeof(MxRecord)))) { delete s; return rc; }
+        if ((rc = s->records.alloc(c, (uint64_t)total_mx * sizeof(MxRecord)))) return rc;
         EmitArgs E;
         E.packed = T.packed; E.seq_base = T.seq_base; E.nseq = (uint32_t)nseq; E.mask = mask.as<uint32_t>();
         E.nwords = nmask; E.tile_off = tile.as<uint32_t>(); E.word_rank = word_rank.as<uint32_t>();
@@ -582,7 +591,7 @@ extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_
     }
     /* temporaries return to the context's cache here; every later user of those blocks is queued on the
        same stream behind the kernels above, so no wait is needed */
-    *out = s;
+    *out = s_guard.release();
     return NTL_OK;
 }
 
@@ -652,6 +661,7 @@ struct ntl_index {
     mutable bool size_known = false;
     uint32_t n_ctg = 0;
     DevBuf slots, special, ctg_len, cnt; /* cnt: device-side count of kept keys, fetched on demand */
+    std::vector<uint32_t> h_ctg_len;     /* source of the asynchronous upload: must outlive it */
 };
 
 extern "C" int ntl_index_build(ntl_ctx *c, const ntl_sketch *ctg, const uint32_t *ctg_len, uint32_t n_ctg, ntl_index **out)
@@ -661,7 +671,8 @@ extern "C" int ntl_index_build(ntl_ctx *c, const ntl_sketch *ctg, const uint32_t
     if ((uint64_t)n_ctg != ctg->nseq) return fail(c, NTL_EINVAL, "n_ctg must equal the number of sketched contigs");
     if (n_ctg >= (1u << 30)) return fail(c, NTL_EINVAL, "too many contigs");
     hipSetDevice(c->device);
-    ntl_index *ix = new ntl_index();
+    std::unique_ptr<ntl_index> ix_guard(new ntl_index());
+    ntl_index *ix = ix_guard.get();
     ix->c = c; ix->n_ctg = n_ctg;
     int bits = 10;
     while (((uint64_t)1 << bits) < 2 * ctg->count + 2) bits++;
@@ -670,11 +681,12 @@ extern "C" int ntl_index_build(ntl_ctx *c, const ntl_sketch *ctg, const uint32_t
     int rc;
     DevBuf &cnt = ix->cnt;
     if ((rc = ix->slots.alloc(c, ix->nslots * sizeof(IndexSlot))) || (rc = ix->special.alloc(c, sizeof(IndexSpecial))) ||
-        (rc = ix->ctg_len.alloc(c, ((uint64_t)n_ctg + 1) * 4)) || (rc = cnt.alloc(c, 8))) { delete ix; return rc; }
+        (rc = ix->ctg_len.alloc(c, ((uint64_t)n_ctg + 1) * 4)) || (rc = cnt.alloc(c, 8))) return rc;
     unsigned long long size = 0;
     {
         ProfSpan sp(c, "index");
-        if (n_ctg) HIPCHK(c, hipMemcpyAsync(ix->ctg_len.p, ctg_len, (uint64_t)n_ctg * 4, hipMemcpyHostToDevice, c->stream));
+        ix->h_ctg_len.assign(ctg_len, ctg_len + n_ctg);
+        if (n_ctg) HIPCHK(c, hipMemcpyAsync(ix->ctg_len.p, ix->h_ctg_len.data(), (uint64_t)n_ctg * 4, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemsetAsync(ix->special.p, 0, sizeof(IndexSpecial), c->stream));
         HIPCHK(c, hipMemsetAsync(cnt.p, 0, 8, c->stream));
         hipLaunchKernelGGL(index_clear_kernel, dim3((unsigned)((ix->nslots + 255) / 256)), dim3(256), 0, c->stream,
@@ -689,7 +701,7 @@ extern "C" int ntl_index_build(ntl_ctx *c, const ntl_sketch *ctg, const uint32_t
         HIPCHK(c, hipGetLastError());
     }
     (void)size;
-    *out = ix;
+    *out = ix_guard.release();
     return NTL_OK;
 }
 
@@ -725,7 +737,8 @@ extern "C" int ntl_map_run(ntl_ctx *c, const ntl_index *ix, const ntl_sketch *re
     *out = nullptr;
     hipSetDevice(c->device);
     const uint64_t nreads = reads->nseq, nmx = reads->count;
-    ntl_mapres *R = new ntl_mapres();
+    std::unique_ptr<ntl_mapres> R_guard(new ntl_mapres());
+    ntl_mapres *R = R_guard.get();
     R->c = c;
     int rc;
     DevBuf cand, rlen, smaps, shits, spafs, n3, off3, scr, nfound, err;
@@ -734,7 +747,7 @@ extern "C" int ntl_map_run(ntl_ctx *c, const ntl_index *ix, const ntl_sketch *re
         (rc = smaps.alloc(c, cap * sizeof(MapRec))) || (rc = shits.alloc(c, cap * sizeof(HitRec))) ||
         (rc = spafs.alloc(c, cap * sizeof(PafRec))) || (rc = n3.alloc(c, 3 * (nreads + 1) * 4)) ||
         (rc = off3.alloc(c, 3 * (nreads + 1) * 4)) || (rc = scr.alloc(c, (uint64_t)(MAP_NHA + MAP_NRA) * cap * 4)) ||
-        (rc = nfound.alloc(c, 8)) || (rc = err.alloc(c, 4))) { delete R; return rc; }
+        (rc = nfound.alloc(c, 8)) || (rc = err.alloc(c, 4))) return rc;
     if (nreads) HIPCHK(c, hipMemcpyAsync(rlen.p, read_len, nreads * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(nfound.p, 0, 8, c->stream));
     HIPCHK(c, hipMemsetAsync(err.p, 0, 4, c->stream));
@@ -767,7 +780,7 @@ extern "C" int ntl_map_run(ntl_ctx *c, const ntl_index *ix, const ntl_sketch *re
         ProfSpan sp(c, "compact");
         uint32_t *o = off3.as<uint32_t>();
         for (int i = 0; i < 3; i++)
-            if ((rc = device_scan(c, n3.as<uint32_t>() + i * (nreads + 1), o + i * (nreads + 1), nreads, nullptr))) { delete R; return rc; }
+            if ((rc = device_scan(c, n3.as<uint32_t>() + i * (nreads + 1), o + i * (nreads + 1), nreads, nullptr))) return rc;
         /* the only wait of the call: three totals (to size the dense arrays), hit count, invariant flag */
         for (int i = 0; i < 3; i++)
             HIPCHK(c, hipMemcpyAsync(&tot[i], o + i * (nreads + 1) + nreads, 4, hipMemcpyDeviceToHost, c->stream));
@@ -776,15 +789,15 @@ extern "C" int ntl_map_run(ntl_ctx *c, const ntl_index *ix, const ntl_sketch *re
         HIPCHK(c, hipStreamSynchronize(c->stream));
         R->n_maps = tot[0]; R->n_hits = tot[1]; R->n_pafs = tot[2];
         if ((rc = R->maps.alloc(c, (uint64_t)tot[0] * sizeof(MapRec))) || (rc = R->hits.alloc(c, (uint64_t)tot[1] * sizeof(HitRec))) ||
-            (rc = R->pafs.alloc(c, (uint64_t)tot[2] * sizeof(PafRec)))) { delete R; return rc; }
+            (rc = R->pafs.alloc(c, (uint64_t)tot[2] * sizeof(PafRec)))) return rc;
         hipLaunchKernelGGL(map_gather_kernel, dim3((unsigned)nreads), dim3(64), 0, c->stream, A, (const uint32_t *)o,
                            (const uint32_t *)(o + (nreads + 1)), (const uint32_t *)(o + 2 * (nreads + 1)),
                            R->maps.as<MapRec>(), R->hits.as<HitRec>(), R->pafs.as<PafRec>());
         HIPCHK(c, hipGetLastError());
     }
     R->n_index_hits = nf;
-    if (errflag) { delete R; return fail(c, NTL_EINTERNAL, "an accepted contig appeared twice in one read (bin/ntlink_utils.py:262-266)"); }
-    *out = R;
+    if (errflag) return fail(c, NTL_EINTERNAL, "an accepted contig appeared twice in one read (bin/ntlink_utils.py:262-266)");
+    *out = R_guard.release();
     return NTL_OK;
 }
 
