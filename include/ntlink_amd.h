@@ -154,6 +154,35 @@ uint64_t ntl_mapres_n_pafs(const ntl_mapres *r);
 uint64_t ntl_mapres_n_index_hits(const ntl_mapres *r);
 int ntl_mapres_download(const ntl_mapres *r, ntl_mapping *maps, ntl_hit *hits, ntl_paf *pafs);
 
+/* ---- host-side native I/O (no GPU involved) ------------------------------------------------ */
+
+/* FASTA/FASTQ(.gz) reader = `gzip -cd -f FILE | SeqReader` of the reference's pipe
+ * (ntLink:113-117,222-223); record semantics of bin/read_fasta.py:6-46.  path "-" = stdin. */
+typedef struct ntl_fastx ntl_fastx;
+int ntl_fastx_open(const char *path, ntl_fastx **out);
+void ntl_fastx_close(ntl_fastx *r);
+const char *ntl_fastx_error(const ntl_fastx *r);
+/* Collects records until at least max_bases bases are held (0 = whole input); *nseq == 0 at the end.
+ * The accessors below stay valid until the next call: sequence i is seqs[offsets[i]..offsets[i+1]),
+ * its id names[name_offsets[i]..name_offsets[i+1]). */
+int ntl_fastx_next(ntl_fastx *r, uint64_t max_bases, uint64_t *nseq);
+const char *ntl_fastx_seqs(const ntl_fastx *r);
+const uint64_t *ntl_fastx_offsets(const ntl_fastx *r);
+const char *ntl_fastx_names(const ntl_fastx *r);
+const uint64_t *ntl_fastx_name_offsets(const ntl_fastx *r);
+
+/* Text emitters, written to file descriptor fd.  Names are concatenated ids + offsets[n+1].
+ * ntl_write_indexlr: `id\t[len\t]H:pos:strand ...` (ntLink:199,223); lengths == NULL omits --len.
+ * ntl_write_verbose: <prefix>.verbose_mapping.tsv (bin/ntlink_pair.py:308-313,382-388).
+ * ntl_write_paf:     <prefix>.paf (bin/ntlink_paf_output.py:131-135). */
+int ntl_write_indexlr(int fd, uint64_t nseq, const char *names, const uint64_t *name_off, const uint32_t *lengths,
+                      const uint64_t *mx_off, const uint64_t *hash, const uint32_t *pos, const uint8_t *strand);
+int ntl_write_verbose(int fd, const ntl_mapping *maps, uint64_t n_maps, const ntl_hit *hits,
+                      const char *read_names, const uint64_t *read_name_off,
+                      const char *ctg_names, const uint64_t *ctg_name_off);
+int ntl_write_paf(int fd, const ntl_paf *pafs, uint64_t n, const char *read_names, const uint64_t *read_name_off,
+                  const uint32_t *read_len, const char *ctg_names, const uint64_t *ctg_name_off, const uint32_t *ctg_len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,6 +22,8 @@ SYMBOLS = [
     "ntl_index_build", "ntl_index_destroy", "ntl_index_size",
     "ntl_map_run", "ntl_mapres_destroy", "ntl_mapres_n_mappings", "ntl_mapres_n_hits", "ntl_mapres_n_pafs",
     "ntl_mapres_n_index_hits", "ntl_mapres_download",
+    "ntl_fastx_open", "ntl_fastx_close", "ntl_fastx_error", "ntl_fastx_next", "ntl_fastx_seqs", "ntl_fastx_offsets",
+    "ntl_fastx_names", "ntl_fastx_name_offsets", "ntl_write_indexlr", "ntl_write_verbose", "ntl_write_paf",
 ]
 
 MAPPING_DT = np.dtype([("read", "<u4"), ("ctg", "<u4"), ("n_hits", "<u4"), ("pad", "<u4"), ("hit_off", "<u8")])
@@ -92,6 +94,19 @@ def load(path=None):
         f.argtypes = [vp]
         f.restype = C.c_uint64
     L.ntl_mapres_download.argtypes = [vp, vp, vp, vp]
+    L.ntl_fastx_open.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.ntl_fastx_close.argtypes = [vp]
+    L.ntl_fastx_close.restype = None
+    L.ntl_fastx_error.argtypes = [vp]
+    L.ntl_fastx_error.restype = C.c_char_p
+    L.ntl_fastx_next.argtypes = [vp, C.c_uint64, u64p]
+    for nm in ("seqs", "offsets", "names", "name_offsets"):
+        f = getattr(L, "ntl_fastx_" + nm)
+        f.argtypes = [vp]
+        f.restype = vp
+    L.ntl_write_indexlr.argtypes = [C.c_int, C.c_uint64, vp, u64p, u32p, u64p, u64p, u32p, u8p]
+    L.ntl_write_verbose.argtypes = [C.c_int, vp, C.c_uint64, vp, vp, u64p, vp, u64p]
+    L.ntl_write_paf.argtypes = [C.c_int, vp, C.c_uint64, vp, u64p, u32p, vp, u64p, u32p]
     _libs[path] = L
     return L
 

@@ -6,14 +6,50 @@
                   (bin/ntlink_pair.py:308-313,382-388)
 * PAF-like        12 columns (bin/ntlink_paf_output.py:131-135)
 """
+import ctypes as C
+
 import numpy as np
 
+from .seqio import Names
+
 _STRAND = ("-", "+")
+
+
+def _fd(fh):
+    """File descriptor of a real file (native writers), or None for in-memory text objects."""
+    try:
+        fd = fh.fileno()
+    except (AttributeError, OSError, ValueError):
+        return None
+    fh.flush()
+    return fd
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def _native():
+    from . import capi
+    return capi.load()
 
 
 def write_indexlr(fh, names, lengths, mx_off, mx_hash, pos, strand, with_len):
     """Every record prints its id even without minimizers (such lines are skipped by the consumers,
     bin/ntlink_pair.py:200,357)."""
+    fd = _fd(fh)
+    if fd is not None:  # native emitter (csrc/ntl_io.cpp)
+        nm = Names.of(names)
+        ln = np.ascontiguousarray(lengths, np.uint32) if with_len else None
+        off64 = np.ascontiguousarray(mx_off, np.uint64)
+        h = np.ascontiguousarray(mx_hash, np.uint64); p = np.ascontiguousarray(pos, np.uint32)
+        st = np.ascontiguousarray(strand, np.uint8)
+        rc = _native().ntl_write_indexlr(fd, len(nm), nm.blob.ctypes.data, _p(nm.off, C.c_uint64),
+                                         _p(ln, C.c_uint32) if with_len else None, _p(off64, C.c_uint64),
+                                         _p(h, C.c_uint64), _p(p, C.c_uint32), _p(st, C.c_uint8))
+        if rc != 0:
+            raise OSError("write failed")
+        return
     hs = mx_hash.tolist()
     ps = pos.tolist()
     ss = strand.tolist()
@@ -50,6 +86,15 @@ def parse_indexlr(fh, with_len):
 
 def write_verbose(fh, res, read_names, ctg_names, read_base=0):
     maps, hits = res["maps"], res["hits"]
+    fd = _fd(fh)
+    if fd is not None and read_base == 0:
+        rn, cn = Names.of(read_names), Names.of(ctg_names)
+        m = np.ascontiguousarray(maps); h = np.ascontiguousarray(hits)
+        rc = _native().ntl_write_verbose(fd, m.ctypes.data, len(m), h.ctypes.data, rn.blob.ctypes.data, _p(rn.off, C.c_uint64),
+                                         cn.blob.ctypes.data, _p(cn.off, C.c_uint64))
+        if rc != 0:
+            raise OSError("write failed")
+        return
     cp = hits["ctg_pos"].tolist(); rp = hits["read_pos"].tolist()
     cs = hits["ctg_strand"].tolist(); rs = hits["read_strand"].tolist()
     for r, c, n, o in zip(maps["read"].tolist(), maps["ctg"].tolist(), maps["n_hits"].tolist(), maps["hit_off"].tolist()):
@@ -59,6 +104,16 @@ def write_verbose(fh, res, read_names, ctg_names, read_base=0):
 
 def write_paf(fh, res, read_names, read_len, ctg_names, ctg_len, read_base=0):
     p = res["pafs"]
+    fd = _fd(fh)
+    if fd is not None and read_base == 0:
+        rn, cn = Names.of(read_names), Names.of(ctg_names)
+        q = np.ascontiguousarray(p)
+        rl = np.ascontiguousarray(read_len, np.uint32); cl = np.ascontiguousarray(ctg_len, np.uint32)
+        rc = _native().ntl_write_paf(fd, q.ctypes.data, len(q), rn.blob.ctypes.data, _p(rn.off, C.c_uint64), _p(rl, C.c_uint32),
+                                     cn.blob.ctypes.data, _p(cn.off, C.c_uint64), _p(cl, C.c_uint32))
+        if rc != 0:
+            raise OSError("write failed")
+        return
     for r, c, qs, qe, ts, te, n, st in zip(p["read"].tolist(), p["ctg"].tolist(), p["q_start"].tolist(), p["q_end"].tolist(),
                                             p["t_start"].tolist(), p["t_end"].tolist(), p["n_hits"].tolist(), p["strand"].tolist()):
         fh.write(f"{read_names[r + read_base]}\t{int(read_len[r + read_base])}\t{qs}\t{qe}\t{_STRAND[st]}\t"

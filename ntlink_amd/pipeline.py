@@ -78,11 +78,8 @@ def run_indexlr(dev, paths, k, w, out, with_len, batch_bases=DEFAULT_BATCH_BASES
 
 
 def _contig_lengths(fasta):
-    names, lens = [], []
-    for name, seq in seqio.read_fastx(fasta):
-        names.append(name)
-        lens.append(len(seq))
-    return names, np.array(lens, np.uint32)
+    ss = seqio.load_all([fasta])
+    return ss.names.tolist(), ss.lengths
 
 
 def run_ntlink_pair(dev, args):

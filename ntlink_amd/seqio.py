@@ -62,11 +62,59 @@ def read_fastx(path):
                 yield name, seq
 
 
+class Names:
+    """Sequence ids as one byte blob + offsets[n+1] (the form the native reader and writers use), with
+    list-like access for the Python host."""
+
+    def __init__(self, blob, off):
+        self.blob = blob if isinstance(blob, np.ndarray) else np.frombuffer(blob, np.uint8)
+        self.off = np.ascontiguousarray(off, np.uint64)
+        self._list = None
+
+    @classmethod
+    def from_list(cls, names):
+        enc = [n.encode() for n in names]
+        off = np.zeros(len(enc) + 1, np.uint64)
+        if enc:
+            np.cumsum(np.fromiter((len(e) for e in enc), np.uint64, len(enc)), out=off[1:])
+        obj = cls(np.frombuffer(b"".join(enc), np.uint8) if enc else np.zeros(0, np.uint8), off)
+        obj._list = list(names)
+        return obj
+
+    @classmethod
+    def of(cls, names):
+        return names if isinstance(names, cls) else cls.from_list(names)
+
+    def tolist(self):
+        if self._list is None:
+            raw = self.blob.tobytes()
+            o = self.off.tolist()
+            self._list = [raw[o[i]:o[i + 1]].decode() for i in range(len(o) - 1)]
+        return self._list
+
+    def __len__(self):
+        return len(self.off) - 1
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            lo, hi, step = i.indices(len(self))
+            assert step == 1
+            b0, b1 = int(self.off[lo]), int(self.off[hi]) if hi > lo else int(self.off[lo])
+            return Names(self.blob[b0:b1], self.off[lo:max(hi, lo) + 1] - np.uint64(b0))
+        return self.tolist()[i]
+
+    def __iter__(self):
+        return iter(self.tolist())
+
+    def __eq__(self, other):
+        return self.tolist() == (other.tolist() if isinstance(other, Names) else list(other))
+
+
 class SeqSet:
     """Names + one contiguous uint8 buffer + offsets: the form ntl_batch_create takes."""
 
     def __init__(self, names, buf, offsets):
-        self.names, self.buf, self.offsets = names, buf, offsets
+        self.names, self.buf, self.offsets = Names.of(names), buf, offsets
 
     def __len__(self):
         return len(self.names)
@@ -81,32 +129,58 @@ class SeqSet:
 
 
 def load(paths, max_bases=None):
-    """Read whole files.  With max_bases, yields SeqSets of about that many bases (batches)."""
+    """Native reader (ntl_fastx_*, csrc/ntl_io.cpp).  Whole input as one SeqSet, or, with max_bases,
+    SeqSets of about that many bases; several files are concatenated in the order given and a batch
+    never spans two files."""
+    import ctypes as C
+    from . import capi
+    L = capi.load()
     if isinstance(paths, str):
         paths = [paths]
+    whole = []
+    for path in paths:
+        h = C.c_void_p()
+        if L.ntl_fastx_open(path.encode(), C.byref(h)) != 0:
+            raise OSError(f"cannot open {path}")
+        try:
+            while True:
+                n = C.c_uint64()
+                if L.ntl_fastx_next(h, int(max_bases or 0), C.byref(n)) != 0:
+                    raise OSError(f"{path}: {L.ntl_fastx_error(h).decode()}")
+                n = n.value
+                if n == 0:
+                    break
+                off = np.frombuffer((C.c_uint64 * (n + 1)).from_address(L.ntl_fastx_offsets(h)), np.uint64).copy()
+                noff = np.frombuffer((C.c_uint64 * (n + 1)).from_address(L.ntl_fastx_name_offsets(h)), np.uint64).copy()
+                nb, nn = int(off[-1]), int(noff[-1])
+                buf = np.frombuffer((C.c_uint8 * nb).from_address(L.ntl_fastx_seqs(h)), np.uint8).copy() if nb else np.zeros(0, np.uint8)
+                names = np.frombuffer((C.c_uint8 * nn).from_address(L.ntl_fastx_names(h)), np.uint8).copy() if nn else np.zeros(0, np.uint8)
+                ss = SeqSet(Names(names, noff), buf, off)
+                if max_bases is None:
+                    whole.append(ss)
+                else:
+                    yield ss
+                if max_bases is None:
+                    break
+        finally:
+            L.ntl_fastx_close(h)
+    if max_bases is None:
+        yield concat(whole)
 
-    def gen():
-        for p in paths:
-            yield from read_fastx(p)
 
-    names, parts, total = [], [], 0
-    for name, seq in gen():
-        names.append(name)
-        parts.append(seq)
-        total += len(seq)
-        if max_bases is not None and total >= max_bases:
-            yield _pack(names, parts)
-            names, parts, total = [], [], 0
-    if names or max_bases is None:
-        yield _pack(names, parts)
-
-
-def _pack(names, parts):
-    off = np.zeros(len(parts) + 1, np.uint64)
-    if parts:
-        np.cumsum(np.fromiter((len(p) for p in parts), np.uint64, len(parts)), out=off[1:])
-    buf = np.frombuffer(b"".join(parts), np.uint8) if parts else np.zeros(0, np.uint8)
-    return SeqSet(names, buf, off)
+def concat(sets):
+    if len(sets) == 1:
+        return sets[0]
+    if not sets:
+        return SeqSet(Names(np.zeros(0, np.uint8), np.zeros(1, np.uint64)), np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+    bufs = [s.buf for s in sets]
+    offs, noffs, b0, n0 = [np.zeros(1, np.uint64)], [np.zeros(1, np.uint64)], 0, 0
+    for s in sets:
+        offs.append(s.offsets[1:] + np.uint64(b0))
+        noffs.append(s.names.off[1:] + np.uint64(n0))
+        b0 += int(s.offsets[-1])
+        n0 += int(s.names.off[-1])
+    return SeqSet(Names(np.concatenate([s.names.blob for s in sets]), np.concatenate(noffs)), np.concatenate(bufs), np.concatenate(offs))
 
 
 def load_all(paths):

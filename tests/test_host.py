@@ -123,3 +123,42 @@ def test_cli_surfaces():
     assert cli.ntlink_main(["help"]) == 0
     assert cli.ntlink_main(["scaffold", "target=a", "reads=b"]) == 2
     assert cli.ntlink_main(["pair", "-B", "target=a"]) == 2
+
+
+@pytest.mark.parametrize("tag,target,reads,k,w,gold", [FIXTURES[1], FIXTURES[3]])
+def test_native_writers_equal_python_writers(tag, target, reads, k, w, gold, tmp_path):
+    """csrc/ntl_io.cpp emitters (real file descriptors) == the Python emitters == the goldens."""
+    cs_, rs_, res = _oracle_records(target, reads, k, w)
+    d = os.path.join(GEN, "fixtures")
+    with open(tmp_path / "v.tsv", "w") as fh:
+        formats.write_verbose(fh, res, rs_.names, cs_.names)
+    with open(tmp_path / "p.paf", "w") as fh:
+        formats.write_paf(fh, res, rs_.names, rs_.lengths, cs_.names, cs_.lengths)
+    assert read_text(str(tmp_path / "v.tsv")) == read_text(os.path.join(d, tag + ".verbose_mapping.tsv"))
+    assert read_text(str(tmp_path / "p.paf")) == read_text(os.path.join(d, tag + ".paf"))
+    off, h, p, s = oracle.sketch_batch(cs_.buf, cs_.offsets, k, w)
+    with open(tmp_path / "c.tsv", "w") as fh:
+        formats.write_indexlr(fh, cs_.names, cs_.lengths, off, h, p, s, False)
+    assert read_text(str(tmp_path / "c.tsv")) == read_text(os.path.join(REF, "expected_outputs", gold + ".tsv"))
+    roff, rh, rp, rst = oracle.sketch_batch(rs_.buf, rs_.offsets, k, w)
+    with open(tmp_path / "r.tsv", "w") as fh:
+        formats.write_indexlr(fh, rs_.names, rs_.lengths, roff, rh, rp, rst, True)
+    buf = io.StringIO()
+    formats.write_indexlr(buf, rs_.names.tolist(), rs_.lengths, roff, rh, rp, rst, True)
+    assert read_text(str(tmp_path / "r.tsv")) == buf.getvalue()
+
+
+def test_native_reader_batches_and_stdin(tmp_path):
+    import subprocess
+    import sys
+    src = os.path.join(REF, "long_reads_2.fq.gz")
+    whole = seqio.load_all([src])
+    parts = list(seqio.load([src], max_bases=500_000))
+    assert len(parts) > 3 and sum(len(p) for p in parts) == len(whole)
+    assert b"".join(p.buf.tobytes() for p in parts) == whole.buf.tobytes()
+    assert [n for p in parts for n in p.names] == whole.names.tolist()
+    code = ("import sys; sys.path.insert(0, %r); from ntlink_amd import seqio; s = seqio.load_all(['-']); "
+            "print(len(s), s.bases)" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    with open(src, "rb") as fin:
+        out = subprocess.check_output([sys.executable, "-c", code], stdin=fin).decode().split()
+    assert [int(v) for v in out] == [len(whole), whole.bases]
