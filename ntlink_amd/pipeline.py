@@ -13,6 +13,7 @@ records between files and the device and runs the small CPU tail (pairing.py).
 import datetime
 import os
 import sys
+import time
 
 import numpy as np
 
@@ -34,13 +35,18 @@ class PairOutputs:
         self.verbose_fh = open(prefix + ".verbose_mapping.tsv", "w") if verbose else None
         self.paf_fh = open(prefix + ".paf", "w") if paf else None
         self.tally = pairing.PairTally(ctg_names, ctg_len, k, f)
+        self.t_write = self.t_tally = 0.0
 
     def add(self, res, read_names, read_len):
+        t0 = time.perf_counter()
         if self.verbose_fh:
             formats.write_verbose(self.verbose_fh, res, read_names, self.ctg_names)
         if self.paf_fh:
             formats.write_paf(self.paf_fh, res, read_names, read_len, self.ctg_names, self.ctg_len)
+        t1 = time.perf_counter()
         self.tally.add_batch(res, read_len)
+        self.t_write += t1 - t0
+        self.t_tally += time.perf_counter() - t1
 
     def close(self):
         for fh in (self.verbose_fh, self.paf_fh):
@@ -189,7 +195,8 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
     ctg = seqio.load_all([target])
     ctg_len = ctg.lengths
     out = PairOutputs(prefix, ctg.names, ctg_len, k, f, verbose, paf) if root else None
-    stats = dict(read_bases=0, reads=0, read_minimizers=0, index_hits=0)
+    stats = dict(read_bases=0, reads=0, read_minimizers=0, index_hits=0, t_ingest=0.0, t_device=0.0)
+    t_mark = time.perf_counter()
     try:
         with dev.batch(ctg.buf, ctg.offsets) as cb, dev.sketch(cb, k, w) as csk:
             if write_contig_tsv and root:
@@ -201,6 +208,8 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
                 for rs_ in seqio.load(reads.split() if isinstance(reads, str) else list(reads), max_bases=batch_bases * comm.world):
                     if not len(rs_):
                         continue
+                    stats["t_ingest"] += time.perf_counter() - t_mark  # FASTA/FASTQ(.gz) parse of this batch
+                    t_dev = time.perf_counter()
                     rl = rs_.lengths
                     lo, hi = shard_range(rs_.offsets, comm.rank, comm.world)
                     b0 = int(rs_.offsets[lo])
@@ -208,6 +217,7 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
                     with dev.batch(rs_.buf[b0:int(rs_.offsets[hi])], sub_off) as rb, dev.sketch(rb, k, w) as rsk, \
                             dev.map(ix, rsk, rl[lo:hi], k=k, z=z, x=x, sensitive=sensitive, repeat_filter=repeats) as res:
                         mine = (lo, hi, res.download(), rsk.count, res.n_index_hits)
+                    stats["t_device"] += time.perf_counter() - t_dev  # pack + H2D + kernels + D2H
                     parts = comm.gather(mine)
                     if root:
                         for plo, phi, pres, pmx, phits in parts:
@@ -216,9 +226,11 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
                             stats["index_hits"] += phits
                         stats["read_bases"] += rs_.bases
                         stats["reads"] += len(rs_)
+                    t_mark = time.perf_counter()
         if root:
             out.close()
             finish_pairs(out.tally, prefix, n, a, pairs_tsv)
+            stats["t_write"], stats["t_tally"] = out.t_write, out.t_tally
         comm.barrier()
     except BaseException:
         if out:

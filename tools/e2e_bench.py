@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""End-to-end (file to file) timing of `ntLink pair` on synthetic data: FASTA in the page cache ->
+.tsv/.verbose_mapping.tsv/.paf/.pairs.tsv/.dot on disk.  Complements bench.py (device-resident).
+Usage: tools/e2e_bench.py [--scale S] [--gz]"""
+import argparse
+import gzip
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from ntlink_amd import capi, pipeline, synth  # noqa: E402
+
+
+def write_fasta(path, buf, off, names, gz=False):
+    opener = (lambda p: gzip.open(p, "wb", compresslevel=1)) if gz else (lambda p: open(p, "wb"))
+    with opener(path) as f:
+        raw = buf.tobytes()
+        for i, n in enumerate(names):
+            f.write(b">" + n.encode() + b"\n" + raw[int(off[i]):int(off[i + 1])] + b"\n")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scale", type=float, default=0.2)
+    ap.add_argument("--gz", action="store_true")
+    a = ap.parse_args()
+    W = synth.workload("C2", a.scale)
+    chroms, cbuf, coff, cn, _ = synth.make_assembly(1, W["n_chrom"], W["contigs_per_chrom"], W["contig_len"])
+    rbuf, roff, rn = synth.make_reads(2, chroms, W["read_bases"], W["read_len"], W["sub"], W["ins"], W["dele"], lognormal_sigma=0.4)
+    d = tempfile.mkdtemp(prefix="ntl_e2e_")
+    tgt, rds = os.path.join(d, "asm.fa"), os.path.join(d, "reads.fa" + (".gz" if a.gz else ""))
+    write_fasta(tgt, cbuf, coff, cn)
+    write_fasta(rds, rbuf, roff, rn, a.gz)
+    dev = capi.Device(0)
+    os.chdir(d)
+    t0 = time.perf_counter()
+    st = pipeline.run_pair(dev, "asm.fa", os.path.basename(rds), k=W["k"], w=W["w"], paf=True, pairs_tsv=True)
+    dt = time.perf_counter() - t0
+    out_bytes = sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d) if f.startswith("asm.fa."))
+    print(json.dumps({"end_to_end_Gbases_per_s": round(st["read_bases"] / dt / 1e9, 4), "seconds": round(dt, 3),
+                      "read_bases": st["read_bases"], "reads": st["reads"], "gz": a.gz, "output_bytes": out_bytes,
+                      "t_ingest": round(st["t_ingest"], 3), "t_device_incl_pack_pcie": round(st["t_device"], 3),
+                      "t_write": round(st["t_write"], 3), "t_tally": round(st["t_tally"], 3), "device": dev.name}))
+    dev.close()
+
+
+if __name__ == "__main__":
+    main()
