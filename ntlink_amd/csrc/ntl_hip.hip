@@ -532,11 +532,11 @@ extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_
     }
     if (ub_strips >= 0x7FFFFFFFull) return fail(c, NTL_EINVAL, "batch too large: too many strips");
     DevBuf strip_tab;
-    if ((rc = strip_tab.alloc(c, (ub_strips + 1) * sizeof(StripEnt)))) return rc;
+    if ((rc = strip_tab.alloc(c, (ub_strips + 1) * sizeof(StripInfo)))) return rc;
     {
         ProfSpan sp(c, "sketch_meta");
         HIPCHK(c, hipMemsetAsync(mask.p, 0, nmask * 4, c->stream));
-        HIPCHK(c, hipMemsetAsync(strip_tab.p, 0xFF, (ub_strips + 1) * sizeof(StripEnt), c->stream));
+        HIPCHK(c, hipMemsetAsync(strip_tab.p, 0xFF, (ub_strips + 1) * sizeof(StripInfo), c->stream));
         if (nseq) {
             KTables K;
             K.run_n = run_n.as<uint32_t>(); K.run_ord = run_ord.as<uint32_t>();
@@ -544,9 +544,10 @@ extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_
             hipLaunchKernelGGL(seq_meta_kernel, dim3((unsigned)((nseq + 255) / 256)), dim3(256), 0, c->stream, T, K, k, w, G.NWO);
             HIPCHK(c, hipGetLastError());
             if ((rc = device_scan(c, nstrips.as<uint32_t>(), strip_first.as<uint32_t>(), nseq, nullptr))) return rc;
-            hipLaunchKernelGGL(strip_table_kernel, dim3((unsigned)((nseq + 255) / 256)), dim3(256), 0, c->stream,
-                               (const uint32_t *)strip_first.as<uint32_t>(), (uint32_t)nseq, G.NWO, strip_tab.as<StripEnt>(),
-                               (uint32_t)ub_strips);
+            hipLaunchKernelGGL(strip_table_kernel, dim3((unsigned)((ub_strips + 255) / 256 + 1)), dim3(256), 0, c->stream, T,
+                               (const uint32_t *)run_n.as<uint32_t>(), (const uint32_t *)run_ord.as<uint32_t>(),
+                               (const uint32_t *)seq_M.as<uint32_t>(), (const uint32_t *)strip_first.as<uint32_t>(), G.NWO,
+                               C * nt, strip_tab.as<StripInfo>(), (uint32_t)ub_strips);
             HIPCHK(c, hipGetLastError());
         }
     }
@@ -554,7 +555,7 @@ extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_
         SketchArgs A;
         A.T = T;
         A.run_n = run_n.as<uint32_t>(); A.run_ord = run_ord.as<uint32_t>(); A.seq_M = seq_M.as<uint32_t>();
-        A.strip_tab = strip_tab.as<StripEnt>(); A.mask = mask.as<uint32_t>(); A.G = G;
+        A.strip_tab = strip_tab.as<StripInfo>(); A.mask = mask.as<uint32_t>(); A.G = G;
         make_tables(k, A.roll_tab, A.seed_tab);
         A.g4 = (const uint64_t (*)[2])c->g4;
         ProfSpan sp(c, "sketch_mask");

@@ -67,29 +67,59 @@ __global__ void seq_meta_kernel(SeqTables T, KTables K, int k, int w, int NWO)
     K.seq_nstrips[s] = (nwin + (uint32_t)NWO - 1u) / (uint32_t)NWO;
 }
 
-struct StripEnt {
+struct StripInfo {
     uint32_t seq;
-    int32_t E0;
+    int32_t E0;      /* ordinal of the strip's first element (may be -1) */
+    uint32_t M;      /* valid k-mers of the sequence */
+    uint32_t run;    /* run containing the first real element */
+    int32_t multi;   /* strip spans more than one ACGT run */
+    int64_t P0;      /* single-run strips: position (in the sequence) of element E0 */
+    uint64_t base;   /* seq_base */
 };
 
-/* strip table: strip_first[s] + i -> (s, i*NWO - 1) */
-__global__ void strip_table_kernel(const uint32_t *strip_first, uint32_t nseq, int NWO, StripEnt *tab, uint32_t cap)
+/*
+ * One entry per strip, computed once per sketch call (one thread per sequence walks its strips), so
+ * that a strip's workgroup starts from a single 40-byte load instead of a chain of dependent ones.
+ * strip_first[s] + i -> strip i of sequence s, first ordinal i*NWO - 1.
+ */
+__global__ void strip_table_kernel(SeqTables T, const uint32_t *run_n, const uint32_t *run_ord, const uint32_t *seq_M,
+                                   const uint32_t *strip_first, int NWO, int strip_elems, StripInfo *tab, uint32_t cap)
 {
-    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= nseq) return;
-    const uint32_t a = strip_first[s], b = strip_first[s + 1];
-    for (uint32_t i = a; i < b && i < cap; i++) {
-        StripEnt e;
-        e.seq = s;
-        e.E0 = (int32_t)((i - a) * (uint32_t)NWO) - 1;
-        tab[i] = e;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; /* one thread per strip */
+    if (i >= cap || i >= strip_first[T.nseq]) return;
+    uint32_t lo = 0, hi = T.nseq; /* largest s with strip_first[s] <= i */
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (strip_first[mid] <= i) lo = mid; else hi = mid;
     }
+    const uint32_t s = lo;
+    StripInfo I;
+    I.seq = s;
+    I.E0 = (int32_t)((i - strip_first[s]) * (uint32_t)NWO) - 1;
+    I.M = seq_M[s];
+    I.base = T.seq_base[s];
+    const uint32_t e_lo = I.E0 < 0 ? 0u : (uint32_t)I.E0;
+    uint32_t e_hi = (uint32_t)(I.E0 + strip_elems);
+    if (e_hi > I.M) e_hi = I.M;
+    /* run containing e_lo: last run with run_ord <= e_lo, then past runs without k-mers */
+    const uint32_t g0 = T.seq_run_first[s], g1 = T.seq_run_first[s + 1];
+    uint32_t rl = g0, rh = g1;
+    while (rh - rl > 1) {
+        const uint32_t mid = (rl + rh) >> 1;
+        if (run_ord[mid] <= e_lo) rl = mid; else rh = mid;
+    }
+    while (rl > g0 && run_n[rl] == 0) rl--;
+    while (rl + 1 < g1 && (run_n[rl] == 0 || e_lo >= run_ord[rl] + run_n[rl])) rl++;
+    I.run = rl;
+    I.multi = (e_hi > run_ord[rl] + run_n[rl]) ? 1 : 0;
+    I.P0 = (int64_t)T.run_start[rl] - (int64_t)run_ord[rl] + (int64_t)I.E0;
+    tab[i] = I;
 }
 
 struct SketchArgs {
     SeqTables T;
     const uint32_t *run_n, *run_ord, *seq_M;
-    const struct StripEnt *strip_tab; /* [grid] strip -> (sequence, first ordinal); seq = NTL_NONE past the last strip */
+    const struct StripInfo *strip_tab; /* [grid] everything a strip needs to start; seq = NTL_NONE past the last strip */
     uint32_t *mask;              /* 1 bit per global base index: k-mer starting there is a minimizer */
     SketchGeom G;
     uint64_t roll_tab[16][2];    /* [in<<2|out] = {seed[in]^srol^k(seed[out]), srol^k(seedc[in])^seedc[out]} */
@@ -103,15 +133,6 @@ __device__ __forceinline__ uint32_t ntl_idx16(uint16_t v) { return v == 0xFFFFu 
 struct NtlTrue { static constexpr bool value = true; };
 struct NtlFalse { static constexpr bool value = false; };
 
-struct StripInfo {
-    uint32_t seq;
-    int32_t E0;      /* ordinal of the strip's first element (may be -1) */
-    uint32_t M;      /* valid k-mers of the sequence */
-    uint32_t run;    /* run containing the first real element */
-    int32_t multi;   /* strip spans more than one ACGT run */
-    int64_t P0;      /* single-run strips: position (in the sequence) of element E0 */
-    uint64_t base;   /* seq_base */
-};
 
 /*
  * MULTI = false: strips whose k-mers lie in one ACGT run (positions contiguous): register rolling.
@@ -131,44 +152,17 @@ __global__ __launch_bounds__(NT) void sketch_mask_kernel(SketchArgs A)
     __shared__ uint16_t s_bm_i[NT], s_pr_i[NT], s_last[NT]; /* strip-local indices < 65535; 0xFFFF = none */
     __shared__ uint32_t s_bits[NBW + 64]; /* + one dummy word per lane of a wavefront */
     __shared__ uint64_t s_roll[16][2], s_seed[4][2];
-    __shared__ StripInfo s_info;
 
     const int L = threadIdx.x;
     const SketchGeom G = A.G; /* G.r0 == R0 (the host picks the instantiation) */
 
-    const StripEnt ent = A.strip_tab[blockIdx.x];
-    if (ent.seq == NTL_NONE) return; /* the grid is an upper bound of the number of strips */
-    if (L == 0) {
-        const uint32_t s = ent.seq;
-        StripInfo I;
-        I.seq = s;
-        I.E0 = ent.E0;
-        I.M = A.seq_M[s];
-        I.base = A.T.seq_base[s];
-        const uint32_t e_lo = I.E0 < 0 ? 0u : (uint32_t)I.E0;
-        uint32_t e_hi = (uint32_t)(I.E0 + C * NT);
-        if (e_hi > I.M) e_hi = I.M;
-        /* run containing e_lo: last run with run_ord <= e_lo and run_n > 0 */
-        uint32_t g0 = A.T.seq_run_first[s], g1 = A.T.seq_run_first[s + 1];
-        uint32_t rl = g0, rh = g1;
-        while (rh - rl > 1) {
-            uint32_t mid = (rl + rh) >> 1;
-            if (A.run_ord[mid] <= e_lo) rl = mid; else rh = mid;
-        }
-        /* runs with zero k-mers share the ordinal of their successor: step back over them */
-        while (rl > g0 && A.run_n[rl] == 0) rl--;
-        while (rl + 1 < g1 && e_lo >= A.run_ord[rl] + A.run_n[rl]) rl++;
-        I.run = rl;
-        I.multi = (e_hi > A.run_ord[rl] + A.run_n[rl]) ? 1 : 0;
-        I.P0 = (int64_t)A.T.run_start[rl] - (int64_t)A.run_ord[rl] + (int64_t)I.E0;
-        s_info = I;
-    }
+    const StripInfo I = A.strip_tab[blockIdx.x];
+    if (I.seq == NTL_NONE) return; /* the grid is an upper bound of the number of strips */
     if (L < 16) { s_roll[L][0] = A.roll_tab[L][0]; s_roll[L][1] = A.roll_tab[L][1]; }
     if (L < 4) { s_seed[L][0] = A.seed_tab[L][0]; s_seed[L][1] = A.seed_tab[L][1]; }
     if (L < NBW) s_bits[L] = 0;
-    __syncthreads();
-    const StripInfo I = s_info;
     if ((I.multi != 0) != MULTI) return;
+    __syncthreads();
 
     const int64_t e_lane = (int64_t)I.E0 + (int64_t)L * C; /* ordinal of this lane's element t = 0 */
     uint64_t h[C];
