@@ -421,8 +421,11 @@ __global__ __launch_bounds__(EMIT_NT) void emit_kernel(EmitArgs A)
     __shared__ uint64_t s_seed[4][2];
     __shared__ uint64_t s_base[EMIT_SEQ_CAP];
     __shared__ uint32_t s_range[2];
+    __shared__ uint64_t s_g4[256][2]; /* four-base init table: LDS copy (EMIT_NT == 256 entries) */
     const int t = threadIdx.x;
     if (t < 4) { s_seed[t][0] = A.seed_tab[t][0]; s_seed[t][1] = A.seed_tab[t][1]; }
+    s_g4[t][0] = A.g4[t][0];
+    s_g4[t][1] = A.g4[t][1];
     const uint64_t tile_w0 = (uint64_t)blockIdx.x * EMIT_TILE;
     if (t == 0) { /* sequences that overlap this tile of 65536 base positions */
         s_range[0] = seq_of(A.seq_base, 0, A.nseq, tile_w0 * 32);
@@ -470,7 +473,7 @@ __global__ __launch_bounds__(EMIT_NT) void emit_kernel(EmitArgs A)
             const uint32_t sq = cached ? s_lo + seq_of(s_base, 0, s_hi - s_lo, gp) : seq_of(A.seq_base, s_lo, s_hi, gp);
             const uint64_t sb = cached ? s_base[sq - s_lo] : A.seq_base[sq];
             uint64_t fwd, rev;
-            hash_init(A.packed, gp, A.k, A.g4, s_seed, fwd, rev);
+            hash_init(A.packed, gp, A.k, s_g4, s_seed, fwd, rev);
             uint64_t tt = (fwd + rev) * A.mult;
             tt ^= tt >> 27;
             MxRecord R;

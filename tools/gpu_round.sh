@@ -8,6 +8,7 @@ timeout 1800 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee gpurun_ou
 timeout 300 python __graft_entry__.py smoke 2>&1 | tail -2 | tee gpurun_out/$TAG/smoke.log
 timeout 900 python bench.py --steps 5 --warmup 2 > gpurun_out/$TAG/bench.json 2> gpurun_out/$TAG/bench.err
 cat gpurun_out/$TAG/bench.json
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/$TAG/bench_torchrun1.json 2> gpurun_out/$TAG/bench_torchrun1.err; tail -c 600 gpurun_out/$TAG/bench_torchrun1.json; tail -3 gpurun_out/$TAG/bench_torchrun1.err
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
