@@ -129,3 +129,21 @@ def test_full_size_properties(dev):
     with dev.batch(cbuf[:int(coff[half])], coff[:half + 1]) as b1, dev.sketch(b1, k, w) as s1:
         o1, h1, p1, st1 = s1.download()
     assert np.array_equal(h[:len(h1)], h1) and np.array_equal(p[:len(p1)], p1) and np.array_equal(s[:len(st1)], st1)
+
+
+@pytest.mark.parametrize("seed,k,w", [(1, 32, 100), (2, 32, 250), (3, 24, 100), (4, 15, 5), (5, 20, 10), (6, 7, 33), (7, 40, 16),
+                                      (8, 80, 100), (9, 100, 47), (10, 12, 2), (11, 31, 64), (12, 64, 129)])
+def test_fuzz_sketch(dev, seed, k, w):
+    """Adversarial sequences (ties, N patterns, boundary lengths) incl. k > 64 (loop form of the hash init)."""
+    import fuzz_cases
+    pc.check_sketch(dev, fuzz_cases.fuzz_sequences(seed), k, w)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_mapping(dev, seed):
+    import fuzz_cases
+    arrs = fuzz_cases.fuzz_mapping(seed)
+    kw = dict(k=24, z=[1000, 500, 1000, 1][seed % 4], x=[0.0, 0.0, 1.2, 0.4][seed % 4], sensitive=bool(seed & 1),
+              repeat_filter=bool(seed & 2))
+    got, _ = pc.check_pair_arrays(dev, *arrs, **kw)
+    assert len(got["maps"]) > 0

@@ -62,3 +62,18 @@ def test_sim_pair_driver_files(dev, tmp_path):
     assert read_text(pre + ".pairs.tsv") == read_text(d + ".pairs.tsv")
     assert read_text(str(tmp_path / "scaffolds_4.fa.k40.w100.tsv")) == read_text(os.path.join(REF, "expected_outputs", "scaffolds_4.fa.k40.w100.tsv"))
     assert os.path.exists(pre + ".n1.scaffold.dot")
+
+
+@pytest.mark.parametrize("seed,k,w", [(21, 32, 100), (22, 80, 20), (23, 9, 3)])
+def test_sim_fuzz_sketch(dev, seed, k, w):
+    import fuzz_cases
+    pc.check_sketch(dev, fuzz_cases.fuzz_sequences(seed, n=16, max_len=5000), k, w)
+
+
+@pytest.mark.parametrize("seed", [0, 3])
+def test_sim_fuzz_mapping(dev, seed):
+    import fuzz_cases
+    arrs = fuzz_cases.fuzz_mapping(seed, n_reads=60)
+    kw = dict(k=24, z=[1000, 500, 1000, 1][seed % 4], x=[0.0, 0.0, 1.2, 0.4][seed % 4], sensitive=bool(seed & 1),
+              repeat_filter=bool(seed & 2))
+    pc.check_pair_arrays(dev, *arrs, **kw)
