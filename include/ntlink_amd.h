@@ -172,7 +172,8 @@ const char *ntl_fastx_names(const ntl_fastx *r);
 const uint64_t *ntl_fastx_name_offsets(const ntl_fastx *r);
 
 /* Text emitters, written to file descriptor fd.  Names are concatenated ids + offsets[n+1].
- * ntl_write_indexlr: `id\t[len\t]H:pos:strand ...` (ntLink:199,223); lengths == NULL omits --len.
+ * ntl_write_indexlr: `id\t[len\t]H:pos:strand ...` (ntLink:199,223); lengths == NULL omits --len,
+ *                    strand == NULL prints `H:pos` (the `--pos`-only form of ntLink:244,249).
  * ntl_write_verbose: <prefix>.verbose_mapping.tsv (bin/ntlink_pair.py:308-313,382-388).
  * ntl_write_paf:     <prefix>.paf (bin/ntlink_paf_output.py:131-135). */
 int ntl_write_indexlr(int fd, uint64_t nseq, const char *names, const uint64_t *name_off, const uint32_t *lengths,

@@ -27,12 +27,12 @@ def indexlr_main(argv=None):
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("files", nargs="+")
     a = ap.parse_args(argv)
-    if not (a.pos and a.strand):
-        ap.error("only the `--pos --strand` output of the pair stage is implemented")
+    if not a.pos:
+        ap.error("only the `--pos [--strand]` outputs that ntLink uses are implemented")
     from . import pipeline
     dev = _device(a.device)
     try:
-        pipeline.run_indexlr(dev, a.files, a.k, a.w, sys.stdout, a.with_len)
+        pipeline.run_indexlr(dev, a.files, a.k, a.w, sys.stdout, a.with_len, with_strand=a.strand)
     finally:
         dev.close()
     return 0

@@ -220,8 +220,8 @@ extern "C" int ntl_write_indexlr(int fd, uint64_t nseq, const char *names, const
             if (lengths) { put_u64(s, lengths[i]); s.push_back('\t'); }
             for (uint64_t j = mx_off[i]; j < mx_off[i + 1]; j++) {
                 if (j > mx_off[i]) s.push_back(' ');
-                put_u64(s, hash[j]); s.push_back(':'); put_u64(s, pos[j]); s.push_back(':');
-                s.push_back(strand[j] ? '+' : '-');
+                put_u64(s, hash[j]); s.push_back(':'); put_u64(s, pos[j]);
+                if (strand) { s.push_back(':'); s.push_back(strand[j] ? '+' : '-'); } /* NULL: `--pos` without `--strand` */
             }
             s.push_back('\n');
         }

@@ -34,7 +34,7 @@ def _native():
     return capi.load()
 
 
-def write_indexlr(fh, names, lengths, mx_off, mx_hash, pos, strand, with_len):
+def write_indexlr(fh, names, lengths, mx_off, mx_hash, pos, strand, with_len, with_strand=True):
     """Every record prints its id even without minimizers (such lines are skipped by the consumers,
     bin/ntlink_pair.py:200,357)."""
     fd = _fd(fh)
@@ -46,7 +46,7 @@ def write_indexlr(fh, names, lengths, mx_off, mx_hash, pos, strand, with_len):
         st = np.ascontiguousarray(strand, np.uint8)
         rc = _native().ntl_write_indexlr(fd, len(nm), nm.blob.ctypes.data, _p(nm.off, C.c_uint64),
                                          _p(ln, C.c_uint32) if with_len else None, _p(off64, C.c_uint64),
-                                         _p(h, C.c_uint64), _p(p, C.c_uint32), _p(st, C.c_uint8))
+                                         _p(h, C.c_uint64), _p(p, C.c_uint32), _p(st, C.c_uint8) if with_strand else None)
         if rc != 0:
             raise OSError("write failed")
         return
@@ -56,7 +56,10 @@ def write_indexlr(fh, names, lengths, mx_off, mx_hash, pos, strand, with_len):
     off = [int(v) for v in mx_off]
     for i, name in enumerate(names):
         a, b = off[i], off[i + 1]
-        toks = " ".join(f"{hs[j]}:{ps[j]}:{_STRAND[ss[j]]}" for j in range(a, b))
+        if with_strand:
+            toks = " ".join(f"{hs[j]}:{ps[j]}:{_STRAND[ss[j]]}" for j in range(a, b))
+        else:
+            toks = " ".join(f"{hs[j]}:{ps[j]}" for j in range(a, b))
         if with_len:
             fh.write(f"{name}\t{int(lengths[i])}\t{toks}\n")
         else:

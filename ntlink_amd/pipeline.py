@@ -73,14 +73,14 @@ def finish_pairs(tally, prefix, n, a, write_pairs_tsv):
     return pairs
 
 
-def run_indexlr(dev, paths, k, w, out, with_len, batch_bases=DEFAULT_BATCH_BASES):
+def run_indexlr(dev, paths, k, w, out, with_len, batch_bases=DEFAULT_BATCH_BASES, with_strand=True):
     """Sketch FASTA/FASTQ files on the device and print indexlr's TSV."""
     for ss in seqio.load(paths, max_bases=batch_bases):
         if not len(ss):
             continue
         with dev.batch(ss.buf, ss.offsets) as b, dev.sketch(b, k, w) as sk:
             off, h, p, s = sk.download()
-        formats.write_indexlr(out, ss.names, ss.lengths, off, h, p, s, with_len)
+        formats.write_indexlr(out, ss.names, ss.lengths, off, h, p, s, with_len, with_strand)
 
 
 def _contig_lengths(fasta):

@@ -93,3 +93,35 @@ def test_error_removes_partial_outputs(tmp_path):
     cmd = [sys.executable, os.path.join(BIN, "ntlink_pair.py"), "-p", "o", "-m", "c.tsv", "-s", "scaffolds_4.fa", "-k", "40", "--verbose", "--paf", "bad.tsv"]
     assert subprocess.call(cmd, cwd=tmp_path, stderr=subprocess.DEVNULL) != 0
     assert not (tmp_path / "o.verbose_mapping.tsv").exists() and not (tmp_path / "o.paf").exists()
+
+
+def test_indexlr_pos_only_small_k_w(tmp_path):
+    """`indexlr --long --pos -k 15 -w 5` of the overlap stage (ntLink:243-251): H:pos tokens."""
+    import oracle
+    _stage(tmp_path, "scaffolds_4.fa")
+    out = subprocess.check_output([sys.executable, os.path.join(BIN, "indexlr"), "--long", "--pos", "-k", "15", "-w", "5", "-t", "4",
+                                   "scaffolds_4.fa"], cwd=tmp_path).decode()
+    exp = []
+    for name, seq in oracle.read_fastx(os.path.join(REF, "scaffolds_4.fa")):
+        h, p, s = oracle.sketch_seq(seq, 15, 5)
+        exp.append(name + "\t" + " ".join(f"{int(a)}:{int(b)}" for a, b in zip(h, p)) + "\n")
+    assert out == "".join(exp)
+
+
+def test_btllib_compatible_indexlr_class():
+    """btllib.Indexlr(path, k, w, LONG_MODE, t) as used by bin/ntlink_patch_gaps.py:417-441 (gap-fill k20 w10)."""
+    import oracle
+    import ntlink_amd.btllib as btllib
+    path = os.path.join(REF, "long_reads_4_top5.fa")
+    ref = list(oracle.read_fastx(path))
+    with btllib.Indexlr(path, 20, 10, btllib.IndexlrFlag.LONG_MODE, 4) as recs:
+        first = recs.read()
+        rest = list(recs)
+        assert recs.read() is None
+    got = [first] + rest
+    assert [r.id for r in got] == [n for n, _ in ref] and [r.readlen for r in got] == [len(s) for _, s in ref]
+    for r, (_, seq) in zip(got, ref):
+        h, p, s = oracle.sketch_seq(seq, 20, 10)
+        assert [m.out_hash for m in r.minimizers] == h.tolist() and [m.pos for m in r.minimizers] == p.tolist()
+        assert [m.forward for m in r.minimizers] == [bool(v) for v in s]
+    got[0].id = "renamed"  # records are mutable in the reference's use
