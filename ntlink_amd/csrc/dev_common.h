@@ -94,11 +94,14 @@ __device__ __forceinline__ void hash_init_loop(const uint32_t *__restrict__ pack
     rev = srot(u, (uint32_t)(k - 1) % 33u, (uint32_t)(k - 1) % 31u);
 }
 
-/* k <= 64: straight-line form -- the four base words and the (up to) sixteen table entries are all
- * requested before the first one is used, so one memory latency is paid instead of one per group. */
+/* k <= 64: straight-line form, EIGHT bases per step through g8 (65536 entries x 16 B = 1 MB, L2-resident,
+ * k-independent: g8[w16] = {XOR_j srol^(7-j)(seed[b_j]), XOR_j sror^(7-j)(seed[3-b_j])}, b_j = (w16 >> 2j) & 3):
+ *   f = srol^8(f) ^ g8[w16].f,  u = sror^8(u) ^ g8[w16].u
+ * then one four-base step (g4) if k % 8 >= 4 and single steps for the last k % 4 bases.  All table
+ * entries are requested before the first one is used: one memory latency per init. */
 __device__ __forceinline__ void hash_init(const uint32_t *__restrict__ packed, uint64_t gp, int k,
-                                          const uint64_t (*__restrict__ g4)[2], const uint64_t (*seed_tab)[2],
-                                          uint64_t &fwd, uint64_t &rev)
+                                          const uint64_t (*__restrict__ g8)[2], const uint64_t (*g4)[2],
+                                          const uint64_t (*seed_tab)[2], uint64_t &fwd, uint64_t &rev)
 {
     if (k > 64) { hash_init_loop(packed, gp, k, g4, seed_tab, fwd, rev); return; }
     const uint64_t wi = gp >> 4;
@@ -109,24 +112,65 @@ __device__ __forceinline__ void hash_init(const uint32_t *__restrict__ packed, u
     uint32_t s[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) s[i] = ntl_alignbit(raw[i + 1], raw[i], a2);
-    const int ng = k >> 2;
-    uint64_t gf[16], gu[16];
+    const int n8 = k >> 3;
+    uint64_t gf[8], gu[8];
 #pragma unroll
-    for (int g = 0; g < 16; g++) {
-        const uint32_t byte = (s[g >> 2] >> (8 * (g & 3))) & 255u;
-        const bool on = g < ng;
-        gf[g] = on ? g4[byte][0] : 0ull;
-        gu[g] = on ? g4[byte][1] : 0ull;
+    for (int g = 0; g < 8; g++) {
+        const uint32_t w16 = (s[g >> 1] >> (16 * (g & 1))) & 0xFFFFu;
+        const bool on = g < n8;
+        gf[g] = on ? g8[w16][0] : 0ull;
+        gu[g] = on ? g8[w16][1] : 0ull;
     }
+    uint64_t f = 0, u = 0;
+#pragma unroll
+    for (int g = 0; g < 8; g++) {
+        if (g < n8) { /* uniform */
+            f = srot(f, 8, 8) ^ gf[g];
+            u = srot(u, 25, 23) ^ gu[g];
+        }
+    }
+    int j = n8 * 8;
+    if (k - j >= 4) {
+        const uint32_t byte = (s[(j >> 4) & 3] >> (2 * (j & 15))) & 255u;
+        f = srot(f, 4, 4) ^ g4[byte][0];
+        u = srot(u, 29, 27) ^ g4[byte][1];
+        j += 4;
+    }
+    for (; j < k; j++) { /* k % 4 trailing bases */
+        const uint32_t c = load_base(packed, gp + (uint64_t)j);
+        f = srol1(f) ^ seed_tab[c][0];
+        u = sror1(u) ^ seed_tab[c][1];
+    }
+    fwd = f;
+    rev = srot(u, (uint32_t)(k - 1) % 33u, (uint32_t)(k - 1) % 31u);
+}
+
+/* The same with four bases per step only (g4, e.g. an LDS copy): for callers whose table lookups should
+ * not leave the CU (the emit kernel: few k-mers per lane, latency-bound). */
+__device__ __forceinline__ void hash_init_g4(const uint32_t *__restrict__ packed, uint64_t gp, int k,
+                                             const uint64_t (*g4)[2], const uint64_t (*seed_tab)[2],
+                                             uint64_t &fwd, uint64_t &rev)
+{
+    if (k > 64) { hash_init_loop(packed, gp, k, g4, seed_tab, fwd, rev); return; }
+    const uint64_t wi = gp >> 4;
+    const uint32_t a2 = 2u * ((uint32_t)gp & 15u);
+    uint32_t raw[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) raw[i] = (16 * i < k + 16) ? packed[wi + i] : 0u;
+    uint32_t s[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) s[i] = ntl_alignbit(raw[i + 1], raw[i], a2);
+    const int ng = k >> 2;
     uint64_t f = 0, u = 0;
 #pragma unroll
     for (int g = 0; g < 16; g++) {
         if (g < ng) { /* uniform */
-            f = srot(f, 4, 4) ^ gf[g];
-            u = srot(u, 29, 27) ^ gu[g];
+            const uint32_t byte = (s[g >> 2] >> (8 * (g & 3))) & 255u;
+            f = srot(f, 4, 4) ^ g4[byte][0];
+            u = srot(u, 29, 27) ^ g4[byte][1];
         }
     }
-    for (int j = ng * 4; j < k; j++) { /* k % 4 trailing bases */
+    for (int j = ng * 4; j < k; j++) {
         const uint32_t c = load_base(packed, gp + (uint64_t)j);
         f = srol1(f) ^ seed_tab[c][0];
         u = sror1(u) ^ seed_tab[c][1];

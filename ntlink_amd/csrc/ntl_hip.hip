@@ -41,6 +41,7 @@ struct ntl_ctx {
     std::map<std::string, ProfEntry> profs;
     std::vector<hipEvent_t> ev_free;
     void *g4 = nullptr;                 /* device copy of the four-base init table */
+    void *g8 = nullptr;                 /* device copy of the eight-base init table (1 MB) */
     std::multimap<size_t, void *> pool; /* cached device blocks by size */
     size_t pool_bytes = 0;
 };
@@ -133,6 +134,7 @@ struct ProfSpan {
 };
 
 static void make_g4(uint64_t g4[256][2]);
+static void make_g8(std::vector<uint64_t> &g8);
 
 extern "C" int ntl_ctx_create(int device, ntl_ctx **out)
 {
@@ -150,6 +152,13 @@ extern "C" int ntl_ctx_create(int device, ntl_ctx **out)
         uint64_t g4[256][2];
         make_g4(g4);
         if (hipMalloc(&c->g4, sizeof g4) != hipSuccess || hipMemcpy(c->g4, g4, sizeof g4, hipMemcpyHostToDevice) != hipSuccess) {
+            delete c;
+            return NTL_EDEVICE;
+        }
+        std::vector<uint64_t> g8;
+        make_g8(g8);
+        if (hipMalloc(&c->g8, g8.size() * 8) != hipSuccess ||
+            hipMemcpy(c->g8, g8.data(), g8.size() * 8, hipMemcpyHostToDevice) != hipSuccess) {
             delete c;
             return NTL_EDEVICE;
         }
@@ -172,6 +181,7 @@ extern "C" void ntl_ctx_destroy(ntl_ctx *c)
     hipStreamSynchronize(c->stream);
     for (auto &kv : c->pool) hipFree(kv.second);
     hipFree(c->g4);
+    hipFree(c->g8);
     for (auto &kv : c->profs)
         for (auto &sp : kv.second.spans) { hipEventDestroy(sp.first); hipEventDestroy(sp.second); }
     for (auto e : c->ev_free) hipEventDestroy(e);
@@ -462,6 +472,21 @@ static void make_g4(uint64_t g4[256][2])
     }
 }
 
+static void make_g8(std::vector<uint64_t> &g8)
+{
+    const uint64_t S[4] = {0x3c8bfbb395c60474ull, 0x3193c18562a02b4cull, 0x20323ed082572324ull, 0x295549f54be24456ull};
+    g8.resize(65536 * 2);
+    for (int b = 0; b < 65536; b++) {
+        uint64_t f = 0, u = 0;
+        for (int j = 0; j < 8; j++) {
+            const int c = (b >> (2 * j)) & 3;
+            f = h_srol1(f) ^ S[c];
+            u = h_sror1(u) ^ S[3 - c];
+        }
+        g8[2 * b] = f; g8[2 * b + 1] = u;
+    }
+}
+
 template <int C, int NT, int R0>
 static void launch_mask_r0(ntl_ctx *c, const SketchArgs &A, unsigned strips, bool multi)
 {
@@ -558,6 +583,7 @@ extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_
         A.strip_tab = strip_tab.as<StripInfo>(); A.mask = mask.as<uint32_t>(); A.G = G;
         make_tables(k, A.roll_tab, A.seed_tab);
         A.g4 = (const uint64_t (*)[2])c->g4;
+        A.g8 = (const uint64_t (*)[2])c->g8;
         ProfSpan sp(c, "sketch_mask");
         if (C == 16) launch_mask<16>(c, A, (unsigned)ub_strips, b->any_multi, nt);
         else if (C == 8) launch_mask<8>(c, A, (unsigned)ub_strips, b->any_multi, nt);
@@ -584,6 +610,7 @@ extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_
         uint64_t roll[16][2];
         make_tables(k, roll, E.seed_tab);
         E.g4 = (const uint64_t (*)[2])c->g4;
+        E.g8 = (const uint64_t (*)[2])c->g8;
         hipLaunchKernelGGL(emit_kernel, dim3((unsigned)tiles), dim3(EMIT_NT), 0, c->stream, E);
         hipLaunchKernelGGL(mx_offsets_kernel, dim3((unsigned)((nseq + 1 + 255) / 256)), dim3(256), 0, c->stream,
                            T.seq_base, (uint32_t)nseq, (const uint32_t *)mask.as<uint32_t>(),

@@ -125,6 +125,7 @@ struct SketchArgs {
     uint64_t roll_tab[16][2];    /* [in<<2|out] = {seed[in]^srol^k(seed[out]), srol^k(seedc[in])^seedc[out]} */
     uint64_t seed_tab[4][2];     /* [c] = {seed[c], seed[3-c]} */
     const uint64_t (*g4)[2];     /* [256] four-base init table (dev_common.h hash_init) */
+    const uint64_t (*g8)[2];     /* [65536] eight-base init table */
 };
 
 /* 16-bit strip-local index back to 32 bits (0xFFFF -> NTL_NONE) */
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(NT) void sketch_mask_kernel(SketchArgs A)
                of it is exact, then voided. */
             const uint64_t gp = (uint64_t)((int64_t)I.base + I.P0 + (int64_t)L * C);
             uint64_t fwd, rev;
-            hash_init(A.T.packed, gp, G.k, A.g4, s_seed, fwd, rev);
+            hash_init(A.T.packed, gp, G.k, A.g8, A.g4, s_seed, fwd, rev);
             h[0] = fwd + rev;
             const uint32_t so = load_bases16(A.T.packed, gp);
             const uint32_t si = load_bases16(A.T.packed, gp + (uint64_t)G.k);
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(NT) void sketch_mask_kernel(SketchArgs A)
                     run_end = A.run_ord[g] + A.run_n[g];
                     pv = A.T.run_start[g] + (eo - A.run_ord[g]);
                     gp = I.base + pv;
-                    hash_init(A.T.packed, gp, G.k, A.g4, s_seed, fwd, rev);
+                    hash_init(A.T.packed, gp, G.k, A.g8, A.g4, s_seed, fwd, rev);
                     have = true;
                 } else {
                     const uint32_t cin = load_base(A.T.packed, gp + (uint64_t)G.k);
@@ -400,6 +401,7 @@ struct EmitArgs {
     uint64_t mult;            /* 1 ^ (k * MULTISEED) */
     uint64_t seed_tab[4][2];
     const uint64_t (*g4)[2];
+    const uint64_t (*g8)[2];
 };
 
 #define EMIT_SEQ_CAP 512 /* sequence starts of one tile cached in LDS */
@@ -473,7 +475,7 @@ __global__ __launch_bounds__(EMIT_NT) void emit_kernel(EmitArgs A)
             const uint32_t sq = cached ? s_lo + seq_of(s_base, 0, s_hi - s_lo, gp) : seq_of(A.seq_base, s_lo, s_hi, gp);
             const uint64_t sb = cached ? s_base[sq - s_lo] : A.seq_base[sq];
             uint64_t fwd, rev;
-            hash_init(A.packed, gp, A.k, s_g4, s_seed, fwd, rev);
+            hash_init_g4(A.packed, gp, A.k, s_g4, s_seed, fwd, rev);
             uint64_t tt = (fwd + rev) * A.mult;
             tt ^= tt >> 27;
             MxRecord R;
