@@ -60,12 +60,13 @@ __global__ void index_insert_kernel(const MxRecord *mx, uint64_t n, IndexSlot *s
     for (;;) {
         unsigned long long old = atomicCAS((unsigned long long *)&slots[s].key,
                                            (unsigned long long)NTL_INF, (unsigned long long)R.hash);
+        /* pos and meta are one aligned 64-bit word (pos in the low half): one atomic each way */
+        unsigned long long *pm = (unsigned long long *)&slots[s].pos;
         if (old == NTL_INF) { /* first arrival: OR the payload into the zeroed fields */
-            atomicOr(&slots[s].pos, R.pos);
-            atomicOr(&slots[s].meta, meta);
+            atomicOr(pm, ((unsigned long long)meta << 32) | (unsigned long long)R.pos);
             return;
         }
-        if (old == R.hash) { atomicOr(&slots[s].meta, 1u); return; } /* seen before: duplicate */
+        if (old == R.hash) { atomicOr(pm, 1ull << 32); return; } /* seen before: duplicate */
         s = (s + 1) & mask;
     }
 }

@@ -240,23 +240,24 @@ extern "C" int ntl_prof_get(ntl_ctx *c, const char *name, double *total_ms, uint
 
 /* ------------------------------------------------------------------ scan helper ---------- */
 
-/* out[0..n) = exclusive scan of in[0..n), out[n] = sum (out must hold n+1 entries; in may equal out when
- * in also has n+1).  With total_host the sum also comes back to the host (one stream sync); without it
- * nothing waits. */
-static int device_scan(ntl_ctx *c, const uint32_t *in, uint32_t *out, uint64_t n, uint32_t *total_host)
+/* `batch` independent exclusive scans of equal length in one set of launches: array y is in + y*(n+1) ->
+ * out + y*(n+1), out[n] of each = its sum (arrays hold n+1 entries; in may equal out).  With total_host the
+ * sums also come back to the host (one stream sync); without it nothing waits. */
+static int device_scan(ntl_ctx *c, const uint32_t *in, uint32_t *out, uint64_t n, uint32_t *total_host, unsigned batch = 1)
 {
     uint64_t tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
     if (tiles == 0) tiles = 1;
     DevBuf tile;
     int rc;
-    if ((rc = tile.alloc(c, tiles * 4))) return rc;
-    hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)tiles), dim3(SCAN_NT), 0, c->stream, in, n, tile.as<uint32_t>());
-    hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(SCAN_NT), 0, c->stream, tile.as<uint32_t>(), tiles, out + n);
-    hipLaunchKernelGGL(scan_down_kernel, dim3((unsigned)tiles), dim3(SCAN_NT), 0, c->stream, in, out, n,
-                       (const uint32_t *)tile.as<uint32_t>());
+    if ((rc = tile.alloc(c, tiles * 4 * batch))) return rc;
+    hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)tiles, batch), dim3(SCAN_NT), 0, c->stream, in, n, tile.as<uint32_t>(), n + 1, tiles);
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(1, batch), dim3(SCAN_NT), 0, c->stream, tile.as<uint32_t>(), tiles, out + n, n + 1);
+    hipLaunchKernelGGL(scan_down_kernel, dim3((unsigned)tiles, batch), dim3(SCAN_NT), 0, c->stream, in, out, n,
+                       (const uint32_t *)tile.as<uint32_t>(), n + 1, tiles);
     HIPCHK(c, hipGetLastError());
     if (total_host) {
-        HIPCHK(c, hipMemcpyAsync(total_host, out + n, 4, hipMemcpyDeviceToHost, c->stream));
+        for (unsigned y = 0; y < batch; y++)
+            HIPCHK(c, hipMemcpyAsync(total_host + y, out + y * (n + 1) + n, 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     return NTL_OK;
@@ -597,7 +598,7 @@ extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_
         if ((rc = tile.alloc(c, tiles * 4)) || (rc = tot.alloc(c, 4)) || (rc = word_rank.alloc(c, nmask * 4))) return rc;
         hipLaunchKernelGGL(mask_count_kernel, dim3((unsigned)tiles), dim3(EMIT_NT), 0, c->stream,
                            (const uint32_t *)mask.as<uint32_t>(), nmask, tile.as<uint32_t>());
-        hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(SCAN_NT), 0, c->stream, tile.as<uint32_t>(), tiles, tot.as<uint32_t>());
+        hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(SCAN_NT), 0, c->stream, tile.as<uint32_t>(), tiles, tot.as<uint32_t>(), (uint64_t)0);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(&total_mx, tot.p, 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -807,8 +808,7 @@ extern "C" int ntl_map_run(ntl_ctx *c, const ntl_index *ix, const ntl_sketch *re
         }
         ProfSpan sp(c, "compact");
         uint32_t *o = off3.as<uint32_t>();
-        for (int i = 0; i < 3; i++)
-            if ((rc = device_scan(c, n3.as<uint32_t>() + i * (nreads + 1), o + i * (nreads + 1), nreads, nullptr))) return rc;
+        if ((rc = device_scan(c, n3.as<uint32_t>(), o, nreads, nullptr, 3))) return rc;
         /* the only wait of the call: three totals (to size the dense arrays), hit count, invariant flag */
         for (int i = 0; i < 3; i++)
             HIPCHK(c, hipMemcpyAsync(&tot[i], o + i * (nreads + 1) + nreads, 4, hipMemcpyDeviceToHost, c->stream));

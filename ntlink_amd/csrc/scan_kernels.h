@@ -14,9 +14,14 @@
 #define SCAN_IPT 8
 #define SCAN_TILE (SCAN_NT * SCAN_IPT)
 
-__global__ __launch_bounds__(SCAN_NT) void scan_reduce_kernel(const uint32_t *in, uint64_t n, uint32_t *tile_cnt)
+/* All three kernels take a batch index in blockIdx.y: array y lives at in + y*stride (tiles at
+ * tile + y*tiles), so that several independent scans of equal length share one launch. */
+__global__ __launch_bounds__(SCAN_NT) void scan_reduce_kernel(const uint32_t *in, uint64_t n, uint32_t *tile_cnt,
+                                                              uint64_t stride, uint64_t tiles)
 {
     __shared__ uint32_t s_tmp[SCAN_NT];
+    in += (uint64_t)blockIdx.y * stride;
+    tile_cnt += (uint64_t)blockIdx.y * tiles;
     const uint64_t i0 = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_IPT;
     uint32_t c = 0;
     for (int i = 0; i < SCAN_IPT; i++)
@@ -27,9 +32,12 @@ __global__ __launch_bounds__(SCAN_NT) void scan_reduce_kernel(const uint32_t *in
 }
 
 /* single workgroup; data[0..n) becomes its exclusive scan, *total the sum */
-__global__ __launch_bounds__(SCAN_NT) void scan_tiles_kernel(uint32_t *data, uint64_t n, uint32_t *total_out)
+__global__ __launch_bounds__(SCAN_NT) void scan_tiles_kernel(uint32_t *data, uint64_t n, uint32_t *total_out,
+                                                             uint64_t total_stride)
 {
     __shared__ uint32_t s_tmp[SCAN_NT];
+    data += (uint64_t)blockIdx.y * n;
+    total_out += (uint64_t)blockIdx.y * total_stride;
     uint32_t carry = 0;
     for (uint64_t base = 0; base < n; base += SCAN_TILE) {
         const uint64_t i0 = base + (uint64_t)threadIdx.x * SCAN_IPT;
@@ -54,9 +62,12 @@ __global__ __launch_bounds__(SCAN_NT) void scan_tiles_kernel(uint32_t *data, uin
 
 /* out may alias in; out[n] is not written */
 __global__ __launch_bounds__(SCAN_NT) void scan_down_kernel(const uint32_t *in, uint32_t *out, uint64_t n,
-                                                            const uint32_t *tile_off)
+                                                            const uint32_t *tile_off, uint64_t stride, uint64_t tiles)
 {
     __shared__ uint32_t s_tmp[SCAN_NT];
+    in += (uint64_t)blockIdx.y * stride;
+    out += (uint64_t)blockIdx.y * stride;
+    tile_off += (uint64_t)blockIdx.y * tiles;
     const uint64_t i0 = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_IPT;
     uint32_t v[SCAN_IPT];
     uint32_t c = 0;

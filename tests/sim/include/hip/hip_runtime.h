@@ -40,6 +40,7 @@ struct Block {
     unsigned long long slot[16][64];
 };
 extern Block *cur;
+extern unsigned grid_y; /* blockIdx.y of the running launch (2-D grids run one row at a time) */
 extern thread_local unsigned tid;
 void launch(unsigned grid, unsigned block, const std::function<void()> &fn);
 template <typename K, typename... Args>
@@ -145,5 +146,8 @@ inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b)
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...)                         \
     do {                                                                                  \
         dim3 g_ = (grid), b_ = (block);                                                   \
-        sim::launch_k(g_.x, b_.x, kern, __VA_ARGS__);                                     \
+        for (unsigned y_ = 0; y_ < g_.y; y_++) {                                          \
+            sim::grid_y = y_;                                                             \
+            sim::launch_k(g_.x, b_.x, kern, __VA_ARGS__);                                 \
+        }                                                                                 \
     } while (0)

@@ -3,6 +3,7 @@
 
 namespace sim {
 Block *cur = nullptr;
+unsigned grid_y = 0;
 thread_local unsigned tid = 0;
 
 struct Job {
@@ -17,7 +18,7 @@ static void *worker(void *p)
     tid = j->id;
     threadIdx = dim3(j->id, 0, 0);
     for (unsigned b = 0; b < j->grid; b++) {
-        blockIdx = dim3(b, 0, 0);
+        blockIdx = dim3(b, grid_y, 0);
         (*j->fn)();
         pthread_barrier_wait(&j->blk->bar); /* workgroups run one at a time: static LDS is reused */
     }
