@@ -42,8 +42,13 @@ __global__ void index_clear_kernel(IndexSlot *slots, uint64_t nslots)
     if (i < nslots) { slots[i].key = NTL_INF; slots[i].pos = 0; slots[i].meta = 0; }
 }
 
+/* One-byte tags in front of the 16-byte slots: 0 = empty slot, otherwise 7 bits of the key | 1.  The tag
+ * array is 16x smaller than the table, so it stays in L2 / Infinity Cache while the table does not; ~85 %
+ * of read minimizers are absent from the index and are rejected on tags alone. */
+__device__ __forceinline__ uint8_t index_tag(uint64_t key) { return (uint8_t)(((key >> 20) & 0xFEu) | 1u); }
+
 __global__ void index_insert_kernel(const MxRecord *mx, uint64_t n, IndexSlot *slots, int bits,
-                                    IndexSpecial *special)
+                                    IndexSpecial *special, uint8_t *tags)
 {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -64,6 +69,7 @@ __global__ void index_insert_kernel(const MxRecord *mx, uint64_t n, IndexSlot *s
         unsigned long long *pm = (unsigned long long *)&slots[s].pos;
         if (old == NTL_INF) { /* first arrival: OR the payload into the zeroed fields */
             atomicOr(pm, ((unsigned long long)meta << 32) | (unsigned long long)R.pos);
+            tags[s] = index_tag(R.hash);
             return;
         }
         if (old == R.hash) { atomicOr(pm, 1ull << 32); return; } /* seen before: duplicate */
@@ -100,7 +106,7 @@ struct Cand {
 };
 
 __global__ void probe_kernel(const MxRecord *mx, uint64_t n, const IndexSlot *slots, int bits,
-                             const IndexSpecial *special, Cand *cand, unsigned long long *nfound)
+                             const IndexSpecial *special, Cand *cand, unsigned long long *nfound, const uint8_t *tags)
 {
     unsigned long long found = 0;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -113,12 +119,16 @@ __global__ void probe_kernel(const MxRecord *mx, uint64_t n, const IndexSlot *sl
             if (special->cnt == 1) { c.cpos = special->pos; c.meta = (special->meta & ~1u) | 1u; }
         } else {
             uint64_t s = index_home(key, bits);
+            const uint8_t tg = index_tag(key);
             for (;;) {
-                const IndexSlot e = slots[s];
-                if (e.key == NTL_INF) break;
-                if (e.key == key) {
-                    if (!(e.meta & 1u)) { c.cpos = e.pos; c.meta = e.meta | 1u; }
-                    break;
+                const uint8_t t = tags[s];
+                if (t == 0) break; /* empty slot ends the probe sequence */
+                if (t == tg) {
+                    const IndexSlot e = slots[s];
+                    if (e.key == key) {
+                        if (!(e.meta & 1u)) { c.cpos = e.pos; c.meta = e.meta | 1u; }
+                        break;
+                    }
                 }
                 s = (s + 1) & mask;
             }

@@ -690,6 +690,7 @@ struct ntl_index {
     mutable bool size_known = false;
     uint32_t n_ctg = 0;
     DevBuf slots, special, ctg_len, cnt; /* cnt: device-side count of kept keys, fetched on demand */
+    DevBuf tags;                         /* one byte per slot (map_kernels.h index_tag) */
     std::vector<uint32_t> h_ctg_len;     /* source of the asynchronous upload: must outlive it */
 };
 
@@ -710,7 +711,7 @@ extern "C" int ntl_index_build(ntl_ctx *c, const ntl_sketch *ctg, const uint32_t
     int rc;
     DevBuf &cnt = ix->cnt;
     if ((rc = ix->slots.alloc(c, ix->nslots * sizeof(IndexSlot))) || (rc = ix->special.alloc(c, sizeof(IndexSpecial))) ||
-        (rc = ix->ctg_len.alloc(c, ((uint64_t)n_ctg + 1) * 4)) || (rc = cnt.alloc(c, 8))) return rc;
+        (rc = ix->ctg_len.alloc(c, ((uint64_t)n_ctg + 1) * 4)) || (rc = cnt.alloc(c, 8)) || (rc = ix->tags.alloc(c, ix->nslots))) return rc;
     unsigned long long size = 0;
     {
         ProfSpan sp(c, "index");
@@ -718,12 +719,13 @@ extern "C" int ntl_index_build(ntl_ctx *c, const ntl_sketch *ctg, const uint32_t
         if (n_ctg) HIPCHK(c, hipMemcpyAsync(ix->ctg_len.p, ix->h_ctg_len.data(), (uint64_t)n_ctg * 4, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemsetAsync(ix->special.p, 0, sizeof(IndexSpecial), c->stream));
         HIPCHK(c, hipMemsetAsync(cnt.p, 0, 8, c->stream));
+        HIPCHK(c, hipMemsetAsync(ix->tags.p, 0, ix->nslots, c->stream));
         hipLaunchKernelGGL(index_clear_kernel, dim3((unsigned)((ix->nslots + 255) / 256)), dim3(256), 0, c->stream,
                            ix->slots.as<IndexSlot>(), ix->nslots);
         if (ctg->count)
             hipLaunchKernelGGL(index_insert_kernel, dim3((unsigned)((ctg->count + 255) / 256)), dim3(256), 0, c->stream,
                                (const MxRecord *)ctg->records.as<MxRecord>(), ctg->count, ix->slots.as<IndexSlot>(), bits,
-                               ix->special.as<IndexSpecial>());
+                               ix->special.as<IndexSpecial>(), ix->tags.as<uint8_t>());
         hipLaunchKernelGGL(index_count_kernel, dim3((unsigned)std::min<uint64_t>((ix->nslots + 255) / 256, 2048)), dim3(256), 0, c->stream,
                            (const IndexSlot *)ix->slots.as<IndexSlot>(), ix->nslots,
                            (const IndexSpecial *)ix->special.as<IndexSpecial>(), cnt.as<unsigned long long>());
@@ -786,7 +788,7 @@ extern "C" int ntl_map_run(ntl_ctx *c, const ntl_index *ix, const ntl_sketch *re
             hipLaunchKernelGGL(probe_kernel, dim3((unsigned)std::min<uint64_t>((nmx + 255) / 256, 4096)), dim3(256), 0, c->stream,
                                (const MxRecord *)reads->records.as<MxRecord>(), nmx, (const IndexSlot *)ix->slots.as<IndexSlot>(),
                                ix->bits, (const IndexSpecial *)ix->special.as<IndexSpecial>(), cand.as<Cand>(),
-                               nfound.as<unsigned long long>());
+                               nfound.as<unsigned long long>(), (const uint8_t *)ix->tags.as<uint8_t>());
         HIPCHK(c, hipGetLastError());
     }
     MapArgs A;
