@@ -147,3 +147,30 @@ def test_fuzz_mapping(dev, seed):
               repeat_filter=bool(seed & 2))
     got, _ = pc.check_pair_arrays(dev, *arrs, **kw)
     assert len(got["maps"]) > 0
+
+
+def test_c2_baseline_size_bit_exact(dev):
+    """BASELINE configs[1] (C2) at full size -- 50 Mbp / 100 contigs + 0.5 Gbases of ONT-like reads, k32 w100 --
+    every minimizer, mapping, hit and PAF record against the oracle (not only properties)."""
+    W = synth.workload("C2", 1.0)
+    chroms, cbuf, coff, _, _ = synth.make_assembly(1, W["n_chrom"], W["contigs_per_chrom"], W["contig_len"])
+    rbuf, roff, _ = synth.make_reads(2, chroms, W["read_bases"], W["read_len"], W["sub"], W["ins"], W["dele"], lognormal_sigma=0.4)
+    k, w = W["k"], W["w"]
+    ctg_len = np.diff(coff).astype(np.uint32)
+    rlen = np.diff(roff).astype(np.uint32)
+    with dev.batch(cbuf, coff) as cb, dev.sketch(cb, k, w) as csk, dev.index(csk, ctg_len) as ix, \
+            dev.batch(rbuf, roff) as rb, dev.sketch(rb, k, w) as rsk, dev.map(ix, rsk, rlen, k=k, z=1000) as res:
+        got = res.download()
+        c_off, ch, cp, cs = csk.download()
+        r_off, rh, rp, rs = rsk.download()
+        nix = len(ix)
+    o_off, oh, op, os_ = oracle.sketch_batch(cbuf, coff, k, w)
+    assert np.array_equal(c_off, o_off) and np.array_equal(ch, oh) and np.array_equal(cp, op) and np.array_equal(cs, os_)
+    q_off, qh, qp, qs = oracle.sketch_batch(rbuf, roff, k, w)
+    assert np.array_equal(r_off, q_off) and np.array_equal(rh, qh) and np.array_equal(rp, qp) and np.array_equal(rs, qs)
+    from helpers import contig_ids
+    oix = oracle.Index(oh, contig_ids(o_off), op, os_)
+    assert nix == len(oix)
+    exp = oracle.map_reads(oix, ctg_len, q_off, rlen, qh, qp, qs, k=k, z=1000, threads=0)
+    pc.assert_same_records(got, exp)
+    assert len(got["maps"]) > 40000 and len(rh) > 9_000_000
