@@ -238,7 +238,11 @@ __global__ __launch_bounds__(NT) void sketch_mask_kernel(SketchArgs A)
     /* ---- phase 2: suffix minima of the own block, block minimum, prefix of length R0 --- */
     uint64_t S_h[C];
     uint32_t S_i[C];
-    {
+    if (e_lane >= (int64_t)I.M) {
+        /* lanes past the end of the sequence (tail strips): nothing to scan; whole wavefronts skip */
+        s_bm_h[L] = NTL_INF; s_bm_i[L] = 0xFFFFu;
+        s_pr_h[L] = NTL_INF; s_pr_i[L] = 0xFFFFu;
+    } else {
         uint64_t rh = NTL_INF;
         uint32_t ri = NTL_NONE;
 #pragma unroll
@@ -265,7 +269,9 @@ __global__ __launch_bounds__(NT) void sketch_mask_kernel(SketchArgs A)
     __syncthreads();
 
     /* ---- phase 3: minimum over the whole blocks L+1..L+a and L+1..L+a+1 ---------------- */
-    const bool own = L < G.LW;
+    /* lanes that start at least one window lying inside the sequence; in tail strips whole wavefronts
+       have none and skip phases 3 and 4 */
+    const bool own = L < G.LW && e_lane + G.w <= (int64_t)I.M;
     uint64_t fa_h = NTL_INF, fb_h;
     uint32_t fa_i = NTL_NONE, fb_i;
     if (own) {
