@@ -137,7 +137,8 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "bytes_per_base": round(0.25 + 16.0 * d, 4), "avg_launch_ms": round(avg_launch_ms, 4),
                          "launches": mask_n,
-                         "note": "integer/VALU-bound kernel (SURVEY 7): see DESIGN.md for the VALU roofline"},
+                         "note": "integer/VALU-bound kernel (SURVEY 7): see DESIGN.md for the VALU roofline",
+                         "valu": valu_roofline(args.workload, args.scale, avg_launch_ms)},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cbuf, coff, ctg_len, rbuf, roff, read_len, k, w, params, stats)
@@ -160,6 +161,22 @@ def pmc_traffic(workload, scale):
     if not t:
         return None, None
     return t["bytes_per_launch"], t["source"]
+
+
+def valu_roofline(workload, scale, avg_launch_ms):
+    """The roofline that actually binds the kernel: VALU issue.  Peak measured with tools/valu_calib.hip
+    (profiles/r01_valu_calibration.txt): one wave64 VALU instruction per 4 cycles per SIMD.  Instructions per
+    launch come from the committed PMC pass (SQ_INSTS_VALU), the launch time is the live one."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if scale != 1.0 or not os.path.exists(path) or avg_launch_ms <= 0:
+        return None
+    t = json.load(open(path)).get(workload, {})
+    if "valu_wave_instr_per_launch" not in t:
+        return None
+    peak = 1024 * 2.2e9 / 4.0  # wave-instructions per second (256 CUs x 4 SIMDs, ~2.2 GHz under load)
+    ach = t["valu_wave_instr_per_launch"] / (avg_launch_ms * 1e-3)
+    return {"achieved": round(ach / 1e9, 2), "peak": round(peak / 1e9, 1), "unit": "G wave-instr/s", "frac": round(ach / peak, 3),
+            "lane_instr_per_base": t.get("valu_lane_instr_per_base"), "source": t.get("valu_source")}
 
 
 def cpu_baseline(cbuf, coff, ctg_len, rbuf, roff, read_len, k, w, params, stats):

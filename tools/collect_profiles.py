@@ -38,7 +38,15 @@ if mk and "pmc_write" in summary:
     n = sum(summary["pmc_fetch"][k]["FETCH_SIZE"]["launches"] for k in mk)
     w = sum(summary["pmc_write"][k]["WRITE_SIZE"]["avg"] * summary["pmc_write"][k]["WRITE_SIZE"]["launches"] for k in mk)
     f, w = f / n * 1024, w / n * 1024
-    json.dump({"C2": {"bytes_per_launch": int(2 * f + w), "fetch_size_bytes": int(f), "write_size_bytes": int(w),
+    extra = {}
+    if "pmc_sq" in summary:
+        vi = sum(summary["pmc_sq"][k]["SQ_INSTS_VALU"]["avg"] * summary["pmc_sq"][k]["SQ_INSTS_VALU"]["launches"] for k in mk if k in summary["pmc_sq"])
+        vn = sum(summary["pmc_sq"][k]["SQ_INSTS_VALU"]["launches"] for k in mk if k in summary["pmc_sq"])
+        if vn:
+            extra = {"valu_wave_instr_per_launch": int(vi / vn),
+                     "valu_lane_instr_per_base": round(vi / vn * 64 / 275.08e6, 1),  # C2: (500.09 + 50.06) Mbases per step / 2 launches
+                     "valu_source": f"profiles/{tag}_pmc_sq_counter_collection.csv SQ_INSTS_VALU, average over the sketch_mask_kernel launches"}
+    json.dump({"C2": {**extra, "bytes_per_launch": int(2 * f + w), "fetch_size_bytes": int(f), "write_size_bytes": int(w),
                       "source": f"profiles/{tag}_pmc_fetch/_pmc_write_counter_collection.csv: average over the sketch_mask_kernel "
                                 "launches of one bench step (contig + read sketch), rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate "
                                 "passes; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B on wide "
