@@ -19,7 +19,7 @@ import numpy as np
 
 from . import capi, formats, pairing, seqio
 
-DEFAULT_BATCH_BASES = 2_000_000_000  # read bases per device batch (packed: 0.5 GB)
+DEFAULT_BATCH_BASES = 256_000_000  # read bases per device batch (packed: 64 MB); the next batch is parsed meanwhile
 
 
 def _log(*a):
@@ -143,6 +143,32 @@ def run_ntlink_pair(dev, args):
         raise
 
 
+def prefetched(gen, depth=2):
+    """Runs a generator in a background thread (the native reader releases the GIL), so that parsing the
+    next read batch overlaps device work and output writing of the current one."""
+    import queue
+    import threading
+    q = queue.Queue(maxsize=depth)
+    end = object()
+
+    def run():
+        try:
+            for item in gen:
+                q.put(item)
+            q.put(end)
+        except BaseException as exc:  # re-raised in the consumer
+            q.put(exc)
+
+    threading.Thread(target=run, daemon=True).start()
+    while True:
+        item = q.get()
+        if item is end:
+            return
+        if isinstance(item, BaseException):
+            raise item
+        yield item
+
+
 class LocalComm:
     """Single process.  The multi-GPU launcher passes a torch.distributed-backed object with the same
     three members (ntlink_amd/dist_pair.py)."""
@@ -205,7 +231,8 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
                     formats.write_indexlr(fh, ctg.names, ctg_len, off, h, p, s, False)
             with dev.index(csk, ctg_len) as ix:
                 stats["index_size"] = len(ix)
-                for rs_ in seqio.load(reads.split() if isinstance(reads, str) else list(reads), max_bases=batch_bases * comm.world):
+                for rs_ in prefetched(seqio.load(reads.split() if isinstance(reads, str) else list(reads),
+                                                 max_bases=batch_bases * comm.world)):
                     if not len(rs_):
                         continue
                     stats["t_ingest"] += time.perf_counter() - t_mark  # FASTA/FASTQ(.gz) parse of this batch

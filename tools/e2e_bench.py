@@ -29,6 +29,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scale", type=float, default=0.2)
     ap.add_argument("--gz", action="store_true")
+    ap.add_argument("--batch", type=int, default=pipeline.DEFAULT_BATCH_BASES)
     a = ap.parse_args()
     W = synth.workload("C2", a.scale)
     chroms, cbuf, coff, cn, _ = synth.make_assembly(1, W["n_chrom"], W["contigs_per_chrom"], W["contig_len"])
@@ -40,12 +41,12 @@ def main():
     dev = capi.Device(0)
     os.chdir(d)
     t0 = time.perf_counter()
-    st = pipeline.run_pair(dev, "asm.fa", os.path.basename(rds), k=W["k"], w=W["w"], paf=True, pairs_tsv=True)
+    st = pipeline.run_pair(dev, "asm.fa", os.path.basename(rds), k=W["k"], w=W["w"], paf=True, pairs_tsv=True, batch_bases=a.batch)
     dt = time.perf_counter() - t0
     out_bytes = sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d) if f.startswith("asm.fa."))
     print(json.dumps({"end_to_end_Gbases_per_s": round(st["read_bases"] / dt / 1e9, 4), "seconds": round(dt, 3),
-                      "read_bases": st["read_bases"], "reads": st["reads"], "gz": a.gz, "output_bytes": out_bytes,
-                      "t_ingest": round(st["t_ingest"], 3), "t_device_incl_pack_pcie": round(st["t_device"], 3),
+                      "read_bases": st["read_bases"], "reads": st["reads"], "gz": a.gz, "batch_bases": a.batch, "output_bytes": out_bytes,
+                      "t_wait_for_ingest": round(st["t_ingest"], 3), "t_device_incl_pack_pcie": round(st["t_device"], 3),
                       "t_write": round(st["t_write"], 3), "t_tally": round(st["t_tally"], 3), "device": dev.name}))
     dev.close()
 
