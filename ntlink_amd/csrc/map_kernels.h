@@ -152,8 +152,8 @@ struct HitRec { uint32_t ctg_pos, read_pos; uint8_t ctg_strand, read_strand, pad
 struct PafRec { uint32_t read, ctg, q_start, q_end, t_start, t_end, n_hits, strand; };
 
 #define MAP_NT 64
-#define MAP_CAPH 512 /* hits per read staged in LDS */
-#define MAP_CAPR 128 /* runs per read staged in LDS */
+/* hits / runs per read staged in LDS: template parameters of map_kernel (512/128 for dense sketches,
+   256/64 -- twice the resident wavefronts -- when reads carry few minimizers); larger reads use global scratch */
 #define MAP_NHA 6    /* per-hit u32 arrays */
 #define MAP_NRA 10   /* per-run u32 arrays */
 
@@ -239,6 +239,7 @@ __device__ __forceinline__ void map_fill_runs(HitArr H, uint32_t n, RunArr RU, u
     __syncthreads();
 }
 
+template <int MAP_CAPH, int MAP_CAPR>
 __global__ __launch_bounds__(MAP_NT) void map_kernel(MapArgs A)
 {
     __shared__ uint32_t s_hit[MAP_NHA][MAP_CAPH];

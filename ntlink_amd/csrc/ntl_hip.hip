@@ -805,7 +805,9 @@ extern "C" int ntl_map_run(ntl_ctx *c, const ntl_index *ix, const ntl_sketch *re
     if (nreads) {
         {
             ProfSpan sp(c, "map");
-            hipLaunchKernelGGL(map_kernel, dim3((unsigned)nreads), dim3(MAP_NT), 0, c->stream, A);
+            /* LDS staging sized by the average sketch length of the batch */
+            if (nmx <= 256 * nreads) hipLaunchKernelGGL((map_kernel<256, 64>), dim3((unsigned)nreads), dim3(MAP_NT), 0, c->stream, A);
+            else hipLaunchKernelGGL((map_kernel<512, 128>), dim3((unsigned)nreads), dim3(MAP_NT), 0, c->stream, A);
             HIPCHK(c, hipGetLastError());
         }
         ProfSpan sp(c, "compact");
