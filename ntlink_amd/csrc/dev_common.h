@@ -31,9 +31,8 @@ __device__ __forceinline__ uint64_t sror1(uint64_t x)
 {
     const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
     const uint32_t nlo = ntl_alignbit(hi, lo, 1);               /* bit 32 -> bit 31 */
-    uint32_t nhi = (hi >> 1) & 0x7FFFFFFEu;                     /* bits 34..63 -> 33..62 */
-    nhi |= lo & 1u;                                             /* bit 0 -> bit 32 */
-    nhi |= (hi << 30) & 0x80000000u;                            /* bit 33 -> bit 63 */
+    const uint32_t src = (hi << 30) | (lo & 1u);                /* bit 33 -> bit 63, bit 0 -> bit 32 */
+    const uint32_t nhi = ((hi >> 1) & ~0x80000001u) | (src & 0x80000001u); /* one v_bfi */
     return ((uint64_t)nhi << 32) | nlo;
 }
 

@@ -513,9 +513,9 @@ extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_
     if (k < 1 || k > 4096 || w < 1) return fail(c, NTL_EINVAL, "k must be in 1..4096 and w >= 1");
     hipSetDevice(c->device);
     int C = w >= 16 ? 16 : (w >= 4 ? 4 : 1);
-    if (const char *e = getenv("NTL_SKETCH_C")) { /* tuning knob: k-mers per lane (16, 8, 4, 1) */
+    if (const char *e = getenv("NTL_SKETCH_C")) { /* tuning knob: k-mers per lane (16, 4, 1) */
         const int v = atoi(e);
-        if ((v == 16 || v == 8 || v == 4 || v == 1) && w >= v) C = v;
+        if ((v == 16 || v == 4 || v == 1) && w >= v) C = v;
     }
     SketchGeom G;
     G.k = k; G.w = w;
@@ -587,7 +587,6 @@ extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_
         A.g8 = (const uint64_t (*)[2])c->g8;
         ProfSpan sp(c, "sketch_mask");
         if (C == 16) launch_mask<16>(c, A, (unsigned)ub_strips, b->any_multi, nt);
-        else if (C == 8) launch_mask<8>(c, A, (unsigned)ub_strips, b->any_multi, nt);
         else if (C == 4) launch_mask<4>(c, A, (unsigned)ub_strips, b->any_multi, nt);
         else launch_mask<1>(c, A, (unsigned)ub_strips, b->any_multi, nt);
         HIPCHK(c, hipGetLastError());
