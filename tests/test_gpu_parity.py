@@ -174,3 +174,30 @@ def test_c2_baseline_size_bit_exact(dev):
     exp = oracle.map_reads(oix, ctg_len, q_off, rlen, qh, qp, qs, k=k, z=1000, threads=0)
     pc.assert_same_records(got, exp)
     assert len(got["maps"]) > 40000 and len(rh) > 9_000_000
+
+
+def test_batch_beyond_2_pow_32_bases(dev):
+    """One batch of 4.6 Gbases: global base indices exceed 2^32 (64-bit index arithmetic in every kernel).
+    The reads beyond the 2^32 boundary, and a slice straddling it, are checked against the oracle."""
+    rng = np.random.default_rng(11)
+    unit = synth.random_bases(rng, 64_000_000)           # reads are windows of a 64 Mbp pool: cheap to generate
+    n, rl = 230_000, 20_000
+    starts = rng.integers(0, len(unit) - rl, n)
+    buf = np.empty(n * rl, np.uint8)
+    for i in range(n):
+        buf[i * rl:(i + 1) * rl] = unit[starts[i]:starts[i] + rl]
+    off = (np.arange(n + 1, dtype=np.uint64) * np.uint64(rl))
+    assert int(off[-1]) > 2 ** 32 + 200_000_000
+    k, w = 32, 250
+    with dev.batch(buf, off) as b, dev.sketch(b, k, w) as sk:
+        moff, h, p, s = sk.download()
+    first_beyond = int(np.searchsorted(off, 2 ** 32))
+    for lo, hi in ((first_beyond - 3, first_beyond + 40), (n - 60, n), (0, 20)):
+        sub = buf[int(off[lo]):int(off[hi])]
+        soff = off[lo:hi + 1] - off[lo]
+        ooff, oh, op, os_ = oracle.sketch_batch(sub, soff, k, w)
+        a, bnd = int(moff[lo]), int(moff[hi])
+        assert np.array_equal(moff[lo:hi + 1] - moff[lo], ooff)
+        assert np.array_equal(h[a:bnd], oh) and np.array_equal(p[a:bnd], op) and np.array_equal(s[a:bnd], os_)
+    dens = len(h) / float(off[-1])
+    assert abs(dens - 2.0 / (w + 1)) < 0.0005
