@@ -153,7 +153,8 @@ struct PafRec { uint32_t read, ctg, q_start, q_end, t_start, t_end, n_hits, stra
 
 #define MAP_NT 64
 /* hits / runs per read staged in LDS: template parameters of map_kernel (512/128 for dense sketches,
-   256/64 -- twice the resident wavefronts -- when reads carry few minimizers); larger reads use global scratch */
+   256/64 -- twice the resident wavefronts -- when reads carry few minimizers; 1024/128 measured slower); larger reads
+   use global scratch */
 #define MAP_NHA 6    /* per-hit u32 arrays */
 #define MAP_NRA 10   /* per-run u32 arrays */
 
@@ -323,6 +324,32 @@ __global__ __launch_bounds__(MAP_NT) void map_kernel(MapArgs A)
 
     /* bin/ntlink_utils.py:217-234 noisy contigs: span on the contig longer than the read allows */
     {
+        if (R <= 8) {
+            /* few, possibly long runs (HiFi: hundreds of hits on one contig): the lanes share each run and
+               lane 0 merges the 64 partial results; H.ord is free until the PAF stage (>= 256 entries) */
+            uint32_t *tmp = H.ord;
+            for (uint32_t q = 0; q < R; q++) {
+                const uint32_t s = RU.start[q], e = q + 1 < R ? RU.start[q + 1] : n;
+                uint32_t mn = 0, mni = NTL_NONE, mx = 0, mxi = NTL_NONE;
+                for (uint32_t i = s + lane; i < e; i += MAP_NT) { /* i ascends: strict compares keep the first */
+                    const uint32_t p = H.cpos[i];
+                    if (mni == NTL_NONE || p < mn) { mn = p; mni = i; }
+                    if (mxi == NTL_NONE || p > mx) { mx = p; mxi = i; }
+                }
+                __syncthreads(); /* tmp of the previous run has been consumed */
+                tmp[lane] = mn; tmp[MAP_NT + lane] = mni; tmp[2 * MAP_NT + lane] = mx; tmp[3 * MAP_NT + lane] = mxi;
+                __syncthreads();
+                if (lane == 0) {
+                    uint32_t bmn = 0, bmni = NTL_NONE, bmx = 0, bmxi = NTL_NONE;
+                    for (uint32_t l = 0; l < MAP_NT; l++) {
+                        const uint32_t a = tmp[l], ai = tmp[MAP_NT + l], b = tmp[2 * MAP_NT + l], bi = tmp[3 * MAP_NT + l];
+                        if (ai != NTL_NONE && (bmni == NTL_NONE || a < bmn || (a == bmn && ai < bmni))) { bmn = a; bmni = ai; }
+                        if (bi != NTL_NONE && (bmxi == NTL_NONE || b > bmx || (b == bmx && bi < bmxi))) { bmx = b; bmxi = bi; }
+                    }
+                    RU.cnt[q] = e - s; RU.mn[q] = bmn; RU.mni[q] = bmni; RU.mx[q] = bmx; RU.mxi[q] = bmxi;
+                }
+            }
+        } else
         for (uint32_t q = lane; q < R; q += MAP_NT) {
             const uint32_t s = RU.start[q], e = q + 1 < R ? RU.start[q + 1] : n;
             uint32_t mn = H.cpos[s], mni = s, mx = mn, mxi = s;
