@@ -324,8 +324,8 @@ __global__ __launch_bounds__(MAP_NT) void map_kernel(MapArgs A)
 
     /* bin/ntlink_utils.py:217-234 noisy contigs: span on the contig longer than the read allows */
     {
-        if (R <= 8) {
-            /* few, possibly long runs (HiFi: hundreds of hits on one contig): the lanes share each run and
+        if (R <= 8 && n >= 128) {
+            /* few, long runs (HiFi: hundreds of hits on one contig): the lanes share each run and
                lane 0 merges the 64 partial results; H.ord is free until the PAF stage (>= 256 entries) */
             uint32_t *tmp = H.ord;
             for (uint32_t q = 0; q < R; q++) {
