@@ -43,7 +43,19 @@ def main():
     torch.cuda.set_device(local_rank)
     if "RANK" in os.environ:  # launched by torch.distributed.run: one rank per GPU, RCCL for barrier/max only
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # RCCL prints a version banner on stdout when the communicator comes up: keep stdout for the one JSON line
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            warm = torch.zeros(1, device="cuda")
+            dist.all_reduce(warm)
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
 
     W = synth.workload(args.workload, args.scale)
     if args.workload != "C2":
