@@ -41,6 +41,7 @@ extern "C" {
 #define NTL_EDEVICE (-2)  /* no usable gfx950 device / HIP runtime error */
 #define NTL_ENOMEM (-3)
 #define NTL_EINTERNAL (-4) /* an internal invariant failed (reported, never silently ignored) */
+#define NTL_ERANGE (-5)    /* ntl_tally_add: an overhang came out negative (the reference asserts) */
 
 typedef struct ntl_ctx ntl_ctx;
 typedef struct ntl_batch ntl_batch;
@@ -71,13 +72,19 @@ int ntl_prof_get(ntl_ctx *ctx, const char *name, double *total_ms, uint64_t *lau
 /* ---- sequences ------------------------------------------------------------------------ */
 
 /* Hands nseq sequences over: sequence i is the ASCII bytes seqs[offsets[i] .. offsets[i+1]).
- * They are packed to 2 bits/base plus a table of non-ACGT runs and copied to the device, where
- * they stay until ntl_batch_destroy.  Replaces: SeqReader -> NtHash input (ntLink:199,223). */
+ * The bytes are copied to the device as they are and packed there to 2 bits/base plus a table of
+ * ACGT runs; the result stays on the device until ntl_batch_destroy and the caller's arrays are
+ * free again when the call returns.  Replaces: SeqReader -> NtHash input (ntLink:199,223). */
 int ntl_batch_create(ntl_ctx *ctx, const char *seqs, const uint64_t *offsets, uint64_t nseq,
                      ntl_batch **out);
 void ntl_batch_destroy(ntl_batch *b);
 uint64_t ntl_batch_nseq(const ntl_batch *b);
 uint64_t ntl_batch_bases(const ntl_batch *b);
+
+/* Page-locked host memory for the seqs of ntl_batch_create (one DMA instead of a staged copy);
+ * the FASTA/FASTQ reader below can parse straight into it.  Optional: any host pointer works. */
+int ntl_host_alloc(ntl_ctx *ctx, uint64_t bytes, void **out);
+void ntl_host_free(ntl_ctx *ctx, void *p);
 
 /* ---- sketch ---------------------------------------------------------------------------- */
 
@@ -162,14 +169,20 @@ typedef struct ntl_fastx ntl_fastx;
 int ntl_fastx_open(const char *path, ntl_fastx **out);
 void ntl_fastx_close(ntl_fastx *r);
 const char *ntl_fastx_error(const ntl_fastx *r);
-/* Collects records until at least max_bases bases are held (0 = whole input); *nseq == 0 at the end.
- * The accessors below stay valid until the next call: sequence i is seqs[offsets[i]..offsets[i+1]),
- * its id names[name_offsets[i]..name_offsets[i+1]). */
+/* Collects records until about max_bases bases are held (0 = whole input); *nseq == 0 at the end.
+ * Plain regular files are memory-mapped and parsed by several threads (NTL_IO_THREADS, default
+ * min(cores, 32)) over byte ranges cut at record boundaries; gzip and stdin go through zlib on one.
+ * ntl_fastx_sizes + ntl_fastx_copy gather the batch into caller-allocated arrays (offsets and
+ * name_offsets: nseq + 1 entries): sequence i is seqs[offsets[i]..offsets[i+1]), its id
+ * names[name_offsets[i]..name_offsets[i+1]).  The pointer accessors return a contiguous copy held
+ * by the reader, valid until the next call. */
 int ntl_fastx_next(ntl_fastx *r, uint64_t max_bases, uint64_t *nseq);
-const char *ntl_fastx_seqs(const ntl_fastx *r);
-const uint64_t *ntl_fastx_offsets(const ntl_fastx *r);
-const char *ntl_fastx_names(const ntl_fastx *r);
-const uint64_t *ntl_fastx_name_offsets(const ntl_fastx *r);
+void ntl_fastx_sizes(const ntl_fastx *r, uint64_t *nseq, uint64_t *bases, uint64_t *name_bytes);
+int ntl_fastx_copy(const ntl_fastx *r, char *seqs, uint64_t *offsets, char *names, uint64_t *name_offsets);
+const char *ntl_fastx_seqs(ntl_fastx *r);
+const uint64_t *ntl_fastx_offsets(ntl_fastx *r);
+const char *ntl_fastx_names(ntl_fastx *r);
+const uint64_t *ntl_fastx_name_offsets(ntl_fastx *r);
 
 /* Text emitters, written to file descriptor fd.  Names are concatenated ids + offsets[n+1].
  * ntl_write_indexlr: `id\t[len\t]H:pos:strand ...` (ntLink:199,223); lengths == NULL omits --len,
@@ -183,6 +196,26 @@ int ntl_write_verbose(int fd, const ntl_mapping *maps, uint64_t n_maps, const nt
                       const char *ctg_names, const uint64_t *ctg_name_off);
 int ntl_write_paf(int fd, const ntl_paf *pafs, uint64_t n, const char *read_names, const uint64_t *read_name_off,
                   const uint32_t *read_len, const char *ctg_names, const uint64_t *ctg_name_off, const uint32_t *ctg_len);
+
+/* ---- host-side pair tally (no GPU involved) ------------------------------------------------- */
+
+/* The contig-pair bookkeeping of bin/ntlink_pair.py (tally_pairs_from_mappings :416-435, add_pair
+ * :315-334, calculate_pair_info :222-239, calculate_gap_size :157-187, normalize_pair :213-219)
+ * over the records of ntl_map_run.  Pairs are keyed by contig NAME (byte order decides which
+ * contig comes first); f = the -f chain-length threshold.  ntl_tally_add takes one batch of reads
+ * in order (read_len indexed by ntl_mapping.read) and returns NTL_ERANGE where the reference
+ * raises "Gap distance estimation less than 0".  ntl_tally_export lists every pair in order of
+ * first appearance: contig indices, orientations (1 = '+'), anchor count and
+ * gaps[gap_off[i] .. gap_off[i+1]) in read order (arrays sized from npairs / ngaps). */
+typedef struct ntl_tally ntl_tally;
+int ntl_tally_create(const char *ctg_names, const uint64_t *ctg_name_off, const uint32_t *ctg_len, uint64_t n_ctg,
+                     int k, int f, ntl_tally **out);
+void ntl_tally_destroy(ntl_tally *t);
+int ntl_tally_add(ntl_tally *t, const ntl_mapping *maps, uint64_t n_maps, const ntl_hit *hits, const uint32_t *read_len);
+uint64_t ntl_tally_npairs(const ntl_tally *t);
+uint64_t ntl_tally_ngaps(const ntl_tally *t);
+int ntl_tally_export(const ntl_tally *t, uint32_t *src, uint8_t *src_ori, uint32_t *tgt, uint8_t *tgt_ori,
+                     uint32_t *anchor, uint64_t *gap_off, int64_t *gaps);
 
 #ifdef __cplusplus
 }

@@ -5,6 +5,8 @@ fallback: importing works anywhere (so that CLIs can print --help), but opening 
 the library or without a GPU raises.
 """
 import ctypes as C
+import threading
+import weakref
 import os
 
 import numpy as np
@@ -16,14 +18,15 @@ DEFAULT_LIB = os.path.join(_HERE, "libntlink_hip.so")
 SYMBOLS = [
     "ntl_ctx_create", "ntl_ctx_destroy", "ntl_last_error", "ntl_ctx_device_name", "ntl_ctx_sync",
     "ntl_prof_enable", "ntl_prof_reset", "ntl_prof_get",
-    "ntl_batch_create", "ntl_batch_destroy", "ntl_batch_nseq", "ntl_batch_bases",
+    "ntl_batch_create", "ntl_batch_destroy", "ntl_batch_nseq", "ntl_batch_bases", "ntl_host_alloc", "ntl_host_free",
     "ntl_sketch_run", "ntl_sketch_destroy", "ntl_sketch_nseq", "ntl_sketch_count", "ntl_sketch_download",
     "ntl_sketch_from_host",
     "ntl_index_build", "ntl_index_destroy", "ntl_index_size",
     "ntl_map_run", "ntl_mapres_destroy", "ntl_mapres_n_mappings", "ntl_mapres_n_hits", "ntl_mapres_n_pafs",
     "ntl_mapres_n_index_hits", "ntl_mapres_download",
-    "ntl_fastx_open", "ntl_fastx_close", "ntl_fastx_error", "ntl_fastx_next", "ntl_fastx_seqs", "ntl_fastx_offsets",
+    "ntl_fastx_open", "ntl_fastx_close", "ntl_fastx_error", "ntl_fastx_next", "ntl_fastx_sizes", "ntl_fastx_copy", "ntl_fastx_seqs", "ntl_fastx_offsets",
     "ntl_fastx_names", "ntl_fastx_name_offsets", "ntl_write_indexlr", "ntl_write_verbose", "ntl_write_paf",
+    "ntl_tally_create", "ntl_tally_destroy", "ntl_tally_add", "ntl_tally_npairs", "ntl_tally_ngaps", "ntl_tally_export",
 ]
 
 MAPPING_DT = np.dtype([("read", "<u4"), ("ctg", "<u4"), ("n_hits", "<u4"), ("pad", "<u4"), ("hit_off", "<u8")])
@@ -94,12 +97,18 @@ def load(path=None):
         f.argtypes = [vp]
         f.restype = C.c_uint64
     L.ntl_mapres_download.argtypes = [vp, vp, vp, vp]
+    L.ntl_host_alloc.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
+    L.ntl_host_free.argtypes = [vp, vp]
+    L.ntl_host_free.restype = None
     L.ntl_fastx_open.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.ntl_fastx_close.argtypes = [vp]
     L.ntl_fastx_close.restype = None
     L.ntl_fastx_error.argtypes = [vp]
     L.ntl_fastx_error.restype = C.c_char_p
     L.ntl_fastx_next.argtypes = [vp, C.c_uint64, u64p]
+    L.ntl_fastx_sizes.argtypes = [vp, u64p, u64p, u64p]
+    L.ntl_fastx_sizes.restype = None
+    L.ntl_fastx_copy.argtypes = [vp, vp, vp, vp, vp]
     for nm in ("seqs", "offsets", "names", "name_offsets"):
         f = getattr(L, "ntl_fastx_" + nm)
         f.argtypes = [vp]
@@ -107,6 +116,15 @@ def load(path=None):
     L.ntl_write_indexlr.argtypes = [C.c_int, C.c_uint64, vp, u64p, u32p, u64p, u64p, u32p, u8p]
     L.ntl_write_verbose.argtypes = [C.c_int, vp, C.c_uint64, vp, vp, u64p, vp, u64p]
     L.ntl_write_paf.argtypes = [C.c_int, vp, C.c_uint64, vp, u64p, u32p, vp, u64p, u32p]
+    L.ntl_tally_create.argtypes = [vp, u64p, u32p, C.c_uint64, C.c_int, C.c_int, C.POINTER(vp)]
+    L.ntl_tally_destroy.argtypes = [vp]
+    L.ntl_tally_destroy.restype = None
+    L.ntl_tally_add.argtypes = [vp, vp, C.c_uint64, vp, u32p]
+    for nm in ("npairs", "ngaps"):
+        f = getattr(L, "ntl_tally_" + nm)
+        f.argtypes = [vp]
+        f.restype = C.c_uint64
+    L.ntl_tally_export.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     _libs[path] = L
     return L
 
@@ -120,6 +138,7 @@ class _Handle:
 
     def __init__(self, dev, ptr):
         self.dev, self.ptr = dev, ptr
+        dev._live.add(self)  # closed with the device at the latest
 
     def close(self):
         if self.ptr:
@@ -213,9 +232,17 @@ class Device:
             raise NtlError(f"ntl_ctx_create(device={device}) failed with {rc}: no usable GPU "
                            f"(this package has no CPU path)")
         self.ptr = p
+        self._live = weakref.WeakSet()
+        self._pinned_free, self._pinned_all, self._pinned_out = [], [], {}  # (address, capacity) of page-locked buffers
+        self._pinned_lock = threading.Lock()  # the reader thread takes buffers, the device thread returns them
 
     def close(self):
         if self.ptr:
+            for h in list(self._live):  # device objects die before their context
+                h.close()
+            for addr, _cap in self._pinned_all:
+                self.L.ntl_host_free(self.ptr, addr)
+            self._pinned_free, self._pinned_all, self._pinned_out = [], [], {}
             self.L.ntl_ctx_destroy(self.ptr)
             self.ptr = None
 
@@ -247,6 +274,37 @@ class Device:
         ms, n = C.c_double(), C.c_uint64()
         self._chk(self.L.ntl_prof_get(self.ptr, name.encode(), C.byref(ms), C.byref(n)))
         return ms.value, int(n.value)
+
+    # ---- page-locked staging buffers for sequence bytes
+    def pinned_empty(self, nbytes):
+        """uint8 array of nbytes in page-locked memory from a small pool (reused buffers are already
+        faulted in, and their copy to the device is one DMA).  Give it back with pinned_release();
+        the memory is only valid while this Device is open."""
+        nbytes = int(nbytes)
+        with self._pinned_lock:
+            pick = None
+            for i, (addr, cap) in enumerate(self._pinned_free):
+                if cap >= nbytes and (pick is None or cap < self._pinned_free[pick][1]):
+                    pick = i
+            if pick is None:
+                cap = max(int(nbytes * 1.125) + 4096, 1 << 20)
+                p = C.c_void_p()
+                self._chk(self.L.ntl_host_alloc(self.ptr, cap, C.byref(p)))
+                addr = p.value
+                self._pinned_all.append((addr, cap))
+            else:
+                addr, cap = self._pinned_free.pop(pick)
+            self._pinned_out[addr] = (addr, cap)
+        return np.frombuffer((C.c_uint8 * cap).from_address(addr), np.uint8)[:nbytes]
+
+    def pinned_release(self, arr):
+        """No-op for arrays that did not come from pinned_empty()."""
+        if arr is None:
+            return
+        with self._pinned_lock:
+            ent = self._pinned_out.pop(arr.ctypes.data, None)
+            if ent is not None:
+                self._pinned_free.append(ent)
 
     # ---- the path
     def batch(self, seqs, offsets=None):

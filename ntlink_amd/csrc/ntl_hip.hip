@@ -20,6 +20,7 @@
 #include "scan_kernels.h"
 #include "sketch_kernels.h"
 #include "map_kernels.h"
+#include "pack_kernels.h"
 
 #define NTL_END_PAD 4096u /* bases of padding behind the last sequence (rolling over-reads) */
 #define SK_NT 256
@@ -273,19 +274,9 @@ struct ntl_batch {
     std::vector<uint32_t> seq_len;
 };
 
-static const uint8_t *base_lut()
-{
-    static uint8_t lut[256];
-    static bool init = false;
-    if (!init) {
-        memset(lut, 4, sizeof lut);
-        lut[(int)'A'] = lut[(int)'a'] = 0; lut[(int)'C'] = lut[(int)'c'] = 1;
-        lut[(int)'G'] = lut[(int)'g'] = 2; lut[(int)'T'] = lut[(int)'t'] = 3;
-        init = true;
-    }
-    return lut;
-}
-
+/* Host arrays in, device layout out: the bases travel as they are (one byte each) and are packed and
+ * scanned for ACGT runs on the device (pack_kernels.h).  Pinned memory from ntl_host_alloc makes the
+ * copy a single DMA; anything else goes through the runtime's staging buffers. */
 extern "C" int ntl_batch_create(ntl_ctx *c, const char *seqs, const uint64_t *off, uint64_t nseq, ntl_batch **out)
 {
     if (!c || !out || (!seqs && nseq) || !off) return NTL_EINVAL;
@@ -295,128 +286,94 @@ extern "C" int ntl_batch_create(ntl_ctx *c, const char *seqs, const uint64_t *of
         if (off[i + 1] < off[i]) return fail(c, NTL_EINVAL, "offsets must be non-decreasing");
         if (off[i + 1] - off[i] >= 0xFFFFFFF0ull) return fail(c, NTL_EINVAL, "sequence longer than 2^32 bases");
     }
-    const uint8_t *lut = base_lut();
     const uint64_t o0 = nseq ? off[0] : 0;
     const uint64_t total = nseq ? off[nseq] - o0 : 0;
-    ntl_batch *b = new ntl_batch();
+    std::unique_ptr<ntl_batch> b(new ntl_batch());
     b->c = c;
     b->nseq = nseq;
     b->bases = total;
     b->total_gpos = NTL_LEAD_PAD + total;
     const uint64_t nwords = (NTL_LEAD_PAD + total + NTL_END_PAD + 15) / 16 + 2;
     b->nwords_packed = nwords;
-    std::vector<uint32_t> packed(nwords, 0u);
     std::vector<uint64_t> seq_base(nseq + 1);
     b->seq_len.resize(nseq);
     for (uint64_t i = 0; i <= nseq; i++) seq_base[i] = NTL_LEAD_PAD + ((i < nseq ? off[i] : off[nseq]) - o0);
     for (uint64_t i = 0; i < nseq; i++) b->seq_len[i] = (uint32_t)(off[i + 1] - off[i]);
 
-    unsigned nthr = std::thread::hardware_concurrency();
-    if (nthr == 0) nthr = 1;
-    if (nthr > 16) nthr = 16;
-    if (total < (1u << 20)) nthr = 1;
-    /* pass 1: pack, split by word ranges so that no word is shared */
-    {
-        const uint64_t data_words = (total + NTL_LEAD_PAD + 15) / 16;
-        auto work = [&](uint64_t w0, uint64_t w1) {
-            const unsigned char *src = (const unsigned char *)seqs + o0;
-            for (uint64_t w = w0; w < w1; w++) {
-                uint32_t v = 0;
-                for (int j = 0; j < 16; j++) {
-                    const uint64_t g = w * 16 + j;
-                    if (g < NTL_LEAD_PAD || g >= NTL_LEAD_PAD + total) continue;
-                    const uint8_t cde = lut[src[g - NTL_LEAD_PAD]];
-                    v |= (uint32_t)(cde & 3u) << (2 * j);
-                }
-                packed[w] = v;
-            }
-        };
-        std::vector<std::thread> th;
-        for (unsigned t = 0; t < nthr; t++) {
-            uint64_t w0 = data_words * t / nthr, w1 = data_words * (t + 1) / nthr;
-            if (nthr == 1) work(w0, w1); else th.emplace_back(work, w0, w1);
-        }
-        for (auto &x : th) x.join();
-    }
-    /* pass 2: maximal ACGT runs per sequence */
-    std::vector<uint32_t> seq_run_first(nseq + 1, 0);
-    std::vector<uint32_t> run_start, run_len;
-    {
-        std::vector<std::vector<uint32_t>> rs(nthr), rl(nthr);
-        std::vector<std::vector<uint32_t>> cnt(nthr);
-        std::vector<uint64_t> lo(nthr + 1);
-        /* split sequences so that threads get about equal bases */
-        lo[0] = 0;
-        for (unsigned t = 1; t <= nthr; t++) {
-            const uint64_t target = o0 + total * t / nthr;
-            lo[t] = std::lower_bound(off, off + nseq, target) - off;
-            if (lo[t] < lo[t - 1]) lo[t] = lo[t - 1];
-        }
-        lo[nthr] = nseq;
-        auto work = [&](unsigned t) {
-            for (uint64_t i = lo[t]; i < lo[t + 1]; i++) {
-                const unsigned char *s = (const unsigned char *)seqs + off[i];
-                const uint64_t len = off[i + 1] - off[i];
-                uint32_t nr = 0;
-                uint64_t p = 0;
-                while (p < len) {
-                    while (p < len && lut[s[p]] == 4) p++;
-                    if (p >= len) break;
-                    uint64_t q = p;
-                    while (q < len && lut[s[q]] != 4) q++;
-                    rs[t].push_back((uint32_t)p);
-                    rl[t].push_back((uint32_t)(q - p));
-                    nr++;
-                    p = q;
-                }
-                cnt[t].push_back(nr);
-            }
-        };
-        std::vector<std::thread> th;
-        for (unsigned t = 0; t < nthr; t++) {
-            if (nthr == 1) work(t); else th.emplace_back(work, t);
-        }
-        for (auto &x : th) x.join();
-        uint64_t nr_total = 0;
-        for (unsigned t = 0; t < nthr; t++) nr_total += rs[t].size();
-        if (nr_total >= 0xFFFFFFF0ull) { delete b; return fail(c, NTL_EINVAL, "too many ACGT runs in one batch"); }
-        run_start.reserve(nr_total); run_len.reserve(nr_total);
-        uint32_t acc = 0;
-        for (unsigned t = 0; t < nthr; t++) {
-            run_start.insert(run_start.end(), rs[t].begin(), rs[t].end());
-            run_len.insert(run_len.end(), rl[t].begin(), rl[t].end());
-            for (uint64_t j = 0; j < cnt[t].size(); j++) {
-                seq_run_first[lo[t] + j] = acc;
-                acc += cnt[t][j];
-                if (cnt[t][j] > 1) b->any_multi = true;
-            }
-        }
-        seq_run_first[nseq] = acc;
-        b->nruns = nr_total;
-    }
+    const uint64_t n32 = (NTL_LEAD_PAD + total + 31) / 32; /* threads = 32-position groups that hold data */
     int rc;
     hipSetDevice(c->device);
+    DevBuf raw, valid32, ss32, starts32, rank, any_multi;
     if ((rc = b->packed.alloc(c, nwords * 4)) || (rc = b->seq_base.alloc(c, (nseq + 1) * 8)) ||
-        (rc = b->seq_run_first.alloc(c, (nseq + 1) * 4)) || (rc = b->run_start.alloc(c, (b->nruns + 1) * 4)) ||
-        (rc = b->run_len.alloc(c, (b->nruns + 1) * 4))) {
-        delete b;
+        (rc = b->seq_run_first.alloc(c, (nseq + 1) * 4)) || (rc = raw.alloc(c, total + 64)) ||
+        (rc = valid32.alloc(c, (n32 + 2) * 4)) || (rc = ss32.alloc(c, (n32 + 2) * 4)) ||
+        (rc = starts32.alloc(c, (n32 + 2) * 4)) || (rc = rank.alloc(c, (n32 + 2) * 4)) || (rc = any_multi.alloc(c, 4)))
         return rc;
+    uint32_t nruns = 0, multi = 0;
+    DevBuf start_g, end_g;
+    {
+    ProfSpan span(c, "batch_pack");
+    if (total) HIPCHK(c, hipMemcpyAsync(raw.p, seqs + o0, total, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(b->seq_base.p, seq_base.data(), (nseq + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(b->packed.p, 0, nwords * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(valid32.p, 0, (n32 + 2) * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(ss32.p, 0, (n32 + 2) * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(starts32.p, 0, (n32 + 2) * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(rank.p, 0, (n32 + 2) * 4, c->stream)); /* counts; scanned in place */
+    HIPCHK(c, hipMemsetAsync(any_multi.p, 0, 4, c->stream));
+    const unsigned g32 = (unsigned)((n32 + PACK_NT - 1) / PACK_NT);
+    const unsigned gseq = (unsigned)((nseq + 1 + PACK_NT - 1) / PACK_NT);
+    if (n32) {
+        hipLaunchKernelGGL(pack_kernel, dim3(g32), dim3(PACK_NT), 0, c->stream, raw.as<uint8_t>(), total, b->packed.as<uint32_t>(),
+                           valid32.as<uint32_t>(), n32);
+        hipLaunchKernelGGL(seq_mark_kernel, dim3(gseq), dim3(PACK_NT), 0, c->stream, b->seq_base.as<uint64_t>(), (uint32_t)nseq,
+                           ss32.as<uint32_t>());
+        hipLaunchKernelGGL(run_count_kernel, dim3(g32), dim3(PACK_NT), 0, c->stream, valid32.as<uint32_t>(), ss32.as<uint32_t>(), n32,
+                           starts32.as<uint32_t>(), rank.as<uint32_t>());
+        HIPCHK(c, hipGetLastError());
     }
-    auto up = [&](DevBuf &d, const void *src, size_t n) -> hipError_t {
-        return n ? hipMemcpyAsync(d.p, src, n, hipMemcpyHostToDevice, c->stream) : hipSuccess;
-    };
-    hipError_t e = up(b->packed, packed.data(), nwords * 4);
-    if (e == hipSuccess) e = up(b->seq_base, seq_base.data(), (nseq + 1) * 8);
-    if (e == hipSuccess) e = up(b->seq_run_first, seq_run_first.data(), (nseq + 1) * 4);
-    if (e == hipSuccess) e = up(b->run_start, run_start.data(), b->nruns * 4);
-    if (e == hipSuccess) e = up(b->run_len, run_len.data(), b->nruns * 4);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream); /* host vectors die here */
-    if (e != hipSuccess) { delete b; return fail(c, NTL_EDEVICE, std::string("upload: ") + hipGetErrorString(e)); }
-    *out = b;
+    /* n32 + 1 counts (the last is the zero padding word) so that rank[n32] exists for seq_base[nseq] */
+    if ((rc = device_scan(c, rank.as<uint32_t>(), rank.as<uint32_t>(), n32 + 1, &nruns))) return rc;
+    if (nruns >= 0xFFFFFFF0u) return fail(c, NTL_EINVAL, "too many ACGT runs in one batch");
+    b->nruns = nruns;
+    if ((rc = b->run_start.alloc(c, ((uint64_t)nruns + 1) * 4)) || (rc = b->run_len.alloc(c, ((uint64_t)nruns + 1) * 4)) ||
+        (rc = start_g.alloc(c, ((uint64_t)nruns + 1) * 8)) || (rc = end_g.alloc(c, ((uint64_t)nruns + 1) * 8)))
+        return rc;
+    if (nruns) {
+        hipLaunchKernelGGL(run_fill_kernel, dim3(g32), dim3(PACK_NT), 0, c->stream, valid32.as<uint32_t>(), ss32.as<uint32_t>(),
+                           starts32.as<uint32_t>(), rank.as<uint32_t>(), n32, start_g.as<uint64_t>(), end_g.as<uint64_t>());
+        hipLaunchKernelGGL(run_finish_kernel, dim3((nruns + PACK_NT - 1) / PACK_NT), dim3(PACK_NT), 0, c->stream, start_g.as<uint64_t>(),
+                           end_g.as<uint64_t>(), nruns, b->seq_base.as<uint64_t>(), (uint32_t)nseq, b->run_start.as<uint32_t>(),
+                           b->run_len.as<uint32_t>());
+    }
+    hipLaunchKernelGGL(seq_runs_kernel, dim3(gseq), dim3(PACK_NT), 0, c->stream, starts32.as<uint32_t>(), rank.as<uint32_t>(),
+                       b->seq_base.as<uint64_t>(), (uint32_t)nseq, b->seq_run_first.as<uint32_t>(), any_multi.as<uint32_t>());
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(&multi, any_multi.p, 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream)); /* the caller's arrays and seq_base are free again */
+    b->any_multi = multi != 0;
+    *out = b.release();
     return NTL_OK;
 }
 
 extern "C" void ntl_batch_destroy(ntl_batch *b) { delete b; }
+
+extern "C" int ntl_host_alloc(ntl_ctx *c, uint64_t bytes, void **out)
+{
+    if (!c || !out) return NTL_EINVAL;
+    *out = nullptr;
+    hipSetDevice(c->device);
+    HIPCHK(c, hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return NTL_OK;
+}
+
+extern "C" void ntl_host_free(ntl_ctx *c, void *p)
+{
+    if (!c || !p) return;
+    hipSetDevice(c->device);
+    hipHostFree(p);
+}
 extern "C" uint64_t ntl_batch_nseq(const ntl_batch *b) { return b ? b->nseq : 0; }
 extern "C" uint64_t ntl_batch_bases(const ntl_batch *b) { return b ? b->bases : 0; }
 

@@ -16,6 +16,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
 #include <algorithm>
@@ -27,18 +30,174 @@
 
 /* ------------------------------------------------------------------ reader -------------- */
 
+/* Records of a stream batch (gzip / stdin); offsets are local to the chunk. */
+struct Chunk {
+    std::vector<char> seqs, names;
+    std::vector<uint64_t> off{0}, name_off{0};
+    void clear() { seqs.clear(); names.clear(); off.assign(1, 0); name_off.assign(1, 0); }
+    uint64_t nrec() const { return off.size() - 1; }
+};
+
+/* One byte range of a mapped file: counted by ntl_fastx_next, parsed into place by ntl_fastx_copy. */
+struct Range {
+    const char *b = nullptr, *e = nullptr;
+    bool at_eof = false;
+    uint64_t stop_bases = 0;
+    uint64_t nrec = 0, bases = 0, name_bytes = 0;
+    bool bad_end = false; /* ended inside a FASTQ quality section: e was not a record boundary */
+};
+
 struct ntl_fastx {
+    /* stream mode (gzip, stdin, pipes): zlib does the `gzip -cd -f` of ntLink:113-117 */
     gzFile gz = nullptr;
     std::vector<char> buf;
     size_t pos = 0, end = 0;
     bool eof = false;
     std::string pending;     /* header line read ahead (without the newline) */
     bool has_pending = false;
-    /* current batch */
-    std::string seqs, names;
-    std::vector<uint64_t> off, name_off;
+    Chunk chunk;
+    /* mapped mode (plain regular files): byte ranges of the file are parsed by several threads */
+    const char *map = nullptr;
+    size_t map_size = 0, cur = 0;
+    bool fastq = false;
+    std::vector<Range> ranges;
+    /* contiguous copies of the current batch for the pointer accessors */
+    std::vector<char> m_seqs, m_names;
+    std::vector<uint64_t> m_off, m_name_off;
+    bool materialized = false;
     std::string err;
 };
+
+static unsigned io_threads()
+{
+    if (const char *e = getenv("NTL_IO_THREADS")) { int v = atoi(e); if (v > 0) return (unsigned)std::min(v, 256); }
+    unsigned n = std::thread::hardware_concurrency();
+    return n == 0 ? 1 : std::min(n, 32u);
+}
+
+template <typename F>
+static void run_threads(size_t n, F work)
+{
+    if (n <= 1) { if (n) work((size_t)0); return; }
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < n; t++) th.emplace_back(work, t);
+    for (auto &x : th) x.join();
+}
+
+static inline bool id_blank(char ch) { return ch == ' ' || ch == '\t' || ch == '\r' || ch == '\f' || ch == '\v'; }
+
+/* id = header up to the first whitespace; str.split(None, 1) skips leading blanks (bin/read_fasta.py:22) */
+static inline void id_span(const char *h, size_t hl, size_t &a, size_t &b)
+{
+    a = 1;
+    while (a < hl && (h[a] == ' ' || h[a] == '\t')) a++;
+    b = a;
+    while (b < hl && !id_blank(h[b])) b++;
+}
+
+/* where parse_range puts what it finds: counters only, or the caller's arrays */
+struct CountSink {
+    uint64_t nrec = 0, nbases = 0, name_bytes = 0;
+    void id(const char *, size_t n) { name_bytes += n; }
+    void seq(const char *, size_t n) { nbases += n; }
+    void end_record() { nrec++; }
+    uint64_t bases() const { return nbases; }
+};
+struct WriteSink {
+    char *seqs; uint64_t *off; char *names; uint64_t *name_off; /* off / name_off point at this range's first record */
+    uint64_t b0, n0;                                             /* global positions of the range's first base / name byte */
+    uint64_t nb = 0, nn = 0, i = 0;
+    void id(const char *p, size_t n) { memcpy(names + n0 + nn, p, n); nn += n; name_off[i + 1] = n0 + nn; }
+    void seq(const char *p, size_t n) { memcpy(seqs + b0 + nb, p, n); nb += n; }
+    void end_record() { off[i + 1] = b0 + nb; i++; }
+    uint64_t bases() const { return nb; }
+};
+
+/*
+ * The record state machine of bin/read_fasta.py:6-46 over the bytes [p, e): a line starting with
+ * '>' or '@' is a header unless it falls inside a quality section; sequence lines run to the next
+ * line starting with '>', '@' or '+'; after '+', quality lines are skipped until they are as long as
+ * the sequence (at least one line).  stop_bases != 0: stop after the record that brings the range
+ * to that many bases.  Returns where the next record (or e) starts; *bad_end is set when the range
+ * ends inside a quality section.
+ */
+template <typename Sink>
+static const char *parse_range(const char *p, const char *e, uint64_t stop_bases, bool at_eof, Sink &c, bool *bad_end)
+{
+    auto line = [&](const char *&q, size_t &len) -> bool {
+        if (p >= e) return false;
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(e - p));
+        const char *le = nl ? nl : e;
+        q = p; len = (size_t)(le - p);
+        p = nl ? nl + 1 : e;
+        if (len && q[len - 1] == '\r') len--;
+        return true;
+    };
+    const char *q = nullptr, *h = nullptr;
+    size_t len = 0, hl = 0;
+    bool have_hdr = false;
+    for (;;) {
+        if (!have_hdr) {
+            bool found = false;
+            while (line(q, len))
+                if (len && (q[0] == '>' || q[0] == '@')) { h = q; hl = len; found = true; break; }
+            if (!found) break;
+        }
+        have_hdr = false;
+        size_t ia, ib;
+        id_span(h, hl, ia, ib);
+        c.id(h + ia, ib - ia);
+        bool plus = false;
+        const uint64_t s0 = c.bases();
+        while (line(q, len)) {
+            if (len && (q[0] == '>' || q[0] == '@' || q[0] == '+')) {
+                if (q[0] == '+') plus = true;
+                else { h = q; hl = len; have_hdr = true; }
+                break;
+            }
+            c.seq(q, len);
+        }
+        const uint64_t slen = c.bases() - s0;
+        c.end_record();
+        if (plus) {
+            uint64_t got = 0;
+            bool done = false;
+            while (line(q, len)) {
+                got += len;
+                if (got >= slen) { done = true; break; }
+            }
+            if (!done && !at_eof && bad_end) *bad_end = true;
+        }
+        if (stop_bases && c.bases() >= stop_bases) break;
+    }
+    return have_hdr ? h : p;
+}
+
+/* First line start in [p, e) that begins a record: '>' for FASTA; for FASTQ an '@' line whose
+ * next-but-one line starts with '+' (a quality line may start with '@', a sequence line cannot
+ * start with '+').  A wrong guess is caught by Chunk::bad_end and the batch is re-parsed serially. */
+static const char *find_boundary(const char *p, const char *e, bool fastq)
+{
+    while (p < e) {
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(e - p));
+        if (!nl || nl + 1 >= e) return e;
+        p = nl + 1;
+        if (!fastq) {
+            if (*p == '>') return p;
+            const char *g = (const char *)memchr(p, '>', (size_t)(e - p)); /* skip whole lines at memchr speed */
+            if (!g) return e;
+            if (g[-1] == '\n') return g;
+            p = g;
+        } else if (*p == '@') {
+            const char *n1 = (const char *)memchr(p, '\n', (size_t)(e - p));
+            if (!n1) return e;
+            const char *n2 = (const char *)memchr(n1 + 1, '\n', (size_t)(e - (n1 + 1)));
+            if (!n2 || n2 + 1 >= e) return e;
+            if (n2[1] == '+') return p;
+        }
+    }
+    return e;
+}
 
 static bool fill(ntl_fastx *r)
 {
@@ -87,7 +246,28 @@ extern "C" int ntl_fastx_open(const char *path, ntl_fastx **out)
     if (!path || !out) return NTL_EINVAL;
     *out = nullptr;
     ntl_fastx *r = new ntl_fastx();
-    r->gz = strcmp(path, "-") == 0 ? gzdopen(dup(0), "rb") : gzopen(path, "rb");
+    const bool is_stdin = strcmp(path, "-") == 0;
+    if (!is_stdin && !getenv("NTL_IO_NO_MMAP")) { /* plain regular file: map it */
+        int fd = open(path, O_RDONLY);
+        if (fd < 0) { delete r; return NTL_EINVAL; }
+        struct stat st;
+        unsigned char magic[2] = {0, 0};
+        if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0 && pread(fd, magic, 2, 0) == 2 &&
+            !(magic[0] == 0x1f && magic[1] == 0x8b)) {
+            void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m != MAP_FAILED) {
+                madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+                r->map = (const char *)m;
+                r->map_size = (size_t)st.st_size;
+                const char *p = r->map, *e = r->map + r->map_size; /* format = first header character */
+                while (p < e && (*p == '\n' || *p == '\r')) p++;
+                r->fastq = p < e && *p == '@';
+            }
+        }
+        close(fd);
+        if (r->map) { *out = r; return NTL_OK; }
+    }
+    r->gz = is_stdin ? gzdopen(dup(0), "rb") : gzopen(path, "rb");
     if (!r->gz) { delete r; return NTL_EINVAL; }
     gzbuffer(r->gz, 1 << 20);
     r->buf.resize(8 << 20);
@@ -99,16 +279,16 @@ extern "C" void ntl_fastx_close(ntl_fastx *r)
 {
     if (!r) return;
     if (r->gz) gzclose(r->gz);
+    if (r->map) munmap((void *)r->map, r->map_size);
     delete r;
 }
 
 extern "C" const char *ntl_fastx_error(const ntl_fastx *r) { return r ? r->err.c_str() : "no reader"; }
 
-/* Collects records until at least max_bases bases are held (0 = to the end of the input). */
-extern "C" int ntl_fastx_next(ntl_fastx *r, uint64_t max_bases, uint64_t *nseq)
+static void next_stream(ntl_fastx *r, uint64_t max_bases)
 {
-    if (!r || !nseq) return NTL_EINVAL;
-    r->seqs.clear(); r->names.clear(); r->off.assign(1, 0); r->name_off.assign(1, 0);
+    Chunk &c = r->chunk;
+    c.clear();
     std::string spill;
     const char *p; size_t len;
     for (;;) {
@@ -121,28 +301,23 @@ extern "C" int ntl_fastx_next(ntl_fastx *r, uint64_t max_bases, uint64_t *nseq)
             if (!found) break;
         }
         r->has_pending = false;
-        /* id = header up to the first whitespace */
-        {
-            const std::string &h = r->pending;
-            size_t a = 1;
-            while (a < h.size() && (h[a] == ' ' || h[a] == '\t')) a++; /* str.split(None, 1) skips leading blanks */
-            size_t b = a;
-            while (b < h.size() && h[b] != ' ' && h[b] != '\t' && h[b] != '\r' && h[b] != '\f' && h[b] != '\v') b++;
-            r->names.append(h, a, b - a);
-            r->name_off.push_back(r->names.size());
-        }
+        size_t ia, ib;
+        id_span(r->pending.data(), r->pending.size(), ia, ib);
+        c.names.insert(c.names.end(), r->pending.data() + ia, r->pending.data() + ib);
+        c.name_off.push_back(c.names.size());
         /* sequence lines */
-        bool plus = false, more = false;
-        while ((more = next_line(r, &p, &len, spill))) {
+        bool plus = false;
+        const uint64_t s0 = c.seqs.size();
+        while (next_line(r, &p, &len, spill)) {
             if (len && (p[0] == '>' || p[0] == '@' || p[0] == '+')) {
                 if (p[0] == '+') plus = true;
                 else { r->pending.assign(p, len); r->has_pending = true; }
                 break;
             }
-            r->seqs.append(p, len);
+            c.seqs.insert(c.seqs.end(), p, p + len);
         }
-        const uint64_t slen = r->seqs.size() - r->off.back();
-        r->off.push_back(r->seqs.size());
+        const uint64_t slen = c.seqs.size() - s0;
+        c.off.push_back(c.seqs.size());
         if (plus) { /* FASTQ: skip quality lines until their length reaches the sequence length */
             uint64_t got = 0;
             while (next_line(r, &p, &len, spill)) {
@@ -150,18 +325,125 @@ extern "C" int ntl_fastx_next(ntl_fastx *r, uint64_t max_bases, uint64_t *nseq)
                 if (got >= slen) break;
             }
         }
-        (void)more;
-        if (max_bases && r->seqs.size() >= max_bases) break;
+        if (max_bases && c.seqs.size() >= max_bases) break;
     }
+}
+
+/* Cuts the byte range of the next batch into per-thread ranges and counts their records. */
+static void next_mapped(ntl_fastx *r, uint64_t max_bases)
+{
+    const char *base = r->map, *fe = r->map + r->map_size;
+    const char *p0 = base + r->cur;
+    r->ranges.clear();
+    if (p0 >= fe) return;
+    const char *pe = fe; /* about max_bases bases, cut at a record boundary */
+    if (max_bases) {
+        const uint64_t want = max_bases * (r->fastq ? 2u : 1u) + (max_bases >> 6);
+        if (want < (uint64_t)(fe - p0)) pe = find_boundary(p0 + want, fe, r->fastq);
+    }
+    const size_t span = (size_t)(pe - p0);
+    size_t min_chunk = 2u << 20; /* bytes per thread below which more threads do not pay */
+    if (const char *e = getenv("NTL_IO_MIN_CHUNK")) { long v = atol(e); if (v > 0) min_chunk = (size_t)v; }
+    const unsigned T = (unsigned)std::min<size_t>(io_threads(), std::max<size_t>(1, span / min_chunk));
+    r->ranges.resize(T);
+    const char *prev = p0;
+    for (unsigned t = 0; t < T; t++) {
+        const char *nxt = t + 1 == T ? pe : std::max(prev, find_boundary(p0 + span / T * (t + 1), pe, r->fastq));
+        r->ranges[t].b = prev; r->ranges[t].e = nxt; r->ranges[t].at_eof = nxt == fe;
+        prev = nxt;
+    }
+    auto count = [&](size_t t) {
+        Range &g = r->ranges[t];
+        CountSink cs;
+        parse_range(g.b, g.e, g.stop_bases, g.at_eof, cs, &g.bad_end);
+        g.nrec = cs.nrec; g.bases = cs.nbases; g.name_bytes = cs.name_bytes;
+    };
+    run_threads(T, count);
+    bool bad = false;
+    for (auto &g : r->ranges) bad |= g.bad_end;
+    if (bad) { /* a cut fell inside a quality section (multi-line FASTQ): one range, no cuts */
+        if (getenv("NTL_IO_TRACE")) fprintf(stderr, "ntl_fastx: range cut inside a quality section, batch re-read on one thread\n");
+        r->ranges.resize(1);
+        Range &g = r->ranges[0];
+        g = Range();
+        g.b = p0; g.e = fe; g.at_eof = true; g.stop_bases = max_bases;
+        CountSink cs;
+        pe = parse_range(g.b, g.e, g.stop_bases, true, cs, nullptr);
+        g.nrec = cs.nrec; g.bases = cs.nbases; g.name_bytes = cs.name_bytes;
+    }
+    r->cur = (size_t)(pe - base);
+}
+
+extern "C" void ntl_fastx_sizes(const ntl_fastx *r, uint64_t *nseq, uint64_t *bases, uint64_t *name_bytes)
+{
+    uint64_t n = 0, b = 0, nb = 0;
+    if (r && r->map) for (auto &g : r->ranges) { n += g.nrec; b += g.bases; nb += g.name_bytes; }
+    else if (r) { n = r->chunk.nrec(); b = r->chunk.seqs.size(); nb = r->chunk.names.size(); }
+    if (nseq) *nseq = n;
+    if (bases) *bases = b;
+    if (name_bytes) *name_bytes = nb;
+}
+
+/* Collects records until about max_bases bases are held (0 = to the end of the input). */
+extern "C" int ntl_fastx_next(ntl_fastx *r, uint64_t max_bases, uint64_t *nseq)
+{
+    if (!r || !nseq) return NTL_EINVAL;
+    r->materialized = false;
+    if (r->map) next_mapped(r, max_bases);
+    else next_stream(r, max_bases);
     if (!r->err.empty()) return NTL_EINVAL;
-    *nseq = r->off.size() - 1;
+    ntl_fastx_sizes(r, nseq, nullptr, nullptr);
     return NTL_OK;
 }
 
-extern "C" const char *ntl_fastx_seqs(const ntl_fastx *r) { return r->seqs.data(); }
-extern "C" const uint64_t *ntl_fastx_offsets(const ntl_fastx *r) { return r->off.data(); }
-extern "C" const char *ntl_fastx_names(const ntl_fastx *r) { return r->names.data(); }
-extern "C" const uint64_t *ntl_fastx_name_offsets(const ntl_fastx *r) { return r->name_off.data(); }
+/* Puts the current batch into caller-allocated arrays (sizes from ntl_fastx_sizes; offsets and
+ * name_offsets have nseq + 1 entries).  Mapped files are parsed straight into place, one thread
+ * per range. */
+extern "C" int ntl_fastx_copy(const ntl_fastx *r, char *seqs, uint64_t *offsets, char *names, uint64_t *name_offsets)
+{
+    if (!r || !offsets || !name_offsets) return NTL_EINVAL;
+    uint64_t n, b, nb;
+    ntl_fastx_sizes(r, &n, &b, &nb);
+    if ((b && !seqs) || (nb && !names)) return NTL_EINVAL;
+    offsets[0] = 0; name_offsets[0] = 0;
+    if (!r->map) {
+        const Chunk &c = r->chunk;
+        if (b) memcpy(seqs, c.seqs.data(), b);
+        if (nb) memcpy(names, c.names.data(), nb);
+        memcpy(offsets, c.off.data(), (n + 1) * sizeof(uint64_t));
+        memcpy(name_offsets, c.name_off.data(), (n + 1) * sizeof(uint64_t));
+        return NTL_OK;
+    }
+    const size_t T = r->ranges.size();
+    std::vector<uint64_t> rec0(T + 1, 0), b0(T + 1, 0), n0(T + 1, 0);
+    for (size_t t = 0; t < T; t++) {
+        rec0[t + 1] = rec0[t] + r->ranges[t].nrec;
+        b0[t + 1] = b0[t] + r->ranges[t].bases;
+        n0[t + 1] = n0[t] + r->ranges[t].name_bytes;
+    }
+    run_threads(T, [&](size_t t) {
+        const Range &g = r->ranges[t];
+        WriteSink ws{seqs, offsets + rec0[t], names, name_offsets + rec0[t], b0[t], n0[t]};
+        parse_range(g.b, g.e, g.stop_bases, g.at_eof, ws, nullptr);
+    });
+    return NTL_OK;
+}
+
+static void materialize(ntl_fastx *r)
+{
+    if (r->materialized) return;
+    uint64_t n, b, nb;
+    ntl_fastx_sizes(r, &n, &b, &nb);
+    r->m_seqs.resize(b); r->m_names.resize(nb); r->m_off.resize(n + 1); r->m_name_off.resize(n + 1);
+    ntl_fastx_copy(r, r->m_seqs.data(), r->m_off.data(), r->m_names.data(), r->m_name_off.data());
+    r->materialized = true;
+}
+
+/* contiguous views of the current batch (a copy is made on first use; ntl_fastx_copy avoids it) */
+extern "C" const char *ntl_fastx_seqs(ntl_fastx *r) { materialize(r); return r->m_seqs.data(); }
+extern "C" const uint64_t *ntl_fastx_offsets(ntl_fastx *r) { materialize(r); return r->m_off.data(); }
+extern "C" const char *ntl_fastx_names(ntl_fastx *r) { materialize(r); return r->m_names.data(); }
+extern "C" const uint64_t *ntl_fastx_name_offsets(ntl_fastx *r) { materialize(r); return r->m_name_off.data(); }
 
 /* ------------------------------------------------------------------ writers -------------- */
 

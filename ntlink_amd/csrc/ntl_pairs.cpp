@@ -1,0 +1,164 @@
+/*
+ * Host tail of the pair stage in native code: the contig-pair tally that
+ * bin/ntlink_pair.py keeps while it walks the reads (no GPU code; BASELINE north_star leaves the
+ * scaffold graph on the CPU).  Restated from
+ *   tally_pairs_from_mappings :416-435   add_pair :315-334   calculate_pair_info :222-239
+ *   calculate_gap_size :157-187          normalize_pair :213-219   PairInfo :58-83
+ * Input = the mapping records of ntl_map_run, in read order; the tally is order-sensitive (gap
+ * lists keep the order of the reads, pairs the order of first appearance), so it runs on one
+ * thread -- a few tens of nanoseconds per pair against microseconds in the Python loop.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <numeric>
+#include <string>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+#include "../../include/ntlink_amd.h"
+
+struct PairEntry {
+    uint64_t key;
+    uint32_t src, tgt;          /* contig indices as first seen (any contig carrying the name) */
+    std::vector<int64_t> gaps;
+    uint32_t anchor = 0;
+};
+
+struct ntl_tally {
+    int k = 0, f = 10;
+    std::vector<uint32_t> ctg_len;
+    std::vector<uint32_t> rank;  /* dense rank of the contig's NAME in byte order; equal names share one */
+    std::unordered_map<uint64_t, uint32_t> slot;
+    std::vector<PairEntry> pairs; /* first-insertion order */
+    uint64_t ngaps = 0;
+};
+
+extern "C" int ntl_tally_create(const char *ctg_names, const uint64_t *ctg_name_off, const uint32_t *ctg_len, uint64_t n_ctg,
+                                int k, int f, ntl_tally **out)
+{
+    if (!out || (n_ctg && (!ctg_names || !ctg_name_off || !ctg_len)) || n_ctg >= ((uint64_t)1 << 30)) return NTL_EINVAL;
+    ntl_tally *t = new ntl_tally();
+    t->k = k; t->f = f;
+    t->ctg_len.assign(ctg_len, ctg_len + n_ctg);
+    std::vector<uint32_t> order(n_ctg);
+    std::iota(order.begin(), order.end(), 0u);
+    auto cmp3 = [&](uint32_t a, uint32_t b) { /* str.__lt__ on ids = byte order, shorter first on a tie */
+        const uint64_t la = ctg_name_off[a + 1] - ctg_name_off[a], lb = ctg_name_off[b + 1] - ctg_name_off[b];
+        const int c = memcmp(ctg_names + ctg_name_off[a], ctg_names + ctg_name_off[b], (size_t)std::min(la, lb));
+        return c ? c : (la < lb ? -1 : la > lb ? 1 : 0);
+    };
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cmp3(a, b) < 0; });
+    t->rank.resize(n_ctg);
+    uint32_t r = 0;
+    for (uint64_t i = 0; i < n_ctg; i++) {
+        if (i && cmp3(order[i - 1], order[i]) != 0) r++;
+        t->rank[order[i]] = r;
+    }
+    *out = t;
+    return NTL_OK;
+}
+
+extern "C" void ntl_tally_destroy(ntl_tally *t) { delete t; }
+
+/* One batch of mappings (reads in order; read_len is indexed by ntl_mapping.read).  Returns NTL_ERANGE
+ * when an overhang comes out negative -- the reference's "Gap distance estimation less than 0". */
+extern "C" int ntl_tally_add(ntl_tally *t, const ntl_mapping *maps, uint64_t n_maps, const ntl_hit *hits, const uint32_t *read_len)
+{
+    if (!t || (n_maps && (!maps || !hits || !read_len))) return NTL_EINVAL;
+    if (n_maps < 2) return NTL_OK;
+    const int64_t k = t->k;
+    /* per mapping: overhang behind its terminal hit when it is the source of a pair (a), in front of its
+     * first hit when it is the target (b); bin/ntlink_pair.py:394-406,317-320 */
+    std::vector<int64_t> a(n_maps), b(n_maps);
+    std::vector<uint8_t> sp(n_maps), tp(n_maps);
+    for (uint64_t i = 0; i < n_maps; i++) {
+        const ntl_mapping &m = maps[i];
+        if (m.ctg >= t->ctg_len.size() || m.n_hits == 0) return NTL_EINVAL;
+        const ntl_hit &hf = hits[m.hit_off], &hl = hits[m.hit_off + m.n_hits - 1];
+        const int64_t clen = t->ctg_len[m.ctg];
+        sp[i] = hl.read_strand == hl.ctg_strand;
+        tp[i] = hf.read_strand == hf.ctg_strand;
+        a[i] = sp[i] ? clen - (int64_t)hl.ctg_pos - k : (int64_t)hl.ctg_pos;
+        b[i] = tp[i] ? (int64_t)hf.ctg_pos : clen - (int64_t)hf.ctg_pos - k;
+        if (a[i] < 0 || b[i] < 0) return NTL_ERANGE;
+    }
+    std::unordered_set<uint64_t> added;
+    std::vector<uint64_t> strong;
+    uint64_t s0 = 0;
+    while (s0 < n_maps) {
+        uint64_t s1 = s0 + 1;
+        while (s1 < n_maps && maps[s1].read == maps[s0].read) s1++;
+        const uint64_t m = s1 - s0;
+        if (m > 1) {
+            const int64_t rl = read_len[maps[s0].read];
+            /* returns the normalized key, or 0 when the pair was not recorded (keys are never 0: see below) */
+            auto add = [&](uint64_t i, uint64_t j, const std::unordered_set<uint64_t> *check) -> uint64_t {
+                const ntl_hit &hf = hits[maps[j].hit_off], &hl = hits[maps[i].hit_off + maps[i].n_hits - 1];
+                const int64_t gap = (int64_t)hf.read_pos - (int64_t)hl.read_pos - a[i] - b[j];
+                uint32_t ci = maps[i].ctg, cj = maps[j].ctg;
+                uint32_t so = sp[i], to = tp[j];
+                if (!(t->rank[ci] < t->rank[cj])) { /* normalize_pair: smaller name first, both orientations flipped */
+                    std::swap(ci, cj);
+                    const uint32_t x = so; so = to ^ 1u; to = x ^ 1u;
+                }
+                const uint64_t key = ((uint64_t)t->rank[ci] << 33) | ((uint64_t)so << 32) | ((uint64_t)t->rank[cj] << 1) | to | (1ull << 63);
+                if ((gap < 0 ? -gap : gap) > rl) return 0;
+                if (check && check->count(key)) return 0;
+                auto it = t->slot.find(key);
+                uint32_t e;
+                if (it == t->slot.end()) {
+                    e = (uint32_t)t->pairs.size();
+                    t->slot.emplace(key, e);
+                    t->pairs.emplace_back();
+                    t->pairs[e].key = key; t->pairs[e].src = ci; t->pairs[e].tgt = cj;
+                } else e = it->second;
+                t->pairs[e].gaps.push_back(gap);
+                t->ngaps++;
+                if (maps[i].n_hits > 1 && maps[j].n_hits > 1) t->pairs[e].anchor++;
+                return key;
+            };
+            if (m <= (uint64_t)t->f) {
+                for (uint64_t i = s0; i < s1; i++)
+                    for (uint64_t j = i + 1; j < s1; j++) add(i, j, nullptr);
+            } else { /* long chains: neighbours, then neighbours among the contigs with more than one hit */
+                added.clear();
+                for (uint64_t i = s0; i + 1 < s1; i++) {
+                    const uint64_t key = add(i, i + 1, nullptr);
+                    if (key) added.insert(key);
+                }
+                strong.clear();
+                for (uint64_t i = s0; i < s1; i++) if (maps[i].n_hits > 1) strong.push_back(i);
+                for (size_t q = 0; q + 1 < strong.size(); q++) add(strong[q], strong[q + 1], &added);
+            }
+        }
+        s0 = s1;
+    }
+    return NTL_OK;
+}
+
+extern "C" uint64_t ntl_tally_npairs(const ntl_tally *t) { return t ? t->pairs.size() : 0; }
+extern "C" uint64_t ntl_tally_ngaps(const ntl_tally *t) { return t ? t->ngaps : 0; }
+
+/* All pairs in order of first appearance: contig indices + orientations (1 = '+') of the normalized
+ * pair, anchor count, and gaps[gap_off[i] .. gap_off[i+1]) in read order. */
+extern "C" int ntl_tally_export(const ntl_tally *t, uint32_t *src, uint8_t *src_ori, uint32_t *tgt, uint8_t *tgt_ori,
+                                uint32_t *anchor, uint64_t *gap_off, int64_t *gaps)
+{
+    if (!t || !gap_off) return NTL_EINVAL;
+    uint64_t g = 0;
+    gap_off[0] = 0;
+    for (size_t i = 0; i < t->pairs.size(); i++) {
+        const PairEntry &e = t->pairs[i];
+        src[i] = e.src; tgt[i] = e.tgt;
+        src_ori[i] = (uint8_t)((e.key >> 32) & 1u);
+        tgt_ori[i] = (uint8_t)(e.key & 1u);
+        anchor[i] = e.anchor;
+        if (!e.gaps.empty()) memcpy(gaps + g, e.gaps.data(), e.gaps.size() * sizeof(int64_t));
+        g += e.gaps.size();
+        gap_off[i + 1] = g;
+    }
+    return NTL_OK;
+}

@@ -294,8 +294,8 @@ __global__ __launch_bounds__(NT) void sketch_mask_kernel(SketchArgs A)
     auto emit = [&](uint32_t idx, bool flag) {
         if (!MULTI) {
             /* lanes with nothing to emit OR a zero into a private dummy word: no same-address serialisation */
-            const uint32_t wi = flag ? ((idx >> 5) & (uint32_t)(NBW - 1)) : (uint32_t)(NBW + (L & 63));
-            atomicOr(&s_bits[wi], flag ? 1u << (idx & 31u) : 0u);
+            const uint32_t wi = flag ? (idx >> 5) : (uint32_t)(NBW + (L & 63)); /* flag implies a real index */
+            atomicOr(&s_bits[wi], (flag ? 1u : 0u) << (idx & 31u));
         } else if (flag) {
             const uint64_t g = I.base + s_pos[(idx % C) * NT + (idx / C)];
             atomicOr(&A.mask[g >> 5], 1u << ((uint32_t)g & 31u));

@@ -6,98 +6,97 @@ the mapping records the GPU produced.  Behaviour restated from bin/ntlink_pair.p
   calculate_gap_size :157-187          normalize_pair :213-219   PairInfo :58-83
   filter_pairs_distances :247-255      filter_weak_anchor_pairs :241-244   write_pairs :490-496
   build_scaffold_graph :263-305        filter_graph_global :498-506        print_directed_graph :133-155
-The per-mapping quantities (orientation and overhang of a contig used as source / as target) are
-computed for all mappings at once with numpy; only reads that touch >= 2 contigs enter the Python loop.
+The order-sensitive per-read tally itself is native (csrc/ntl_pairs.cpp); filters and the two small
+writers work on its export.
 """
+import ctypes as C
 import re
 
 import numpy as np
 
 
 class PairTally:
-    """Accumulates pairs over batches of reads, in read order (gap lists are order-sensitive)."""
+    """Accumulates pairs over batches of reads, in read order (gap lists are order-sensitive).  The
+    per-read loop is native (csrc/ntl_pairs.cpp, ntl_tally_*); this class feeds it record arrays and
+    turns its export into the dict the writers below take."""
 
     def __init__(self, ctg_names, ctg_len, k, f=10):
+        from . import capi
+        from .seqio import Names
         self.names = ctg_names
         self.ctg_len = np.asarray(ctg_len, np.int64)
         self.k, self.f = int(k), int(f)
-        self.pairs = {}  # (src, src_ori, tgt, tgt_ori) -> [gaps, anchor]; insertion-ordered
+        self._L = capi.load()
+        self._maps_dt, self._hits_dt = capi.MAPPING_DT, capi.HIT_DT
+        nm = Names.of(ctg_names)
+        cl = np.ascontiguousarray(ctg_len, np.uint32)
+        h = C.c_void_p()
+        blob = np.ascontiguousarray(nm.blob)
+        rc = self._L.ntl_tally_create(blob.ctypes.data if len(blob) else None, nm.off.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                      cl.ctypes.data_as(C.POINTER(C.c_uint32)), len(nm), self.k, self.f, C.byref(h))
+        if rc != 0:
+            raise ValueError(f"ntl_tally_create failed with {rc}")
+        self._h = h
+        self._pairs = None
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._L.ntl_tally_destroy(h)
+
+    @staticmethod
+    def _as(arr, dt):
+        if arr.dtype == dt:
+            return np.ascontiguousarray(arr)
+        out = np.zeros(len(arr), dt)
+        for name in arr.dtype.names:
+            out[name] = arr[name]
+        return out
 
     def add_batch(self, res, read_len):
-        maps, hits = res["maps"], res["hits"]
-        if len(maps) < 2:
-            return
-        rd = maps["read"].astype(np.int64)
-        # reads with at least two accepted contigs
-        starts = np.flatnonzero(np.r_[True, rd[1:] != rd[:-1]])
-        counts = np.diff(np.r_[starts, len(rd)])
-        first = maps["hit_off"].astype(np.int64)
-        last = first + maps["n_hits"].astype(np.int64) - 1
-        ctg = maps["ctg"].astype(np.int64)
-        clen = self.ctg_len[ctg]
-        nh = maps["n_hits"].astype(np.int64)
-        hl, hf = hits[last], hits[first]
-        # as source: terminal hit; as target: first hit (bin/ntlink_pair.py:394-406,317-320)
-        s_plus = hl["read_strand"] == hl["ctg_strand"]
-        t_plus = hf["read_strand"] == hf["ctg_strand"]
-        a = np.where(s_plus, clen - hl["ctg_pos"].astype(np.int64) - self.k, hl["ctg_pos"].astype(np.int64))
-        b = np.where(t_plus, hf["ctg_pos"].astype(np.int64), clen - hf["ctg_pos"].astype(np.int64) - self.k)
-        rp_last = hl["read_pos"].astype(np.int64)
-        rp_first = hf["read_pos"].astype(np.int64)
-        if (a < 0).any() or (b < 0).any():
+        maps, hits = self._as(res["maps"], self._maps_dt), self._as(res["hits"], self._hits_dt)
+        rl = np.ascontiguousarray(read_len, np.uint32)
+        self._pairs = None
+        rc = self._L.ntl_tally_add(self._h, maps.ctypes.data, len(maps), hits.ctypes.data, rl.ctypes.data_as(C.POINTER(C.c_uint32)))
+        if rc == -5:
             raise AssertionError("Gap distance estimation less than 0")  # bin/ntlink_pair.py:173-184
-        names, pairs, f = self.names, self.pairs, self.f
-        for s0, m in zip(starts[counts > 1].tolist(), counts[counts > 1].tolist()):
-            rl = int(read_len[rd[s0]])
+        if rc != 0:
+            raise ValueError(f"ntl_tally_add failed with {rc}")
 
-            def add(i, j, check=None):
-                i, j = s0 + i, s0 + j
-                gap = int(rp_first[j] - rp_last[i] - a[i] - b[j])
-                so = "+" if s_plus[i] else "-"
-                to = "+" if t_plus[j] else "-"
-                ni, nj = names[ctg[i]], names[ctg[j]]
-                if ni < nj:
-                    key = (ni, so, nj, to)
-                else:  # normalize_pair: lexicographically smaller NAME first, orientations flipped
-                    key = (nj, "-" if to == "+" else "+", ni, "-" if so == "+" else "+")
-                if abs(gap) > rl:
-                    return None
-                if check is not None and key in check:
-                    return None
-                e = pairs.get(key)
-                if e is None:
-                    e = pairs[key] = [[], 0]
-                e[0].append(gap)
-                if nh[i] > 1 and nh[j] > 1:
-                    e[1] += 1
-                return key
-
-            if m <= f:
-                for i in range(m):
-                    for j in range(i + 1, m):
-                        add(i, j)
-            else:
-                added = set()
-                for i in range(m - 1):
-                    added.add(add(i, i + 1))
-                strong = [i for i in range(m) if nh[s0 + i] > 1]
-                for i, j in zip(strong, strong[1:]):
-                    add(i, j, check=added)
+    @property
+    def pairs(self):
+        """(src, src_ori, tgt, tgt_ori) -> [gaps, anchor] in order of first appearance."""
+        if self._pairs is None:
+            L, h = self._L, self._h
+            n, g = int(L.ntl_tally_npairs(h)), int(L.ntl_tally_ngaps(h))
+            src, tgt, anchor = np.zeros(n, np.uint32), np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+            so, to = np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+            goff, gaps = np.zeros(n + 1, np.uint64), np.zeros(g, np.int64)
+            L.ntl_tally_export(h, src.ctypes.data, so.ctypes.data, tgt.ctypes.data, to.ctypes.data, anchor.ctypes.data,
+                               goff.ctypes.data, gaps.ctypes.data)
+            names = self.names.tolist() if hasattr(self.names, "tolist") else list(self.names)
+            gl, go = gaps.tolist(), goff.tolist()
+            out = {}
+            for i, (a, ao, b, bo, an) in enumerate(zip(src.tolist(), so.tolist(), tgt.tolist(), to.tolist(), anchor.tolist())):
+                out[(names[a], "+" if ao else "-", names[b], "+" if bo else "-")] = [gl[go[i]:go[i + 1]], an]
+            self._pairs = out
+        return self._pairs
 
     def add_checkpoint_read(self, entries, ctg_index):
         """A read re-read from <prefix>.verbose_mapping.tsv (bin/ntlink_pair.py:460-488): the read
         length is replaced by the largest mapped read position."""
         n = len(entries)
-        maps = np.zeros(n, dtype=[("read", "<u4"), ("ctg", "<u4"), ("n_hits", "<u4"), ("pad", "<u4"), ("hit_off", "<u8")])
+        maps = np.zeros(n, self._maps_dt)
         hl = []
         rmax = 0
         for i, (contig, hs) in enumerate(entries):
             maps[i] = (0, ctg_index[contig], len(hs), 0, len(hl))
             hl.extend(hs)
             rmax = max(rmax, hs[0][2], hs[-1][2])
-        hits = np.zeros(len(hl), dtype=[("ctg_pos", "<u4"), ("read_pos", "<u4"), ("ctg_strand", "u1"), ("read_strand", "u1")])
-        for j, (cp, cs, rp, rs) in enumerate(hl):
-            hits[j] = (cp, rp, cs, rs)
+        hits = np.zeros(len(hl), self._hits_dt)
+        if hl:
+            cols = np.array(hl, np.int64)
+            hits["ctg_pos"], hits["ctg_strand"], hits["read_pos"], hits["read_strand"] = cols[:, 0], cols[:, 1], cols[:, 2], cols[:, 3]
         self.add_batch({"maps": maps, "hits": hits}, [rmax])
 
     # ---- filters and writers -------------------------------------------------------------

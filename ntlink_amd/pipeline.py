@@ -169,6 +169,44 @@ def prefetched(gen, depth=2):
         yield item
 
 
+class Drain:
+    """Ordered background consumer: `put(*args)` hands one batch to `fn` on a worker thread (the native
+    writers release the GIL), `close()` waits for it and re-raises what it raised."""
+
+    def __init__(self, fn, depth=2):
+        import queue
+        import threading
+        self._q, self._exc, self._end = queue.Queue(maxsize=depth), None, object()
+
+        def run():
+            while True:
+                item = self._q.get()
+                if item is self._end:
+                    return
+                if self._exc is None:
+                    try:
+                        fn(*item)
+                    except BaseException as exc:  # keep draining so that put() never blocks forever
+                        self._exc = exc
+
+        self._t = threading.Thread(target=run, daemon=True)
+        self._t.start()
+
+    def put(self, *args):
+        if self._exc is not None:
+            self.close()
+        self._q.put(args)
+
+    def close(self):
+        if self._t is not None:
+            self._q.put(self._end)
+            self._t.join()
+            self._t = None
+        if self._exc is not None:
+            exc, self._exc = self._exc, None
+            raise exc
+
+
 class LocalComm:
     """Single process.  The multi-GPU launcher passes a torch.distributed-backed object with the same
     three members (ntlink_amd/dist_pair.py)."""
@@ -221,6 +259,7 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
     ctg = seqio.load_all([target])
     ctg_len = ctg.lengths
     out = PairOutputs(prefix, ctg.names, ctg_len, k, f, verbose, paf) if root else None
+    drain = Drain(out.add) if root else None  # text emitters + pair tally run behind the device
     stats = dict(read_bases=0, reads=0, read_minimizers=0, index_hits=0, t_ingest=0.0, t_device=0.0)
     t_mark = time.perf_counter()
     try:
@@ -232,7 +271,7 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
             with dev.index(csk, ctg_len) as ix:
                 stats["index_size"] = len(ix)
                 for rs_ in prefetched(seqio.load(reads.split() if isinstance(reads, str) else list(reads),
-                                                 max_bases=batch_bases * comm.world)):
+                                                 max_bases=batch_bases * comm.world, alloc=dev.pinned_empty)):
                     if not len(rs_):
                         continue
                     stats["t_ingest"] += time.perf_counter() - t_mark  # FASTA/FASTQ(.gz) parse of this batch
@@ -241,26 +280,34 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
                     lo, hi = shard_range(rs_.offsets, comm.rank, comm.world)
                     b0 = int(rs_.offsets[lo])
                     sub_off = rs_.offsets[lo:hi + 1] - np.uint64(b0)
-                    with dev.batch(rs_.buf[b0:int(rs_.offsets[hi])], sub_off) as rb, dev.sketch(rb, k, w) as rsk, \
-                            dev.map(ix, rsk, rl[lo:hi], k=k, z=z, x=x, sensitive=sensitive, repeat_filter=repeats) as res:
-                        mine = (lo, hi, res.download(), rsk.count, res.n_index_hits)
+                    with dev.batch(rs_.buf[b0:int(rs_.offsets[hi])], sub_off) as rb:
+                        dev.pinned_release(rs_.buf)  # the bases are on the device: the reader may refill this buffer
+                        rs_.buf = None
+                        with dev.sketch(rb, k, w) as rsk, \
+                                dev.map(ix, rsk, rl[lo:hi], k=k, z=z, x=x, sensitive=sensitive, repeat_filter=repeats) as res:
+                            mine = (lo, hi, res.download(), rsk.count, res.n_index_hits)
                     stats["t_device"] += time.perf_counter() - t_dev  # pack + H2D + kernels + D2H
                     parts = comm.gather(mine)
                     if root:
                         for plo, phi, pres, pmx, phits in parts:
-                            out.add(pres, rs_.names[plo:phi], rl[plo:phi])
+                            drain.put(pres, rs_.names[plo:phi], rl[plo:phi])
                             stats["read_minimizers"] += pmx
                             stats["index_hits"] += phits
                         stats["read_bases"] += rs_.bases
                         stats["reads"] += len(rs_)
                     t_mark = time.perf_counter()
         if root:
+            drain.close()
             out.close()
             finish_pairs(out.tally, prefix, n, a, pairs_tsv)
             stats["t_write"], stats["t_tally"] = out.t_write, out.t_tally
         comm.barrier()
     except BaseException:
         if out:
+            try:
+                drain.close()
+            except BaseException:
+                pass
             out.remove_partial()
         raise
     return stats

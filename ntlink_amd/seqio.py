@@ -128,10 +128,15 @@ class SeqSet:
         return int(self.offsets[-1])
 
 
-def load(paths, max_bases=None):
+def _np_empty(nbytes):
+    return np.empty(nbytes, np.uint8)
+
+
+def load(paths, max_bases=None, alloc=None):
     """Native reader (ntl_fastx_*, csrc/ntl_io.cpp).  Whole input as one SeqSet, or, with max_bases,
     SeqSets of about that many bases; several files are concatenated in the order given and a batch
-    never spans two files."""
+    never spans two files.  alloc(nbytes) -> uint8 array supplies the sequence buffers (the pair
+    driver passes the device's page-locked pool); default numpy."""
     import ctypes as C
     from . import capi
     L = capi.load()
@@ -150,11 +155,12 @@ def load(paths, max_bases=None):
                 n = n.value
                 if n == 0:
                     break
-                off = np.frombuffer((C.c_uint64 * (n + 1)).from_address(L.ntl_fastx_offsets(h)), np.uint64).copy()
-                noff = np.frombuffer((C.c_uint64 * (n + 1)).from_address(L.ntl_fastx_name_offsets(h)), np.uint64).copy()
-                nb, nn = int(off[-1]), int(noff[-1])
-                buf = np.frombuffer((C.c_uint8 * nb).from_address(L.ntl_fastx_seqs(h)), np.uint8).copy() if nb else np.zeros(0, np.uint8)
-                names = np.frombuffer((C.c_uint8 * nn).from_address(L.ntl_fastx_names(h)), np.uint8).copy() if nn else np.zeros(0, np.uint8)
+                nb, nn = C.c_uint64(), C.c_uint64()
+                L.ntl_fastx_sizes(h, None, C.byref(nb), C.byref(nn))
+                buf, names = (alloc or _np_empty)(nb.value), np.empty(nn.value, np.uint8)
+                off, noff = np.empty(n + 1, np.uint64), np.empty(n + 1, np.uint64)
+                if L.ntl_fastx_copy(h, buf.ctypes.data, off.ctypes.data, names.ctypes.data, noff.ctypes.data) != 0:
+                    raise OSError(f"{path}: gather failed")
                 ss = SeqSet(Names(names, noff), buf, off)
                 if max_bases is None:
                     whole.append(ss)
@@ -183,5 +189,5 @@ def concat(sets):
     return SeqSet(Names(np.concatenate([s.names.blob for s in sets]), np.concatenate(noffs)), np.concatenate(bufs), np.concatenate(offs))
 
 
-def load_all(paths):
-    return next(load(paths))
+def load_all(paths, alloc=None):
+    return next(load(paths, alloc=alloc))

@@ -26,8 +26,77 @@ def test_seqio_edge_records(tmp_path):
     p.write_text(">a desc here\nACGT\nAC\n>b\n\n>c\tz\nGG\n@q1 x\nACGT\n+\nIIII\n@q2\nAC\nGT\n+q2\nII\nII\n>d\nTT")
     recs = list(seqio.read_fastx(str(p)))
     assert recs == [("a", b"ACGTAC"), ("b", b""), ("c", b"GG"), ("q1", b"ACGT"), ("q2", b"ACGT"), ("d", b"TT")]
-    batches = list(seqio.load([str(p)], max_bases=6))
-    assert [len(b) for b in batches] == [1, 3, 2] and sum(b.bases for b in batches) == 18
+    for env in ({}, {"NTL_IO_NO_MMAP": "1"}):  # mapped (byte-range) and stream (zlib) readers
+        with _env(env):
+            batches = list(seqio.load([str(p)], max_bases=6))
+        assert all(len(b) > 0 for b in batches) and len(batches) >= 2
+        assert _records(batches) == recs
+        if env:  # the stream reader cuts after the record that reaches max_bases
+            assert [len(b) for b in batches] == [1, 3, 2]
+
+
+class _env:
+    def __init__(self, kv):
+        self.kv, self.old = kv, {}
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            self.old[k] = os.environ.get(k)
+            os.environ[k] = v
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _records(batches):
+    out = []
+    for b in batches:
+        raw, off = b.buf.tobytes(), b.offsets.tolist()
+        out += [(n, raw[off[i]:off[i + 1]]) for i, n in enumerate(b.names)]
+    return out
+
+
+def _random_fastx(rng, nrec, fastq, multiline, crlf=False):
+    """Text with the layouts the record state machine has to survive: wrapped sequences, empty
+    records, quality lines that start with '@' or '>', headers with descriptions."""
+    nl = "\r\n" if crlf else "\n"
+    out = []
+    for i in range(nrec):
+        n = int(rng.integers(0, 400)) if rng.random() < 0.9 else int(rng.integers(2000, 9000))
+        seq = "".join(rng.choice(list("ACGTNacgt"), n))
+        wrap = int(rng.integers(20, 90)) if multiline else max(n, 1)
+        lines = [seq[j:j + wrap] for j in range(0, n, wrap)] or [""]
+        hdr = f"r{i}" + (" some description" if rng.random() < 0.3 else "")
+        if fastq:
+            q = "".join(rng.choice(list("@>+!IJ5"), n))
+            qlines = [q[j:j + wrap] for j in range(0, n, wrap)] or [""]
+            out += ["@" + hdr] + lines + ["+" + (hdr if rng.random() < 0.2 else "")] + qlines
+        else:
+            out += [">" + hdr] + lines
+    return nl.join(out) + (nl if rng.random() < 0.7 else "")
+
+
+@pytest.mark.parametrize("fastq,multiline", [(False, True), (False, False), (True, False), (True, True)])
+def test_parallel_reader_equals_serial_semantics(tmp_path, fastq, multiline):
+    """Byte ranges cut at guessed record boundaries and parsed by many threads give the records of
+    the one-pass reader (bin/read_fasta.py:6-46), also when a guess lands inside a quality section."""
+    rng = np.random.default_rng(5 + 2 * fastq + multiline)
+    for rep in range(3):
+        p = tmp_path / f"x{rep}.{'fq' if fastq else 'fa'}"
+        p.write_text(_random_fastx(rng, 6000, fastq, multiline, crlf=(rep == 2)), newline="")
+        want = list(seqio.read_fastx(str(p)))
+        assert len(want) == 6000
+        with _env({"NTL_IO_THREADS": "13", "NTL_IO_MIN_CHUNK": "3000"}):
+            whole = seqio.load_all([str(p)])
+            parts = list(seqio.load([str(p)], max_bases=300_000))
+        assert _records([whole]) == want
+        assert len(parts) > 2 and _records(parts) == want
+        with _env({"NTL_IO_NO_MMAP": "1"}):
+            assert _records(list(seqio.load([str(p)], max_bases=300_000))) == want
 
 
 @pytest.mark.parametrize("tag,target,reads,k,w,gold", [f for f in FIXTURES if f[5]])

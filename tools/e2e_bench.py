@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--scale", type=float, default=0.2)
     ap.add_argument("--gz", action="store_true")
     ap.add_argument("--batch", type=int, default=pipeline.DEFAULT_BATCH_BASES)
+    ap.add_argument("--stages", action="store_true", help="also time every stage of one whole-input batch on its own")
     a = ap.parse_args()
     W = synth.workload("C2", a.scale)
     chroms, cbuf, coff, cn, _ = synth.make_assembly(1, W["n_chrom"], W["contigs_per_chrom"], W["contig_len"])
@@ -48,6 +49,31 @@ def main():
                       "read_bases": st["read_bases"], "reads": st["reads"], "gz": a.gz, "batch_bases": a.batch, "output_bytes": out_bytes,
                       "t_wait_for_ingest": round(st["t_ingest"], 3), "t_device_incl_pack_pcie": round(st["t_device"], 3),
                       "t_write": round(st["t_write"], 3), "t_tally": round(st["t_tally"], 3), "device": dev.name}))
+    if a.stages:
+        from ntlink_amd import formats, seqio
+        T = {}
+
+        def lap(name, t0):
+            dev.sync()
+            T[name] = round(time.perf_counter() - t0, 4)
+
+        t = time.perf_counter(); ctg = seqio.load_all(["asm.fa"]); rs = seqio.load_all([os.path.basename(rds)], alloc=dev.pinned_empty); lap("parse_first", t)
+        dev.pinned_release(rs.buf)
+        t = time.perf_counter(); rs = seqio.load_all([os.path.basename(rds)], alloc=dev.pinned_empty); lap("parse_reused_buffer", t)
+        t = time.perf_counter(); cb = dev.batch(ctg.buf, ctg.offsets); csk = dev.sketch(cb, W["k"], W["w"]); ix = dev.index(csk, ctg.lengths); lap("contigs", t)
+        t = time.perf_counter(); rb = dev.batch(rs.buf, rs.offsets); lap("pack_h2d", t)
+        t = time.perf_counter(); rsk = dev.sketch(rb, W["k"], W["w"]); lap("sketch", t)
+        t = time.perf_counter(); res = dev.map(ix, rsk, rs.lengths, k=W["k"]); lap("map", t)
+        t = time.perf_counter(); rec = res.download(); lap("download", t)
+        t = time.perf_counter()
+        with open("stage.verbose", "w") as fh:
+            formats.write_verbose(fh, rec, rs.names, ctg.names)
+        with open("stage.paf", "w") as fh:
+            formats.write_paf(fh, rec, rs.names, rs.lengths, ctg.names, ctg.lengths)
+        lap("write", t)
+        for h in (res, rsk, rb, ix, csk, cb):
+            h.close()
+        print(json.dumps({"stages_s": T, "io_threads": os.environ.get("NTL_IO_THREADS", "default"), "cores": os.cpu_count()}))
     dev.close()
 
 
