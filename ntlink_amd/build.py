@@ -21,7 +21,7 @@ def build_hip(force=False, extra_flags=()):
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(s) for s in srcs):
         return OUT
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-result",
-           "-I", CSRC, *extra_flags, os.path.join(CSRC, "ntl_hip.hip"), os.path.join(CSRC, "ntl_io.cpp"), os.path.join(CSRC, "ntl_pairs.cpp"), "-lz", "-lpthread", "-o", OUT]
+           "-I", CSRC, *extra_flags, os.path.join(CSRC, "ntl_hip.hip"), os.path.join(CSRC, "ntl_io.cpp"), os.path.join(CSRC, "ntl_pairs.cpp"), "-lz", "-ldl", "-lpthread", "-o", OUT]
     subprocess.check_call(cmd)
     return OUT
 

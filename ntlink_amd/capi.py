@@ -213,9 +213,21 @@ class MapResult(_Handle):
         return (int(L.ntl_mapres_n_mappings(self.ptr)), int(L.ntl_mapres_n_hits(self.ptr)),
                 int(L.ntl_mapres_n_pafs(self.ptr)))
 
-    def download(self):
-        """dict(maps=, hits=, pafs=) of structured arrays, read order."""
+    def download(self, pinned=False):
+        """dict(maps=, hits=, pafs=) of structured arrays, read order.  pinned=True puts them in one
+        page-locked buffer of the device's pool (a single fast DMA instead of staged copies into fresh
+        pages); hand dict["_pinned"] to Device.pinned_release() when the records have been consumed."""
         nm, nh, npf = self.counts()
+        if pinned:
+            sizes = [nm * MAPPING_DT.itemsize, nh * HIT_DT.itemsize, npf * PAF_DT.itemsize]
+            offs = [0, (sizes[0] + 63) & ~63, 0]
+            offs[2] = (offs[1] + sizes[1] + 63) & ~63
+            base = self.dev.pinned_empty(offs[2] + sizes[2] + 64)
+            maps = base[offs[0]:offs[0] + sizes[0]].view(MAPPING_DT)
+            hits = base[offs[1]:offs[1] + sizes[1]].view(HIT_DT)
+            pafs = base[offs[2]:offs[2] + sizes[2]].view(PAF_DT)
+            self.dev._chk(self.dev.L.ntl_mapres_download(self.ptr, maps.ctypes.data, hits.ctypes.data, pafs.ctypes.data))
+            return {"maps": maps, "hits": hits, "pafs": pafs, "_pinned": base}
         maps = np.empty(nm, MAPPING_DT); hits = np.empty(nh, HIT_DT); pafs = np.empty(npf, PAF_DT)
         self.dev._chk(self.dev.L.ntl_mapres_download(self.ptr, maps.ctypes.data, hits.ctypes.data, pafs.ctypes.data))
         return {"maps": maps, "hits": hits, "pafs": pafs}
@@ -284,7 +296,7 @@ class Device:
         with self._pinned_lock:
             pick = None
             for i, (addr, cap) in enumerate(self._pinned_free):
-                if cap >= nbytes and (pick is None or cap < self._pinned_free[pick][1]):
+                if nbytes <= cap <= 4 * nbytes + (1 << 20) and (pick is None or cap < self._pinned_free[pick][1]):
                     pick = i
             if pick is None:
                 cap = max(int(nbytes * 1.125) + 4096, 1 << 20)

@@ -4,7 +4,11 @@
  *
  *   ntl_fastx_*        gzip -cd + SeqReader of the reference's pipe (ntLink:113-117,222-223); record
  *                      semantics of bin/read_fasta.py:6-46 (id = header up to the first whitespace,
- *                      multi-line sequences joined, FASTQ qualities skipped by length).
+ *                      multi-line sequences joined, FASTQ qualities skipped by length).  Plain files
+ *                      are mapped, gzip files up to 1 GiB inflated in one go (libdeflate when present),
+ *                      and byte ranges cut at record boundaries are parsed by several threads straight
+ *                      into the caller's (page-locked) arrays; larger gzip files and stdin stream
+ *                      through zlib on one thread.
  *   ntl_write_indexlr  the TSV `indexlr --long --pos --strand [--len]` prints (ntLink:199,223).
  *   ntl_write_verbose  <prefix>.verbose_mapping.tsv lines (bin/ntlink_pair.py:308-313,382-388).
  *   ntl_write_paf      <prefix>.paf lines (bin/ntlink_paf_output.py:131-135).
@@ -16,12 +20,14 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
 #include <algorithm>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -59,6 +65,8 @@ struct ntl_fastx {
     /* mapped mode (plain regular files): byte ranges of the file are parsed by several threads */
     const char *map = nullptr;
     size_t map_size = 0, cur = 0;
+    bool map_owned = false; /* map is a malloc'd buffer of inflated data, not a mapping */
+    size_t map_cap = 0;
     bool fastq = false;
     std::vector<Range> ranges;
     /* contiguous copies of the current batch for the pointer accessors */
@@ -173,9 +181,11 @@ static const char *parse_range(const char *p, const char *e, uint64_t stop_bases
     return have_hdr ? h : p;
 }
 
-/* First line start in [p, e) that begins a record: '>' for FASTA; for FASTQ an '@' line whose
- * next-but-one line starts with '+' (a quality line may start with '@', a sequence line cannot
- * start with '+').  A wrong guess is caught by Chunk::bad_end and the batch is re-parsed serially. */
+/* First line start in [p, e) that begins a record: '>' for FASTA; for FASTQ an '@' line followed by
+ * sequence-looking lines (they start with a letter, '*', '-' or '.') up to a '+' line.  A quality line
+ * may start with '@' too, but what follows it inside a quality section is, sooner or later, the next
+ * header -- another '@' -- before any '+' separator.  A wrong guess (possible with wrapped quality
+ * lines) is caught by Range::bad_end and the batch is re-read without cuts. */
 static const char *find_boundary(const char *p, const char *e, bool fastq)
 {
     while (p < e) {
@@ -189,11 +199,17 @@ static const char *find_boundary(const char *p, const char *e, bool fastq)
             if (g[-1] == '\n') return g;
             p = g;
         } else if (*p == '@') {
-            const char *n1 = (const char *)memchr(p, '\n', (size_t)(e - p));
-            if (!n1) return e;
-            const char *n2 = (const char *)memchr(n1 + 1, '\n', (size_t)(e - (n1 + 1)));
-            if (!n2 || n2 + 1 >= e) return e;
-            if (n2[1] == '+') return p;
+            const char *q = p;
+            for (;;) { /* q: start of a line after the candidate header */
+                const char *n1 = (const char *)memchr(q, '\n', (size_t)(e - q));
+                if (!n1 || n1 + 1 >= e) return e; /* cannot tell this close to the end */
+                q = n1 + 1;
+                const char ch = *q;
+                if (ch == '+') return p;
+                const bool seq_like = (ch >= 'A' && ch <= 'Z') || (ch >= 'a' && ch <= 'z') || ch == '*' || ch == '-' || ch == '.' ||
+                                      ch == '\r' || ch == '\n';
+                if (!seq_like) break;
+            }
         }
     }
     return e;
@@ -241,25 +257,128 @@ static bool next_line(ntl_fastx *r, const char **p, size_t *len, std::string &sp
     }
 }
 
+/* libdeflate (whole-buffer inflate, about three times zlib's speed) is used when the image has it;
+ * there is no header for it here, so the three entry points are bound by hand. */
+struct LibDeflate {
+    void *(*alloc)(void) = nullptr;
+    int (*gzip_ex)(void *, const void *, size_t, void *, size_t, size_t *, size_t *) = nullptr;
+    void (*release)(void *) = nullptr;
+    bool ok = false;
+    LibDeflate()
+    {
+        if (getenv("NTL_IO_NO_LIBDEFLATE")) return;
+        void *h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return;
+        alloc = (void *(*)(void))dlsym(h, "libdeflate_alloc_decompressor");
+        gzip_ex = (int (*)(void *, const void *, size_t, void *, size_t, size_t *, size_t *))dlsym(h, "libdeflate_gzip_decompress_ex");
+        release = (void (*)(void *))dlsym(h, "libdeflate_free_decompressor");
+        ok = alloc && gzip_ex && release;
+    }
+};
+static const LibDeflate &libdeflate() { static LibDeflate L; return L; }
+
+/* Inflate buffers are kept for the next file: fresh pages cost more than the inflate itself. */
+struct BufCache {
+    std::mutex mu;
+    std::vector<std::pair<char *, size_t>> free_list;
+    char *take(size_t want, size_t *cap)
+    {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            int pick = -1;
+            for (size_t i = 0; i < free_list.size(); i++)
+                if (free_list[i].second >= want && (pick < 0 || free_list[i].second < free_list[(size_t)pick].second)) pick = (int)i;
+            if (pick >= 0) {
+                char *p = free_list[(size_t)pick].first;
+                *cap = free_list[(size_t)pick].second;
+                free_list.erase(free_list.begin() + pick);
+                return p;
+            }
+        }
+        *cap = want;
+        return (char *)malloc(want);
+    }
+    void give(char *p, size_t cap)
+    {
+        std::lock_guard<std::mutex> g(mu);
+        free_list.emplace_back(p, cap);
+        while (free_list.size() > 8) { /* drop the smallest */
+            size_t m = 0;
+            for (size_t i = 1; i < free_list.size(); i++) if (free_list[i].second < free_list[m].second) m = i;
+            free(free_list[m].first);
+            free_list.erase(free_list.begin() + (long)m);
+        }
+    }
+};
+static BufCache &buf_cache() { static BufCache c; return c; }
+
+/* Inflates every gzip member of [in, in + n) into one malloc'd buffer (`gzip -cd` of a whole file held in
+ * memory).  False on corrupt data or when libdeflate is missing; the caller then streams through zlib. */
+static bool inflate_whole(const unsigned char *in, size_t n, char **out, size_t *out_n, size_t *out_cap)
+{
+    const LibDeflate &L = libdeflate();
+    if (!L.ok || n < 18) return false;
+    void *d = L.alloc();
+    if (!d) return false;
+    uint32_t isize;
+    memcpy(&isize, in + n - 4, 4); /* exact for a single member below 4 GiB; a starting point otherwise */
+    size_t cap = 0;
+    char *buf = buf_cache().take(std::max<size_t>((size_t)isize + 64, 3 * n + (1u << 16)), &cap);
+    size_t ipos = 0, opos = 0;
+    bool good = buf != nullptr;
+    while (good && ipos < n) {
+        if (in[ipos] == 0) { ipos++; continue; } /* zero padding between / after members, as gzip tolerates */
+        size_t ain = 0, aout = 0;
+        const int rc = L.gzip_ex(d, in + ipos, n - ipos, buf + opos, cap - opos, &ain, &aout);
+        if (rc == 3) { /* LIBDEFLATE_INSUFFICIENT_SPACE: grow and retry this member */
+            cap *= 2;
+            char *nb = (char *)realloc(buf, cap);
+            if (!nb) { good = false; break; }
+            buf = nb;
+            continue;
+        }
+        if (rc != 0) { good = false; break; }
+        ipos += ain; opos += aout;
+    }
+    L.release(d);
+    if (!good) { free(buf); return false; }
+    *out = buf; *out_n = opos; *out_cap = cap;
+    return true;
+}
+
 extern "C" int ntl_fastx_open(const char *path, ntl_fastx **out)
 {
     if (!path || !out) return NTL_EINVAL;
     *out = nullptr;
     ntl_fastx *r = new ntl_fastx();
     const bool is_stdin = strcmp(path, "-") == 0;
-    if (!is_stdin && !getenv("NTL_IO_NO_MMAP")) { /* plain regular file: map it */
+    if (!is_stdin && !getenv("NTL_IO_NO_MMAP")) { /* regular file: map it */
         int fd = open(path, O_RDONLY);
         if (fd < 0) { delete r; return NTL_EINVAL; }
         struct stat st;
         unsigned char magic[2] = {0, 0};
-        if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0 && pread(fd, magic, 2, 0) == 2 &&
-            !(magic[0] == 0x1f && magic[1] == 0x8b)) {
-            void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
-            if (m != MAP_FAILED) {
-                madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
-                r->map = (const char *)m;
-                r->map_size = (size_t)st.st_size;
-                const char *p = r->map, *e = r->map + r->map_size; /* format = first header character */
+        if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0 && pread(fd, magic, 2, 0) == 2) {
+            const bool gz = magic[0] == 0x1f && magic[1] == 0x8b;
+            size_t whole_max = (size_t)1 << 30; /* compressed bytes up to which a gzip file is inflated in one go */
+            if (const char *e = getenv("NTL_IO_GZ_WHOLE_MAX")) whole_max = (size_t)atoll(e);
+            if (!gz || (size_t)st.st_size <= whole_max) {
+                void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+                if (m != MAP_FAILED) {
+                    madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+                    if (!gz) {
+                        r->map = (const char *)m;
+                        r->map_size = (size_t)st.st_size;
+                    } else {
+                        char *buf = nullptr; size_t bn = 0, bcap = 0;
+                        if (inflate_whole((const unsigned char *)m, (size_t)st.st_size, &buf, &bn, &bcap)) {
+                            r->map = buf; r->map_size = bn; r->map_owned = true; r->map_cap = bcap;
+                        }
+                        munmap(m, (size_t)st.st_size);
+                    }
+                }
+            }
+            if (r->map) { /* format = first header character */
+                const char *p = r->map, *e = r->map + r->map_size;
                 while (p < e && (*p == '\n' || *p == '\r')) p++;
                 r->fastq = p < e && *p == '@';
             }
@@ -279,7 +398,8 @@ extern "C" void ntl_fastx_close(ntl_fastx *r)
 {
     if (!r) return;
     if (r->gz) gzclose(r->gz);
-    if (r->map) munmap((void *)r->map, r->map_size);
+    if (r->map && r->map_owned) buf_cache().give((char *)r->map, r->map_cap);
+    else if (r->map) munmap((void *)r->map, r->map_size);
     delete r;
 }
 

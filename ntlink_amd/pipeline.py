@@ -259,7 +259,13 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
     ctg = seqio.load_all([target])
     ctg_len = ctg.lengths
     out = PairOutputs(prefix, ctg.names, ctg_len, k, f, verbose, paf) if root else None
-    drain = Drain(out.add) if root else None  # text emitters + pair tally run behind the device
+    pin_out = comm.world == 1  # records land in page-locked pool buffers (not when they are pickled to rank 0)
+
+    def consume(pres, names, lens):
+        out.add(pres, names, lens)
+        dev.pinned_release(pres.get("_pinned"))
+
+    drain = Drain(consume) if root else None  # text emitters + pair tally run behind the device
     stats = dict(read_bases=0, reads=0, read_minimizers=0, index_hits=0, t_ingest=0.0, t_device=0.0)
     t_mark = time.perf_counter()
     try:
@@ -285,7 +291,7 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
                         rs_.buf = None
                         with dev.sketch(rb, k, w) as rsk, \
                                 dev.map(ix, rsk, rl[lo:hi], k=k, z=z, x=x, sensitive=sensitive, repeat_filter=repeats) as res:
-                            mine = (lo, hi, res.download(), rsk.count, res.n_index_hits)
+                            mine = (lo, hi, res.download(pinned=pin_out), rsk.count, res.n_index_hits)
                     stats["t_device"] += time.perf_counter() - t_dev  # pack + H2D + kernels + D2H
                     parts = comm.gather(mine)
                     if root:

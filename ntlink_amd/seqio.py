@@ -7,6 +7,7 @@ files are concatenated in the order given.
 """
 import gzip
 import io
+import os
 import sys
 
 import numpy as np
@@ -132,44 +133,79 @@ def _np_empty(nbytes):
     return np.empty(nbytes, np.uint8)
 
 
-def load(paths, max_bases=None, alloc=None):
+def _open_native(L, path):
+    import ctypes as C
+    h = C.c_void_p()
+    if L.ntl_fastx_open(path.encode(), C.byref(h)) != 0:
+        raise OSError(f"cannot open {path}")
+    return h
+
+
+def load(paths, max_bases=None, alloc=None, ahead=None):
     """Native reader (ntl_fastx_*, csrc/ntl_io.cpp).  Whole input as one SeqSet, or, with max_bases,
     SeqSets of about that many bases; several files are concatenated in the order given and a batch
     never spans two files.  alloc(nbytes) -> uint8 array supplies the sequence buffers (the pair
-    driver passes the device's page-locked pool); default numpy."""
+    driver passes the device's page-locked pool); default numpy.  Opening a gzip file inflates it, so
+    the next `ahead` files (default min(8, cores/4), at most 2 GiB of compressed input) are opened by
+    background threads while the current one is consumed: many .fq.gz files decode in parallel."""
+    import collections
     import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
     from . import capi
     L = capi.load()
     if isinstance(paths, str):
         paths = [paths]
+    n_ahead = ahead if ahead is not None else min(8, max(1, (os.cpu_count() or 1) // 4))
     whole = []
-    for path in paths:
-        h = C.c_void_p()
-        if L.ntl_fastx_open(path.encode(), C.byref(h)) != 0:
-            raise OSError(f"cannot open {path}")
-        try:
-            while True:
-                n = C.c_uint64()
-                if L.ntl_fastx_next(h, int(max_bases or 0), C.byref(n)) != 0:
-                    raise OSError(f"{path}: {L.ntl_fastx_error(h).decode()}")
-                n = n.value
-                if n == 0:
-                    break
-                nb, nn = C.c_uint64(), C.c_uint64()
-                L.ntl_fastx_sizes(h, None, C.byref(nb), C.byref(nn))
-                buf, names = (alloc or _np_empty)(nb.value), np.empty(nn.value, np.uint8)
-                off, noff = np.empty(n + 1, np.uint64), np.empty(n + 1, np.uint64)
-                if L.ntl_fastx_copy(h, buf.ctypes.data, off.ctypes.data, names.ctypes.data, noff.ctypes.data) != 0:
-                    raise OSError(f"{path}: gather failed")
-                ss = SeqSet(Names(names, noff), buf, off)
-                if max_bases is None:
-                    whole.append(ss)
-                else:
+    pending = collections.deque()  # (path, future of an open handle, compressed bytes)
+    todo = iter(paths)
+    pool = ThreadPoolExecutor(max_workers=max(1, n_ahead))
+
+    def top_up():
+        while len(pending) < max(1, n_ahead) and (not pending or sum(p[2] for p in pending) < (2 << 30)):
+            path = next(todo, None)
+            if path is None:
+                return
+            try:
+                size = os.path.getsize(path)
+            except OSError:
+                size = 0
+            pending.append((path, pool.submit(_open_native, L, path), size))
+
+    try:
+        top_up()
+        while pending:
+            path, fut, _size = pending.popleft()
+            h = fut.result()
+            top_up()
+            try:
+                while True:
+                    n = C.c_uint64()
+                    if L.ntl_fastx_next(h, int(max_bases or 0), C.byref(n)) != 0:
+                        raise OSError(f"{path}: {L.ntl_fastx_error(h).decode()}")
+                    n = n.value
+                    if n == 0:
+                        break
+                    nb, nn = C.c_uint64(), C.c_uint64()
+                    L.ntl_fastx_sizes(h, None, C.byref(nb), C.byref(nn))
+                    buf, names = (alloc or _np_empty)(nb.value), np.empty(nn.value, np.uint8)
+                    off, noff = np.empty(n + 1, np.uint64), np.empty(n + 1, np.uint64)
+                    if L.ntl_fastx_copy(h, buf.ctypes.data, off.ctypes.data, names.ctypes.data, noff.ctypes.data) != 0:
+                        raise OSError(f"{path}: gather failed")
+                    ss = SeqSet(Names(names, noff), buf, off)
+                    if max_bases is None:
+                        whole.append(ss)
+                        break
                     yield ss
-                if max_bases is None:
-                    break
-        finally:
-            L.ntl_fastx_close(h)
+            finally:
+                L.ntl_fastx_close(h)
+    finally:
+        for _path, fut, _size in pending:  # abandoned early: close what the background threads opened
+            try:
+                L.ntl_fastx_close(fut.result())
+            except OSError:
+                pass
+        pool.shutdown(wait=True)
     if max_bases is None:
         yield concat(whole)
 

@@ -21,7 +21,7 @@ def build(sanitize=False):
     cmd = ["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-pthread", "-ffp-contract=off", "-Wall",
            "-Wno-unused-function", "-Wno-unknown-pragmas", "-x", "c++",
            "-I", os.path.join(HERE, "include"), "-I", os.path.join(ROOT, "ntlink_amd", "csrc"),
-           SRC[0], SRC[1], SRC[2], os.path.join(HERE, "sim_runtime.cpp"), "-lz", "-o", out]
+           SRC[0], SRC[1], SRC[2], os.path.join(HERE, "sim_runtime.cpp"), "-lz", "-ldl", "-o", out]
     if sanitize:
         cmd[1:1] = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer"]
     subprocess.check_call(cmd)

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--scale", type=float, default=0.2)
     ap.add_argument("--gz", action="store_true")
     ap.add_argument("--batch", type=int, default=pipeline.DEFAULT_BATCH_BASES)
+    ap.add_argument("--files", type=int, default=1, help="split the reads over this many files (FASTQ when --gz)")
     ap.add_argument("--stages", action="store_true", help="also time every stage of one whole-input batch on its own")
     a = ap.parse_args()
     W = synth.workload("C2", a.scale)
@@ -38,15 +39,31 @@ def main():
     d = tempfile.mkdtemp(prefix="ntl_e2e_")
     tgt, rds = os.path.join(d, "asm.fa"), os.path.join(d, "reads.fa" + (".gz" if a.gz else ""))
     write_fasta(tgt, cbuf, coff, cn)
-    write_fasta(rds, rbuf, roff, rn, a.gz)
+    if a.files == 1:
+        write_fasta(rds, rbuf, roff, rn, a.gz)
+        read_arg = os.path.basename(rds)
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+        per = (len(rn) + a.files - 1) // a.files
+        parts = []
+
+        def one(f):
+            lo, hi = f * per, min(len(rn), (f + 1) * per)
+            path = os.path.join(d, f"reads_{f:03d}.fa" + (".gz" if a.gz else ""))
+            write_fasta(path, rbuf[int(roff[lo]):int(roff[hi])], roff[lo:hi + 1] - roff[lo], rn[lo:hi], a.gz)
+            return os.path.basename(path)
+
+        with ThreadPoolExecutor(16) as ex:
+            parts = list(ex.map(one, range(a.files)))
+        read_arg = " ".join(parts)
     dev = capi.Device(0)
     os.chdir(d)
     t0 = time.perf_counter()
-    st = pipeline.run_pair(dev, "asm.fa", os.path.basename(rds), k=W["k"], w=W["w"], paf=True, pairs_tsv=True, batch_bases=a.batch)
+    st = pipeline.run_pair(dev, "asm.fa", read_arg, k=W["k"], w=W["w"], paf=True, pairs_tsv=True, batch_bases=a.batch)
     dt = time.perf_counter() - t0
     out_bytes = sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d) if f.startswith("asm.fa."))
     print(json.dumps({"end_to_end_Gbases_per_s": round(st["read_bases"] / dt / 1e9, 4), "seconds": round(dt, 3),
-                      "read_bases": st["read_bases"], "reads": st["reads"], "gz": a.gz, "batch_bases": a.batch, "output_bytes": out_bytes,
+                      "read_bases": st["read_bases"], "reads": st["reads"], "gz": a.gz, "files": a.files, "batch_bases": a.batch, "output_bytes": out_bytes,
                       "t_wait_for_ingest": round(st["t_ingest"], 3), "t_device_incl_pack_pcie": round(st["t_device"], 3),
                       "t_write": round(st["t_write"], 3), "t_tally": round(st["t_tally"], 3), "device": dev.name}))
     if a.stages:
