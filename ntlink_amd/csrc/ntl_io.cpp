@@ -62,9 +62,16 @@ struct ntl_fastx {
     std::string pending;     /* header line read ahead (without the newline) */
     bool has_pending = false;
     Chunk chunk;
-    /* mapped mode (plain regular files): byte ranges of the file are parsed by several threads */
+    /* block mode: byte ranges of the input are parsed by several threads.  Either the whole input is in
+     * memory (`map`: an inflated gzip file), or a plain file is read batch by batch into `stage` with
+     * parallel pread()s -- reused pages, unlike a mapping, which would fault every page once. */
     const char *map = nullptr;
     size_t map_size = 0, cur = 0;
+    int fd = -1;
+    size_t file_size = 0;
+    char *stage = nullptr; /* from the buffer cache: pages already faulted in by an earlier file */
+    size_t stage_cap = 0;
+    size_t stage_off = 0, stage_have = 0; /* stage[0 .. stage_have) = file bytes from stage_off on */
     bool map_owned = false; /* map is a malloc'd buffer of inflated data, not a mapping */
     size_t map_cap = 0;
     bool fastq = false;
@@ -75,6 +82,8 @@ struct ntl_fastx {
     bool materialized = false;
     std::string err;
 };
+
+static bool block_mode(const ntl_fastx *r) { return r->map != nullptr || r->fd >= 0; }
 
 static unsigned io_threads()
 {
@@ -352,39 +361,40 @@ extern "C" int ntl_fastx_open(const char *path, ntl_fastx **out)
     *out = nullptr;
     ntl_fastx *r = new ntl_fastx();
     const bool is_stdin = strcmp(path, "-") == 0;
-    if (!is_stdin && !getenv("NTL_IO_NO_MMAP")) { /* regular file: map it */
+    if (!is_stdin && !getenv("NTL_IO_NO_MMAP")) { /* regular file: block mode */
         int fd = open(path, O_RDONLY);
         if (fd < 0) { delete r; return NTL_EINVAL; }
         struct stat st;
-        unsigned char magic[2] = {0, 0};
-        if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0 && pread(fd, magic, 2, 0) == 2) {
-            const bool gz = magic[0] == 0x1f && magic[1] == 0x8b;
+        unsigned char head[64];
+        ssize_t hn = 0;
+        if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0 && (hn = pread(fd, head, sizeof head, 0)) >= 2) {
+            const bool gz = head[0] == 0x1f && head[1] == 0x8b;
             size_t whole_max = (size_t)1 << 30; /* compressed bytes up to which a gzip file is inflated in one go */
             if (const char *e = getenv("NTL_IO_GZ_WHOLE_MAX")) whole_max = (size_t)atoll(e);
-            if (!gz || (size_t)st.st_size <= whole_max) {
+            const char *p = nullptr, *e = nullptr;
+            if (!gz) { /* read batch by batch with pread */
+                r->fd = fd;
+                r->file_size = (size_t)st.st_size;
+                p = (const char *)head; e = p + hn;
+            } else if ((size_t)st.st_size <= whole_max) {
                 void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
                 if (m != MAP_FAILED) {
                     madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
-                    if (!gz) {
-                        r->map = (const char *)m;
-                        r->map_size = (size_t)st.st_size;
-                    } else {
-                        char *buf = nullptr; size_t bn = 0, bcap = 0;
-                        if (inflate_whole((const unsigned char *)m, (size_t)st.st_size, &buf, &bn, &bcap)) {
-                            r->map = buf; r->map_size = bn; r->map_owned = true; r->map_cap = bcap;
-                        }
-                        munmap(m, (size_t)st.st_size);
+                    char *buf = nullptr; size_t bn = 0, bcap = 0;
+                    if (inflate_whole((const unsigned char *)m, (size_t)st.st_size, &buf, &bn, &bcap)) {
+                        r->map = buf; r->map_size = bn; r->map_owned = true; r->map_cap = bcap;
+                        p = r->map; e = p + std::min<size_t>(bn, 64);
                     }
+                    munmap(m, (size_t)st.st_size);
                 }
             }
-            if (r->map) { /* format = first header character */
-                const char *p = r->map, *e = r->map + r->map_size;
+            if (p) { /* format = first header character */
                 while (p < e && (*p == '\n' || *p == '\r')) p++;
                 r->fastq = p < e && *p == '@';
             }
         }
-        close(fd);
-        if (r->map) { *out = r; return NTL_OK; }
+        if (r->fd < 0) close(fd);
+        if (block_mode(r)) { *out = r; return NTL_OK; }
     }
     r->gz = is_stdin ? gzdopen(dup(0), "rb") : gzopen(path, "rb");
     if (!r->gz) { delete r; return NTL_EINVAL; }
@@ -399,7 +409,8 @@ extern "C" void ntl_fastx_close(ntl_fastx *r)
     if (!r) return;
     if (r->gz) gzclose(r->gz);
     if (r->map && r->map_owned) buf_cache().give((char *)r->map, r->map_cap);
-    else if (r->map) munmap((void *)r->map, r->map_size);
+    if (r->fd >= 0) close(r->fd);
+    if (r->stage) buf_cache().give(r->stage, r->stage_cap);
     delete r;
 }
 
@@ -449,19 +460,75 @@ static void next_stream(ntl_fastx *r, uint64_t max_bases)
     }
 }
 
-/* Cuts the byte range of the next batch into per-thread ranges and counts their records. */
-static void next_mapped(ntl_fastx *r, uint64_t max_bases)
+/* Makes the input bytes [cur, cur + need) (clipped to the end) addressable; returns their start, *avail = how
+ * many there are, *at_eof = they reach the end of the input. */
+static const char *view(ntl_fastx *r, size_t need, size_t *avail, bool *at_eof)
 {
-    const char *base = r->map, *fe = r->map + r->map_size;
-    const char *p0 = base + r->cur;
-    r->ranges.clear();
-    if (p0 >= fe) return;
-    const char *pe = fe; /* about max_bases bases, cut at a record boundary */
-    if (max_bases) {
-        const uint64_t want = max_bases * (r->fastq ? 2u : 1u) + (max_bases >> 6);
-        if (want < (uint64_t)(fe - p0)) pe = find_boundary(p0 + want, fe, r->fastq);
+    if (r->map) {
+        *avail = r->map_size - r->cur;
+        *at_eof = true;
+        return r->map + r->cur;
     }
-    const size_t span = (size_t)(pe - p0);
+    const size_t remain = r->file_size - r->cur;
+    const size_t target = std::min(need, remain);
+    if (r->stage_off != r->cur) { /* keep what was read beyond the previous batch */
+        const size_t end = r->stage_off + r->stage_have;
+        if (r->cur >= r->stage_off && r->cur < end) {
+            memmove(r->stage, r->stage + (r->cur - r->stage_off), end - r->cur);
+            r->stage_have = end - r->cur;
+        } else r->stage_have = 0;
+        r->stage_off = r->cur;
+    }
+    if (r->stage_have < target) {
+        if (r->stage_cap < target) {
+            size_t cap = 0;
+            char *nb = buf_cache().take(target + target / 8, &cap);
+            if (!nb) { r->err = "out of memory"; *avail = 0; *at_eof = true; return r->stage; }
+            if (r->stage_have) memcpy(nb, r->stage, r->stage_have);
+            if (r->stage) buf_cache().give(r->stage, r->stage_cap);
+            r->stage = nb; r->stage_cap = cap;
+        }
+        const size_t from = r->stage_have, len = target - from;
+        const size_t T = std::min<size_t>(io_threads(), std::max<size_t>(1, len / (4u << 20)));
+        std::vector<int> bad(T, 0);
+        run_threads(T, [&](size_t t) {
+            size_t a = from + len / T * t, b = t + 1 == T ? from + len : from + len / T * (t + 1);
+            while (a < b) {
+                const ssize_t n = pread(r->fd, r->stage + a, b - a, (off_t)(r->stage_off + a));
+                if (n <= 0) { bad[t] = 1; return; }
+                a += (size_t)n;
+            }
+        });
+        for (int x : bad) if (x) r->err = "read error";
+        r->stage_have = target;
+    }
+    *avail = target;
+    *at_eof = target == remain;
+    return r->stage;
+}
+
+/* Cuts the byte range of the next batch into per-thread ranges and counts their records. */
+static void next_blocks(ntl_fastx *r, uint64_t max_bases)
+{
+    r->ranges.clear();
+    const size_t total_left = r->map ? r->map_size - r->cur : r->file_size - r->cur;
+    if (total_left == 0) return;
+    const uint64_t want = max_bases ? max_bases * (r->fastq ? 2u : 1u) + (max_bases >> 6) : 0;
+    size_t need = max_bases ? (size_t)want + (1u << 20) : total_left;
+    size_t avail; bool at_eof;
+    const char *p0 = view(r, need, &avail, &at_eof);
+    size_t end = avail; /* about max_bases bases, cut at a record boundary */
+    if (max_bases && want < avail) {
+        for (;;) {
+            end = (size_t)(find_boundary(p0 + want, p0 + avail, r->fastq) - p0);
+            if (end < avail || at_eof) break;
+            need = avail * 2; /* a record longer than what was read beyond the cut: read on */
+            p0 = view(r, need, &avail, &at_eof);
+        }
+    }
+    if (!r->err.empty()) return;
+    const char *pe = p0 + end, *fe = p0 + avail;
+    const size_t span = end;
     size_t min_chunk = 2u << 20; /* bytes per thread below which more threads do not pay */
     if (const char *e = getenv("NTL_IO_MIN_CHUNK")) { long v = atol(e); if (v > 0) min_chunk = (size_t)v; }
     const unsigned T = (unsigned)std::min<size_t>(io_threads(), std::max<size_t>(1, span / min_chunk));
@@ -469,7 +536,7 @@ static void next_mapped(ntl_fastx *r, uint64_t max_bases)
     const char *prev = p0;
     for (unsigned t = 0; t < T; t++) {
         const char *nxt = t + 1 == T ? pe : std::max(prev, find_boundary(p0 + span / T * (t + 1), pe, r->fastq));
-        r->ranges[t].b = prev; r->ranges[t].e = nxt; r->ranges[t].at_eof = nxt == fe;
+        r->ranges[t].b = prev; r->ranges[t].e = nxt; r->ranges[t].at_eof = nxt == fe && at_eof;
         prev = nxt;
     }
     auto count = [&](size_t t) {
@@ -481,23 +548,28 @@ static void next_mapped(ntl_fastx *r, uint64_t max_bases)
     run_threads(T, count);
     bool bad = false;
     for (auto &g : r->ranges) bad |= g.bad_end;
-    if (bad) { /* a cut fell inside a quality section (multi-line FASTQ): one range, no cuts */
+    if (bad) { /* a cut fell inside a quality section (wrapped FASTQ): one range, no cuts */
         if (getenv("NTL_IO_TRACE")) fprintf(stderr, "ntl_fastx: range cut inside a quality section, batch re-read on one thread\n");
-        r->ranges.resize(1);
-        Range &g = r->ranges[0];
-        g = Range();
-        g.b = p0; g.e = fe; g.at_eof = true; g.stop_bases = max_bases;
-        CountSink cs;
-        pe = parse_range(g.b, g.e, g.stop_bases, true, cs, nullptr);
-        g.nrec = cs.nrec; g.bases = cs.nbases; g.name_bytes = cs.name_bytes;
+        for (;;) {
+            r->ranges.resize(1);
+            Range &g = r->ranges[0];
+            g = Range();
+            g.b = p0; g.e = p0 + avail; g.at_eof = at_eof; g.stop_bases = max_bases;
+            CountSink cs;
+            pe = parse_range(g.b, g.e, g.stop_bases, at_eof, cs, nullptr);
+            g.nrec = cs.nrec; g.bases = cs.nbases; g.name_bytes = cs.name_bytes;
+            if (at_eof || pe < p0 + avail) break; /* stopped on a complete record */
+            p0 = view(r, avail * 2, &avail, &at_eof);
+            if (!r->err.empty()) return;
+        }
     }
-    r->cur = (size_t)(pe - base);
+    r->cur += (size_t)(pe - p0);
 }
 
 extern "C" void ntl_fastx_sizes(const ntl_fastx *r, uint64_t *nseq, uint64_t *bases, uint64_t *name_bytes)
 {
     uint64_t n = 0, b = 0, nb = 0;
-    if (r && r->map) for (auto &g : r->ranges) { n += g.nrec; b += g.bases; nb += g.name_bytes; }
+    if (r && block_mode(r)) for (auto &g : r->ranges) { n += g.nrec; b += g.bases; nb += g.name_bytes; }
     else if (r) { n = r->chunk.nrec(); b = r->chunk.seqs.size(); nb = r->chunk.names.size(); }
     if (nseq) *nseq = n;
     if (bases) *bases = b;
@@ -509,7 +581,7 @@ extern "C" int ntl_fastx_next(ntl_fastx *r, uint64_t max_bases, uint64_t *nseq)
 {
     if (!r || !nseq) return NTL_EINVAL;
     r->materialized = false;
-    if (r->map) next_mapped(r, max_bases);
+    if (block_mode(r)) next_blocks(r, max_bases);
     else next_stream(r, max_bases);
     if (!r->err.empty()) return NTL_EINVAL;
     ntl_fastx_sizes(r, nseq, nullptr, nullptr);
@@ -526,7 +598,7 @@ extern "C" int ntl_fastx_copy(const ntl_fastx *r, char *seqs, uint64_t *offsets,
     ntl_fastx_sizes(r, &n, &b, &nb);
     if ((b && !seqs) || (nb && !names)) return NTL_EINVAL;
     offsets[0] = 0; name_offsets[0] = 0;
-    if (!r->map) {
+    if (!block_mode(r)) {
         const Chunk &c = r->chunk;
         if (b) memcpy(seqs, c.seqs.data(), b);
         if (nb) memcpy(names, c.names.data(), nb);
