@@ -45,7 +45,26 @@ struct ntl_ctx {
     void *g8 = nullptr;                 /* device copy of the eight-base init table (1 MB) */
     std::multimap<size_t, void *> pool; /* cached device blocks by size */
     size_t pool_bytes = 0;
+    void *host_tmp = nullptr;           /* page-locked bounce buffer for record downloads (grows, never shrinks) */
+    size_t host_tmp_cap = 0;
 };
+
+static int host_tmp(ntl_ctx *c, size_t bytes, void **out)
+{
+    if (c->host_tmp_cap < bytes) {
+        if (c->host_tmp) (void)hipHostFree(c->host_tmp);
+        c->host_tmp = nullptr; c->host_tmp_cap = 0;
+        const size_t cap = bytes + bytes / 4 + 4096;
+        if (hipHostMalloc(&c->host_tmp, cap, hipHostMallocDefault) != hipSuccess) {
+            c->host_tmp = nullptr;
+            c->err = "hipHostMalloc failed";
+            return NTL_ENOMEM;
+        }
+        c->host_tmp_cap = cap;
+    }
+    *out = c->host_tmp;
+    return NTL_OK;
+}
 
 static int fail(ntl_ctx *c, int code, const std::string &msg)
 {
@@ -183,6 +202,7 @@ extern "C" void ntl_ctx_destroy(ntl_ctx *c)
     for (auto &kv : c->pool) hipFree(kv.second);
     hipFree(c->g4);
     hipFree(c->g8);
+    if (c->host_tmp) hipHostFree(c->host_tmp);
     for (auto &kv : c->profs)
         for (auto &sp : kv.second.spans) { hipEventDestroy(sp.first); hipEventDestroy(sp.second); }
     for (auto e : c->ev_free) hipEventDestroy(e);
@@ -589,16 +609,32 @@ extern "C" int ntl_sketch_download(const ntl_sketch *s, uint64_t *mx_off, uint64
     if (!s) return NTL_EINVAL;
     ntl_ctx *c = s->c;
     hipSetDevice(c->device);
-    std::vector<uint32_t> off(s->nseq + 1);
-    std::vector<MxRecord> rec(s->count);
-    HIPCHK(c, hipMemcpyAsync(off.data(), s->mx_off.p, (s->nseq + 1) * 4, hipMemcpyDeviceToHost, c->stream));
-    if (s->count) HIPCHK(c, hipMemcpyAsync(rec.data(), s->records.p, s->count * sizeof(MxRecord), hipMemcpyDeviceToHost, c->stream));
+    const size_t off_bytes = ((s->nseq + 1) * 4 + 63) & ~(size_t)63;
+    void *tmp = nullptr;
+    int rc = host_tmp(c, off_bytes + s->count * sizeof(MxRecord), &tmp);
+    if (rc) return rc;
+    const uint32_t *off = (const uint32_t *)tmp;
+    const MxRecord *rec = (const MxRecord *)((const char *)tmp + off_bytes);
+    HIPCHK(c, hipMemcpyAsync(tmp, s->mx_off.p, (s->nseq + 1) * 4, hipMemcpyDeviceToHost, c->stream));
+    if (s->count) HIPCHK(c, hipMemcpyAsync((void *)rec, s->records.p, s->count * sizeof(MxRecord), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (mx_off) for (uint64_t i = 0; i <= s->nseq; i++) mx_off[i] = off[i];
-    for (uint64_t i = 0; i < s->count; i++) {
-        if (hash) hash[i] = rec[i].hash;
-        if (pos) pos[i] = rec[i].pos;
-        if (strand) strand[i] = (uint8_t)(rec[i].meta & 1u);
+    /* records -> the caller's column arrays, split over threads */
+    unsigned nthr = std::thread::hardware_concurrency();
+    nthr = nthr == 0 ? 1 : std::min(nthr, 16u);
+    if (s->count < (1u << 18)) nthr = 1;
+    auto work = [&](uint64_t a, uint64_t b) {
+        for (uint64_t i = a; i < b; i++) {
+            if (hash) hash[i] = rec[i].hash;
+            if (pos) pos[i] = rec[i].pos;
+            if (strand) strand[i] = (uint8_t)(rec[i].meta & 1u);
+        }
+    };
+    if (nthr == 1) work(0, s->count);
+    else {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nthr; t++) th.emplace_back(work, s->count * t / nthr, s->count * (t + 1) / nthr);
+        for (auto &x : th) x.join();
     }
     return NTL_OK;
 }

@@ -143,30 +143,38 @@ def run_ntlink_pair(dev, args):
         raise
 
 
+class Prefetch:
+    """Runs a generator in a background thread from the moment it is created (the native reader
+    releases the GIL), so that parsing the next read batch overlaps device work and output writing of
+    the current one -- and the first batch overlaps the contig stage."""
+
+    def __init__(self, gen, depth=2):
+        import queue
+        import threading
+        self._q, self._end = queue.Queue(maxsize=depth), object()
+
+        def run():
+            try:
+                for item in gen:
+                    self._q.put(item)
+                self._q.put(self._end)
+            except BaseException as exc:  # re-raised in the consumer
+                self._q.put(exc)
+
+        threading.Thread(target=run, daemon=True).start()
+
+    def __iter__(self):
+        while True:
+            item = self._q.get()
+            if item is self._end:
+                return
+            if isinstance(item, BaseException):
+                raise item
+            yield item
+
+
 def prefetched(gen, depth=2):
-    """Runs a generator in a background thread (the native reader releases the GIL), so that parsing the
-    next read batch overlaps device work and output writing of the current one."""
-    import queue
-    import threading
-    q = queue.Queue(maxsize=depth)
-    end = object()
-
-    def run():
-        try:
-            for item in gen:
-                q.put(item)
-            q.put(end)
-        except BaseException as exc:  # re-raised in the consumer
-            q.put(exc)
-
-    threading.Thread(target=run, daemon=True).start()
-    while True:
-        item = q.get()
-        if item is end:
-            return
-        if isinstance(item, BaseException):
-            raise item
-        yield item
+    return iter(Prefetch(gen, depth))
 
 
 class Drain:
@@ -256,7 +264,11 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
         comm.barrier()
         return None
     comm.barrier()  # nobody creates the verbose file before everyone has looked for it
-    ctg = seqio.load_all([target])
+    t_start = time.perf_counter()
+    read_paths = reads.split() if isinstance(reads, str) else list(reads)
+    # the read files are opened, inflated and parsed from now on, behind the contig stage
+    batches = Prefetch(seqio.load(read_paths, max_bases=batch_bases * comm.world, alloc=dev.pinned_empty))
+    ctg = seqio.load_all([target], alloc=dev.pinned_empty)
     ctg_len = ctg.lengths
     out = PairOutputs(prefix, ctg.names, ctg_len, k, f, verbose, paf) if root else None
     pin_out = comm.world == 1  # records land in page-locked pool buffers (not when they are pickled to rank 0)
@@ -265,55 +277,65 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
         out.add(pres, names, lens)
         dev.pinned_release(pres.get("_pinned"))
 
+    def emit_contig_tsv(off, h, p, s):
+        with open(f"{target}.k{k}.w{w}.tsv", "w") as fh:
+            formats.write_indexlr(fh, ctg.names, ctg_len, off, h, p, s, False)
+
     drain = Drain(consume) if root else None  # text emitters + pair tally run behind the device
-    stats = dict(read_bases=0, reads=0, read_minimizers=0, index_hits=0, t_ingest=0.0, t_device=0.0)
-    t_mark = time.perf_counter()
+    tsv_drain = Drain(emit_contig_tsv) if root and write_contig_tsv else None
+    stats = dict(read_bases=0, reads=0, read_minimizers=0, index_hits=0, t_contigs=0.0, t_ingest=0.0, t_device=0.0)
     try:
-        with dev.batch(ctg.buf, ctg.offsets) as cb, dev.sketch(cb, k, w) as csk:
-            if write_contig_tsv and root:
-                off, h, p, s = csk.download()
-                with open(f"{target}.k{k}.w{w}.tsv", "w") as fh:
-                    formats.write_indexlr(fh, ctg.names, ctg_len, off, h, p, s, False)
-            with dev.index(csk, ctg_len) as ix:
-                stats["index_size"] = len(ix)
-                for rs_ in prefetched(seqio.load(reads.split() if isinstance(reads, str) else list(reads),
-                                                 max_bases=batch_bases * comm.world, alloc=dev.pinned_empty)):
-                    if not len(rs_):
-                        continue
-                    stats["t_ingest"] += time.perf_counter() - t_mark  # FASTA/FASTQ(.gz) parse of this batch
-                    t_dev = time.perf_counter()
-                    rl = rs_.lengths
-                    lo, hi = shard_range(rs_.offsets, comm.rank, comm.world)
-                    b0 = int(rs_.offsets[lo])
-                    sub_off = rs_.offsets[lo:hi + 1] - np.uint64(b0)
-                    with dev.batch(rs_.buf[b0:int(rs_.offsets[hi])], sub_off) as rb:
-                        dev.pinned_release(rs_.buf)  # the bases are on the device: the reader may refill this buffer
-                        rs_.buf = None
-                        with dev.sketch(rb, k, w) as rsk, \
-                                dev.map(ix, rsk, rl[lo:hi], k=k, z=z, x=x, sensitive=sensitive, repeat_filter=repeats) as res:
-                            mine = (lo, hi, res.download(pinned=pin_out), rsk.count, res.n_index_hits)
-                    stats["t_device"] += time.perf_counter() - t_dev  # pack + H2D + kernels + D2H
-                    parts = comm.gather(mine)
-                    if root:
-                        for plo, phi, pres, pmx, phits in parts:
-                            drain.put(pres, rs_.names[plo:phi], rl[plo:phi])
-                            stats["read_minimizers"] += pmx
-                            stats["index_hits"] += phits
-                        stats["read_bases"] += rs_.bases
-                        stats["reads"] += len(rs_)
+        with dev.batch(ctg.buf, ctg.offsets) as cb:
+            dev.pinned_release(ctg.buf)
+            ctg.buf = None
+            with dev.sketch(cb, k, w) as csk:
+                if tsv_drain:
+                    tsv_drain.put(*csk.download())  # <target>.k<k>.w<w>.tsv is written while the reads are mapped
+                with dev.index(csk, ctg_len) as ix:
+                    stats["index_size"] = len(ix)
                     t_mark = time.perf_counter()
+                    stats["t_contigs"] = t_mark - t_start
+                    for rs_ in batches:
+                        if not len(rs_):
+                            continue
+                        stats["t_ingest"] += time.perf_counter() - t_mark  # waiting for the reader thread
+                        t_dev = time.perf_counter()
+                        rl = rs_.lengths
+                        lo, hi = shard_range(rs_.offsets, comm.rank, comm.world)
+                        b0 = int(rs_.offsets[lo])
+                        sub_off = rs_.offsets[lo:hi + 1] - np.uint64(b0)
+                        with dev.batch(rs_.buf[b0:int(rs_.offsets[hi])], sub_off) as rb:
+                            dev.pinned_release(rs_.buf)  # the bases are on the device: the reader may refill this buffer
+                            rs_.buf = None
+                            with dev.sketch(rb, k, w) as rsk, \
+                                    dev.map(ix, rsk, rl[lo:hi], k=k, z=z, x=x, sensitive=sensitive, repeat_filter=repeats) as res:
+                                mine = (lo, hi, res.download(pinned=pin_out), rsk.count, res.n_index_hits)
+                        stats["t_device"] += time.perf_counter() - t_dev  # H2D + pack + kernels + D2H
+                        parts = comm.gather(mine)
+                        if root:
+                            for plo, phi, pres, pmx, phits in parts:
+                                drain.put(pres, rs_.names[plo:phi], rl[plo:phi])
+                                stats["read_minimizers"] += pmx
+                                stats["index_hits"] += phits
+                            stats["read_bases"] += rs_.bases
+                            stats["reads"] += len(rs_)
+                        t_mark = time.perf_counter()
         if root:
             drain.close()
+            if tsv_drain:
+                tsv_drain.close()
             out.close()
             finish_pairs(out.tally, prefix, n, a, pairs_tsv)
             stats["t_write"], stats["t_tally"] = out.t_write, out.t_tally
         comm.barrier()
     except BaseException:
         if out:
-            try:
-                drain.close()
-            except BaseException:
-                pass
+            for d in (drain, tsv_drain):
+                try:
+                    if d:
+                        d.close()
+                except BaseException:
+                    pass
             out.remove_partial()
         raise
     return stats

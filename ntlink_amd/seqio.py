@@ -9,6 +9,7 @@ import gzip
 import io
 import os
 import sys
+import time
 
 import numpy as np
 
@@ -155,6 +156,7 @@ def load(paths, max_bases=None, alloc=None, ahead=None):
     L = capi.load()
     if isinstance(paths, str):
         paths = [paths]
+    trace = bool(os.environ.get("NTL_IO_TRACE"))
     n_ahead = ahead if ahead is not None else min(8, max(1, (os.cpu_count() or 1) // 4))
     whole = []
     pending = collections.deque()  # (path, future of an open handle, compressed bytes)
@@ -181,17 +183,23 @@ def load(paths, max_bases=None, alloc=None, ahead=None):
             try:
                 while True:
                     n = C.c_uint64()
+                    t_0 = time.perf_counter()
                     if L.ntl_fastx_next(h, int(max_bases or 0), C.byref(n)) != 0:
                         raise OSError(f"{path}: {L.ntl_fastx_error(h).decode()}")
                     n = n.value
                     if n == 0:
                         break
+                    t_1 = time.perf_counter()
                     nb, nn = C.c_uint64(), C.c_uint64()
                     L.ntl_fastx_sizes(h, None, C.byref(nb), C.byref(nn))
                     buf, names = (alloc or _np_empty)(nb.value), np.empty(nn.value, np.uint8)
                     off, noff = np.empty(n + 1, np.uint64), np.empty(n + 1, np.uint64)
+                    t_2 = time.perf_counter()
                     if L.ntl_fastx_copy(h, buf.ctypes.data, off.ctypes.data, names.ctypes.data, noff.ctypes.data) != 0:
                         raise OSError(f"{path}: gather failed")
+                    if trace:
+                        print(f"ntl_fastx batch: read+count {t_1 - t_0:.4f}s alloc {t_2 - t_1:.4f}s parse {time.perf_counter() - t_2:.4f}s "
+                              f"bases {nb.value} t={time.perf_counter():.4f}", file=sys.stderr)
                     ss = SeqSet(Names(names, noff), buf, off)
                     if max_bases is None:
                         whole.append(ss)

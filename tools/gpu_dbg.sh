@@ -1,7 +1,7 @@
 #!/bin/bash
 mkdir -p gpurun_out/dbg
 python __graft_entry__.py > gpurun_out/dbg/build.log 2>&1 || { tail -20 gpurun_out/dbg/build.log; exit 1; }
-for args in "--scale 1.0" "--scale 1.0 --stages" ; do
-  echo "== $args"
-  timeout 600 python -u -X faulthandler tools/e2e_bench.py $args 2>&1 | tail -40
+timeout 900 python -m pytest tests/test_gpu_cli.py -x -q 2>&1 | tail -2
+for args in "--scale 1.0 --batch 64000000" "--scale 8.0 --batch 64000000" "--scale 8.0 --batch 256000000" "--scale 2.0 --gz --files 32 --batch 64000000"; do
+timeout 600 python -u tools/e2e_bench.py $args 2>&1 | grep -v Printing | tail -3
 done
