@@ -658,26 +658,55 @@ static int write_all(int fd, const std::string &s)
     return NTL_OK;
 }
 
+static int pwrite_all(int fd, const std::string &s, off_t at)
+{
+    size_t done = 0;
+    while (done < s.size()) {
+        ssize_t n = pwrite(fd, s.data() + done, s.size() - done, at + (off_t)done);
+        if (n <= 0) return NTL_EINVAL;
+        done += (size_t)n;
+    }
+    return NTL_OK;
+}
+
+/* Formats records [0, n) in chunks on several threads and writes the chunks in order.  On a seekable
+ * descriptor every thread pwrite()s its own chunks at their final offsets (the page-cache copy is then
+ * parallel too); pipes get the chunks one after the other. */
 template <typename F>
 static int format_parallel(int fd, uint64_t n, uint64_t weight_hint, F fmt)
 {
     unsigned nthr = std::thread::hardware_concurrency();
     if (nthr == 0) nthr = 1;
-    if (nthr > 16) nthr = 16;
+    if (nthr > 32) nthr = 32;
     if (weight_hint < (1u << 16)) nthr = 1;
-    const uint64_t chunk = 4096; /* records per work item: keeps buffers small and order simple */
+    const uint64_t chunk = 2048; /* records per work item */
     const uint64_t nchunks = (n + chunk - 1) / chunk;
+    off_t base = nthr > 1 ? lseek(fd, 0, SEEK_CUR) : (off_t)-1;
+    if (base != (off_t)-1) { /* O_APPEND would ignore pwrite offsets */
+        const int fl = fcntl(fd, F_GETFL);
+        if (fl < 0 || (fl & O_APPEND)) base = (off_t)-1;
+    }
     uint64_t c0 = 0;
     while (c0 < nchunks) {
-        const uint64_t c1 = std::min<uint64_t>(nchunks, c0 + (uint64_t)nthr * 8);
+        const uint64_t c1 = std::min<uint64_t>(nchunks, c0 + (uint64_t)nthr * 16);
         std::vector<std::string> bufs(c1 - c0);
-        std::vector<std::thread> th;
-        auto work = [&](unsigned t) {
+        run_threads(nthr, [&](size_t t) {
             for (uint64_t c = c0 + t; c < c1; c += nthr) fmt(c * chunk, std::min<uint64_t>(n, (c + 1) * chunk), bufs[c - c0]);
-        };
-        if (nthr == 1) work(0);
-        else { for (unsigned t = 0; t < nthr; t++) th.emplace_back(work, t); for (auto &x : th) x.join(); }
-        for (auto &b : bufs) { int rc = write_all(fd, b); if (rc) return rc; }
+        });
+        if (base == (off_t)-1) {
+            for (auto &b : bufs) { int rc = write_all(fd, b); if (rc) return rc; }
+        } else {
+            std::vector<off_t> at(bufs.size() + 1, base);
+            for (size_t i = 0; i < bufs.size(); i++) at[i + 1] = at[i] + (off_t)bufs[i].size();
+            std::vector<int> rcs(nthr, 0);
+            run_threads(nthr, [&](size_t t) {
+                for (size_t i = t; i < bufs.size(); i += nthr)
+                    if (pwrite_all(fd, bufs[i], at[i])) rcs[t] = NTL_EINVAL;
+            });
+            for (int rc : rcs) if (rc) return rc;
+            base = at[bufs.size()];
+            if (lseek(fd, base, SEEK_SET) == (off_t)-1) return NTL_EINVAL;
+        }
         c0 = c1;
     }
     return NTL_OK;

@@ -36,17 +36,35 @@ class PairOutputs:
         self.paf_fh = open(prefix + ".paf", "w") if paf else None
         self.tally = pairing.PairTally(ctg_names, ctg_len, k, f)
         self.t_write = self.t_tally = 0.0
+        self._exc = None
 
     def add(self, res, read_names, read_len):
         t0 = time.perf_counter()
-        if self.verbose_fh:
-            formats.write_verbose(self.verbose_fh, res, read_names, self.ctg_names)
-        if self.paf_fh:
-            formats.write_paf(self.paf_fh, res, read_names, read_len, self.ctg_names, self.ctg_len)
-        t1 = time.perf_counter()
-        self.tally.add_batch(res, read_len)
+        paf_job = None
+        if self.paf_fh:  # the two files are independent: the PAF is written next to the verbose mapping
+            import threading
+            paf_job = threading.Thread(target=self._guard, args=(formats.write_paf, self.paf_fh, res, read_names, read_len,
+                                                                  self.ctg_names, self.ctg_len))
+            paf_job.start()
+        try:
+            if self.verbose_fh:
+                formats.write_verbose(self.verbose_fh, res, read_names, self.ctg_names)
+            t1 = time.perf_counter()
+            self.tally.add_batch(res, read_len)
+        finally:
+            if paf_job:
+                paf_job.join()
+        if self._exc is not None:
+            exc, self._exc = self._exc, None
+            raise exc
         self.t_write += t1 - t0
         self.t_tally += time.perf_counter() - t1
+
+    def _guard(self, fn, *args):
+        try:
+            fn(*args)
+        except BaseException as exc:
+            self._exc = exc
 
     def close(self):
         for fh in (self.verbose_fh, self.paf_fh):
