@@ -639,13 +639,49 @@ extern "C" const uint64_t *ntl_fastx_name_offsets(ntl_fastx *r) { materialize(r)
 
 /* ------------------------------------------------------------------ writers -------------- */
 
-static inline void put_u64(std::string &s, uint64_t v)
-{
-    char tmp[24];
-    int n = 0;
-    do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
-    while (n) s.push_back(tmp[--n]);
-}
+/* Append-only text buffer over a std::string: raw pointer writes, two digits per division. */
+struct Out {
+    std::string &s;
+    char *p, *end;
+    explicit Out(std::string &str, size_t cap = 1 << 16) : s(str)
+    {
+        s.resize(cap);
+        p = &s[0]; end = p + cap;
+    }
+    inline void need(size_t n)
+    {
+        if ((size_t)(end - p) >= n) return;
+        const size_t used = (size_t)(p - &s[0]);
+        s.resize(std::max(s.size() * 2, used + n + 4096));
+        p = &s[0] + used; end = &s[0] + s.size();
+    }
+    inline void ch(char c) { *p++ = c; } /* callers reserve with need() */
+    inline void bytes(const char *b, size_t n) { need(n + 96); memcpy(p, b, n); p += n; }
+    inline void u32(uint32_t v)
+    {
+        static const char D2[] = "00010203040506070809101112131415161718192021222324252627282930313233343536373839"
+                                 "40414243444546474849505152535455565758596061626364656667686970717273747576777879"
+                                 "8081828384858687888990919293949596979899";
+        char tmp[12];
+        int n = 0;
+        while (v >= 100) { const uint32_t r = v % 100; v /= 100; tmp[n++] = D2[2 * r + 1]; tmp[n++] = D2[2 * r]; }
+        if (v >= 10) { tmp[n++] = D2[2 * v + 1]; tmp[n++] = D2[2 * v]; } else tmp[n++] = (char)('0' + v);
+        while (n) *p++ = tmp[--n];
+    }
+    inline void u64(uint64_t v)
+    {
+        if (v <= 0xFFFFFFFFull) { u32((uint32_t)v); return; }
+        /* split at 10^9: at most three 32-bit pieces */
+        const uint64_t hi = v / 1000000000ull;
+        const uint32_t lo = (uint32_t)(v % 1000000000ull);
+        u64(hi);
+        char tmp[9];
+        uint32_t x = lo;
+        for (int i = 8; i >= 0; i--) { tmp[i] = (char)('0' + x % 10); x /= 10; }
+        memcpy(p, tmp, 9); p += 9;
+    }
+    void finish() { s.resize((size_t)(p - &s[0])); }
+};
 
 static int write_all(int fd, const std::string &s)
 {
@@ -717,17 +753,21 @@ extern "C" int ntl_write_indexlr(int fd, uint64_t nseq, const char *names, const
 {
     if (nseq && (!names || !name_off || !mx_off)) return NTL_EINVAL;
     return format_parallel(fd, nseq, nseq ? mx_off[nseq] : 0, [&](uint64_t a, uint64_t b, std::string &s) {
+        Out o(s, (size_t)(mx_off[b] - mx_off[a]) * 30 + (size_t)(b - a) * 48 + 256);
         for (uint64_t i = a; i < b; i++) {
-            s.append(names + name_off[i], name_off[i + 1] - name_off[i]);
-            s.push_back('\t');
-            if (lengths) { put_u64(s, lengths[i]); s.push_back('\t'); }
+            o.bytes(names + name_off[i], name_off[i + 1] - name_off[i]);
+            o.ch('\t');
+            if (lengths) { o.u32(lengths[i]); o.ch('\t'); }
             for (uint64_t j = mx_off[i]; j < mx_off[i + 1]; j++) {
-                if (j > mx_off[i]) s.push_back(' ');
-                put_u64(s, hash[j]); s.push_back(':'); put_u64(s, pos[j]);
-                if (strand) { s.push_back(':'); s.push_back(strand[j] ? '+' : '-'); } /* NULL: `--pos` without `--strand` */
+                o.need(64);
+                if (j > mx_off[i]) o.ch(' ');
+                o.u64(hash[j]); o.ch(':'); o.u32(pos[j]);
+                if (strand) { o.ch(':'); o.ch(strand[j] ? '+' : '-'); } /* NULL: `--pos` without `--strand` */
             }
-            s.push_back('\n');
+            o.need(8);
+            o.ch('\n');
         }
+        o.finish();
     });
 }
 
@@ -739,22 +779,27 @@ extern "C" int ntl_write_verbose(int fd, const ntl_mapping *maps, uint64_t n_map
     uint64_t w = 0;
     if (n_maps) w = maps[n_maps - 1].hit_off + maps[n_maps - 1].n_hits;
     return format_parallel(fd, n_maps, w, [&](uint64_t a, uint64_t b, std::string &s) {
+        const uint64_t nh = b > a ? maps[b - 1].hit_off + maps[b - 1].n_hits - maps[a].hit_off : 0;
+        Out o(s, (size_t)nh * 22 + (size_t)(b - a) * 80 + 256);
         for (uint64_t i = a; i < b; i++) {
             const ntl_mapping &m = maps[i];
-            s.append(read_names + read_name_off[m.read], read_name_off[m.read + 1] - read_name_off[m.read]);
-            s.push_back('\t');
-            s.append(ctg_names + ctg_name_off[m.ctg], ctg_name_off[m.ctg + 1] - ctg_name_off[m.ctg]);
-            s.push_back('\t');
-            put_u64(s, m.n_hits);
-            s.push_back('\t');
+            o.bytes(read_names + read_name_off[m.read], read_name_off[m.read + 1] - read_name_off[m.read]);
+            o.ch('\t');
+            o.bytes(ctg_names + ctg_name_off[m.ctg], ctg_name_off[m.ctg + 1] - ctg_name_off[m.ctg]);
+            o.ch('\t');
+            o.u32(m.n_hits);
+            o.ch('\t');
             for (uint32_t j = 0; j < m.n_hits; j++) {
                 const ntl_hit &h = hits[m.hit_off + j];
-                if (j) s.push_back(' ');
-                put_u64(s, h.ctg_pos); s.push_back(':'); s.push_back(h.ctg_strand ? '+' : '-'); s.push_back('_');
-                put_u64(s, h.read_pos); s.push_back(':'); s.push_back(h.read_strand ? '+' : '-');
+                o.need(40);
+                if (j) o.ch(' ');
+                o.u32(h.ctg_pos); o.ch(':'); o.ch(h.ctg_strand ? '+' : '-'); o.ch('_');
+                o.u32(h.read_pos); o.ch(':'); o.ch(h.read_strand ? '+' : '-');
             }
-            s.push_back('\n');
+            o.need(8);
+            o.ch('\n');
         }
+        o.finish();
     });
 }
 
@@ -763,21 +808,23 @@ extern "C" int ntl_write_paf(int fd, const ntl_paf *pafs, uint64_t n, const char
 {
     if (n && (!pafs || !read_names || !read_name_off || !read_len || !ctg_names || !ctg_name_off || !ctg_len)) return NTL_EINVAL;
     return format_parallel(fd, n, n * 12, [&](uint64_t a, uint64_t b, std::string &s) {
+        Out o(s, (size_t)(b - a) * 160 + 256);
         for (uint64_t i = a; i < b; i++) {
             const ntl_paf &p = pafs[i];
-            s.append(read_names + read_name_off[p.read], read_name_off[p.read + 1] - read_name_off[p.read]);
-            s.push_back('\t'); put_u64(s, read_len[p.read]);
-            s.push_back('\t'); put_u64(s, p.q_start);
-            s.push_back('\t'); put_u64(s, p.q_end);
-            s.push_back('\t'); s.push_back(p.strand ? '+' : '-');
-            s.push_back('\t');
-            s.append(ctg_names + ctg_name_off[p.ctg], ctg_name_off[p.ctg + 1] - ctg_name_off[p.ctg]);
-            s.push_back('\t'); put_u64(s, ctg_len[p.ctg]);
-            s.push_back('\t'); put_u64(s, p.t_start);
-            s.push_back('\t'); put_u64(s, p.t_end);
-            s.push_back('\t'); put_u64(s, p.n_hits);
-            s.push_back('\t'); put_u64(s, (uint64_t)p.t_end - p.t_start);
-            s.append("\t255\n");
+            o.bytes(read_names + read_name_off[p.read], read_name_off[p.read + 1] - read_name_off[p.read]);
+            o.ch('\t'); o.u32(read_len[p.read]);
+            o.ch('\t'); o.u32(p.q_start);
+            o.ch('\t'); o.u32(p.q_end);
+            o.ch('\t'); o.ch(p.strand ? '+' : '-');
+            o.ch('\t');
+            o.bytes(ctg_names + ctg_name_off[p.ctg], ctg_name_off[p.ctg + 1] - ctg_name_off[p.ctg]);
+            o.ch('\t'); o.u32(ctg_len[p.ctg]);
+            o.ch('\t'); o.u32(p.t_start);
+            o.ch('\t'); o.u32(p.t_end);
+            o.ch('\t'); o.u32(p.n_hits);
+            o.ch('\t'); o.u64((uint64_t)p.t_end - p.t_start);
+            o.bytes("\t255\n", 5);
         }
+        o.finish();
     });
 }

@@ -301,7 +301,7 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
 
     drain = Drain(consume) if root else None  # text emitters + pair tally run behind the device
     tsv_drain = Drain(emit_contig_tsv) if root and write_contig_tsv else None
-    stats = dict(read_bases=0, reads=0, read_minimizers=0, index_hits=0, t_contigs=0.0, t_ingest=0.0, t_device=0.0)
+    stats = dict(read_bases=0, reads=0, read_minimizers=0, index_hits=0, t_contigs=0.0, t_ingest=0.0, t_device=0.0, t_handover=0.0)
     try:
         with dev.batch(ctg.buf, ctg.offsets) as cb:
             dev.pinned_release(ctg.buf)
@@ -329,6 +329,7 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
                                     dev.map(ix, rsk, rl[lo:hi], k=k, z=z, x=x, sensitive=sensitive, repeat_filter=repeats) as res:
                                 mine = (lo, hi, res.download(pinned=pin_out), rsk.count, res.n_index_hits)
                         stats["t_device"] += time.perf_counter() - t_dev  # H2D + pack + kernels + D2H
+                        t_put = time.perf_counter()
                         parts = comm.gather(mine)
                         if root:
                             for plo, phi, pres, pmx, phits in parts:
@@ -338,12 +339,17 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
                             stats["read_bases"] += rs_.bases
                             stats["reads"] += len(rs_)
                         t_mark = time.perf_counter()
+                        stats["t_handover"] += t_mark - t_put  # gather + waiting for the writer thread to take the batch
         if root:
+            t_fin = time.perf_counter()
             drain.close()
             if tsv_drain:
                 tsv_drain.close()
             out.close()
+            stats["t_drain_tail"] = time.perf_counter() - t_fin  # writers still busy after the last device batch
+            t_fin = time.perf_counter()
             finish_pairs(out.tally, prefix, n, a, pairs_tsv)
+            stats["t_graph"] = time.perf_counter() - t_fin
             stats["t_write"], stats["t_tally"] = out.t_write, out.t_tally
         comm.barrier()
     except BaseException:
