@@ -197,6 +197,22 @@ int ntl_write_verbose(int fd, const ntl_mapping *maps, uint64_t n_maps, const nt
 int ntl_write_paf(int fd, const ntl_paf *pafs, uint64_t n, const char *read_names, const uint64_t *read_name_off,
                   const uint32_t *read_len, const char *ctg_names, const uint64_t *ctg_name_off, const uint32_t *ctg_len);
 
+/* indexlr TSV parser: the text input of operator B2 (`id\t[len\t]H:pos:strand ...`, split the way
+ * bin/ntlink_pair.py:197-207,355-378 split it), several threads over blocks of whole lines.  path "-"
+ * = stdin.  ntl_tsv_next reads about max_bytes of text (0 = all of it) and counts; ntl_tsv_copy
+ * fills caller-allocated arrays (name_off / mx_off: nrec + 1 entries, lengths may be NULL): record i
+ * has the id names[name_off[i]..name_off[i+1]) and the minimizers mx_off[i]..mx_off[i+1]; strand 1 = '+'.
+ * A malformed token fails the call (the reference raises ValueError there).  The arrays are what
+ * ntl_sketch_from_host takes. */
+typedef struct ntl_tsv ntl_tsv;
+int ntl_tsv_open(const char *path, int with_len, ntl_tsv **out);
+void ntl_tsv_close(ntl_tsv *r);
+const char *ntl_tsv_error(const ntl_tsv *r);
+int ntl_tsv_next(ntl_tsv *r, uint64_t max_bytes, uint64_t *nrec);
+void ntl_tsv_sizes(const ntl_tsv *r, uint64_t *nrec, uint64_t *nmx, uint64_t *name_bytes);
+int ntl_tsv_copy(const ntl_tsv *r, char *names, uint64_t *name_off, uint32_t *lengths, uint64_t *mx_off,
+                 uint64_t *hash, uint32_t *pos, uint8_t *strand);
+
 /* ---- host-side pair tally (no GPU involved) ------------------------------------------------- */
 
 /* The contig-pair bookkeeping of bin/ntlink_pair.py (tally_pairs_from_mappings :416-435, add_pair

@@ -26,6 +26,7 @@ SYMBOLS = [
     "ntl_mapres_n_index_hits", "ntl_mapres_download",
     "ntl_fastx_open", "ntl_fastx_close", "ntl_fastx_error", "ntl_fastx_next", "ntl_fastx_sizes", "ntl_fastx_copy", "ntl_fastx_seqs", "ntl_fastx_offsets",
     "ntl_fastx_names", "ntl_fastx_name_offsets", "ntl_write_indexlr", "ntl_write_verbose", "ntl_write_paf",
+    "ntl_tsv_open", "ntl_tsv_close", "ntl_tsv_error", "ntl_tsv_next", "ntl_tsv_sizes", "ntl_tsv_copy",
     "ntl_tally_create", "ntl_tally_destroy", "ntl_tally_add", "ntl_tally_npairs", "ntl_tally_ngaps", "ntl_tally_export",
 ]
 
@@ -116,6 +117,15 @@ def load(path=None):
     L.ntl_write_indexlr.argtypes = [C.c_int, C.c_uint64, vp, u64p, u32p, u64p, u64p, u32p, u8p]
     L.ntl_write_verbose.argtypes = [C.c_int, vp, C.c_uint64, vp, vp, u64p, vp, u64p]
     L.ntl_write_paf.argtypes = [C.c_int, vp, C.c_uint64, vp, u64p, u32p, vp, u64p, u32p]
+    L.ntl_tsv_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
+    L.ntl_tsv_close.argtypes = [vp]
+    L.ntl_tsv_close.restype = None
+    L.ntl_tsv_error.argtypes = [vp]
+    L.ntl_tsv_error.restype = C.c_char_p
+    L.ntl_tsv_next.argtypes = [vp, C.c_uint64, u64p]
+    L.ntl_tsv_sizes.argtypes = [vp, u64p, u64p, u64p]
+    L.ntl_tsv_sizes.restype = None
+    L.ntl_tsv_copy.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     L.ntl_tally_create.argtypes = [vp, u64p, u32p, C.c_uint64, C.c_int, C.c_int, C.POINTER(vp)]
     L.ntl_tally_destroy.argtypes = [vp]
     L.ntl_tally_destroy.restype = None

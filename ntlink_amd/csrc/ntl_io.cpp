@@ -828,3 +828,233 @@ extern "C" int ntl_write_paf(int fd, const ntl_paf *pafs, uint64_t n, const char
         o.finish();
     });
 }
+
+/* ------------------------------------------------------------------ indexlr TSV parser ---- */
+
+/*
+ * The text side of operator B2: `id\t[len\t]H:pos:strand H:pos:strand ...` lines as the reference
+ * splits them (bin/ntlink_pair.py:197-207 for contigs, :355-378 for reads: strip, split on tabs,
+ * tokens separated by single spaces, `mx:pos:strand`).  Blocks of the input are cut at line ends
+ * and parsed by several threads, first counting, then writing into the caller's arrays -- the same
+ * two-pass scheme as the FASTA reader.  Every non-empty line keeps its place, with or without
+ * minimizers.
+ */
+struct TsvRange {
+    const char *b = nullptr, *e = nullptr;
+    uint64_t nrec = 0, nmx = 0, name_bytes = 0;
+    int bad = 0;
+};
+
+struct ntl_tsv {
+    int fd = -1;
+    bool with_len = false, eof = false;
+    char *buf = nullptr;   /* block being parsed + the partial line behind it (from the buffer cache) */
+    size_t cap = 0, size_hint = 0;
+    size_t have = 0, used = 0; /* buf[0..have) read; buf[0..used) = whole lines of the current batch */
+    std::vector<TsvRange> ranges;
+    std::string err;
+};
+
+static inline bool tsv_space(char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\v' || c == '\f'; }
+
+struct TsvCount {
+    uint64_t nrec = 0, nmx = 0, name_bytes = 0;
+    void rec(const char *, size_t n, uint32_t) { nrec++; name_bytes += n; }
+    void mx(uint64_t, uint32_t, uint8_t) { nmx++; }
+    void end() {}
+};
+struct TsvWrite {
+    char *names; uint64_t *name_off; uint32_t *lengths; uint64_t *mx_off; uint64_t *hash; uint32_t *pos; uint8_t *strand;
+    uint64_t r, m, nb; /* running record / minimizer / name-byte position (global) */
+    void rec(const char *p, size_t n, uint32_t len)
+    {
+        memcpy(names + nb, p, n); nb += n;
+        name_off[r + 1] = nb;
+        if (lengths) lengths[r] = len;
+    }
+    void mx(uint64_t h, uint32_t p, uint8_t s) { hash[m] = h; pos[m] = p; strand[m] = s; m++; }
+    void end() { mx_off[r + 1] = m; r++; }
+};
+
+/* parses the lines of [p, e) (e at a line end); returns 0 or the 1-based line of the first malformed token */
+template <typename Sink>
+static int tsv_parse(const char *p, const char *e, bool with_len, Sink &out)
+{
+    int line_no = 0;
+    while (p < e) {
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(e - p));
+        const char *le = nl ? nl : e;
+        const char *a = p, *b = le;
+        p = nl ? nl + 1 : e;
+        line_no++;
+        while (a < b && tsv_space(*a)) a++;
+        while (b > a && tsv_space(b[-1])) b--;
+        if (a == b) continue;
+        const char *t1 = (const char *)memchr(a, '\t', (size_t)(b - a));
+        const char *name_e = t1 ? t1 : b;
+        const char *f = t1 ? t1 + 1 : b; /* field after the id */
+        uint32_t len = 0;
+        if (with_len) {
+            const char *t2 = f < b ? (const char *)memchr(f, '\t', (size_t)(b - f)) : nullptr;
+            const char *le2 = t2 ? t2 : b;
+            uint64_t v = 0;
+            for (const char *q = f; q < le2; q++) {
+                if (*q < '0' || *q > '9') return line_no;
+                v = v * 10 + (uint64_t)(*q - '0');
+            }
+            len = (uint32_t)v;
+            f = t2 ? t2 + 1 : b;
+        }
+        out.rec(a, (size_t)(name_e - a), len);
+        const char *fe = f < b ? (const char *)memchr(f, '\t', (size_t)(b - f)) : nullptr; /* later columns are ignored */
+        if (!fe) fe = b;
+        const char *q = f;
+        while (q < fe) {
+            if (*q == ' ') { q++; continue; }
+            uint64_t h = 0;
+            const char *s0 = q;
+            while (q < fe && *q >= '0' && *q <= '9') { h = h * 10 + (uint64_t)(*q - '0'); q++; }
+            if (q == s0 || q >= fe || *q != ':') return line_no;
+            q++;
+            uint64_t ps = 0;
+            s0 = q;
+            while (q < fe && *q >= '0' && *q <= '9') { ps = ps * 10 + (uint64_t)(*q - '0'); q++; }
+            if (q == s0 || q >= fe || *q != ':') return line_no;
+            q++;
+            if (q >= fe || (*q != '+' && *q != '-')) return line_no;
+            out.mx(h, (uint32_t)ps, *q == '+' ? 1 : 0);
+            q++;
+            if (q < fe && *q != ' ') return line_no;
+        }
+        out.end();
+    }
+    return 0;
+}
+
+extern "C" int ntl_tsv_open(const char *path, int with_len, ntl_tsv **out)
+{
+    if (!path || !out) return NTL_EINVAL;
+    *out = nullptr;
+    int fd = strcmp(path, "-") == 0 ? dup(0) : open(path, O_RDONLY);
+    if (fd < 0) return NTL_EINVAL;
+    ntl_tsv *r = new ntl_tsv();
+    r->fd = fd;
+    r->with_len = with_len != 0;
+    struct stat st;
+    if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode)) r->size_hint = (size_t)st.st_size + 1;
+    *out = r;
+    return NTL_OK;
+}
+
+extern "C" void ntl_tsv_close(ntl_tsv *r)
+{
+    if (!r) return;
+    if (r->fd >= 0) close(r->fd);
+    if (r->buf) buf_cache().give(r->buf, r->cap);
+    delete r;
+}
+
+extern "C" const char *ntl_tsv_error(const ntl_tsv *r) { return r ? r->err.c_str() : "no reader"; }
+
+extern "C" void ntl_tsv_sizes(const ntl_tsv *r, uint64_t *nrec, uint64_t *nmx, uint64_t *name_bytes)
+{
+    uint64_t a = 0, b = 0, c = 0;
+    if (r) for (auto &g : r->ranges) { a += g.nrec; b += g.nmx; c += g.name_bytes; }
+    if (nrec) *nrec = a;
+    if (nmx) *nmx = b;
+    if (name_bytes) *name_bytes = c;
+}
+
+/* Reads about max_bytes of text (0 = everything), whole lines only, and counts what it holds;
+ * *nrec == 0 at the end of the input. */
+extern "C" int ntl_tsv_next(ntl_tsv *r, uint64_t max_bytes, uint64_t *nrec)
+{
+    if (!r || !nrec) return NTL_EINVAL;
+    *nrec = 0;
+    /* drop the previous batch, keep the partial line behind it */
+    if (r->used) { memmove(r->buf, r->buf + r->used, r->have - r->used); r->have -= r->used; r->used = 0; }
+    r->ranges.clear();
+    for (;;) {
+        /* fill */
+        const size_t target = max_bytes ? (size_t)max_bytes : (size_t)-1;
+        while (!r->eof && r->have < target) {
+            if (r->cap == r->have) {
+                size_t want_cap = r->cap ? r->cap * 2 : std::max<size_t>((size_t)8 << 20, max_bytes ? (size_t)max_bytes + (1u << 20) : r->size_hint);
+                size_t got = 0;
+                char *nb = buf_cache().take(want_cap, &got);
+                if (!nb) { r->err = "out of memory"; return NTL_ENOMEM; }
+                if (r->have) memcpy(nb, r->buf, r->have);
+                if (r->buf) buf_cache().give(r->buf, r->cap);
+                r->buf = nb; r->cap = got;
+            }
+            const size_t want = std::min(r->cap - r->have, target - r->have);
+            const ssize_t n = read(r->fd, r->buf + r->have, want);
+            if (n < 0) { r->err = "read error"; return NTL_EINVAL; }
+            if (n == 0) { r->eof = true; break; }
+            r->have += (size_t)n;
+        }
+        if (r->have == 0) return NTL_OK;
+        /* whole lines only, unless this is the end */
+        size_t end = r->have;
+        if (!r->eof) {
+            while (end > 0 && r->buf[end - 1] != '\n') end--;
+            if (end == 0) { /* one line longer than the block: read on */
+                if (max_bytes) max_bytes *= 2;
+                continue;
+            }
+        }
+        r->used = end;
+        break;
+    }
+    const char *p0 = r->buf, *pe = p0 + r->used;
+    const size_t span = r->used;
+    size_t min_chunk = 1u << 20;
+    if (const char *e = getenv("NTL_IO_MIN_CHUNK")) { long v = atol(e); if (v > 0) min_chunk = (size_t)v; }
+    const unsigned T = (unsigned)std::min<size_t>(io_threads(), std::max<size_t>(1, span / min_chunk));
+    r->ranges.resize(T);
+    const char *prev = p0;
+    for (unsigned t = 0; t < T; t++) {
+        const char *nxt = pe;
+        if (t + 1 < T) {
+            const char *g = p0 + span / T * (t + 1);
+            if (g < prev) g = prev;
+            const char *nl = (const char *)memchr(g, '\n', (size_t)(pe - g));
+            nxt = nl ? nl + 1 : pe;
+        }
+        r->ranges[t].b = prev; r->ranges[t].e = nxt;
+        prev = nxt;
+    }
+    run_threads(T, [&](size_t t) {
+        TsvRange &g = r->ranges[t];
+        TsvCount c;
+        g.bad = tsv_parse(g.b, g.e, r->with_len, c);
+        g.nrec = c.nrec; g.nmx = c.nmx; g.name_bytes = c.name_bytes;
+    });
+    for (auto &g : r->ranges)
+        if (g.bad) { r->err = "malformed minimizer token (expected hash:pos:strand)"; return NTL_EINVAL; }
+    ntl_tsv_sizes(r, nrec, nullptr, nullptr);
+    if (*nrec == 0 && !r->eof) return ntl_tsv_next(r, max_bytes, nrec); /* a block of blank lines */
+    return NTL_OK;
+}
+
+/* name_off and mx_off have nrec + 1 entries; lengths may be NULL */
+extern "C" int ntl_tsv_copy(const ntl_tsv *r, char *names, uint64_t *name_off, uint32_t *lengths, uint64_t *mx_off,
+                            uint64_t *hash, uint32_t *pos, uint8_t *strand)
+{
+    if (!r || !name_off || !mx_off) return NTL_EINVAL;
+    const size_t T = r->ranges.size();
+    std::vector<uint64_t> r0(T + 1, 0), m0(T + 1, 0), n0(T + 1, 0);
+    for (size_t t = 0; t < T; t++) {
+        r0[t + 1] = r0[t] + r->ranges[t].nrec;
+        m0[t + 1] = m0[t] + r->ranges[t].nmx;
+        n0[t + 1] = n0[t] + r->ranges[t].name_bytes;
+    }
+    if ((m0[T] && (!hash || !pos || !strand)) || (n0[T] && !names)) return NTL_EINVAL;
+    name_off[0] = 0; mx_off[0] = 0;
+    run_threads(T, [&](size_t t) {
+        const TsvRange &g = r->ranges[t];
+        TsvWrite w{names, name_off, lengths, mx_off, hash, pos, strand, r0[t], m0[t], n0[t]};
+        tsv_parse(g.b, g.e, r->with_len, w);
+    });
+    return NTL_OK;
+}

@@ -87,6 +87,36 @@ def parse_indexlr(fh, with_len):
             np.array(hs, np.uint64), np.array(ps, np.uint32), np.array(ss, np.uint8))
 
 
+def read_indexlr(path, with_len, max_bytes=0):
+    """Native, multi-threaded form of parse_indexlr (csrc/ntl_io.cpp, ntl_tsv_*): yields
+    (Names, lengths u32 or None, mx_off u64[n+1], hash u64, pos u32, strand u8) per block of about
+    max_bytes of text (0: the whole input as one block).  path "-" = stdin."""
+    L = _native()
+    h = C.c_void_p()
+    if L.ntl_tsv_open(path.encode(), 1 if with_len else 0, C.byref(h)) != 0:
+        raise OSError(f"cannot open {path}")
+    try:
+        while True:
+            n = C.c_uint64()
+            if L.ntl_tsv_next(h, int(max_bytes), C.byref(n)) != 0:
+                raise ValueError(f"{path}: {L.ntl_tsv_error(h).decode()}")
+            n = n.value
+            if n == 0:
+                return
+            nmx, nb = C.c_uint64(), C.c_uint64()
+            L.ntl_tsv_sizes(h, None, C.byref(nmx), C.byref(nb))
+            names, noff = np.empty(nb.value, np.uint8), np.empty(n + 1, np.uint64)
+            lens = np.empty(n, np.uint32) if with_len else None
+            off = np.empty(n + 1, np.uint64)
+            hs, ps, ss = np.empty(nmx.value, np.uint64), np.empty(nmx.value, np.uint32), np.empty(nmx.value, np.uint8)
+            if L.ntl_tsv_copy(h, names.ctypes.data, noff.ctypes.data, lens.ctypes.data if with_len else None, off.ctypes.data,
+                              hs.ctypes.data, ps.ctypes.data, ss.ctypes.data) != 0:
+                raise ValueError(f"{path}: copy failed")
+            yield Names(names, noff), lens, off, hs, ps, ss
+    finally:
+        L.ntl_tsv_close(h)
+
+
 def write_verbose(fh, res, read_names, ctg_names, read_base=0):
     maps, hits = res["maps"], res["hits"]
     fd = _fd(fh)

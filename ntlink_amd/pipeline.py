@@ -19,6 +19,7 @@ import numpy as np
 
 from . import capi, formats, pairing, seqio
 
+TSV_BLOCK_BYTES = 256 << 20  # text of the read-minimizer TSV parsed per device batch (operator B2)
 DEFAULT_BATCH_BASES = 256_000_000  # read bases per device batch (packed: 64 MB); the next batch is parsed meanwhile
 
 
@@ -132,8 +133,11 @@ def run_ntlink_pair(dev, args):
         _log("DONE!")
         return
     _log("Reading minimizers", args.s)
-    with (sys.stdin if args.m == "-" else open(args.m)) as fh:
-        cn, _, coff, ch, cp, cs = formats.parse_indexlr(fh, False)
+    blocks = list(formats.read_indexlr(args.m, False))  # native parser; "-" = stdin
+    if blocks:
+        cn, _, coff, ch, cp, cs = blocks[0]
+    else:
+        cn, coff, ch, cp, cs = [], np.zeros(1, np.uint64), np.zeros(0, np.uint64), np.zeros(0, np.uint32), np.zeros(0, np.uint8)
     # contig-id order = order of the FASTA; TSV lines may be any subset in any order
     nctg = len(names)
     ids = np.array([index_of[n] for n in cn], np.int64)
@@ -147,12 +151,12 @@ def run_ntlink_pair(dev, args):
         with dev.sketch_from_arrays(full_off, ch[order], cp[order], cs[order]) as csk, dev.index(csk, ctg_len) as ix:
             _log("Finding pairs")
             for path in args.FILES:
-                with (sys.stdin if path == "-" else open(path)) as fh:
-                    rn, rlen, roff, rh, rp, rs = formats.parse_indexlr(fh, True)
-                with dev.sketch_from_arrays(roff, rh, rp, rs) as rsk, \
-                        dev.map(ix, rsk, rlen, k=args.k, z=args.z, x=args.x, sensitive=args.sensitive,
-                                repeat_filter=args.repeat_filter) as res:
-                    out.add(res.download(), rn, rlen)
+                # blocks of whole lines, parsed by several threads while the previous block is on the device
+                for rn, rlen, roff, rh, rp, rs in prefetched(formats.read_indexlr(path, True, TSV_BLOCK_BYTES), depth=1):
+                    with dev.sketch_from_arrays(roff, rh, rp, rs) as rsk, \
+                            dev.map(ix, rsk, rlen, k=args.k, z=args.z, x=args.x, sensitive=args.sensitive,
+                                    repeat_filter=args.repeat_filter) as res:
+                        out.add(res.download(), rn, rlen)
         out.close()
         finish_pairs(out.tally, args.p, args.n, args.a, args.pairs)
         _log("DONE!")

@@ -231,3 +231,39 @@ def test_native_reader_batches_and_stdin(tmp_path):
     with open(src, "rb") as fin:
         out = subprocess.check_output([sys.executable, "-c", code], stdin=fin).decode().split()
     assert [int(v) for v in out] == [len(whole), whole.bases]
+
+
+def test_native_tsv_parser_equals_python_parser(tmp_path):
+    """ntl_tsv_* (blocks of lines on several threads) == formats.parse_indexlr == what the reference's
+    split()s see (bin/ntlink_pair.py:197-207,355-378): blank lines, records without minimizers,
+    CRLF, a last line without newline, blocks smaller than a line."""
+    rng = np.random.default_rng(3)
+    lines = []
+    for i in range(3000):
+        n = int(rng.integers(0, 40)) if rng.random() < 0.9 else 0
+        toks = " ".join(f"{int(rng.integers(0, 2**63)) * 2 + int(rng.integers(0, 2))}:{int(rng.integers(0, 2**31))}:{'+-'[int(rng.integers(0, 2))]}"
+                        for _ in range(n))
+        lines.append(f"read_{i}\t{int(rng.integers(1, 10**6))}\t{toks}")
+        if rng.random() < 0.02:
+            lines.append("")
+    for with_len, nl, tail in ((True, "\n", "\n"), (True, "\r\n", ""), (False, "\n", "")):
+        body = [l if with_len else l.split("\t")[0] + "\t" + l.split("\t")[2] if l else l for l in lines]
+        p = tmp_path / f"x_{with_len}_{len(nl)}.tsv"
+        p.write_text(nl.join(body) + tail, newline="")
+        with open(p) as fh:
+            want = formats.parse_indexlr(fh, with_len)
+        for max_bytes, thr in ((0, "7"), (5000, "3"), (100, "1")):
+            with _env({"NTL_IO_THREADS": thr, "NTL_IO_MIN_CHUNK": "700"}):
+                parts = list(formats.read_indexlr(str(p), with_len, max_bytes))
+            assert [n for x in parts for n in x[0]] == want[0]
+            if with_len:
+                assert np.array_equal(np.concatenate([x[1] for x in parts]), want[1])
+            assert np.array_equal(np.concatenate([np.diff(x[2]) for x in parts]), np.diff(want[2]))
+            for col in (3, 4, 5):
+                assert np.array_equal(np.concatenate([x[col] for x in parts]), want[col])
+            if max_bytes:
+                assert len(parts) > 3
+    bad = tmp_path / "bad.tsv"
+    bad.write_text("r1\t100\t12:5:+ 13:x:-\n")
+    with pytest.raises(ValueError):
+        list(formats.read_indexlr(str(bad), True))

@@ -64,6 +64,29 @@ def test_sim_pair_driver_files(dev, tmp_path):
     assert os.path.exists(pre + ".n1.scaffold.dot")
 
 
+def test_sim_two_operator_files(dev, tmp_path):
+    """Operator A then operator B2 through text, as the reference's Makefile joins them
+    (ntLink:198-199,221-225): run_indexlr -> TSV files -> run_ntlink_pair (native TSV parser)."""
+    import argparse
+    import os
+    from helpers import GEN, REF, TEST7_PAF, read_text
+    from ntlink_amd import pipeline
+    ctsv, rtsv = str(tmp_path / "c.tsv"), str(tmp_path / "r.tsv")
+    with open(ctsv, "w") as fh:
+        pipeline.run_indexlr(dev, [os.path.join(REF, "scaffolds_4.fa")], 40, 100, fh, False)
+    with open(rtsv, "w") as fh:
+        pipeline.run_indexlr(dev, [os.path.join(REF, "long_reads_4_top5.fa")], 40, 100, fh, True)
+    assert read_text(ctsv) == read_text(os.path.join(REF, "expected_outputs", "scaffolds_4.fa.k40.w100.tsv"))
+    pre = str(tmp_path / "out")
+    pipeline.run_ntlink_pair(dev, argparse.Namespace(FILES=[rtsv], s=os.path.join(REF, "scaffolds_4.fa"), m=ctsv, p=pre, n=1, k=40,
+                                                     z=1000, a=1, f=10, x=0.0, checkpoint=None, pairs=True, paf=True,
+                                                     sensitive=False, repeat_filter=False, verbose=True))
+    d = os.path.join(GEN, "fixtures", "t7_top5_k40_w100")
+    assert read_text(pre + ".verbose_mapping.tsv") == read_text(d + ".verbose_mapping.tsv")
+    assert set(read_text(pre + ".paf").splitlines()) == TEST7_PAF
+    assert read_text(pre + ".pairs.tsv") == read_text(d + ".pairs.tsv")
+
+
 @pytest.mark.parametrize("seed,k,w", [(21, 32, 100), (22, 80, 20), (23, 9, 3)])
 def test_sim_fuzz_sketch(dev, seed, k, w):
     import fuzz_cases
