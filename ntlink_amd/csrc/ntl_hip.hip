@@ -84,7 +84,7 @@ static int dev_alloc(ntl_ctx *c, size_t bytes, void **out)
     hipError_t e = hipMalloc(out, bytes);
     if (e != hipSuccess) {
         /* drop the cache and retry once */
-        for (auto &kv : c->pool) hipFree(kv.second);
+        for (auto &kv : c->pool) (void)hipFree(kv.second);
         c->pool.clear();
         c->pool_bytes = 0;
         e = hipMalloc(out, bytes);
@@ -141,12 +141,12 @@ struct ProfSpan {
             else if (hipEventCreate(&e) != hipSuccess) e = nullptr;
         };
         get(a); get(b);
-        if (a) hipEventRecord(a, c->stream);
+        if (a) (void)hipEventRecord(a, c->stream);
     }
     ~ProfSpan()
     {
         if (!c->prof || !a || !b) return;
-        hipEventRecord(b, c->stream);
+        (void)hipEventRecord(b, c->stream);
         ProfEntry &P = c->profs[name];
         P.spans.push_back({a, b});
         P.launches++;
@@ -197,16 +197,16 @@ extern "C" int ntl_ctx_create(int device, ntl_ctx **out)
 extern "C" void ntl_ctx_destroy(ntl_ctx *c)
 {
     if (!c) return;
-    hipSetDevice(c->device);
-    hipStreamSynchronize(c->stream);
-    for (auto &kv : c->pool) hipFree(kv.second);
-    hipFree(c->g4);
-    hipFree(c->g8);
-    if (c->host_tmp) hipHostFree(c->host_tmp);
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto &kv : c->pool) (void)hipFree(kv.second);
+    (void)hipFree(c->g4);
+    (void)hipFree(c->g8);
+    if (c->host_tmp) (void)hipHostFree(c->host_tmp);
     for (auto &kv : c->profs)
-        for (auto &sp : kv.second.spans) { hipEventDestroy(sp.first); hipEventDestroy(sp.second); }
-    for (auto e : c->ev_free) hipEventDestroy(e);
-    hipStreamDestroy(c->stream);
+        for (auto &sp : kv.second.spans) { (void)hipEventDestroy(sp.first); (void)hipEventDestroy(sp.second); }
+    for (auto e : c->ev_free) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -229,7 +229,7 @@ extern "C" int ntl_prof_enable(ntl_ctx *c, int on)
 
 static void prof_collect(ntl_ctx *c)
 {
-    hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->stream);
     for (auto &kv : c->profs) {
         for (auto &sp : kv.second.spans) {
             float ms = 0;
@@ -322,7 +322,7 @@ extern "C" int ntl_batch_create(ntl_ctx *c, const char *seqs, const uint64_t *of
 
     const uint64_t n32 = (NTL_LEAD_PAD + total + 31) / 32; /* threads = 32-position groups that hold data */
     int rc;
-    hipSetDevice(c->device);
+    (void)hipSetDevice(c->device);
     DevBuf raw, valid32, ss32, starts32, rank, any_multi;
     if ((rc = b->packed.alloc(c, nwords * 4)) || (rc = b->seq_base.alloc(c, (nseq + 1) * 8)) ||
         (rc = b->seq_run_first.alloc(c, (nseq + 1) * 4)) || (rc = raw.alloc(c, total + 64)) ||
@@ -383,7 +383,7 @@ extern "C" int ntl_host_alloc(ntl_ctx *c, uint64_t bytes, void **out)
 {
     if (!c || !out) return NTL_EINVAL;
     *out = nullptr;
-    hipSetDevice(c->device);
+    (void)hipSetDevice(c->device);
     HIPCHK(c, hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
     return NTL_OK;
 }
@@ -391,8 +391,8 @@ extern "C" int ntl_host_alloc(ntl_ctx *c, uint64_t bytes, void **out)
 extern "C" void ntl_host_free(ntl_ctx *c, void *p)
 {
     if (!c || !p) return;
-    hipSetDevice(c->device);
-    hipHostFree(p);
+    (void)hipSetDevice(c->device);
+    (void)hipHostFree(p);
 }
 extern "C" uint64_t ntl_batch_nseq(const ntl_batch *b) { return b ? b->nseq : 0; }
 extern "C" uint64_t ntl_batch_bases(const ntl_batch *b) { return b ? b->bases : 0; }
@@ -488,7 +488,7 @@ extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_
     if (!c || !b || !out) return NTL_EINVAL;
     *out = nullptr;
     if (k < 1 || k > 4096 || w < 1) return fail(c, NTL_EINVAL, "k must be in 1..4096 and w >= 1");
-    hipSetDevice(c->device);
+    (void)hipSetDevice(c->device);
     int C = w >= 16 ? 16 : (w >= 4 ? 4 : 1);
     if (const char *e = getenv("NTL_SKETCH_C")) { /* tuning knob: k-mers per lane (16, 4, 1) */
         const int v = atoi(e);
@@ -608,7 +608,7 @@ extern "C" int ntl_sketch_download(const ntl_sketch *s, uint64_t *mx_off, uint64
 {
     if (!s) return NTL_EINVAL;
     ntl_ctx *c = s->c;
-    hipSetDevice(c->device);
+    (void)hipSetDevice(c->device);
     const size_t off_bytes = ((s->nseq + 1) * 4 + 63) & ~(size_t)63;
     void *tmp = nullptr;
     int rc = host_tmp(c, off_bytes + s->count * sizeof(MxRecord), &tmp);
@@ -647,28 +647,49 @@ extern "C" int ntl_sketch_from_host(ntl_ctx *c, uint64_t nseq, const uint64_t *m
     const uint64_t n = mx_off[nseq];
     if (n >= 0xFFFFFFF0ull || nseq >= ((uint64_t)1 << 31)) return fail(c, NTL_EINVAL, "sketch too large for one batch");
     if (n && (!hash || !pos || !strand)) return NTL_EINVAL;
-    hipSetDevice(c->device);
-    std::vector<MxRecord> rec(n);
-    std::vector<uint32_t> off(nseq + 1);
-    for (uint64_t i = 0; i <= nseq; i++) {
-        if (i && mx_off[i] < mx_off[i - 1]) return fail(c, NTL_EINVAL, "mx_off must be non-decreasing");
-        off[i] = (uint32_t)mx_off[i];
-    }
-    for (uint64_t s = 0; s < nseq; s++)
-        for (uint64_t i = mx_off[s]; i < mx_off[s + 1]; i++) {
-            rec[i].hash = hash[i]; rec[i].pos = pos[i];
-            rec[i].meta = ((uint32_t)s << 1) | (strand[i] ? 1u : 0u);
+    (void)hipSetDevice(c->device);
+    if (mx_off[0] != 0) return fail(c, NTL_EINVAL, "mx_off[0] must be 0");
+    for (uint64_t i = 1; i <= nseq; i++)
+        if (mx_off[i] < mx_off[i - 1]) return fail(c, NTL_EINVAL, "mx_off must be non-decreasing");
+    /* columns -> 16-byte records in the page-locked bounce buffer, sequences split over threads */
+    const size_t off_bytes = ((nseq + 1) * 4 + 63) & ~(size_t)63;
+    void *tmp = nullptr;
+    int rc = host_tmp(c, off_bytes + n * sizeof(MxRecord), &tmp);
+    if (rc) return rc;
+    uint32_t *off = (uint32_t *)tmp;
+    MxRecord *rec = (MxRecord *)((char *)tmp + off_bytes);
+    unsigned nthr = std::thread::hardware_concurrency();
+    nthr = nthr == 0 ? 1 : std::min(nthr, 16u);
+    if (n < (1u << 18)) nthr = 1;
+    auto work = [&](uint64_t s0, uint64_t s1) {
+        for (uint64_t s = s0; s < s1; s++) {
+            off[s] = (uint32_t)mx_off[s];
+            for (uint64_t i = mx_off[s]; i < mx_off[s + 1]; i++) {
+                rec[i].hash = hash[i]; rec[i].pos = pos[i];
+                rec[i].meta = ((uint32_t)s << 1) | (strand[i] ? 1u : 0u);
+            }
         }
-    ntl_sketch *sk = new ntl_sketch();
+    };
+    if (nthr == 1) work(0, nseq);
+    else {
+        std::vector<std::thread> th;
+        std::vector<uint64_t> cut(nthr + 1, nseq); /* about equal numbers of minimizers per thread */
+        cut[0] = 0;
+        for (unsigned t = 1; t < nthr; t++)
+            cut[t] = std::max<uint64_t>(cut[t - 1], (uint64_t)(std::lower_bound(mx_off, mx_off + nseq, n * t / nthr) - mx_off));
+        for (unsigned t = 0; t < nthr; t++) th.emplace_back(work, cut[t], cut[t + 1]);
+        for (auto &x : th) x.join();
+    }
+    off[nseq] = (uint32_t)mx_off[nseq];
+    std::unique_ptr<ntl_sketch> sk(new ntl_sketch());
     sk->c = c; sk->nseq = nseq; sk->count = n;
-    int rc;
-    if ((rc = sk->records.alloc(c, n * sizeof(MxRecord))) || (rc = sk->mx_off.alloc(c, (nseq + 1) * 4))) { delete sk; return rc; }
+    if ((rc = sk->records.alloc(c, n * sizeof(MxRecord))) || (rc = sk->mx_off.alloc(c, (nseq + 1) * 4))) return rc;
     hipError_t e = hipSuccess;
-    if (n) e = hipMemcpyAsync(sk->records.p, rec.data(), n * sizeof(MxRecord), hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(sk->mx_off.p, off.data(), (nseq + 1) * 4, hipMemcpyHostToDevice, c->stream);
+    if (n) e = hipMemcpyAsync(sk->records.p, rec, n * sizeof(MxRecord), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(sk->mx_off.p, off, (nseq + 1) * 4, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (e != hipSuccess) { delete sk; return fail(c, NTL_EDEVICE, hipGetErrorString(e)); }
-    *out = sk;
+    if (e != hipSuccess) return fail(c, NTL_EDEVICE, hipGetErrorString(e));
+    *out = sk.release();
     return NTL_OK;
 }
 
@@ -692,7 +713,7 @@ extern "C" int ntl_index_build(ntl_ctx *c, const ntl_sketch *ctg, const uint32_t
     *out = nullptr;
     if ((uint64_t)n_ctg != ctg->nseq) return fail(c, NTL_EINVAL, "n_ctg must equal the number of sketched contigs");
     if (n_ctg >= (1u << 30)) return fail(c, NTL_EINVAL, "too many contigs");
-    hipSetDevice(c->device);
+    (void)hipSetDevice(c->device);
     std::unique_ptr<ntl_index> ix_guard(new ntl_index());
     ntl_index *ix = ix_guard.get();
     ix->c = c; ix->n_ctg = n_ctg;
@@ -735,7 +756,7 @@ extern "C" uint64_t ntl_index_size(const ntl_index *ix)
     if (!ix) return 0;
     if (!ix->size_known) {
         unsigned long long v = 0;
-        hipSetDevice(ix->c->device);
+        (void)hipSetDevice(ix->c->device);
         if (hipMemcpyAsync(&v, ix->cnt.p, 8, hipMemcpyDeviceToHost, ix->c->stream) == hipSuccess &&
             hipStreamSynchronize(ix->c->stream) == hipSuccess) {
             ix->size = v;
@@ -758,7 +779,7 @@ extern "C" int ntl_map_run(ntl_ctx *c, const ntl_index *ix, const ntl_sketch *re
 {
     if (!c || !ix || !reads || !params || !out || (!read_len && reads->nseq)) return NTL_EINVAL;
     *out = nullptr;
-    hipSetDevice(c->device);
+    (void)hipSetDevice(c->device);
     const uint64_t nreads = reads->nseq, nmx = reads->count;
     std::unique_ptr<ntl_mapres> R_guard(new ntl_mapres());
     ntl_mapres *R = R_guard.get();
@@ -835,7 +856,7 @@ extern "C" int ntl_mapres_download(const ntl_mapres *r, ntl_mapping *maps, ntl_h
 {
     if (!r) return NTL_EINVAL;
     ntl_ctx *c = r->c;
-    hipSetDevice(c->device);
+    (void)hipSetDevice(c->device);
     static_assert(sizeof(ntl_mapping) == sizeof(MapRec) && sizeof(ntl_hit) == sizeof(HitRec) && sizeof(ntl_paf) == sizeof(PafRec),
                   "ABI records must match the device records");
     if (maps && r->n_maps) HIPCHK(c, hipMemcpyAsync(maps, r->maps.p, r->n_maps * sizeof(MapRec), hipMemcpyDeviceToHost, c->stream));

@@ -64,6 +64,22 @@ def test_sim_pair_driver_files(dev, tmp_path):
     assert os.path.exists(pre + ".n1.scaffold.dot")
 
 
+def test_sim_sketch_arrays_round_trip_threaded(dev):
+    """ntl_sketch_from_host / ntl_sketch_download split their column <-> record conversion over
+    threads above 2^18 minimizers."""
+    import numpy as np
+    rng = np.random.default_rng(9)
+    nseq, n = 5000, 400_000
+    cuts = np.sort(rng.integers(0, n + 1, nseq - 1))
+    off = np.concatenate([[0], cuts, [n]]).astype(np.uint64)
+    h = rng.integers(0, 2**63, n, dtype=np.uint64) * 2 + 1
+    p = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
+    st = rng.integers(0, 2, n).astype(np.uint8)
+    with dev.sketch_from_arrays(off, h, p, st) as sk:
+        o2, h2, p2, s2 = sk.download()
+    assert np.array_equal(o2, off) and np.array_equal(h2, h) and np.array_equal(p2, p) and np.array_equal(s2, st)
+
+
 def test_sim_two_operator_files(dev, tmp_path):
     """Operator A then operator B2 through text, as the reference's Makefile joins them
     (ntLink:198-199,221-225): run_indexlr -> TSV files -> run_ntlink_pair (native TSV parser)."""
