@@ -268,22 +268,17 @@ __global__ __launch_bounds__(NT) void sketch_mask_kernel(SketchArgs A)
     }
     __syncthreads();
 
-    /* ---- phase 3: minimum over the whole blocks L+1..L+a and L+1..L+a+1 ---------------- */
+    /* ---- phase 3: minimum over the whole blocks L+1..L+a -------------------------------- */
     /* lanes that start at least one window lying inside the sequence; in tail strips whole wavefronts
        have none and skip phases 3 and 4 */
     const bool own = L < G.LW && e_lane + G.w <= (int64_t)I.M;
-    uint64_t fa_h = NTL_INF, fb_h;
-    uint32_t fa_i = NTL_NONE, fb_i;
+    uint64_t fa_h = NTL_INF;
+    uint32_t fa_i = NTL_NONE;
     if (own) {
         for (int d = 1; d <= G.a; d++) {
             const uint64_t hh = s_bm_h[L + d];
             if (hh <= fa_h) { fa_h = hh; fa_i = ntl_idx16(s_bm_i[L + d]); }
         }
-        fb_h = fa_h; fb_i = fa_i;
-        const uint64_t hh = s_bm_h[L + G.a + 1];
-        if (hh <= fb_h) { fb_h = hh; fb_i = ntl_idx16(s_bm_i[L + G.a + 1]); }
-    } else {
-        fb_h = NTL_INF; fb_i = NTL_NONE;
     }
 
     /* ---- phase 4: every window starting in the own block -------------------------------- */
@@ -304,26 +299,28 @@ __global__ __launch_bounds__(NT) void sketch_mask_kernel(SketchArgs A)
     /* CHECK = false: every window of every owning lane of this wavefront lies inside the sequence */
     auto window_pass = [&](auto chk) {
         constexpr bool CHECK = decltype(chk)::value;
-        int Lr = L + G.a + 1;
-        uint64_t P_h = s_pr_h[Lr];
-        uint32_t P_i = ntl_idx16(s_pr_i[Lr]);
+        /* Everything right of the own block is one stream: the a whole blocks, then the elements of
+           blocks Lr and Lr+1 in order.  Window j sees the stream up to element R0+j-1 of those two
+           blocks, so a single running minimum, seeded with the whole-block minimum and the first R0
+           elements (phase 2), serves all C windows. */
+        const int Lr = L + G.a + 1;
+        uint64_t P_h = fa_h;
+        uint32_t P_i = fa_i;
+        {
+            const uint64_t hh = s_pr_h[Lr];
+            if (hh <= P_h) { P_h = hh; P_i = ntl_idx16(s_pr_i[Lr]); }
+        }
 #pragma unroll
         for (int j = 0; j < C; j++) {
-            constexpr int dummy = 0; (void)dummy;
             const int rt = R0 + j; /* compile-time after unrolling */
             if (j > 0) {
-                if (rt == C) { Lr++; P_h = NTL_INF; P_i = NTL_NONE; }
-                else {
-                    const int tp = rt - 1 < C ? rt - 1 : rt - 1 - C;
-                    const uint64_t hh = s_h[tp * NT + Lr];
-                    if (hh <= P_h) { P_h = hh; P_i = (uint32_t)(Lr * C + tp); }
-                }
+                const int tp = rt - 1 < C ? rt - 1 : rt - 1 - C;
+                const int Lb = rt - 1 < C ? Lr : Lr + 1;
+                const uint64_t hh = s_h[tp * NT + Lb];
+                if (hh <= P_h) { P_h = hh; P_i = (uint32_t)(Lb * C + tp); }
             }
             uint64_t x_h = S_h[j];
             uint32_t x_i = S_i[j];
-            const uint64_t F_h = rt < C ? fa_h : fb_h;
-            const uint32_t F_i = rt < C ? fa_i : fb_i;
-            if (F_h <= x_h) { x_h = F_h; x_i = F_i; }
             if (P_h <= x_h) { x_h = P_h; x_i = P_i; }
             bool valid = true;
             if (CHECK) {
