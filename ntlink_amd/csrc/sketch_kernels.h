@@ -283,22 +283,26 @@ __global__ __launch_bounds__(NT) void sketch_mask_kernel(SketchArgs A)
 
     /* ---- phase 4: every window starting in the own block -------------------------------- */
     uint32_t prev_i = NTL_NONE, A0_i = NTL_NONE;
-    uint64_t A0_h = NTL_INF;
+    bool A0_fin = false;
     /* emitted minimizers: single-run strips set bits in the strip-local LDS bitmask without a branch
        (OR of 0 when nothing is emitted); multi-run strips go straight to the global bitmask */
     auto emit = [&](uint32_t idx, bool flag) {
         if (!MULTI) {
-            /* lanes with nothing to emit OR a zero into a private dummy word: no same-address serialisation */
-            const uint32_t wi = flag ? (idx >> 5) : (uint32_t)(NBW + (L & 63)); /* flag implies a real index */
-            atomicOr(&s_bits[wi], (flag ? 1u : 0u) << (idx & 31u));
+            /* lanes with nothing to emit set a bit in a private dummy word behind the bitmask (harmless, never
+               read): no branch, no same-address serialisation; a flag implies a real index */
+            const uint32_t ii = flag ? idx : (uint32_t)((NBW + (L & 63)) * 32);
+            atomicOr(&s_bits[ii >> 5], 1u << (ii & 31u));
         } else if (flag) {
             const uint64_t g = I.base + s_pos[(idx % C) * NT + (idx / C)];
             atomicOr(&A.mask[g >> 5], 1u << ((uint32_t)g & 31u));
         }
     };
-    /* CHECK = false: every window of every owning lane of this wavefront lies inside the sequence */
-    auto window_pass = [&](auto chk) {
+    /* CHECK = false: every window of every owning lane of this wavefront lies inside the sequence.
+       INFCHK = false: every owning lane of this wavefront has a finite minimum over its whole blocks, so no
+       window minimum can be the never-emitted value 2^64-1 and the selected hash need not be tracked. */
+    auto window_pass = [&](auto chk, auto infchk) {
         constexpr bool CHECK = decltype(chk)::value;
+        constexpr bool INFCHK = decltype(infchk)::value;
         /* Everything right of the own block is one stream: the a whole blocks, then the elements of
            blocks Lr and Lr+1 in order.  Window j sees the stream up to element R0+j-1 of those two
            blocks, so a single running minimum, seeded with the whole-block minimum and the first R0
@@ -319,33 +323,36 @@ __global__ __launch_bounds__(NT) void sketch_mask_kernel(SketchArgs A)
                 const uint64_t hh = s_h[tp * NT + Lb];
                 if (hh <= P_h) { P_h = hh; P_i = (uint32_t)(Lb * C + tp); }
             }
-            uint64_t x_h = S_h[j];
-            uint32_t x_i = S_i[j];
-            if (P_h <= x_h) { x_h = P_h; x_i = P_i; }
+            const bool right = P_h <= S_h[j];
+            const uint32_t x_i = right ? P_i : S_i[j];
+            bool finite = true;
+            if (INFCHK) finite = (right ? P_h : S_h[j]) != NTL_INF;
             bool valid = true;
             if (CHECK) {
                 const int64_t s = e_lane + j; /* window = ordinals [s, s+w) */
                 valid = s >= 0 && s + G.w <= (int64_t)I.M;
             }
             const uint32_t a_i = valid ? x_i : NTL_NONE;
-            if (j == 0) { A0_i = a_i; A0_h = x_h; }
-            else emit(a_i, valid && a_i != prev_i && x_h != NTL_INF);
+            if (j == 0) { A0_i = a_i; A0_fin = finite; }
+            else emit(a_i, valid && a_i != prev_i && finite);
             prev_i = a_i;
         }
     };
     {
         const bool inside = e_lane >= 0 && e_lane + (C - 1) + G.w <= (int64_t)I.M;
         const bool all_inside = __ballot(own && !inside) == 0ull;
+        const bool all_finite = __ballot(own && fa_h == NTL_INF) == 0ull;
         if (own) {
-            if (all_inside) window_pass(NtlFalse());
-            else window_pass(NtlTrue());
+            if (all_inside && all_finite) window_pass(NtlFalse(), NtlFalse());
+            else if (all_inside) window_pass(NtlFalse(), NtlTrue());
+            else window_pass(NtlTrue(), NtlTrue());
         }
     }
     s_last[L] = (uint16_t)prev_i;
     __syncthreads();
     /* window (L,0) compares with the last window of lane L-1; (0,0) belongs to the previous strip */
     {
-        const bool f0 = own && L > 0 && A0_i != NTL_NONE && A0_i != ntl_idx16(s_last[L - 1]) && A0_h != NTL_INF;
+        const bool f0 = own && L > 0 && A0_i != NTL_NONE && A0_i != ntl_idx16(s_last[L - 1]) && A0_fin;
         if (!MULTI) emit(A0_i, f0);
         else if (f0) emit(A0_i, true);
     }
