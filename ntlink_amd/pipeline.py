@@ -173,17 +173,32 @@ class Prefetch:
     def __init__(self, gen, depth=2):
         import queue
         import threading
-        self._q, self._end = queue.Queue(maxsize=depth), object()
+        self._q, self._end, self._stop = queue.Queue(maxsize=depth), object(), False
 
         def run():
             try:
                 for item in gen:
                     self._q.put(item)
+                    if self._stop:
+                        gen.close()  # closes the readers the generator holds
+                        return
                 self._q.put(self._end)
             except BaseException as exc:  # re-raised in the consumer
                 self._q.put(exc)
 
-        threading.Thread(target=run, daemon=True).start()
+        self._t = threading.Thread(target=run, daemon=True)
+        self._t.start()
+
+    def stop(self):
+        """Abandon the stream (error path): lets the producer finish its current item and exit, so that
+        nothing is parsing into device-owned buffers when the device goes away."""
+        import queue
+        self._stop = True
+        while self._t.is_alive():
+            try:
+                self._q.get(timeout=0.05)
+            except queue.Empty:
+                pass
 
     def __iter__(self):
         while True:
@@ -365,5 +380,6 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
                 except BaseException:
                     pass
             out.remove_partial()
+        batches.stop()
         raise
     return stats

@@ -64,6 +64,28 @@ def test_sim_pair_driver_files(dev, tmp_path):
     assert os.path.exists(pre + ".n1.scaffold.dot")
 
 
+def test_sim_pair_driver_error_removes_partial_outputs(dev, tmp_path):
+    """bin/ntlink_pair.py:608-613: on an error nothing half-written stays behind; the reader thread's
+    exception surfaces in the driver."""
+    import os
+    import shutil
+    from helpers import REF
+    from ntlink_amd import pipeline
+    shutil.copy(os.path.join(REF, "scaffolds_4.fa"), tmp_path / "scaffolds_4.fa")
+    (tmp_path / "broken.fa.gz").write_bytes(b"\x1f\x8b\x08\x00garbage-not-a-gzip-stream" * 10)
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        with pytest.raises(OSError):
+            pipeline.run_pair(dev, "scaffolds_4.fa", "long_reads_missing.fa", k=40, w=100, paf=True)
+        with pytest.raises(OSError):
+            pipeline.run_pair(dev, "scaffolds_4.fa", "broken.fa.gz", k=40, w=100, paf=True)
+    finally:
+        os.chdir(cwd)
+    left = sorted(os.listdir(tmp_path))
+    assert not [f for f in left if f.endswith(".verbose_mapping.tsv") or f.endswith(".paf")], left
+
+
 def test_sim_sketch_arrays_round_trip_threaded(dev):
     """ntl_sketch_from_host / ntl_sketch_download split their column <-> record conversion over
     threads above 2^18 minimizers."""
