@@ -22,3 +22,7 @@ __device__ __forceinline__ double ntl_mul_add_rn(double x, double d, double k)
 {
     return __dadd_rn(__dmul_rn(x, d), k);
 }
+
+/* streaming (non-temporal) 64-bit global accesses: data touched once should not evict reused lines from L2 */
+__device__ __forceinline__ uint64_t ntl_stream_load(const uint64_t *p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void ntl_stream_store(uint64_t *p, uint64_t v) { __builtin_nontemporal_store(v, p); }

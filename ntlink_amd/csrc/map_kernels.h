@@ -105,36 +105,56 @@ struct Cand {
     uint32_t meta; /* bit 0: found and unique, bit 1: contig strand, bits 2..31: contig */
 };
 
+#define PROBE_U 4 /* minimizers per thread and round: their loads are issued together (memory-level parallelism) */
+
 __global__ void probe_kernel(const MxRecord *mx, uint64_t n, const IndexSlot *slots, int bits,
                              const IndexSpecial *special, Cand *cand, unsigned long long *nfound, const uint8_t *tags)
 {
     unsigned long long found = 0;
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x * PROBE_U;
     const uint64_t mask = ((uint64_t)1 << bits) - 1;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        Cand c;
-        c.cpos = 0; c.meta = 0;
-        const uint64_t key = mx[i].hash;
-        if (key == NTL_INF) {
-            if (special->cnt == 1) { c.cpos = special->pos; c.meta = (special->meta & ~1u) | 1u; }
-        } else {
-            uint64_t s = index_home(key, bits);
-            const uint8_t tg = index_tag(key);
-            for (;;) {
-                const uint8_t t = tags[s];
-                if (t == 0) break; /* empty slot ends the probe sequence */
-                if (t == tg) {
-                    const IndexSlot e = slots[s];
-                    if (e.key == key) {
-                        if (!(e.meta & 1u)) { c.cpos = e.pos; c.meta = e.meta | 1u; }
-                        break;
-                    }
-                }
-                s = (s + 1) & mask;
-            }
+    for (uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x * PROBE_U + threadIdx.x; i0 < n; i0 += stride) {
+        uint64_t key[PROBE_U], s[PROBE_U];
+        uint8_t t[PROBE_U];
+        bool live[PROBE_U];
+#pragma unroll
+        for (int u = 0; u < PROBE_U; u++) {
+            const uint64_t i = i0 + (uint64_t)u * blockDim.x;
+            live[u] = i < n;
+            key[u] = live[u] ? ntl_stream_load(&mx[i].hash) : 0; /* streamed once: keep L2 for the tags */
         }
-        cand[i] = c;
-        found += c.meta & 1u;
+#pragma unroll
+        for (int u = 0; u < PROBE_U; u++) {
+            s[u] = index_home(key[u], bits);
+            t[u] = live[u] && key[u] != NTL_INF ? tags[s[u]] : (uint8_t)0;
+        }
+#pragma unroll
+        for (int u = 0; u < PROBE_U; u++) {
+            if (!live[u]) continue;
+            Cand c;
+            c.cpos = 0; c.meta = 0;
+            if (key[u] == NTL_INF) {
+                if (special->cnt == 1) { c.cpos = special->pos; c.meta = (special->meta & ~1u) | 1u; }
+            } else {
+                const uint8_t tg = index_tag(key[u]);
+                uint64_t q = s[u];
+                uint8_t tq = t[u];
+                for (;;) {
+                    if (tq == 0) break; /* empty slot ends the probe sequence */
+                    if (tq == tg) {
+                        const IndexSlot e = slots[q];
+                        if (e.key == key[u]) {
+                            if (!(e.meta & 1u)) { c.cpos = e.pos; c.meta = e.meta | 1u; }
+                            break;
+                        }
+                    }
+                    q = (q + 1) & mask;
+                    tq = tags[q];
+                }
+            }
+            ntl_stream_store((uint64_t *)&cand[i0 + (uint64_t)u * blockDim.x], (uint64_t)c.cpos | ((uint64_t)c.meta << 32));
+            found += c.meta & 1u;
+        }
     }
     block_count_add(found, nfound);
 }

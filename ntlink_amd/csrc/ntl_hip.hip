@@ -798,7 +798,7 @@ extern "C" int ntl_map_run(ntl_ctx *c, const ntl_index *ix, const ntl_sketch *re
     {
         ProfSpan sp(c, "probe");
         if (nmx)
-            hipLaunchKernelGGL(probe_kernel, dim3((unsigned)std::min<uint64_t>((nmx + 255) / 256, 4096)), dim3(256), 0, c->stream,
+            hipLaunchKernelGGL(probe_kernel, dim3((unsigned)std::min<uint64_t>((nmx + 256 * PROBE_U - 1) / (256 * PROBE_U), 4096)), dim3(256), 0, c->stream,
                                (const MxRecord *)reads->records.as<MxRecord>(), nmx, (const IndexSlot *)ix->slots.as<IndexSlot>(),
                                ix->bits, (const IndexSpecial *)ix->special.as<IndexSpecial>(), cand.as<Cand>(),
                                nfound.as<unsigned long long>(), (const uint8_t *)ix->tags.as<uint8_t>());

@@ -19,3 +19,6 @@ inline double ntl_mul_add_rn(double x, double d, double k)
     volatile double m = x * d; /* built with -ffp-contract=off; volatile keeps the two roundings */
     return m + k;
 }
+
+inline uint64_t ntl_stream_load(const uint64_t *p) { return *p; }
+inline void ntl_stream_store(uint64_t *p, uint64_t v) { *p = v; }
