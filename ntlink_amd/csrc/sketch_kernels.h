@@ -382,7 +382,7 @@ struct MxRecord {
 #define EMIT_NT 256
 #define EMIT_WPT 8                       /* mask words per thread */
 #define EMIT_TILE (EMIT_NT * EMIT_WPT)   /* mask words per workgroup */
-#define EMIT_CAP 4096                    /* positions staged in LDS per round */
+#define EMIT_CAP 2048                    /* positions staged in LDS per round (16-bit offsets inside the tile) */
 
 /* pass 1 of the rank scan: set bits per tile */
 __global__ __launch_bounds__(EMIT_NT) void mask_count_kernel(const uint32_t *mask, uint64_t nwords,
@@ -429,7 +429,7 @@ __device__ __forceinline__ uint32_t seq_of(const uint64_t *base, uint32_t lo, ui
 __global__ __launch_bounds__(EMIT_NT) void emit_kernel(EmitArgs A)
 {
     __shared__ uint32_t s_tmp[EMIT_NT];
-    __shared__ uint32_t s_list[EMIT_CAP];
+    __shared__ uint16_t s_list[EMIT_CAP];
     __shared__ uint64_t s_seed[4][2];
     __shared__ uint64_t s_base[EMIT_SEQ_CAP];
     __shared__ uint32_t s_range[2];
@@ -439,9 +439,29 @@ __global__ __launch_bounds__(EMIT_NT) void emit_kernel(EmitArgs A)
     s_g4[t][0] = A.g4[t][0];
     s_g4[t][1] = A.g4[t][1];
     const uint64_t tile_w0 = (uint64_t)blockIdx.x * EMIT_TILE;
-    if (t == 0) { /* sequences that overlap this tile of 65536 base positions */
-        s_range[0] = seq_of(A.seq_base, 0, A.nseq, tile_w0 * 32);
-        s_range[1] = seq_of(A.seq_base, 0, A.nseq, tile_w0 * 32 + (uint64_t)EMIT_TILE * 32 - 1) + 1;
+    /* Sequences that overlap this tile of 65536 base positions.  First sequence: largest s with
+       seq_base[s] <= first position, found by the whole workgroup -- every round the threads test 256
+       evenly spaced candidates of the remaining range and count the hits (two dependent loads for 65 k
+       sequences instead of the sixteen of a one-thread binary search). */
+    {
+        const uint64_t gp0 = tile_w0 * 32;
+        uint32_t lo = 0, len = A.nseq; /* answer lies in [lo, lo + len); candidate 0 of a round always counts */
+        while (len > 1) {
+            const uint32_t step = (len + EMIT_NT - 1) / EMIT_NT;
+            const uint32_t cand = lo + (uint32_t)t * step;
+            if (t == 0) s_range[0] = 0;
+            __syncthreads();
+            if ((uint32_t)t * step < len && (t == 0 || A.seq_base[cand] <= gp0)) atomicAdd(&s_range[0], 1u);
+            __syncthreads();
+            const uint32_t hit = s_range[0]; /* >= 1 */
+            __syncthreads();
+            const uint32_t nlo = lo + (hit - 1) * step;
+            const uint32_t rest = lo + len - nlo;
+            lo = nlo;
+            len = rest < step ? rest : step;
+        }
+        if (t == 0) s_range[0] = lo;
+        __syncthreads();
     }
     const uint64_t w0 = tile_w0 + (uint64_t)t * EMIT_WPT;
     uint32_t words[EMIT_WPT];
@@ -453,10 +473,21 @@ __global__ __launch_bounds__(EMIT_NT) void emit_kernel(EmitArgs A)
     }
     uint32_t total;
     const uint32_t excl = block_excl_scan<EMIT_NT>(c, s_tmp, total);
-    const uint32_t s_lo = s_range[0], s_hi = s_range[1]; /* candidates [s_lo, s_hi) */
-    const bool cached = s_hi - s_lo <= EMIT_SEQ_CAP;
-    if (cached)
-        for (uint32_t i = t; i < s_hi - s_lo; i += EMIT_NT) s_base[i] = A.seq_base[s_lo + i];
+    /* last sequence: count the cached starts that lie inside the tile; more than EMIT_SEQ_CAP of them
+       (tiny sequences) falls back to binary searches in global memory */
+    const uint32_t s_lo = s_range[0];
+    const uint64_t gp_last = tile_w0 * 32 + (uint64_t)EMIT_TILE * 32 - 1;
+    const uint32_t ncache = A.nseq - s_lo < EMIT_SEQ_CAP ? A.nseq - s_lo : EMIT_SEQ_CAP;
+    if (t == 0) s_range[1] = 0;
+    __syncthreads();
+    for (uint32_t i = t; i < ncache; i += EMIT_NT) {
+        const uint64_t v = A.seq_base[s_lo + i];
+        s_base[i] = v;
+        if (v <= gp_last) atomicAdd(&s_range[1], 1u);
+    }
+    __syncthreads();
+    const bool cached = s_range[1] < ncache || s_lo + ncache == A.nseq;
+    const uint32_t s_hi = cached ? s_lo + s_range[1] : A.nseq; /* candidates [s_lo, s_hi) */
     const uint32_t tile_base = A.tile_off[blockIdx.x];
     {
         uint32_t r = tile_base + excl;
@@ -474,7 +505,7 @@ __global__ __launch_bounds__(EMIT_NT) void emit_kernel(EmitArgs A)
             while (m) {
                 const int b = __ffs(m) - 1;
                 m &= m - 1;
-                if (r >= r0 && r < r0 + EMIT_CAP) s_list[r - r0] = (uint32_t)((t * EMIT_WPT + i) * 32 + b);
+                if (r >= r0 && r < r0 + EMIT_CAP) s_list[r - r0] = (uint16_t)((t * EMIT_WPT + i) * 32 + b);
                 r++;
             }
         }

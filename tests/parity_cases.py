@@ -98,6 +98,14 @@ def fixture_seqs(fname):
     return [s for _, s in oracle.read_fastx(os.path.join(REF, fname))]
 
 
+def tiny_sequences(n=3000, seed=8):
+    """Thousands of sequences of 0..120 bases: more than 512 sequence starts inside one 65536-position
+    tile of the emit kernel (uncached sequence lookup) and several rounds of its workgroup-wide search."""
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGTN", np.uint8)
+    return [bytes(acgt[rng.choice(5, int(rng.integers(0, 121)), p=[0.245, 0.245, 0.245, 0.245, 0.02])]) for _ in range(n)]
+
+
 def edge_sequences(seed=5):
     rng = np.random.default_rng(seed)
 

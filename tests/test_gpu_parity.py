@@ -49,6 +49,12 @@ def test_sketch_edge_cases(dev, k, w):
     pc.check_sketch(dev, pc.edge_sequences(), k, w)
 
 
+@pytest.mark.parametrize("k,w", [(12, 8), (20, 40), (5, 1)])
+def test_sketch_many_tiny_sequences(dev, k, w):
+    """> 512 sequence starts per emit tile and several rounds of the workgroup-wide sequence search."""
+    pc.check_sketch(dev, pc.tiny_sequences(20000), k, w)
+
+
 def test_sketch_empty_batch(dev):
     with dev.batch([]) as b, dev.sketch(b, 32, 100) as sk:
         assert sk.count == 0

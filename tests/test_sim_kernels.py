@@ -24,6 +24,10 @@ def test_sim_sketch_edges(dev, k, w):
     pc.check_sketch(dev, pc.edge_sequences(), k, w)
 
 
+def test_sim_sketch_many_tiny_sequences(dev):
+    pc.check_sketch(dev, pc.tiny_sequences(1500), 12, 8)
+
+
 def test_sim_sketch_reads_small_w(dev):
     reads = pc.fixture_seqs("long_reads_4_top5.fa")
     pc.check_sketch(dev, reads[:2], 15, 5)
