@@ -47,8 +47,23 @@ __global__ void index_clear_kernel(IndexSlot *slots, uint64_t nslots)
  * of read minimizers are absent from the index and are rejected on tags alone. */
 __device__ __forceinline__ uint8_t index_tag(uint64_t key) { return (uint8_t)(((key >> 20) & 0xFEu) | 1u); }
 
+/* one atomic per workgroup: sum of per-thread counts (all threads must call) */
+__device__ __forceinline__ void block_count_add(unsigned long long mine, unsigned long long *counter)
+{
+    __shared__ unsigned long long s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    if (mine) atomicAdd(&s_cnt, mine);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_cnt) atomicAdd(counter, s_cnt);
+}
+
+/* One atomic per minimizer: the compare-and-swap that claims the slot.  The winner then stores its payload
+ * with a plain 64-bit write (pos and meta are one aligned word); a later arrival of the same key only sets
+ * the slot's bit in `dup`, which index_finish_kernel folds into the slot -- so no arrival ever
+ * read-modify-writes a payload another one may be writing. */
 __global__ void index_insert_kernel(const MxRecord *mx, uint64_t n, IndexSlot *slots, int bits,
-                                    IndexSpecial *special, uint8_t *tags)
+                                    IndexSpecial *special, uint32_t *dup)
 {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -65,37 +80,37 @@ __global__ void index_insert_kernel(const MxRecord *mx, uint64_t n, IndexSlot *s
     for (;;) {
         unsigned long long old = atomicCAS((unsigned long long *)&slots[s].key,
                                            (unsigned long long)NTL_INF, (unsigned long long)R.hash);
-        /* pos and meta are one aligned 64-bit word (pos in the low half): one atomic each way */
-        unsigned long long *pm = (unsigned long long *)&slots[s].pos;
-        if (old == NTL_INF) { /* first arrival: OR the payload into the zeroed fields */
-            atomicOr(pm, ((unsigned long long)meta << 32) | (unsigned long long)R.pos);
-            tags[s] = index_tag(R.hash);
+        if (old == NTL_INF) { /* first arrival owns the payload */
+            *reinterpret_cast<uint64_t *>(&slots[s].pos) = ((uint64_t)meta << 32) | (uint64_t)R.pos;
             return;
         }
-        if (old == R.hash) { atomicOr(pm, 1ull << 32); return; } /* seen before: duplicate */
+        if (old == R.hash) { atomicOr(&dup[s >> 5], 1u << (s & 31u)); return; } /* seen before: duplicate */
         s = (s + 1) & mask;
     }
 }
 
-/* one atomic per workgroup: sum of per-thread counts (all threads must call) */
-__device__ __forceinline__ void block_count_add(unsigned long long mine, unsigned long long *counter)
-{
-    __shared__ unsigned long long s_cnt;
-    if (threadIdx.x == 0) s_cnt = 0;
-    __syncthreads();
-    if (mine) atomicAdd(&s_cnt, mine);
-    __syncthreads();
-    if (threadIdx.x == 0 && s_cnt) atomicAdd(counter, s_cnt);
-}
-
-/* grid-stride: launch a bounded number of workgroups */
-__global__ void index_count_kernel(const IndexSlot *slots, uint64_t nslots, const IndexSpecial *special,
-                                   unsigned long long *count)
+/* After the inserts, one streaming pass over the table: folds the duplicate bits into the slots, writes the
+ * tag byte of every slot (four slots, one 32-bit store per thread and round) and counts the keys that are
+ * kept.  nslots is a multiple of 32.  Grid-stride: launch a bounded number of workgroups. */
+__global__ void index_finish_kernel(IndexSlot *slots, uint64_t nslots, const IndexSpecial *special, const uint32_t *dup,
+                                    uint8_t *tags, unsigned long long *count)
 {
     unsigned long long u = 0;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nslots; i += stride)
-        u += (slots[i].key != NTL_INF && !(slots[i].meta & 1u)) ? 1u : 0u;
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nslots / 4; q += stride) {
+        const uint32_t d = (dup[q >> 3] >> ((q & 7u) * 4u)) & 0xFu;
+        uint32_t four = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint64_t key = slots[4 * q + j].key;
+            if (key != NTL_INF) {
+                four |= (uint32_t)index_tag(key) << (8 * j);
+                if ((d >> j) & 1u) slots[4 * q + j].meta |= 1u;
+                else u++;
+            }
+        }
+        reinterpret_cast<uint32_t *>(tags)[q] = four;
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0 && special->cnt == 1) u++;
     block_count_add(u, count);
 }

@@ -732,16 +732,18 @@ extern "C" int ntl_index_build(ntl_ctx *c, const ntl_sketch *ctg, const uint32_t
         if (n_ctg) HIPCHK(c, hipMemcpyAsync(ix->ctg_len.p, ix->h_ctg_len.data(), (uint64_t)n_ctg * 4, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemsetAsync(ix->special.p, 0, sizeof(IndexSpecial), c->stream));
         HIPCHK(c, hipMemsetAsync(cnt.p, 0, 8, c->stream));
-        HIPCHK(c, hipMemsetAsync(ix->tags.p, 0, ix->nslots, c->stream));
+        DevBuf dup; /* one bit per slot: the key arrived more than once */
+        if ((rc = dup.alloc(c, ix->nslots / 8))) return rc;
+        HIPCHK(c, hipMemsetAsync(dup.p, 0, ix->nslots / 8, c->stream));
         hipLaunchKernelGGL(index_clear_kernel, dim3((unsigned)((ix->nslots + 255) / 256)), dim3(256), 0, c->stream,
                            ix->slots.as<IndexSlot>(), ix->nslots);
         if (ctg->count)
             hipLaunchKernelGGL(index_insert_kernel, dim3((unsigned)((ctg->count + 255) / 256)), dim3(256), 0, c->stream,
                                (const MxRecord *)ctg->records.as<MxRecord>(), ctg->count, ix->slots.as<IndexSlot>(), bits,
-                               ix->special.as<IndexSpecial>(), ix->tags.as<uint8_t>());
-        hipLaunchKernelGGL(index_count_kernel, dim3((unsigned)std::min<uint64_t>((ix->nslots + 255) / 256, 2048)), dim3(256), 0, c->stream,
-                           (const IndexSlot *)ix->slots.as<IndexSlot>(), ix->nslots,
-                           (const IndexSpecial *)ix->special.as<IndexSpecial>(), cnt.as<unsigned long long>());
+                               ix->special.as<IndexSpecial>(), dup.as<uint32_t>());
+        hipLaunchKernelGGL(index_finish_kernel, dim3((unsigned)std::min<uint64_t>((ix->nslots / 4 + 255) / 256, 4096)), dim3(256), 0, c->stream,
+                           ix->slots.as<IndexSlot>(), ix->nslots, (const IndexSpecial *)ix->special.as<IndexSpecial>(),
+                           (const uint32_t *)dup.as<uint32_t>(), ix->tags.as<uint8_t>(), cnt.as<unsigned long long>());
         HIPCHK(c, hipGetLastError());
     }
     (void)size;
