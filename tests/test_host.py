@@ -267,3 +267,44 @@ def test_native_tsv_parser_equals_python_parser(tmp_path):
     bad.write_text("r1\t100\t12:5:+ 13:x:-\n")
     with pytest.raises(ValueError):
         list(formats.read_indexlr(str(bad), True))
+
+
+def test_prefetch_and_drain_keep_order_and_propagate_errors():
+    from ntlink_amd.pipeline import Drain, Prefetch
+    assert list(Prefetch(iter(range(50)), depth=2)) == list(range(50))
+
+    def boom():
+        yield 1
+        raise OSError("reader failed")
+    it = iter(Prefetch(boom()))
+    assert next(it) == 1
+    with pytest.raises(OSError):
+        next(it)
+    got = []
+    d = Drain(lambda a, b: got.append((a, b)))
+    for i in range(20):
+        d.put(i, -i)
+    d.close()
+    assert got == [(i, -i) for i in range(20)]
+
+    def bad(x):
+        if x == 3:
+            raise ValueError("writer failed")
+    d = Drain(bad)
+    with pytest.raises(ValueError):
+        for i in range(10):
+            d.put(i)
+        d.close()
+    # an abandoned stream stops its producer
+    closed = []
+
+    def gen():
+        try:
+            for i in range(10**6):
+                yield i
+        finally:
+            closed.append(True)
+    p = Prefetch(gen(), depth=1)
+    assert next(iter(p)) == 0
+    p.stop()
+    assert closed == [True]

@@ -90,6 +90,28 @@ def test_sim_pair_driver_error_removes_partial_outputs(dev, tmp_path):
     assert not [f for f in left if f.endswith(".verbose_mapping.tsv") or f.endswith(".paf")], left
 
 
+def test_sim_pinned_pool_reuses_buffers(dev):
+    """Device.pinned_empty / pinned_release: best-fit reuse, no small request on a large buffer, release
+    of foreign arrays is a no-op; the bytes are usable as ntl_batch_create input."""
+    import numpy as np
+    a = dev.pinned_empty(3_000_000)
+    addr_a = a.ctypes.data
+    a[:] = np.frombuffer(b"ACGT", np.uint8)[np.arange(3_000_000) % 4]
+    with dev.batch(a, np.array([0, 1_000_000, 3_000_000], np.uint64)) as b:
+        assert b.nseq == 2 and b.bases == 3_000_000
+    dev.pinned_release(a)
+    dev.pinned_release(np.zeros(4, np.uint8))
+    b2 = dev.pinned_empty(2_900_000)
+    assert b2.ctypes.data == addr_a  # reused
+    c = dev.pinned_empty(1000)
+    assert c.ctypes.data != addr_a
+    dev.pinned_release(b2)
+    d = dev.pinned_empty(1000)       # a 1 kB request must not take the 3 MB buffer
+    assert d.ctypes.data != addr_a
+    for x in (c, d):
+        dev.pinned_release(x)
+
+
 def test_sim_sketch_arrays_round_trip_threaded(dev):
     """ntl_sketch_from_host / ntl_sketch_download split their column <-> record conversion over
     threads above 2^18 minimizers."""
