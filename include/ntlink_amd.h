@@ -19,6 +19,13 @@
  *                                                      get_accepted_anchor_contigs
  *                                                      (bin/ntlink_utils.py:200-294),
  *                                                      print_paf (bin/ntlink_paf_output.py:103-135)
+ *   ntl_fastx_*   FASTA/FASTQ(.gz) records          <- `gzip -cd -f FILES |` + SeqReader
+ *                                                      (ntLink:113-117,222-223)
+ *   ntl_tsv_*     indexlr TSV -> arrays             <- the split()s of bin/ntlink_pair.py:197-207,355-378
+ *   ntl_write_*   indexlr TSV / verbose / PAF text  <- indexlr stdout (ntLink:199,223),
+ *                                                      bin/ntlink_pair.py:308-313,382-388,
+ *                                                      bin/ntlink_paf_output.py:131-135
+ *   ntl_tally_*   contig-pair tally                 <- bin/ntlink_pair.py:416-435,315-334,157-239
  *
  * Conventions: every call returns 0 on success or a negative NTL_E* code; the message is
  * available from ntl_last_error().  All pointers in signatures are HOST pointers unless the
@@ -26,6 +33,13 @@
  * Handles are opaque; one context per device; calls on one context are not thread-safe.
  * Strands are encoded 1 = '+', 0 = '-'.  Results are in input order (reads, then minimizers in
  * position order), exactly as the reference emits them.
+ *
+ * Environment (tuning and tests; none is needed): NTL_IO_THREADS (parser threads, default
+ * min(cores, 32)), NTL_IO_MIN_CHUNK (bytes per parser thread below which fewer threads are used),
+ * NTL_IO_NO_MMAP=1 (stream every input through zlib on one thread), NTL_IO_NO_LIBDEFLATE=1,
+ * NTL_IO_GZ_WHOLE_MAX (compressed bytes up to which a gzip file is inflated in one go, default
+ * 1 GiB), NTL_IO_TRACE=1 (reader diagnostics on stderr), NTL_SKETCH_C / NTL_SKETCH_NT (k-mers per
+ * lane, lanes per strip of the sketch kernel).
  */
 #ifndef NTLINK_AMD_H
 #define NTLINK_AMD_H
