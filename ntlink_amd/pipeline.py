@@ -93,13 +93,29 @@ def finish_pairs(tally, prefix, n, a, write_pairs_tsv):
 
 
 def run_indexlr(dev, paths, k, w, out, with_len, batch_bases=DEFAULT_BATCH_BASES, with_strand=True):
-    """Sketch FASTA/FASTQ files on the device and print indexlr's TSV."""
-    for ss in seqio.load(paths, max_bases=batch_bases):
-        if not len(ss):
-            continue
-        with dev.batch(ss.buf, ss.offsets) as b, dev.sketch(b, k, w) as sk:
-            off, h, p, s = sk.download()
-        formats.write_indexlr(out, ss.names, ss.lengths, off, h, p, s, with_len, with_strand)
+    """Sketch FASTA/FASTQ files on the device and print indexlr's TSV.  Three stages on threads: the reader
+    parses the next batch into page-locked memory, the device sketches the current one, the emitter
+    formats and writes the previous one."""
+    batches = Prefetch(seqio.load(paths, max_bases=batch_bases, alloc=dev.pinned_empty))
+    drain = Drain(lambda names, lens, off, h, p, s: formats.write_indexlr(out, names, lens, off, h, p, s, with_len, with_strand))
+    try:
+        for ss in batches:
+            if not len(ss):
+                continue
+            with dev.batch(ss.buf, ss.offsets) as b:
+                dev.pinned_release(ss.buf)
+                ss.buf = None
+                with dev.sketch(b, k, w) as sk:
+                    off, h, p, s = sk.download()
+            drain.put(ss.names, ss.lengths, off, h, p, s)
+        drain.close()
+    except BaseException:
+        batches.stop()
+        try:
+            drain.close()
+        except BaseException:
+            pass
+        raise
 
 
 def _contig_lengths(fasta):

@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--gz", action="store_true")
     ap.add_argument("--batch", type=int, default=pipeline.DEFAULT_BATCH_BASES)
     ap.add_argument("--files", type=int, default=1, help="split the reads over this many files (FASTQ when --gz)")
+    ap.add_argument("--pipe", action="store_true", help="time the reference's two-operator recipe (bin/indexlr | bin/ntlink_pair.py) instead")
     ap.add_argument("--stages", action="store_true", help="also time every stage of one whole-input batch on its own")
     a = ap.parse_args()
     W = synth.workload("C2", a.scale)
@@ -56,6 +57,21 @@ def main():
         with ThreadPoolExecutor(16) as ex:
             parts = list(ex.map(one, range(a.files)))
         read_arg = " ".join(parts)
+    if a.pipe:  # ntLink:198-199,221-225 with the drop-in executables, three processes and a pipe
+        import subprocess
+        env = dict(os.environ, PATH=os.path.join(ROOT, "bin") + os.pathsep + os.environ["PATH"])
+        k, w = W["k"], W["w"]
+        cat = "gzip -cd -f" if a.gz else "cat"
+        sh = (f"indexlr --long --pos --strand -k {k} -w {w} -t 8 asm.fa > asm.fa.k{k}.w{w}.tsv && "
+              f"{cat} {read_arg} | indexlr --long --pos --strand --len -k {k} -w {w} -t 8 - | "
+              f"ntlink_pair.py -p out -n 1 -m asm.fa.k{k}.w{w}.tsv -s asm.fa -k {k} -a 1 -z 1000 -f 10 -x 0 --verbose --pairs --paf -")
+        t0 = time.perf_counter()
+        subprocess.check_call(["bash", "-e", "-o", "pipefail", "-c", sh], cwd=d, env=env, stdout=subprocess.DEVNULL)
+        dt = time.perf_counter() - t0
+        nb = int(roff[-1])
+        print(json.dumps({"mode": "indexlr | ntlink_pair.py (three processes, text between them)", "seconds": round(dt, 3),
+                          "end_to_end_Gbases_per_s": round(nb / dt / 1e9, 4), "read_bases": nb, "gz": a.gz}))
+        return
     dev = capi.Device(0)
     os.chdir(d)
     t0 = time.perf_counter()
