@@ -36,15 +36,7 @@
 
 /* ------------------------------------------------------------------ reader -------------- */
 
-/* Records of a stream batch (gzip / stdin); offsets are local to the chunk. */
-struct Chunk {
-    std::vector<char> seqs, names;
-    std::vector<uint64_t> off{0}, name_off{0};
-    void clear() { seqs.clear(); names.clear(); off.assign(1, 0); name_off.assign(1, 0); }
-    uint64_t nrec() const { return off.size() - 1; }
-};
-
-/* One byte range of a mapped file: counted by ntl_fastx_next, parsed into place by ntl_fastx_copy. */
+/* One byte range of the current block: counted by ntl_fastx_next, parsed into place by ntl_fastx_copy. */
 struct Range {
     const char *b = nullptr, *e = nullptr;
     bool at_eof = false;
@@ -53,27 +45,29 @@ struct Range {
     bool bad_end = false; /* ended inside a FASTQ quality section: e was not a record boundary */
 };
 
+/*
+ * The reader works on blocks of input bytes that are cut into per-thread ranges.  Where the bytes
+ * come from:
+ *   whole    the entire input is in memory (`map`): a gzip file inflated in one go
+ *   file     a plain regular file, read block by block with parallel pread()s
+ *   serial   a pipe / stdin, or a gzip stream too large to inflate whole: read() (through zlib's
+ *            inflate() when the data starts with the gzip magic) on the calling thread
+ * A mapping is not used: it would fault every page once, a reused staging buffer does not.
+ */
 struct ntl_fastx {
-    /* stream mode (gzip, stdin, pipes): zlib does the `gzip -cd -f` of ntLink:113-117 */
-    gzFile gz = nullptr;
-    std::vector<char> buf;
-    size_t pos = 0, end = 0;
-    bool eof = false;
-    std::string pending;     /* header line read ahead (without the newline) */
-    bool has_pending = false;
-    Chunk chunk;
-    /* block mode: byte ranges of the input are parsed by several threads.  Either the whole input is in
-     * memory (`map`: an inflated gzip file), or a plain file is read batch by batch into `stage` with
-     * parallel pread()s -- reused pages, unlike a mapping, which would fault every page once. */
-    const char *map = nullptr;
-    size_t map_size = 0, cur = 0;
-    int fd = -1;
+    const char *map = nullptr; /* whole */
+    size_t map_size = 0, map_cap = 0;
+    int fd = -1;               /* file / serial */
+    bool seekable = false;
     size_t file_size = 0;
-    char *stage = nullptr; /* from the buffer cache: pages already faulted in by an earlier file */
+    bool gz = false, z_init = false, src_eof = false; /* serial */
+    z_stream zs;
+    std::vector<unsigned char> zin;
+    size_t zin_pos = 0, zin_have = 0;
+    size_t cur = 0;            /* logical offset of the next unread byte of the (inflated) input */
+    char *stage = nullptr;     /* from the buffer cache: pages already faulted in by an earlier file */
     size_t stage_cap = 0;
-    size_t stage_off = 0, stage_have = 0; /* stage[0 .. stage_have) = file bytes from stage_off on */
-    bool map_owned = false; /* map is a malloc'd buffer of inflated data, not a mapping */
-    size_t map_cap = 0;
+    size_t stage_off = 0, stage_have = 0; /* stage[0 .. stage_have) = input bytes from stage_off on */
     bool fastq = false;
     std::vector<Range> ranges;
     /* contiguous copies of the current batch for the pointer accessors */
@@ -82,8 +76,6 @@ struct ntl_fastx {
     bool materialized = false;
     std::string err;
 };
-
-static bool block_mode(const ntl_fastx *r) { return r->map != nullptr || r->fd >= 0; }
 
 static unsigned io_threads()
 {
@@ -224,48 +216,6 @@ static const char *find_boundary(const char *p, const char *e, bool fastq)
     return e;
 }
 
-static bool fill(ntl_fastx *r)
-{
-    if (r->eof) return false;
-    if (r->pos < r->end) {
-        memmove(r->buf.data(), r->buf.data() + r->pos, r->end - r->pos);
-    }
-    r->end -= r->pos;
-    r->pos = 0;
-    int n = gzread(r->gz, r->buf.data() + r->end, (unsigned)(r->buf.size() - r->end));
-    if (n < 0) { int e; r->err = gzerror(r->gz, &e); r->eof = true; return false; }
-    if (n == 0) { r->eof = true; return false; }
-    r->end += (size_t)n;
-    return true;
-}
-
-/* next line without its newline (and without a trailing '\r'); false at end of input */
-static bool next_line(ntl_fastx *r, const char **p, size_t *len, std::string &spill)
-{
-    for (;;) {
-        char *b = r->buf.data() + r->pos;
-        char *nl = (char *)memchr(b, '\n', r->end - r->pos);
-        if (nl) {
-            size_t l = (size_t)(nl - b);
-            r->pos += l + 1;
-            if (l && b[l - 1] == '\r') l--;
-            *p = b; *len = l;
-            return true;
-        }
-        if (r->end - r->pos == r->buf.size()) r->buf.resize(r->buf.size() * 2); /* very long line */
-        const size_t before = r->end - r->pos;
-        if (!fill(r)) {
-            if (before == 0) return false;
-            /* last line without newline */
-            spill.assign(r->buf.data() + r->pos, before);
-            r->pos = r->end;
-            if (!spill.empty() && spill.back() == '\r') spill.pop_back();
-            *p = spill.data(); *len = spill.size();
-            return true;
-        }
-    }
-}
-
 /* libdeflate (whole-buffer inflate, about three times zlib's speed) is used when the image has it;
  * there is no header for it here, so the three entry points are bound by hand. */
 struct LibDeflate {
@@ -355,51 +305,57 @@ static bool inflate_whole(const unsigned char *in, size_t n, char **out, size_t 
     return true;
 }
 
+static void set_format(ntl_fastx *r, const char *p, const char *e)
+{
+    while (p < e && (*p == '\n' || *p == '\r')) p++; /* format = first header character */
+    r->fastq = p < e && *p == '@';
+}
+
 extern "C" int ntl_fastx_open(const char *path, ntl_fastx **out)
 {
     if (!path || !out) return NTL_EINVAL;
     *out = nullptr;
-    ntl_fastx *r = new ntl_fastx();
     const bool is_stdin = strcmp(path, "-") == 0;
-    if (!is_stdin && !getenv("NTL_IO_NO_MMAP")) { /* regular file: block mode */
-        int fd = open(path, O_RDONLY);
-        if (fd < 0) { delete r; return NTL_EINVAL; }
-        struct stat st;
-        unsigned char head[64];
-        ssize_t hn = 0;
-        if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0 && (hn = pread(fd, head, sizeof head, 0)) >= 2) {
-            const bool gz = head[0] == 0x1f && head[1] == 0x8b;
-            size_t whole_max = (size_t)1 << 30; /* compressed bytes up to which a gzip file is inflated in one go */
-            if (const char *e = getenv("NTL_IO_GZ_WHOLE_MAX")) whole_max = (size_t)atoll(e);
-            const char *p = nullptr, *e = nullptr;
-            if (!gz) { /* read batch by batch with pread */
-                r->fd = fd;
-                r->file_size = (size_t)st.st_size;
-                p = (const char *)head; e = p + hn;
-            } else if ((size_t)st.st_size <= whole_max) {
-                void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
-                if (m != MAP_FAILED) {
-                    madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
-                    char *buf = nullptr; size_t bn = 0, bcap = 0;
-                    if (inflate_whole((const unsigned char *)m, (size_t)st.st_size, &buf, &bn, &bcap)) {
-                        r->map = buf; r->map_size = bn; r->map_owned = true; r->map_cap = bcap;
-                        p = r->map; e = p + std::min<size_t>(bn, 64);
-                    }
-                    munmap(m, (size_t)st.st_size);
+    const int fd = is_stdin ? dup(0) : open(path, O_RDONLY);
+    if (fd < 0) return NTL_EINVAL;
+    ntl_fastx *r = new ntl_fastx();
+    r->fd = fd;
+    struct stat st;
+    const bool regular = !is_stdin && fstat(fd, &st) == 0 && S_ISREG(st.st_mode);
+    const bool serial_only = getenv("NTL_IO_NO_MMAP") != nullptr; /* tests: every input through the serial source */
+    unsigned char head[64];
+    ssize_t hn = 0;
+    if (regular && st.st_size > 0 && !serial_only && (hn = pread(fd, head, sizeof head, 0)) >= 2) {
+        const bool gz = head[0] == 0x1f && head[1] == 0x8b;
+        size_t whole_max = (size_t)1 << 30; /* compressed bytes up to which a gzip file is inflated in one go */
+        if (const char *e = getenv("NTL_IO_GZ_WHOLE_MAX")) whole_max = (size_t)atoll(e);
+        if (!gz) { /* file source: parallel pread */
+            r->seekable = true;
+            r->file_size = (size_t)st.st_size;
+            set_format(r, (const char *)head, (const char *)head + hn);
+            *out = r;
+            return NTL_OK;
+        }
+        if ((size_t)st.st_size <= whole_max) {
+            void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m != MAP_FAILED) {
+                madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+                char *buf = nullptr; size_t bn = 0, bcap = 0;
+                const bool ok = inflate_whole((const unsigned char *)m, (size_t)st.st_size, &buf, &bn, &bcap);
+                munmap(m, (size_t)st.st_size);
+                if (ok) { /* whole source */
+                    r->map = buf; r->map_size = bn; r->map_cap = bcap;
+                    set_format(r, buf, buf + std::min<size_t>(bn, 64));
+                    close(fd);
+                    r->fd = -1;
+                    *out = r;
+                    return NTL_OK;
                 }
             }
-            if (p) { /* format = first header character */
-                while (p < e && (*p == '\n' || *p == '\r')) p++;
-                r->fastq = p < e && *p == '@';
-            }
         }
-        if (r->fd < 0) close(fd);
-        if (block_mode(r)) { *out = r; return NTL_OK; }
     }
-    r->gz = is_stdin ? gzdopen(dup(0), "rb") : gzopen(path, "rb");
-    if (!r->gz) { delete r; return NTL_EINVAL; }
-    gzbuffer(r->gz, 1 << 20);
-    r->buf.resize(8 << 20);
+    /* serial source: the format and the gzip magic are looked at when the first bytes arrive */
+    r->zin.resize(1u << 20);
     *out = r;
     return NTL_OK;
 }
@@ -407,8 +363,8 @@ extern "C" int ntl_fastx_open(const char *path, ntl_fastx **out)
 extern "C" void ntl_fastx_close(ntl_fastx *r)
 {
     if (!r) return;
-    if (r->gz) gzclose(r->gz);
-    if (r->map && r->map_owned) buf_cache().give((char *)r->map, r->map_cap);
+    if (r->z_init) inflateEnd(&r->zs);
+    if (r->map) buf_cache().give((char *)r->map, r->map_cap);
     if (r->fd >= 0) close(r->fd);
     if (r->stage) buf_cache().give(r->stage, r->stage_cap);
     delete r;
@@ -416,61 +372,86 @@ extern "C" void ntl_fastx_close(ntl_fastx *r)
 
 extern "C" const char *ntl_fastx_error(const ntl_fastx *r) { return r ? r->err.c_str() : "no reader"; }
 
-static void next_stream(ntl_fastx *r, uint64_t max_bases)
+/* serial source: up to n bytes of the (inflated) input into dst; 0 at the end or on an error (r->err) */
+static size_t serial_read(ntl_fastx *r, char *dst, size_t n)
 {
-    Chunk &c = r->chunk;
-    c.clear();
-    std::string spill;
-    const char *p; size_t len;
-    for (;;) {
-        /* find the next header */
-        if (!r->has_pending) {
-            bool found = false;
-            while (next_line(r, &p, &len, spill)) {
-                if (len && (p[0] == '>' || p[0] == '@')) { r->pending.assign(p, len); found = true; break; }
-            }
-            if (!found) break;
+    if (r->src_eof || n == 0) return 0;
+    auto refill = [&]() -> bool { /* compressed / raw bytes from the descriptor into zin */
+        const ssize_t got = read(r->fd, r->zin.data(), r->zin.size());
+        if (got < 0) { r->err = "read error"; r->src_eof = true; return false; }
+        r->zin_pos = 0; r->zin_have = (size_t)got;
+        return got > 0;
+    };
+    if (r->cur == 0 && r->stage_have == 0 && !r->z_init && r->zin_have == 0) { /* very first call: sniff */
+        if (!refill()) { r->src_eof = true; return 0; }
+        r->gz = r->zin_have >= 2 && r->zin[0] == 0x1f && r->zin[1] == 0x8b;
+        if (r->gz) {
+            memset(&r->zs, 0, sizeof r->zs);
+            if (inflateInit2(&r->zs, 16 + MAX_WBITS) != Z_OK) { r->err = "zlib init failed"; r->src_eof = true; return 0; }
+            r->z_init = true;
         }
-        r->has_pending = false;
-        size_t ia, ib;
-        id_span(r->pending.data(), r->pending.size(), ia, ib);
-        c.names.insert(c.names.end(), r->pending.data() + ia, r->pending.data() + ib);
-        c.name_off.push_back(c.names.size());
-        /* sequence lines */
-        bool plus = false;
-        const uint64_t s0 = c.seqs.size();
-        while (next_line(r, &p, &len, spill)) {
-            if (len && (p[0] == '>' || p[0] == '@' || p[0] == '+')) {
-                if (p[0] == '+') plus = true;
-                else { r->pending.assign(p, len); r->has_pending = true; }
-                break;
-            }
-            c.seqs.insert(c.seqs.end(), p, p + len);
-        }
-        const uint64_t slen = c.seqs.size() - s0;
-        c.off.push_back(c.seqs.size());
-        if (plus) { /* FASTQ: skip quality lines until their length reaches the sequence length */
-            uint64_t got = 0;
-            while (next_line(r, &p, &len, spill)) {
-                got += len;
-                if (got >= slen) break;
-            }
-        }
-        if (max_bases && c.seqs.size() >= max_bases) break;
     }
+    if (!r->gz) {
+        if (r->zin_pos < r->zin_have) { /* bytes left from the sniff */
+            const size_t m = std::min(n, r->zin_have - r->zin_pos);
+            memcpy(dst, r->zin.data() + r->zin_pos, m);
+            r->zin_pos += m;
+            return m;
+        }
+        const ssize_t got = read(r->fd, dst, n);
+        if (got < 0) { r->err = "read error"; r->src_eof = true; return 0; }
+        if (got == 0) r->src_eof = true;
+        return (size_t)got;
+    }
+    size_t done = 0;
+    while (done < n) {
+        if (r->zin_pos == r->zin_have && !refill()) {
+            if (r->err.empty()) r->err = "unexpected end of gzip data"; /* a member was cut short */
+            r->src_eof = true;
+            break;
+        }
+        r->zs.next_in = r->zin.data() + r->zin_pos;
+        r->zs.avail_in = (uInt)(r->zin_have - r->zin_pos);
+        r->zs.next_out = (Bytef *)dst + done;
+        r->zs.avail_out = (uInt)std::min<size_t>(n - done, (size_t)1 << 30);
+        const size_t out_before = r->zs.avail_out;
+        const int rc = inflate(&r->zs, Z_NO_FLUSH);
+        r->zin_pos = r->zin_have - r->zs.avail_in;
+        done += out_before - r->zs.avail_out;
+        if (rc == Z_STREAM_END) { /* next member, if any (gzip -cd concatenates them) */
+            while (r->zin_pos < r->zin_have && r->zin[r->zin_pos] == 0) r->zin_pos++; /* zero padding */
+            if (r->zin_pos == r->zin_have && !refill()) { r->src_eof = true; break; }
+            inflateReset(&r->zs);
+        } else if (rc != Z_OK && rc != Z_BUF_ERROR) {
+            r->err = r->zs.msg ? r->zs.msg : "corrupt gzip data";
+            r->src_eof = true;
+            break;
+        }
+    }
+    return done;
+}
+
+static bool stage_reserve(ntl_fastx *r, size_t want)
+{
+    if (r->stage_cap >= want) return true;
+    size_t cap = 0;
+    char *nb = buf_cache().take(want + want / 8, &cap);
+    if (!nb) { r->err = "out of memory"; return false; }
+    if (r->stage_have) memcpy(nb, r->stage, r->stage_have);
+    if (r->stage) buf_cache().give(r->stage, r->stage_cap);
+    r->stage = nb; r->stage_cap = cap;
+    return true;
 }
 
 /* Makes the input bytes [cur, cur + need) (clipped to the end) addressable; returns their start, *avail = how
  * many there are, *at_eof = they reach the end of the input. */
 static const char *view(ntl_fastx *r, size_t need, size_t *avail, bool *at_eof)
 {
+    *avail = 0; *at_eof = true;
     if (r->map) {
         *avail = r->map_size - r->cur;
-        *at_eof = true;
         return r->map + r->cur;
     }
-    const size_t remain = r->file_size - r->cur;
-    const size_t target = std::min(need, remain);
     if (r->stage_off != r->cur) { /* keep what was read beyond the previous batch */
         const size_t end = r->stage_off + r->stage_have;
         if (r->cur >= r->stage_off && r->cur < end) {
@@ -479,31 +460,45 @@ static const char *view(ntl_fastx *r, size_t need, size_t *avail, bool *at_eof)
         } else r->stage_have = 0;
         r->stage_off = r->cur;
     }
-    if (r->stage_have < target) {
-        if (r->stage_cap < target) {
-            size_t cap = 0;
-            char *nb = buf_cache().take(target + target / 8, &cap);
-            if (!nb) { r->err = "out of memory"; *avail = 0; *at_eof = true; return r->stage; }
-            if (r->stage_have) memcpy(nb, r->stage, r->stage_have);
-            if (r->stage) buf_cache().give(r->stage, r->stage_cap);
-            r->stage = nb; r->stage_cap = cap;
+    if (r->seekable) {
+        const size_t remain = r->file_size - r->cur;
+        const size_t target = std::min(need, remain);
+        if (r->stage_have < target) {
+            if (!stage_reserve(r, target)) return r->stage;
+            const size_t from = r->stage_have, len = target - from;
+            const size_t T = std::min<size_t>(io_threads(), std::max<size_t>(1, len / (4u << 20)));
+            std::vector<int> bad(T, 0);
+            run_threads(T, [&](size_t t) {
+                size_t a = from + len / T * t, b = t + 1 == T ? from + len : from + len / T * (t + 1);
+                while (a < b) {
+                    const ssize_t n = pread(r->fd, r->stage + a, b - a, (off_t)(r->stage_off + a));
+                    if (n <= 0) { bad[t] = 1; return; }
+                    a += (size_t)n;
+                }
+            });
+            for (int x : bad) if (x) r->err = "read error";
+            r->stage_have = target;
         }
-        const size_t from = r->stage_have, len = target - from;
-        const size_t T = std::min<size_t>(io_threads(), std::max<size_t>(1, len / (4u << 20)));
-        std::vector<int> bad(T, 0);
-        run_threads(T, [&](size_t t) {
-            size_t a = from + len / T * t, b = t + 1 == T ? from + len : from + len / T * (t + 1);
-            while (a < b) {
-                const ssize_t n = pread(r->fd, r->stage + a, b - a, (off_t)(r->stage_off + a));
-                if (n <= 0) { bad[t] = 1; return; }
-                a += (size_t)n;
-            }
-        });
-        for (int x : bad) if (x) r->err = "read error";
-        r->stage_have = target;
+        *avail = target;
+        *at_eof = target == remain;
+        return r->stage;
     }
-    *avail = target;
-    *at_eof = target == remain;
+    /* serial: read on until `need` bytes are there or the source ends */
+    while (r->stage_have < need && !r->src_eof) {
+        if (r->stage_cap == r->stage_have) { /* full (or not there yet): a bounded need is reserved at once */
+            size_t want = need != (size_t)-1 ? need : std::max<size_t>(r->stage_cap * 2, (size_t)64 << 20);
+            if (want <= r->stage_cap) want = r->stage_cap * 2;
+            if (!stage_reserve(r, want)) break;
+        }
+        const size_t room = std::min(r->stage_cap, need) - r->stage_have;
+        const bool first = r->cur == 0 && r->stage_have == 0;
+        const size_t got = serial_read(r, r->stage + r->stage_have, room);
+        if (first && got) set_format(r, r->stage, r->stage + std::min<size_t>(got, 64));
+        r->stage_have += got;
+        if (got == 0) break;
+    }
+    *avail = std::min(r->stage_have, need);
+    *at_eof = r->src_eof && *avail == r->stage_have;
     return r->stage;
 }
 
@@ -511,12 +506,18 @@ static const char *view(ntl_fastx *r, size_t need, size_t *avail, bool *at_eof)
 static void next_blocks(ntl_fastx *r, uint64_t max_bases)
 {
     r->ranges.clear();
-    const size_t total_left = r->map ? r->map_size - r->cur : r->file_size - r->cur;
-    if (total_left == 0) return;
-    const uint64_t want = max_bases ? max_bases * (r->fastq ? 2u : 1u) + (max_bases >> 6) : 0;
-    size_t need = max_bases ? (size_t)want + (1u << 20) : total_left;
+    const uint64_t want0 = max_bases ? max_bases * (r->fastq ? 2u : 1u) + (max_bases >> 6) : 0;
+    size_t need = max_bases ? (size_t)want0 + (1u << 20) : (size_t)-1;
     size_t avail; bool at_eof;
     const char *p0 = view(r, need, &avail, &at_eof);
+    if (!r->err.empty() || avail == 0) return;
+    /* the format is known once the first bytes are there (serial source): FASTQ takes two bytes per base */
+    const uint64_t want = max_bases ? max_bases * (r->fastq ? 2u : 1u) + (max_bases >> 6) : 0;
+    if (max_bases && want > want0 && !at_eof) {
+        need = (size_t)want + (1u << 20);
+        p0 = view(r, need, &avail, &at_eof);
+        if (!r->err.empty()) return;
+    }
     size_t end = avail; /* about max_bases bases, cut at a record boundary */
     if (max_bases && want < avail) {
         for (;;) {
@@ -524,9 +525,9 @@ static void next_blocks(ntl_fastx *r, uint64_t max_bases)
             if (end < avail || at_eof) break;
             need = avail * 2; /* a record longer than what was read beyond the cut: read on */
             p0 = view(r, need, &avail, &at_eof);
+            if (!r->err.empty()) return;
         }
     }
-    if (!r->err.empty()) return;
     const char *pe = p0 + end, *fe = p0 + avail;
     const size_t span = end;
     size_t min_chunk = 2u << 20; /* bytes per thread below which more threads do not pay */
@@ -569,8 +570,7 @@ static void next_blocks(ntl_fastx *r, uint64_t max_bases)
 extern "C" void ntl_fastx_sizes(const ntl_fastx *r, uint64_t *nseq, uint64_t *bases, uint64_t *name_bytes)
 {
     uint64_t n = 0, b = 0, nb = 0;
-    if (r && block_mode(r)) for (auto &g : r->ranges) { n += g.nrec; b += g.bases; nb += g.name_bytes; }
-    else if (r) { n = r->chunk.nrec(); b = r->chunk.seqs.size(); nb = r->chunk.names.size(); }
+    if (r) for (auto &g : r->ranges) { n += g.nrec; b += g.bases; nb += g.name_bytes; }
     if (nseq) *nseq = n;
     if (bases) *bases = b;
     if (name_bytes) *name_bytes = nb;
@@ -581,16 +581,17 @@ extern "C" int ntl_fastx_next(ntl_fastx *r, uint64_t max_bases, uint64_t *nseq)
 {
     if (!r || !nseq) return NTL_EINVAL;
     r->materialized = false;
-    if (block_mode(r)) next_blocks(r, max_bases);
-    else next_stream(r, max_bases);
-    if (!r->err.empty()) return NTL_EINVAL;
-    ntl_fastx_sizes(r, nseq, nullptr, nullptr);
-    return NTL_OK;
+    *nseq = 0;
+    for (;;) {
+        next_blocks(r, max_bases);
+        if (!r->err.empty()) return NTL_EINVAL;
+        ntl_fastx_sizes(r, nseq, nullptr, nullptr);
+        if (*nseq || r->ranges.empty()) return NTL_OK; /* a block without any record (blank lines): read on */
+    }
 }
 
 /* Puts the current batch into caller-allocated arrays (sizes from ntl_fastx_sizes; offsets and
- * name_offsets have nseq + 1 entries).  Mapped files are parsed straight into place, one thread
- * per range. */
+ * name_offsets have nseq + 1 entries): every range is parsed straight into place by its own thread. */
 extern "C" int ntl_fastx_copy(const ntl_fastx *r, char *seqs, uint64_t *offsets, char *names, uint64_t *name_offsets)
 {
     if (!r || !offsets || !name_offsets) return NTL_EINVAL;
@@ -598,14 +599,6 @@ extern "C" int ntl_fastx_copy(const ntl_fastx *r, char *seqs, uint64_t *offsets,
     ntl_fastx_sizes(r, &n, &b, &nb);
     if ((b && !seqs) || (nb && !names)) return NTL_EINVAL;
     offsets[0] = 0; name_offsets[0] = 0;
-    if (!block_mode(r)) {
-        const Chunk &c = r->chunk;
-        if (b) memcpy(seqs, c.seqs.data(), b);
-        if (nb) memcpy(names, c.names.data(), nb);
-        memcpy(offsets, c.off.data(), (n + 1) * sizeof(uint64_t));
-        memcpy(name_offsets, c.name_off.data(), (n + 1) * sizeof(uint64_t));
-        return NTL_OK;
-    }
     const size_t T = r->ranges.size();
     std::vector<uint64_t> rec0(T + 1, 0), b0(T + 1, 0), n0(T + 1, 0);
     for (size_t t = 0; t < T; t++) {

@@ -26,13 +26,11 @@ def test_seqio_edge_records(tmp_path):
     p.write_text(">a desc here\nACGT\nAC\n>b\n\n>c\tz\nGG\n@q1 x\nACGT\n+\nIIII\n@q2\nAC\nGT\n+q2\nII\nII\n>d\nTT")
     recs = list(seqio.read_fastx(str(p)))
     assert recs == [("a", b"ACGTAC"), ("b", b""), ("c", b"GG"), ("q1", b"ACGT"), ("q2", b"ACGT"), ("d", b"TT")]
-    for env in ({}, {"NTL_IO_NO_MMAP": "1"}):  # mapped (byte-range) and stream (zlib) readers
+    for env in ({}, {"NTL_IO_NO_MMAP": "1"}):  # parallel pread source and the serial (pipe / zlib) source
         with _env(env):
             batches = list(seqio.load([str(p)], max_bases=6))
         assert all(len(b) > 0 for b in batches) and len(batches) >= 2
         assert _records(batches) == recs
-        if env:  # the stream reader cuts after the record that reaches max_bases
-            assert [len(b) for b in batches] == [1, 3, 2]
 
 
 class _env:
@@ -308,3 +306,26 @@ def test_prefetch_and_drain_keep_order_and_propagate_errors():
     assert next(iter(p)) == 0
     p.stop()
     assert closed == [True]
+
+
+def test_gzip_sources_members_and_truncation(tmp_path):
+    """`gzip -cd -f` semantics of ntLink:113-117: concatenated members are one stream, whether the file is
+    inflated in one go (libdeflate / zlib) or streamed through inflate(); a cut-off file is an error."""
+    import gzip
+    rng = np.random.default_rng(21)
+    text = _random_fastx(rng, 800, True, False).encode()
+    cut = text.index(b"\n@", len(text) // 2) + 1
+    p = tmp_path / "two_members.fq.gz"
+    p.write_bytes(gzip.compress(text[:cut]) + gzip.compress(text[cut:]))
+    plain = tmp_path / "plain.fq"
+    plain.write_bytes(text)
+    want = list(seqio.read_fastx(str(plain)))
+    assert len(want) == 800
+    for env in ({}, {"NTL_IO_GZ_WHOLE_MAX": "0"}, {"NTL_IO_NO_LIBDEFLATE": "1"}, {"NTL_IO_NO_MMAP": "1"}):
+        with _env(dict(env, NTL_IO_THREADS="4", NTL_IO_MIN_CHUNK="5000")):
+            assert _records(list(seqio.load([str(p)], max_bases=40_000))) == want, env
+    bad = tmp_path / "cut.fq.gz"
+    bad.write_bytes(gzip.compress(text)[:-2000])
+    for env in ({}, {"NTL_IO_GZ_WHOLE_MAX": "0"}):
+        with _env(env), pytest.raises(OSError):
+            list(seqio.load([str(bad)], max_bases=40_000))
