@@ -96,9 +96,9 @@ def test_sim_pinned_pool_reuses_buffers(dev):
     import numpy as np
     a = dev.pinned_empty(3_000_000)
     addr_a = a.ctypes.data
-    a[:] = np.frombuffer(b"ACGT", np.uint8)[np.arange(3_000_000) % 4]
-    with dev.batch(a, np.array([0, 1_000_000, 3_000_000], np.uint64)) as b:
-        assert b.nseq == 2 and b.bases == 3_000_000
+    a[:200_000] = np.frombuffer(b"ACGT", np.uint8)[np.arange(200_000) % 4]
+    with dev.batch(a[:200_000], np.array([0, 50_000, 200_000], np.uint64)) as b:
+        assert b.nseq == 2 and b.bases == 200_000
     dev.pinned_release(a)
     dev.pinned_release(np.zeros(4, np.uint8))
     b2 = dev.pinned_empty(2_900_000)
