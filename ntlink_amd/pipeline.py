@@ -321,7 +321,7 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
     read_paths = reads.split() if isinstance(reads, str) else list(reads)
     # the read files are opened, inflated and parsed from now on, behind the contig stage
     batches = Prefetch(seqio.load(read_paths, max_bases=batch_bases * comm.world, alloc=dev.pinned_empty))
-    ctg = seqio.load_all([target], alloc=dev.pinned_empty)
+    ctg = seqio.load_all([target])  # used once: page-locking a buffer for it would cost more than the staged copy
     ctg_len = ctg.lengths
     out = PairOutputs(prefix, ctg.names, ctg_len, k, f, verbose, paf) if root else None
     pin_out = comm.world == 1  # records land in page-locked pool buffers (not when they are pickled to rank 0)
@@ -339,7 +339,6 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
     stats = dict(read_bases=0, reads=0, read_minimizers=0, index_hits=0, t_contigs=0.0, t_ingest=0.0, t_device=0.0, t_handover=0.0)
     try:
         with dev.batch(ctg.buf, ctg.offsets) as cb:
-            dev.pinned_release(ctg.buf)
             ctg.buf = None
             with dev.sketch(cb, k, w) as csk:
                 if tsv_drain:
