@@ -69,8 +69,21 @@ def main():
         subprocess.check_call(["bash", "-e", "-o", "pipefail", "-c", sh], cwd=d, env=env, stdout=subprocess.DEVNULL)
         dt = time.perf_counter() - t0
         nb = int(roff[-1])
+        # the fused driver on the same files must leave byte-identical outputs (different batch cuts, no text between)
+        import hashlib
+        dev = capi.Device(0)
+        os.chdir(d)
+        pipeline.run_pair(dev, "asm.fa", read_arg, k=k, w=w, paf=True, pairs_tsv=True, batch_bases=a.batch, prefix="fused", write_contig_tsv=False)
+        dev.close()
+        same = {}
+        for ext in (".verbose_mapping.tsv", ".paf", ".pairs.tsv", ".n1.scaffold.dot"):
+            h = [hashlib.md5(open(pre + ext, "rb").read()).hexdigest() for pre in ("out", "fused")]
+            same[ext] = h[0] == h[1]
         print(json.dumps({"mode": "indexlr | ntlink_pair.py (three processes, text between them)", "seconds": round(dt, 3),
-                          "end_to_end_Gbases_per_s": round(nb / dt / 1e9, 4), "read_bases": nb, "gz": a.gz}))
+                          "end_to_end_Gbases_per_s": round(nb / dt / 1e9, 4), "read_bases": nb, "gz": a.gz,
+                          "outputs_equal_fused_driver": same}))
+        if not all(same.values()):
+            sys.exit(1)
         return
     dev = capi.Device(0)
     os.chdir(d)
