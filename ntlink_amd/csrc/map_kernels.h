@@ -36,10 +36,16 @@ __device__ __forceinline__ uint64_t index_home(uint64_t key, int bits)
     return (key * 0x9E3779B97F4A7C15ull) >> (64 - bits);
 }
 
-__global__ void index_clear_kernel(IndexSlot *slots, uint64_t nslots)
+/* also zeroes what the build accumulates into: the duplicate bitmap (one word per 32 slots; nslots is a
+ * multiple of 32), the side slot and the kept-key counter */
+__global__ void index_clear_kernel(IndexSlot *slots, uint64_t nslots, uint32_t *dup, IndexSpecial *special, unsigned long long *count)
 {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nslots) { slots[i].key = NTL_INF; slots[i].pos = 0; slots[i].meta = 0; }
+    if (i < nslots) {
+        slots[i].key = NTL_INF; slots[i].pos = 0; slots[i].meta = 0;
+        if ((i & 31u) == 0) dup[i >> 5] = 0;
+    }
+    if (i == 0) { special->cnt = 0; special->pos = 0; special->meta = 0; special->pad = 0; *count = 0; }
 }
 
 /* One-byte tags in front of the 16-byte slots: 0 = empty slot, otherwise 7 bits of the key | 1.  The tag

@@ -264,7 +264,8 @@ extern "C" int ntl_prof_get(ntl_ctx *c, const char *name, double *total_ms, uint
 /* `batch` independent exclusive scans of equal length in one set of launches: array y is in + y*(n+1) ->
  * out + y*(n+1), out[n] of each = its sum (arrays hold n+1 entries; in may equal out).  With total_host the
  * sums also come back to the host (one stream sync); without it nothing waits. */
-static int device_scan(ntl_ctx *c, const uint32_t *in, uint32_t *out, uint64_t n, uint32_t *total_host, unsigned batch = 1)
+static int device_scan(ntl_ctx *c, const uint32_t *in, uint32_t *out, uint64_t n, uint32_t *total_host, unsigned batch = 1,
+                       uint32_t *sums_dev = nullptr)
 {
     uint64_t tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
     if (tiles == 0) tiles = 1;
@@ -272,7 +273,7 @@ static int device_scan(ntl_ctx *c, const uint32_t *in, uint32_t *out, uint64_t n
     int rc;
     if ((rc = tile.alloc(c, tiles * 4 * batch))) return rc;
     hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)tiles, batch), dim3(SCAN_NT), 0, c->stream, in, n, tile.as<uint32_t>(), n + 1, tiles);
-    hipLaunchKernelGGL(scan_tiles_kernel, dim3(1, batch), dim3(SCAN_NT), 0, c->stream, tile.as<uint32_t>(), tiles, out + n, n + 1);
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(1, batch), dim3(SCAN_NT), 0, c->stream, tile.as<uint32_t>(), tiles, out + n, n + 1, sums_dev);
     hipLaunchKernelGGL(scan_down_kernel, dim3((unsigned)tiles, batch), dim3(SCAN_NT), 0, c->stream, in, out, n,
                        (const uint32_t *)tile.as<uint32_t>(), n + 1, tiles);
     HIPCHK(c, hipGetLastError());
@@ -539,7 +540,6 @@ extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_
     {
         ProfSpan sp(c, "sketch_meta");
         HIPCHK(c, hipMemsetAsync(mask.p, 0, nmask * 4, c->stream));
-        HIPCHK(c, hipMemsetAsync(strip_tab.p, 0xFF, (ub_strips + 1) * sizeof(StripInfo), c->stream));
         if (nseq) {
             KTables K;
             K.run_n = run_n.as<uint32_t>(); K.run_ord = run_ord.as<uint32_t>();
@@ -550,7 +550,7 @@ extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_
             hipLaunchKernelGGL(strip_table_kernel, dim3((unsigned)((ub_strips + 255) / 256 + 1)), dim3(256), 0, c->stream, T,
                                (const uint32_t *)run_n.as<uint32_t>(), (const uint32_t *)run_ord.as<uint32_t>(),
                                (const uint32_t *)seq_M.as<uint32_t>(), (const uint32_t *)strip_first.as<uint32_t>(), G.NWO,
-                               C * nt, strip_tab.as<StripInfo>(), (uint32_t)ub_strips);
+                               C * nt, strip_tab.as<StripInfo>(), (uint32_t)ub_strips + 1u);
             HIPCHK(c, hipGetLastError());
         }
     }
@@ -574,7 +574,7 @@ extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_
         if ((rc = tile.alloc(c, tiles * 4)) || (rc = tot.alloc(c, 4)) || (rc = word_rank.alloc(c, nmask * 4))) return rc;
         hipLaunchKernelGGL(mask_count_kernel, dim3((unsigned)tiles), dim3(EMIT_NT), 0, c->stream,
                            (const uint32_t *)mask.as<uint32_t>(), nmask, tile.as<uint32_t>());
-        hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(SCAN_NT), 0, c->stream, tile.as<uint32_t>(), tiles, tot.as<uint32_t>(), (uint64_t)0);
+        hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(SCAN_NT), 0, c->stream, tile.as<uint32_t>(), tiles, tot.as<uint32_t>(), (uint64_t)0, (uint32_t *)nullptr);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(&total_mx, tot.p, 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -730,13 +730,11 @@ extern "C" int ntl_index_build(ntl_ctx *c, const ntl_sketch *ctg, const uint32_t
         ProfSpan sp(c, "index");
         ix->h_ctg_len.assign(ctg_len, ctg_len + n_ctg);
         if (n_ctg) HIPCHK(c, hipMemcpyAsync(ix->ctg_len.p, ix->h_ctg_len.data(), (uint64_t)n_ctg * 4, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemsetAsync(ix->special.p, 0, sizeof(IndexSpecial), c->stream));
-        HIPCHK(c, hipMemsetAsync(cnt.p, 0, 8, c->stream));
         DevBuf dup; /* one bit per slot: the key arrived more than once */
         if ((rc = dup.alloc(c, ix->nslots / 8))) return rc;
-        HIPCHK(c, hipMemsetAsync(dup.p, 0, ix->nslots / 8, c->stream));
         hipLaunchKernelGGL(index_clear_kernel, dim3((unsigned)((ix->nslots + 255) / 256)), dim3(256), 0, c->stream,
-                           ix->slots.as<IndexSlot>(), ix->nslots);
+                           ix->slots.as<IndexSlot>(), ix->nslots, dup.as<uint32_t>(), ix->special.as<IndexSpecial>(),
+                           cnt.as<unsigned long long>());
         if (ctg->count)
             hipLaunchKernelGGL(index_insert_kernel, dim3((unsigned)((ctg->count + 255) / 256)), dim3(256), 0, c->stream,
                                (const MxRecord *)ctg->records.as<MxRecord>(), ctg->count, ix->slots.as<IndexSlot>(), bits,
@@ -787,23 +785,24 @@ extern "C" int ntl_map_run(ntl_ctx *c, const ntl_index *ix, const ntl_sketch *re
     ntl_mapres *R = R_guard.get();
     R->c = c;
     int rc;
-    DevBuf cand, rlen, smaps, shits, spafs, n3, off3, scr, nfound, err;
+    DevBuf cand, rlen, smaps, shits, spafs, n3, off3, scr, sums;
+    struct MapSums { unsigned long long nfound; uint32_t err; uint32_t tot[3]; uint32_t pad[2]; }; /* one memset, one read-back */
     const uint64_t cap = nmx ? nmx : 1;
     if ((rc = cand.alloc(c, cap * sizeof(Cand))) || (rc = rlen.alloc(c, (nreads + 1) * 4)) ||
         (rc = smaps.alloc(c, cap * sizeof(MapRec))) || (rc = shits.alloc(c, cap * sizeof(HitRec))) ||
         (rc = spafs.alloc(c, cap * sizeof(PafRec))) || (rc = n3.alloc(c, 3 * (nreads + 1) * 4)) ||
         (rc = off3.alloc(c, 3 * (nreads + 1) * 4)) || (rc = scr.alloc(c, (uint64_t)(MAP_NHA + MAP_NRA) * cap * 4)) ||
-        (rc = nfound.alloc(c, 8)) || (rc = err.alloc(c, 4))) return rc;
+        (rc = sums.alloc(c, sizeof(MapSums)))) return rc;
+    MapSums *dsums = sums.as<MapSums>();
     if (nreads) HIPCHK(c, hipMemcpyAsync(rlen.p, read_len, nreads * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemsetAsync(nfound.p, 0, 8, c->stream));
-    HIPCHK(c, hipMemsetAsync(err.p, 0, 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(sums.p, 0, sizeof(MapSums), c->stream));
     {
         ProfSpan sp(c, "probe");
         if (nmx)
             hipLaunchKernelGGL(probe_kernel, dim3((unsigned)std::min<uint64_t>((nmx + 256 * PROBE_U - 1) / (256 * PROBE_U), 4096)), dim3(256), 0, c->stream,
                                (const MxRecord *)reads->records.as<MxRecord>(), nmx, (const IndexSlot *)ix->slots.as<IndexSlot>(),
                                ix->bits, (const IndexSpecial *)ix->special.as<IndexSpecial>(), cand.as<Cand>(),
-                               nfound.as<unsigned long long>(), (const uint8_t *)ix->tags.as<uint8_t>());
+                               &dsums->nfound, (const uint8_t *)ix->tags.as<uint8_t>());
         HIPCHK(c, hipGetLastError());
     }
     MapArgs A;
@@ -813,10 +812,9 @@ extern "C" int ntl_map_run(ntl_ctx *c, const ntl_index *ix, const ntl_sketch *re
     A.P.repeat_filter = params->repeat_filter;
     A.maps = smaps.as<MapRec>(); A.hits = shits.as<HitRec>(); A.pafs = spafs.as<PafRec>();
     A.n_maps = n3.as<uint32_t>(); A.n_hits = A.n_maps + (nreads + 1); A.n_pafs = A.n_hits + (nreads + 1);
-    A.scr = scr.as<uint32_t>(); A.scr_stride = cap; A.err = err.as<uint32_t>();
-    uint32_t tot[3] = {0, 0, 0};
-    unsigned long long nf = 0;
-    uint32_t errflag = 0;
+    A.scr = scr.as<uint32_t>(); A.scr_stride = cap; A.err = &dsums->err;
+    MapSums hs;
+    memset(&hs, 0, sizeof hs);
     if (nreads) {
         {
             ProfSpan sp(c, "map");
@@ -827,23 +825,20 @@ extern "C" int ntl_map_run(ntl_ctx *c, const ntl_index *ix, const ntl_sketch *re
         }
         ProfSpan sp(c, "compact");
         uint32_t *o = off3.as<uint32_t>();
-        if ((rc = device_scan(c, n3.as<uint32_t>(), o, nreads, nullptr, 3))) return rc;
+        if ((rc = device_scan(c, n3.as<uint32_t>(), o, nreads, nullptr, 3, dsums->tot))) return rc;
         /* the only wait of the call: three totals (to size the dense arrays), hit count, invariant flag */
-        for (int i = 0; i < 3; i++)
-            HIPCHK(c, hipMemcpyAsync(&tot[i], o + i * (nreads + 1) + nreads, 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(&nf, nfound.p, 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(&errflag, err.p, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(&hs, sums.p, sizeof(MapSums), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        R->n_maps = tot[0]; R->n_hits = tot[1]; R->n_pafs = tot[2];
-        if ((rc = R->maps.alloc(c, (uint64_t)tot[0] * sizeof(MapRec))) || (rc = R->hits.alloc(c, (uint64_t)tot[1] * sizeof(HitRec))) ||
-            (rc = R->pafs.alloc(c, (uint64_t)tot[2] * sizeof(PafRec)))) return rc;
+        R->n_maps = hs.tot[0]; R->n_hits = hs.tot[1]; R->n_pafs = hs.tot[2];
+        if ((rc = R->maps.alloc(c, (uint64_t)hs.tot[0] * sizeof(MapRec))) || (rc = R->hits.alloc(c, (uint64_t)hs.tot[1] * sizeof(HitRec))) ||
+            (rc = R->pafs.alloc(c, (uint64_t)hs.tot[2] * sizeof(PafRec)))) return rc;
         hipLaunchKernelGGL(map_gather_kernel, dim3((unsigned)nreads), dim3(64), 0, c->stream, A, (const uint32_t *)o,
                            (const uint32_t *)(o + (nreads + 1)), (const uint32_t *)(o + 2 * (nreads + 1)),
                            R->maps.as<MapRec>(), R->hits.as<HitRec>(), R->pafs.as<PafRec>());
         HIPCHK(c, hipGetLastError());
     }
-    R->n_index_hits = nf;
-    if (errflag) return fail(c, NTL_EINTERNAL, "an accepted contig appeared twice in one read (bin/ntlink_utils.py:262-266)");
+    R->n_index_hits = hs.nfound;
+    if (hs.err) return fail(c, NTL_EINTERNAL, "an accepted contig appeared twice in one read (bin/ntlink_utils.py:262-266)");
     *out = R_guard.release();
     return NTL_OK;
 }

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(SCAN_NT) void scan_reduce_kernel(const uint32_t *in
 
 /* single workgroup; data[0..n) becomes its exclusive scan, *total the sum */
 __global__ __launch_bounds__(SCAN_NT) void scan_tiles_kernel(uint32_t *data, uint64_t n, uint32_t *total_out,
-                                                             uint64_t total_stride)
+                                                             uint64_t total_stride, uint32_t *extra = nullptr)
 {
     __shared__ uint32_t s_tmp[SCAN_NT];
     data += (uint64_t)blockIdx.y * n;
@@ -57,7 +57,10 @@ __global__ __launch_bounds__(SCAN_NT) void scan_tiles_kernel(uint32_t *data, uin
         }
         carry += total;
     }
-    if (threadIdx.x == 0) *total_out = carry;
+    if (threadIdx.x == 0) {
+        *total_out = carry;
+        if (extra) extra[blockIdx.y] = carry; /* the sums of a batch side by side, for one read-back */
+    }
 }
 
 /* out may alias in; out[n] is not written */

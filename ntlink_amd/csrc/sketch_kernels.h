@@ -86,7 +86,8 @@ __global__ void strip_table_kernel(SeqTables T, const uint32_t *run_n, const uin
                                    const uint32_t *strip_first, int NWO, int strip_elems, StripInfo *tab, uint32_t cap)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; /* one thread per strip */
-    if (i >= cap || i >= strip_first[T.nseq]) return;
+    if (i >= cap) return;
+    if (i >= strip_first[T.nseq]) { tab[i].seq = NTL_NONE; return; } /* the grid of the sketch kernel is an upper bound */
     uint32_t lo = 0, hi = T.nseq; /* largest s with strip_first[s] <= i */
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
