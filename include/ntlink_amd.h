@@ -30,7 +30,9 @@
  * Conventions: every call returns 0 on success or a negative NTL_E* code; the message is
  * available from ntl_last_error().  All pointers in signatures are HOST pointers unless the
  * name says otherwise; buffers are caller-owned; counts are obtained first, then filled.
- * Handles are opaque; one context per device; calls on one context are not thread-safe.
+ * Handles are opaque; one context per device; calls on one context are not thread-safe, except
+ * ntl_host_alloc / ntl_host_free (a reader thread may take staging buffers while another drives the device)
+ * and the host-only groups (ntl_fastx_*, ntl_tsv_*, ntl_write_*, ntl_tally_*: one object per thread).
  * Strands are encoded 1 = '+', 0 = '-'.  Results are in input order (reads, then minimizers in
  * position order), exactly as the reference emits them.
  *
