@@ -576,14 +576,19 @@ extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_
                            (const uint32_t *)mask.as<uint32_t>(), nmask, tile.as<uint32_t>());
         hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(SCAN_NT), 0, c->stream, tile.as<uint32_t>(), tiles, tot.as<uint32_t>(), (uint64_t)0, (uint32_t *)nullptr);
         HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipMemcpyAsync(&total_mx, tot.p, 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        s->count = total_mx;
-        if ((rc = s->records.alloc(c, (uint64_t)total_mx * sizeof(MxRecord)))) return rc;
+        /* The record array is sized from the expected density before the count is known, so that the device
+           goes straight on to the emit kernel while the host waits for the count; a batch denser than the
+           guess (possible, not seen) is emitted a second time into an exact-size array. */
+        uint64_t cap_guess = (uint64_t)(2.5 * (double)b->bases / (double)(w + 1)) + 65536;
+        if (cap_guess > b->bases + 1) cap_guess = b->bases + 1;
+        if (cap_guess > 0xFFFFFFF0ull) cap_guess = 0xFFFFFFF0ull;
+        if (const char *e = getenv("NTL_SKETCH_CAP_GUESS")) cap_guess = (uint64_t)atoll(e); /* tests: force the second pass */
+        if ((rc = s->records.alloc(c, cap_guess * sizeof(MxRecord)))) return rc;
         EmitArgs E;
         E.packed = T.packed; E.seq_base = T.seq_base; E.nseq = (uint32_t)nseq; E.mask = mask.as<uint32_t>();
         E.nwords = nmask; E.tile_off = tile.as<uint32_t>(); E.word_rank = word_rank.as<uint32_t>();
-        E.out = s->records.as<MxRecord>(); E.k = k; E.mult = 1ull ^ ((uint64_t)k * 0x90b45d39fb6da1faull);
+        E.out = s->records.as<MxRecord>(); E.out_cap = (uint32_t)cap_guess;
+        E.k = k; E.mult = 1ull ^ ((uint64_t)k * 0x90b45d39fb6da1faull);
         uint64_t roll[16][2];
         make_tables(k, roll, E.seed_tab);
         E.g4 = (const uint64_t (*)[2])c->g4;
@@ -591,8 +596,17 @@ extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_
         hipLaunchKernelGGL(emit_kernel, dim3((unsigned)tiles), dim3(EMIT_NT), 0, c->stream, E);
         hipLaunchKernelGGL(mx_offsets_kernel, dim3((unsigned)((nseq + 1 + 255) / 256)), dim3(256), 0, c->stream,
                            T.seq_base, (uint32_t)nseq, (const uint32_t *)mask.as<uint32_t>(),
-                           (const uint32_t *)word_rank.as<uint32_t>(), nmask, total_mx, s->mx_off.as<uint32_t>());
+                           (const uint32_t *)word_rank.as<uint32_t>(), nmask, (const uint32_t *)tot.as<uint32_t>(), s->mx_off.as<uint32_t>());
         HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(&total_mx, tot.p, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        s->count = total_mx;
+        if ((uint64_t)total_mx > cap_guess) {
+            if ((rc = s->records.alloc(c, (uint64_t)total_mx * sizeof(MxRecord)))) return rc;
+            E.out = s->records.as<MxRecord>(); E.out_cap = total_mx;
+            hipLaunchKernelGGL(emit_kernel, dim3((unsigned)tiles), dim3(EMIT_NT), 0, c->stream, E);
+            HIPCHK(c, hipGetLastError());
+        }
     }
     /* temporaries return to the context's cache here; every later user of those blocks is queued on the
        same stream behind the kernels above, so no wait is needed */

@@ -408,6 +408,7 @@ struct EmitArgs {
     const uint32_t *tile_off; /* exclusive scan of tile_cnt */
     uint32_t *word_rank;      /* [nwords] set bits before each word */
     MxRecord *out;
+    uint32_t out_cap;         /* records `out` can hold (it is sized before the count is known) */
     int k;
     uint64_t mult;            /* 1 ^ (k * MULTISEED) */
     uint64_t seed_tab[4][2];
@@ -524,7 +525,7 @@ __global__ __launch_bounds__(EMIT_NT) void emit_kernel(EmitArgs A)
             R.hash = tt;
             R.pos = (uint32_t)(gp - sb);
             R.meta = (sq << 1) | (fwd <= rev ? 1u : 0u);
-            A.out[tile_base + r0 + i] = R;
+            if (tile_base + r0 + i < A.out_cap) A.out[tile_base + r0 + i] = R;
         }
         __syncthreads();
     }
@@ -532,11 +533,12 @@ __global__ __launch_bounds__(EMIT_NT) void emit_kernel(EmitArgs A)
 
 /* minimizers before each sequence start = offsets of the per-sequence lists */
 __global__ void mx_offsets_kernel(const uint64_t *seq_base, uint32_t nseq, const uint32_t *mask,
-                                  const uint32_t *word_rank, uint64_t nwords, uint32_t total,
+                                  const uint32_t *word_rank, uint64_t nwords, const uint32_t *total_dev,
                                   uint32_t *mx_off)
 {
     uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s > nseq) return;
+    const uint32_t total = *total_dev;
     if (s == nseq) { mx_off[s] = total; return; }
     const uint64_t g = seq_base[s];
     const uint64_t wi = g >> 5;

@@ -24,6 +24,14 @@ def test_sim_sketch_edges(dev, k, w):
     pc.check_sketch(dev, pc.edge_sequences(), k, w)
 
 
+def test_sim_sketch_second_emit_pass_when_denser_than_guessed(dev, monkeypatch):
+    """The record array is sized from the expected density before the count is known; a denser batch is
+    emitted again into an exact-size array."""
+    monkeypatch.setenv("NTL_SKETCH_CAP_GUESS", "7")
+    pc.check_sketch(dev, pc.edge_sequences(), 32, 100)
+    pc.check_sketch(dev, [b"ACGTTGCA" * 400, b"AC" * 900], 8, 40)
+
+
 def test_sim_sketch_many_tiny_sequences(dev):
     pc.check_sketch(dev, pc.tiny_sequences(1500), 12, 8)
 
