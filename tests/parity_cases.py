@@ -114,3 +114,59 @@ def edge_sequences(seed=5):
     return [b"", b"ACGT", rnd(50), b"A" * 3000, b"AC" * 2000, rnd(31), rnd(32), rnd(131), rnd(132), b"N" * 500,
             rnd(700) + b"N" * 40 + rnd(800) + b"n" + rnd(33) + b"NN" + rnd(5000) + b"RYK" + rnd(20),
             b"N" + rnd(4500), rnd(4500) + b"N", rnd(4085), rnd(4086), rnd(4087), rnd(8200)]
+
+
+def check_anchor_cases(dev, max_cases=None):
+    """ntlink_amd.anchor.get_accepted_anchor_contigs == the reference's function on the golden cases
+    (tests/golden/gen/anchor_cases.json, made by tools/gen_goldens_anchor.py from the imported reference)."""
+    import argparse
+    import gzip
+    import json
+    import os
+    from collections import namedtuple
+    from helpers import GEN
+    from ntlink_amd import anchor
+    Scaffold = namedtuple("Scaffold", ["id", "length"])
+    cases = json.load(open(os.path.join(GEN, "anchor_cases.json")))
+    if max_cases:
+        cases = cases[::max(1, len(cases) // max_cases)]
+    cache = {}
+    n = 0
+    for c in cases:
+        name = c["scenario"]
+        if name not in cache:
+            d = os.path.join(GEN, "synthetic")
+            meta = json.load(open(os.path.join(d, name + ".json")))
+            p = meta["params"]
+            args = argparse.Namespace(k=meta["k"], z=p.get("z", 1000), x=p.get("x", 0.0), sensitive=p.get("sensitive", False))
+            scaffolds = {nm: Scaffold(nm, ln) for nm, ln in zip(meta["ctg_names"], meta["ctg_len"])}
+            mx_info, dup = {}, set()
+            for line in gzip.open(os.path.join(d, name + ".contigs.tsv.gz"), "rt"):
+                f = line.strip().split("\t")
+                if len(f) > 1:
+                    for tok in f[1].split(" "):
+                        mx, pos, strand = tok.split(":")
+                        if mx in mx_info:
+                            dup.add(mx)
+                        else:
+                            mx_info[mx] = anchor.Minimizer(f[0], int(pos), strand)
+            mx_info = {m: v for m, v in mx_info.items() if m not in dup}
+            reads = [line.strip().split("\t") for line in gzip.open(os.path.join(d, name + ".reads.tsv.gz"), "rt")]
+            cache[name] = (args, scaffolds, mx_info, reads, anchor.AnchorMapper(mx_info, scaffolds, dev))
+        args, scaffolds, mx_info, reads, mapper = cache[name]
+        f = reads[c["read_index"]]
+        assert f[0] == c["read"]
+        mx_list = [(mx, int(pos), strand) for mx, pos, strand in (t.split(":") for t in f[2].split(" ")) if mx in mx_info]
+        for acc, order in (mapper.map_many([(mx_list, int(f[1]))], args)[0],
+                           anchor.get_accepted_anchor_contigs(mx_list, int(f[1]), scaffolds, mx_info, args, dev=dev) if n % 10 == 0 else (None, None)):
+            if acc is None:
+                continue
+            assert order == c["order"], (name, c["read"])
+            for ctg in order:
+                got = [[h.mx, h.ctg_pos, h.ctg_strand, h.read_pos, h.read_strand] for h in acc[ctg].hits]
+                assert got == c["hits"][ctg], (name, c["read"], ctg)
+                assert acc[ctg].hit_count == len(got) and acc[ctg].contig == ctg
+        n += 1
+    for _a, _s, _m, _r, mapper in cache.values():
+        mapper.close()
+    return n

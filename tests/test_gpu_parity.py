@@ -207,3 +207,9 @@ def test_batch_beyond_2_pow_32_bases(dev):
         assert np.array_equal(h[a:bnd], oh) and np.array_equal(p[a:bnd], op) and np.array_equal(s[a:bnd], os_)
     dens = len(h) / float(off[-1])
     assert abs(dens - 2.0 / (w + 1)) < 0.0005
+
+
+def test_anchor_function_matches_reference(dev):
+    """ntlink_amd.anchor.get_accepted_anchor_contigs (gap-fill re-mapping entry point, bin/ntlink_utils.py:200-268)
+    against vectors produced by the imported reference."""
+    assert pc.check_anchor_cases(dev) == 125

@@ -47,6 +47,11 @@ def test_sim_map_scenarios(dev, name):
     pc.check_scenario(dev, name)
 
 
+def test_sim_anchor_function_matches_reference(dev):
+    """get_accepted_anchor_contigs with the reference's signature, on the device."""
+    assert pc.check_anchor_cases(dev, max_cases=12) >= 10
+
+
 def test_sim_full_pipeline_top5(dev):
     got = pc.check_full_pipeline(dev, pc.fixture_seqs("scaffolds_4.fa"), pc.fixture_seqs("long_reads_4_top5.fa"),
                                  40, 100, z=1000)
