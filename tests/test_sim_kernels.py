@@ -33,7 +33,7 @@ def test_sim_sketch_second_emit_pass_when_denser_than_guessed(dev, monkeypatch):
 
 
 def test_sim_sketch_many_tiny_sequences(dev):
-    pc.check_sketch(dev, pc.tiny_sequences(1500), 12, 8)
+    pc.check_sketch(dev, pc.tiny_sequences(700), 12, 8)
 
 
 def test_sim_sketch_reads_small_w(dev):
