@@ -334,46 +334,7 @@ extern "C" int ntl_batch_create(ntl_ctx *c, const char *seqs, const uint64_t *of
     DevBuf start_g, end_g;
     {
     ProfSpan span(c, "batch_pack");
-    if (total) {
-        /* Page-locked sources (ntl_host_alloc) go over in one DMA.  Anything else is staged through the
-           context's page-locked bounce buffer in two alternating halves, filled by a few threads while the
-           other half is on the wire -- the runtime's own staging of pageable memory runs at a fraction of that. */
-        hipPointerAttribute_t attr;
-        const bool pinned = hipPointerGetAttributes(&attr, seqs + o0) == hipSuccess && attr.type == hipMemoryTypeHost;
-        (void)hipGetLastError(); /* an unregistered pointer is not an error here */
-        size_t HALF = (size_t)32 << 20, stage_min = 4u << 20;
-        if (const char *e = getenv("NTL_STAGE_CHUNK")) { const long v = atol(e); if (v >= 64) HALF = (size_t)v; } /* tests */
-        if (const char *e = getenv("NTL_STAGE_MIN")) stage_min = (size_t)atol(e);
-        void *bounce = nullptr;
-        if (pinned || total < stage_min || host_tmp(c, 2 * HALF, &bounce) != NTL_OK) {
-            HIPCHK(c, hipMemcpyAsync(raw.p, seqs + o0, total, hipMemcpyHostToDevice, c->stream));
-        } else {
-            hipEvent_t ev[2] = {nullptr, nullptr};
-            HIPCHK(c, hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
-            HIPCHK(c, hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
-            unsigned nthr = std::thread::hardware_concurrency();
-            nthr = nthr == 0 ? 1 : std::min(nthr, 8u);
-            hipError_t e = hipSuccess;
-            size_t done = 0;
-            for (int i = 0; done < total && e == hipSuccess; i++) {
-                const size_t n = std::min(HALF, (size_t)total - done);
-                char *dst = (char *)bounce + (size_t)(i & 1) * HALF;
-                if (i >= 2) e = hipEventSynchronize(ev[i & 1]); /* the copy that last used this half is over */
-                if (e != hipSuccess) break;
-                std::vector<std::thread> th;
-                for (unsigned t = 0; t < nthr; t++)
-                    th.emplace_back([=] { const size_t a = n * t / nthr, b = n * (t + 1) / nthr; memcpy(dst + a, seqs + o0 + done + a, b - a); });
-                for (auto &x : th) x.join();
-                e = hipMemcpyAsync((char *)raw.p + done, dst, n, hipMemcpyHostToDevice, c->stream);
-                if (e == hipSuccess) e = hipEventRecord(ev[i & 1], c->stream);
-                done += n;
-            }
-            /* the bounce buffer is reused by later calls on this stream only after the final sync of this call */
-            (void)hipEventDestroy(ev[0]);
-            (void)hipEventDestroy(ev[1]);
-            if (e != hipSuccess) return fail(c, NTL_EDEVICE, std::string("staged upload: ") + hipGetErrorString(e));
-        }
-    }
+    if (total) HIPCHK(c, hipMemcpyAsync(raw.p, seqs + o0, total, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(b->seq_base.p, seq_base.data(), (nseq + 1) * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(b->packed.p, 0, nwords * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(valid32.p, 0, (n32 + 2) * 4, c->stream));

@@ -323,7 +323,6 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
     batches = Prefetch(seqio.load(read_paths, max_bases=batch_bases * comm.world, alloc=dev.pinned_empty))
     ctg = seqio.load_all([target])  # used once: page-locking a buffer for it would cost more than the staged copy
     ctg_len = ctg.lengths
-    t_parsed = time.perf_counter()
     out = PairOutputs(prefix, ctg.names, ctg_len, k, f, verbose, paf) if root else None
     pin_out = comm.world == 1  # records land in page-locked pool buffers (not when they are pickled to rank 0)
 
@@ -339,20 +338,15 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
     tsv_drain = Drain(emit_contig_tsv) if root and write_contig_tsv else None
     stats = dict(read_bases=0, reads=0, read_minimizers=0, index_hits=0, t_contigs=0.0, t_ingest=0.0, t_device=0.0, t_handover=0.0)
     try:
-        t_b0 = time.perf_counter()
         with dev.batch(ctg.buf, ctg.offsets) as cb:
             ctg.buf = None
-            t_b1 = time.perf_counter()
             with dev.sketch(cb, k, w) as csk:
-                t_b2 = time.perf_counter()
-                t_b3 = t_b2
+                if tsv_drain:
+                    tsv_drain.put(*csk.download())  # <target>.k<k>.w<w>.tsv is written while the reads are mapped
                 with dev.index(csk, ctg_len) as ix:
                     stats["index_size"] = len(ix)
                     t_mark = time.perf_counter()
                     stats["t_contigs"] = t_mark - t_start
-                    stats["t_contig_parts"] = dict(parse=round(t_parsed - t_start, 4), setup=round(t_b0 - t_parsed, 4),
-                                                   h2d_pack=round(t_b1 - t_b0, 4), sketch=round(t_b2 - t_b1, 4),
-                                                   index=round(t_mark - t_b3, 4))
                     for rs_ in batches:
                         if not len(rs_):
                             continue
@@ -380,12 +374,6 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
                             stats["reads"] += len(rs_)
                         t_mark = time.perf_counter()
                         stats["t_handover"] += t_mark - t_put  # gather + waiting for the writer thread to take the batch
-                    if tsv_drain:
-                        # <target>.k<k>.w<w>.tsv: fetched and written now, while the writer thread still works off
-                        # the last read batches (the contig sketch stayed on the device for this)
-                        t_tsv = time.perf_counter()
-                        tsv_drain.put(*csk.download())
-                        stats["t_contig_tsv_download"] = time.perf_counter() - t_tsv
         if root:
             t_fin = time.perf_counter()
             drain.close()

@@ -140,12 +140,6 @@ inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new sim_event; return hipSuccess; }
-#define hipEventDisableTiming 0u
-inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { return hipEventCreate(e); }
-enum hipMemoryType { hipMemoryTypeUnregistered = 0, hipMemoryTypeHost = 1, hipMemoryTypeDevice = 2 };
-struct hipPointerAttribute_t { hipMemoryType type; };
-/* the mock cannot tell: report ordinary memory, so that the staged-upload path is the one exercised */
-inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t *a, const void *) { a->type = hipMemoryTypeUnregistered; return hipSuccess; }
 inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }

@@ -32,14 +32,6 @@ def test_sim_sketch_second_emit_pass_when_denser_than_guessed(dev, monkeypatch):
     pc.check_sketch(dev, [b"ACGTTGCA" * 400, b"AC" * 900], 8, 40)
 
 
-def test_sim_staged_upload_of_pageable_sequences(dev, monkeypatch):
-    """ntl_batch_create copies ordinary (not page-locked) memory through two alternating halves of a bounce
-    buffer; forced here with tiny halves so that many hand-overs happen."""
-    monkeypatch.setenv("NTL_STAGE_MIN", "1")
-    monkeypatch.setenv("NTL_STAGE_CHUNK", "1000")
-    pc.check_sketch(dev, pc.edge_sequences(), 32, 100)
-
-
 def test_sim_sketch_many_tiny_sequences(dev):
     pc.check_sketch(dev, pc.tiny_sequences(700), 12, 8)
 

@@ -93,7 +93,7 @@ def main():
     out_bytes = sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d) if f.startswith("asm.fa."))
     print(json.dumps({"end_to_end_Gbases_per_s": round(st["read_bases"] / dt / 1e9, 4), "seconds": round(dt, 3),
                       "read_bases": st["read_bases"], "reads": st["reads"], "gz": a.gz, "files": a.files, "batch_bases": a.batch, "output_bytes": out_bytes,
-                      "t_contig_stage": round(st["t_contigs"], 3), "contig_parts": st.get("t_contig_parts"), "t_wait_for_ingest": round(st["t_ingest"], 3), "t_device_incl_pack_pcie": round(st["t_device"], 3),
+                      "t_contig_stage": round(st["t_contigs"], 3), "t_wait_for_ingest": round(st["t_ingest"], 3), "t_device_incl_pack_pcie": round(st["t_device"], 3),
                       "t_handover": round(st["t_handover"], 3), "t_drain_tail": round(st.get("t_drain_tail", 0), 3), "t_graph": round(st.get("t_graph", 0), 3),
                       "t_write": round(st["t_write"], 3), "t_tally": round(st["t_tally"], 3), "device": dev.name}))
     if a.stages:

@@ -1,6 +1,4 @@
 #!/bin/bash
 mkdir -p gpurun_out/dbg
 python __graft_entry__.py > gpurun_out/dbg/build.log 2>&1 || { tail -20 gpurun_out/dbg/build.log; exit 1; }
-for args in "--scale 8.0" "--scale 8.0"; do
-timeout 600 python -u tools/e2e_bench.py $args 2>&1 | grep -v Printing | tail -1 | cut -c1-700
-done
+timeout 900 python tools/bench_f3.py 2>&1 | tail -3 | tee gpurun_out/dbg/f3.json
