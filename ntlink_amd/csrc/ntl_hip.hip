@@ -470,8 +470,8 @@ template <int C, int NT, int R0>
 static void launch_mask_r0(ntl_ctx *c, const SketchArgs &A, unsigned strips, bool multi)
 {
     if (A.G.r0 == R0) {
-        hipLaunchKernelGGL((sketch_mask_kernel<C, NT, false, R0>), dim3(strips), dim3(NT), 0, c->stream, A);
-        if (multi) hipLaunchKernelGGL((sketch_mask_kernel<C, NT, true, R0>), dim3(strips), dim3(NT), 0, c->stream, A);
+        hipLaunchKernelGGL((sketch_mask_kernel<C, NT, false, R0>), dim3((strips + 7u) & ~7u), dim3(NT), 0, c->stream, A);
+        if (multi) hipLaunchKernelGGL((sketch_mask_kernel<C, NT, true, R0>), dim3((strips + 7u) & ~7u), dim3(NT), 0, c->stream, A);
         return;
     }
     if constexpr (R0 + 1 < C) launch_mask_r0<C, NT, R0 + 1>(c, A, strips, multi);
@@ -558,7 +558,7 @@ extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_
         SketchArgs A;
         A.T = T;
         A.run_n = run_n.as<uint32_t>(); A.run_ord = run_ord.as<uint32_t>(); A.seq_M = seq_M.as<uint32_t>();
-        A.strip_tab = strip_tab.as<StripInfo>(); A.mask = mask.as<uint32_t>(); A.G = G;
+        A.strip_tab = strip_tab.as<StripInfo>(); A.nstrips = (uint32_t)ub_strips; A.mask = mask.as<uint32_t>(); A.G = G;
         make_tables(k, A.roll_tab, A.seed_tab);
         A.g4 = (const uint64_t (*)[2])c->g4;
         A.g8 = (const uint64_t (*)[2])c->g8;

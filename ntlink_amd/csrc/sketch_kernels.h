@@ -120,7 +120,8 @@ __global__ void strip_table_kernel(SeqTables T, const uint32_t *run_n, const uin
 struct SketchArgs {
     SeqTables T;
     const uint32_t *run_n, *run_ord, *seq_M;
-    const struct StripInfo *strip_tab; /* [grid] everything a strip needs to start; seq = NTL_NONE past the last strip */
+    const struct StripInfo *strip_tab; /* [nstrips] everything a strip needs to start; seq = NTL_NONE past the last strip */
+    uint32_t nstrips;            /* entries of strip_tab (an upper bound of the real number of strips) */
     uint32_t *mask;              /* 1 bit per global base index: k-mer starting there is a minimizer */
     SketchGeom G;
     uint64_t roll_tab[16][2];    /* [in<<2|out] = {seed[in]^srol^k(seed[out]), srol^k(seedc[in])^seedc[out]} */
@@ -158,7 +159,12 @@ __global__ __launch_bounds__(NT) void sketch_mask_kernel(SketchArgs A)
     const int L = threadIdx.x;
     const SketchGeom G = A.G; /* G.r0 == R0 (the host picks the instantiation) */
 
-    const StripInfo I = A.strip_tab[blockIdx.x];
+    /* Workgroups are handed to the eight XCDs round-robin, and each XCD has its own L2: consecutive strips
+       (which share their halo bases and their strip-table lines) go to one XCD, not to eight. */
+    const uint32_t per_xcd = gridDim.x >> 3; /* the grid is a multiple of 8 */
+    const uint32_t strip = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (strip >= A.nstrips) return;
+    const StripInfo I = A.strip_tab[strip];
     if (I.seq == NTL_NONE) return; /* the grid is an upper bound of the number of strips */
     if (L < 16) { s_roll[L][0] = A.roll_tab[L][0]; s_roll[L][1] = A.roll_tab[L][1]; }
     if (L < 4) { s_seed[L][0] = A.seed_tab[L][0]; s_seed[L][1] = A.seed_tab[L][1]; }
