@@ -28,13 +28,17 @@ def write_fasta(path, buf, off, names, gz=False):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scale", type=float, default=0.2)
+    ap.add_argument("--workload", default="C2", help="C2, or C3 / C5 with --read-bases (their full read sets are 90 / 180 Gbases)")
+    ap.add_argument("--read-bases", type=int, default=0, help="override the workload's read bases")
     ap.add_argument("--gz", action="store_true")
     ap.add_argument("--batch", type=int, default=pipeline.DEFAULT_BATCH_BASES)
     ap.add_argument("--files", type=int, default=1, help="split the reads over this many files (FASTQ when --gz)")
     ap.add_argument("--pipe", action="store_true", help="time the reference's two-operator recipe (bin/indexlr | bin/ntlink_pair.py) instead")
     ap.add_argument("--stages", action="store_true", help="also time every stage of one whole-input batch on its own")
     a = ap.parse_args()
-    W = synth.workload("C2", a.scale)
+    W = synth.workload(a.workload, a.scale)
+    if a.read_bases:
+        W["read_bases"] = a.read_bases
     chroms, cbuf, coff, cn, _ = synth.make_assembly(1, W["n_chrom"], W["contigs_per_chrom"], W["contig_len"])
     rbuf, roff, rn = synth.make_reads(2, chroms, W["read_bases"], W["read_len"], W["sub"], W["ins"], W["dele"], lognormal_sigma=0.4)
     d = tempfile.mkdtemp(prefix="ntl_e2e_")
@@ -88,11 +92,12 @@ def main():
     dev = capi.Device(0)
     os.chdir(d)
     t0 = time.perf_counter()
-    st = pipeline.run_pair(dev, "asm.fa", read_arg, k=W["k"], w=W["w"], paf=True, pairs_tsv=True, batch_bases=a.batch)
+    st = pipeline.run_pair(dev, "asm.fa", read_arg, k=W["k"], w=W["w"], paf=True, pairs_tsv=True, batch_bases=a.batch,
+                           sensitive=W["sensitive"])
     dt = time.perf_counter() - t0
     out_bytes = sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d) if f.startswith("asm.fa."))
     print(json.dumps({"end_to_end_Gbases_per_s": round(st["read_bases"] / dt / 1e9, 4), "seconds": round(dt, 3),
-                      "read_bases": st["read_bases"], "reads": st["reads"], "gz": a.gz, "files": a.files, "batch_bases": a.batch, "output_bytes": out_bytes,
+                      "workload": a.workload, "assembly_bp": int(coff[-1]), "read_bases": st["read_bases"], "reads": st["reads"], "gz": a.gz, "files": a.files, "batch_bases": a.batch, "output_bytes": out_bytes,
                       "t_contig_stage": round(st["t_contigs"], 3), "t_wait_for_ingest": round(st["t_ingest"], 3), "t_device_incl_pack_pcie": round(st["t_device"], 3),
                       "t_handover": round(st["t_handover"], 3), "t_drain_tail": round(st.get("t_drain_tail", 0), 3), "t_graph": round(st.get("t_graph", 0), 3),
                       "t_write": round(st["t_write"], 3), "t_tally": round(st["t_tally"], 3), "device": dev.name}))
