@@ -40,7 +40,7 @@
  * min(cores, 32)), NTL_IO_MIN_CHUNK (bytes per parser thread below which fewer threads are used),
  * NTL_IO_NO_MMAP=1 (stream every input through zlib on one thread), NTL_IO_NO_LIBDEFLATE=1,
  * NTL_IO_GZ_WHOLE_MAX (compressed bytes up to which a gzip file is inflated in one go, default
- * 1 GiB), NTL_IO_TRACE=1 (reader diagnostics on stderr), NTL_SKETCH_C / NTL_SKETCH_NT (k-mers per
+ * 1/40 of the physical memory within 1..16 GiB), NTL_IO_TRACE=1 (reader diagnostics on stderr), NTL_SKETCH_C / NTL_SKETCH_NT (k-mers per
  * lane, lanes per strip of the sketch kernel).
  */
 #ifndef NTLINK_AMD_H

@@ -5,7 +5,8 @@
  *   ntl_fastx_*        gzip -cd + SeqReader of the reference's pipe (ntLink:113-117,222-223); record
  *                      semantics of bin/read_fasta.py:6-46 (id = header up to the first whitespace,
  *                      multi-line sequences joined, FASTQ qualities skipped by length).  Plain files
- *                      are mapped, gzip files up to 1 GiB inflated in one go (libdeflate when present),
+ *                      are read with parallel preads, gzip files up to 1-16 GiB (by host memory) inflated in
+ *                      one go (libdeflate when present),
  *                      and byte ranges cut at record boundaries are parsed by several threads straight
  *                      into the caller's (page-locked) arrays; larger gzip files and stdin stream
  *                      through zlib on one thread.
@@ -341,7 +342,13 @@ extern "C" int ntl_fastx_open(const char *path, ntl_fastx **out)
     ssize_t hn = 0;
     if (regular && st.st_size > 0 && !serial_only && (hn = pread(fd, head, sizeof head, 0)) >= 2) {
         const bool gz = head[0] == 0x1f && head[1] == 0x8b;
-        size_t whole_max = (size_t)1 << 30; /* compressed bytes up to which a gzip file is inflated in one go */
+        /* compressed bytes up to which a gzip file is inflated in one go (the inflated text, ~4x, is then held in
+           memory): 1/40 of the physical memory, between 1 and 16 GiB */
+        size_t whole_max = (size_t)1 << 30;
+        {
+            const long pages = sysconf(_SC_PHYS_PAGES), psz = sysconf(_SC_PAGE_SIZE);
+            if (pages > 0 && psz > 0) whole_max = std::min<size_t>(std::max<size_t>((size_t)pages / 40 * (size_t)psz, (size_t)1 << 30), (size_t)16 << 30);
+        }
         if (const char *e = getenv("NTL_IO_GZ_WHOLE_MAX")) whole_max = (size_t)atoll(e);
         if (!gz) { /* file source: parallel pread */
             r->seekable = true;
