@@ -17,12 +17,19 @@ sys.path.insert(0, ROOT)
 from ntlink_amd import capi, pipeline, synth  # noqa: E402
 
 
+FASTQ = False  # --fastq: four-line records with a constant quality string
+
+
 def write_fasta(path, buf, off, names, gz=False):
     opener = (lambda p: gzip.open(p, "wb", compresslevel=1)) if gz else (lambda p: open(p, "wb"))
     with opener(path) as f:
         raw = buf.tobytes()
         for i, n in enumerate(names):
-            f.write(b">" + n.encode() + b"\n" + raw[int(off[i]):int(off[i + 1])] + b"\n")
+            s = raw[int(off[i]):int(off[i + 1])]
+            if FASTQ:
+                f.write(b"@" + n.encode() + b" some description\n" + s + b"\n+\n" + b"@" * len(s) + b"\n")  # '@' qualities: the hard case
+            else:
+                f.write(b">" + n.encode() + b"\n" + s + b"\n")
 
 
 def main():
@@ -33,9 +40,11 @@ def main():
     ap.add_argument("--gz", action="store_true")
     ap.add_argument("--batch", type=int, default=pipeline.DEFAULT_BATCH_BASES)
     ap.add_argument("--files", type=int, default=1, help="split the reads over this many files (FASTQ when --gz)")
+    ap.add_argument("--fastq", action="store_true", help="reads as four-line FASTQ (qualities all '@')")
     ap.add_argument("--pipe", action="store_true", help="time the reference's two-operator recipe (bin/indexlr | bin/ntlink_pair.py) instead")
     ap.add_argument("--stages", action="store_true", help="also time every stage of one whole-input batch on its own")
     a = ap.parse_args()
+    global FASTQ
     W = synth.workload(a.workload, a.scale)
     if a.read_bases:
         W["read_bases"] = a.read_bases
@@ -44,6 +53,7 @@ def main():
     d = tempfile.mkdtemp(prefix="ntl_e2e_")
     tgt, rds = os.path.join(d, "asm.fa"), os.path.join(d, "reads.fa" + (".gz" if a.gz else ""))
     write_fasta(tgt, cbuf, coff, cn)
+    FASTQ = a.fastq
     if a.files == 1:
         write_fasta(rds, rbuf, roff, rn, a.gz)
         read_arg = os.path.basename(rds)
@@ -96,8 +106,11 @@ def main():
                            sensitive=W["sensitive"])
     dt = time.perf_counter() - t0
     out_bytes = sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d) if f.startswith("asm.fa."))
+    import hashlib
+    md5 = {ext: hashlib.md5(open(os.path.join(d, f"asm.fa.k{W['k']}.w{W['w']}.z1000" + ext), "rb").read()).hexdigest()[:12]
+           for ext in (".verbose_mapping.tsv", ".paf", ".pairs.tsv")}
     print(json.dumps({"end_to_end_Gbases_per_s": round(st["read_bases"] / dt / 1e9, 4), "seconds": round(dt, 3),
-                      "workload": a.workload, "assembly_bp": int(coff[-1]), "read_bases": st["read_bases"], "reads": st["reads"], "gz": a.gz, "files": a.files, "batch_bases": a.batch, "output_bytes": out_bytes,
+                      "workload": a.workload, "assembly_bp": int(coff[-1]), "read_bases": st["read_bases"], "reads": st["reads"], "gz": a.gz, "fastq": a.fastq, "files": a.files, "batch_bases": a.batch, "output_bytes": out_bytes, "md5": md5,
                       "t_contig_stage": round(st["t_contigs"], 3), "t_wait_for_ingest": round(st["t_ingest"], 3), "t_device_incl_pack_pcie": round(st["t_device"], 3),
                       "t_handover": round(st["t_handover"], 3), "t_drain_tail": round(st.get("t_drain_tail", 0), 3), "t_graph": round(st.get("t_graph", 0), 3),
                       "t_write": round(st["t_write"], 3), "t_tally": round(st["t_tally"], 3), "device": dev.name}))
