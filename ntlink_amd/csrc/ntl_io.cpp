@@ -285,12 +285,68 @@ struct BufCache {
 };
 static BufCache &buf_cache() { static BufCache c; return c; }
 
+/* BGZF (bgzip, htslib): every member carries its own compressed size in a 'BC' extra field and its inflated size
+ * in its trailer, so the member table is read by hopping over the file and the members inflate independently.
+ * Fills the offsets of every member in the file and in the output; false when the data is not BGZF throughout. */
+static bool bgzf_table(const unsigned char *in, size_t n, std::vector<size_t> &moff, std::vector<size_t> &ooff)
+{
+    size_t pos = 0, opos = 0;
+    while (pos < n) {
+        if (n - pos < 18 + 8 || in[pos] != 0x1f || in[pos + 1] != 0x8b || in[pos + 2] != 8 || !(in[pos + 3] & 4)) return false;
+        const size_t xlen = (size_t)in[pos + 10] | ((size_t)in[pos + 11] << 8);
+        if (pos + 12 + xlen > n) return false;
+        size_t bsize = 0;
+        for (size_t q = pos + 12; q + 4 <= pos + 12 + xlen;) { /* extra subfields: SI1 SI2 SLEN data */
+            const size_t slen = (size_t)in[q + 2] | ((size_t)in[q + 3] << 8);
+            if (in[q] == 'B' && in[q + 1] == 'C' && slen == 2 && q + 6 <= pos + 12 + xlen) bsize = ((size_t)in[q + 4] | ((size_t)in[q + 5] << 8)) + 1;
+            q += 4 + slen;
+        }
+        if (bsize < 12 + xlen + 8 || pos + bsize > n) return false;
+        uint32_t isize;
+        memcpy(&isize, in + pos + bsize - 4, 4);
+        moff.push_back(pos); ooff.push_back(opos);
+        pos += bsize; opos += isize;
+    }
+    moff.push_back(pos); ooff.push_back(opos);
+    return moff.size() > 2;
+}
+
 /* Inflates every gzip member of [in, in + n) into one malloc'd buffer (`gzip -cd` of a whole file held in
- * memory).  False on corrupt data or when libdeflate is missing; the caller then streams through zlib. */
+ * memory); BGZF members in parallel.  False on corrupt data or when libdeflate is missing; the caller then
+ * streams through zlib. */
 static bool inflate_whole(const unsigned char *in, size_t n, char **out, size_t *out_n, size_t *out_cap)
 {
     const LibDeflate &L = libdeflate();
     if (!L.ok || n < 18) return false;
+    {
+        std::vector<size_t> moff, ooff;
+        if (bgzf_table(in, n, moff, ooff)) {
+            const size_t nm = moff.size() - 1, total = ooff[nm];
+            size_t cap = 0;
+            char *buf = buf_cache().take(total + 64, &cap);
+            if (!buf) return false;
+            const size_t T = std::min<size_t>(io_threads(), std::max<size_t>(1, nm / 16));
+            std::vector<int> bad(T, 0);
+            run_threads(T, [&](size_t t) {
+                void *d = L.alloc();
+                if (!d) { bad[t] = 1; return; }
+                for (size_t i = nm * t / T; i < nm * (t + 1) / T; i++) {
+                    size_t ain = 0, aout = 0;
+                    const size_t want = ooff[i + 1] - ooff[i];
+                    if (L.gzip_ex(d, in + moff[i], moff[i + 1] - moff[i], buf + ooff[i], want, &ain, &aout) != 0 || aout != want) { bad[t] = 1; break; }
+                }
+                L.release(d);
+            });
+            bool ok = true;
+            for (int x : bad) ok &= !x;
+            if (ok) {
+                if (getenv("NTL_IO_TRACE")) fprintf(stderr, "ntl_fastx: BGZF, %zu members inflated on %zu threads\n", nm, T);
+                *out = buf; *out_n = total; *out_cap = cap;
+                return true;
+            }
+            buf_cache().give(buf, cap); /* not what the table promised: take the general path */
+        }
+    }
     void *d = L.alloc();
     if (!d) return false;
     uint32_t isize;

@@ -329,3 +329,38 @@ def test_gzip_sources_members_and_truncation(tmp_path):
     for env in ({}, {"NTL_IO_GZ_WHOLE_MAX": "0"}):
         with _env(env), pytest.raises(OSError):
             list(seqio.load([str(bad)], max_bases=40_000))
+
+
+def _bgzf(data, block=60000):
+    """bgzip's container: gzip members with a 'BC' extra field (compressed size - 1), then the empty EOF member."""
+    import struct
+    import zlib
+    out = []
+    for i in list(range(0, len(data), block)) + [None]:
+        chunk = b"" if i is None else data[i:i + block]
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        raw = c.compress(chunk) + c.flush()
+        bsize = 18 + len(raw) + 8
+        out.append(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", bsize - 1) + raw +
+                   struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+    return b"".join(out)
+
+
+def test_bgzf_members_inflate_in_parallel(tmp_path):
+    """bgzip-compressed reads: the member table comes from the 'BC' fields, members inflate on several threads;
+    a file that only starts as BGZF falls back to the general path."""
+    import gzip
+    rng = np.random.default_rng(33)
+    text = _random_fastx(rng, 3000, True, False).encode()
+    plain = tmp_path / "plain.fq"
+    plain.write_bytes(text)
+    want = list(seqio.read_fastx(str(plain)))
+    p = tmp_path / "reads.fq.gz"
+    p.write_bytes(_bgzf(text))
+    assert gzip.decompress(p.read_bytes()) == text  # the container is valid gzip
+    with _env({"NTL_IO_THREADS": "6", "NTL_IO_MIN_CHUNK": "5000"}):
+        assert _records(list(seqio.load([str(p)], max_bases=200_000))) == want
+    mixed = tmp_path / "mixed.fq.gz"
+    cut = text.index(b"\n@", len(text) // 2) + 1
+    mixed.write_bytes(_bgzf(text[:cut])[:-28] + gzip.compress(text[cut:]))  # BGZF members, then an ordinary one
+    assert _records(list(seqio.load([str(mixed)], max_bases=200_000))) == want
