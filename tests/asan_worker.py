@@ -30,7 +30,7 @@ import tempfile  # noqa: E402
 import numpy as np  # noqa: E402
 from helpers import REF  # noqa: E402
 from ntlink_amd import formats, pipeline, seqio  # noqa: E402
-from test_host import _random_fastx, _records  # noqa: E402
+from test_host import _bgzf, _random_fastx, _records  # noqa: E402
 
 tmp = tempfile.mkdtemp(prefix="ntl_asan_")
 rng = np.random.default_rng(11)
@@ -47,6 +47,9 @@ for fastq, multiline in ((False, True), (True, False), (True, True)):
     os.environ["NTL_IO_NO_MMAP"] = "1"
     assert _records(list(seqio.load([path + ".gz"], max_bases=100_000))) == want
     del os.environ["NTL_IO_NO_MMAP"]
+    with open(path, "rb") as fin, open(path + ".bgzf.gz", "wb") as fout:
+        fout.write(_bgzf(fin.read(), 20000))
+    assert _records(list(seqio.load([path + ".bgzf.gz"], max_bases=100_000))) == want
 cwd = os.getcwd()
 os.chdir(tmp)
 import shutil  # noqa: E402
