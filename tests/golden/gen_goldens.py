@@ -29,7 +29,7 @@ import tempfile
 import types
 
 sys.dont_write_bytecode = True
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 sys.modules["igraph"] = types.ModuleType("igraph")
 sys.path.insert(0, "/root/reference/bin")

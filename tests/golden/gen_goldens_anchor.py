@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Golden vectors for ntlink_amd.anchor: the reference's own get_accepted_anchor_contigs
 (bin/ntlink_utils.py:200-268), imported in the build container, on reads of the synthetic scenarios.
-Output: tests/golden/gen/anchor_cases.json (data only).  Same import recipe as tools/gen_goldens.py."""
+Output: tests/golden/gen/anchor_cases.json (data only).  Same import recipe as tests/golden/gen_goldens.py."""
 import argparse
 import gzip
 import json
@@ -10,7 +10,7 @@ import sys
 import types
 
 sys.dont_write_bytecode = True
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.modules["igraph"] = types.ModuleType("igraph")
 sys.path.insert(0, "/root/reference/bin")
 import ntlink_pair  # noqa: E402  (the reference)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised differential soak on the GPU: product vs oracle over random (k, w), adversarial sequences and
 random hit lists, for a given number of seconds.  Prints the first failing configuration.
-Usage: tools/gpu_soak.py [seconds] [seed0]"""
+Usage: tests/gpu_soak.py [seconds] [seed0]"""
 import os
 import sys
 import time

@@ -118,7 +118,7 @@ def edge_sequences(seed=5):
 
 def check_anchor_cases(dev, max_cases=None):
     """ntlink_amd.anchor.get_accepted_anchor_contigs == the reference's function on the golden cases
-    (tests/golden/gen/anchor_cases.json, made by tools/gen_goldens_anchor.py from the imported reference)."""
+    (tests/golden/gen/anchor_cases.json, made by tests/golden/gen_goldens_anchor.py from the imported reference)."""
     import argparse
     import gzip
     import json

@@ -1,5 +1,5 @@
 """The oracle's index + mapping + pair tally against (a) the goldens the reference ships,
-(b) vectors produced by importing the reference's Python (tools/gen_goldens.py)."""
+(b) vectors produced by importing the reference's Python (tests/golden/gen_goldens.py)."""
 import os
 
 import numpy as np

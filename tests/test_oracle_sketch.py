@@ -23,7 +23,7 @@ def test_contig_tsv_matches_reference_golden(tag, target, reads, k, w, gold):
 @pytest.mark.parametrize("tag,target,reads,k,w,gold", FIXTURES)
 def test_read_sketch_md5(tag, target, reads, k, w, gold):
     """Read sketches have no golden file of their own; their md5 is recorded when the mapping goldens
-    are generated (tools/gen_goldens.py) and agrees with SURVEY.md appendix A."""
+    are generated (tests/golden/gen_goldens.py) and agrees with SURVEY.md appendix A."""
     summ = json.load(open(os.path.join(GEN, "fixtures", "summary.json")))[tag]
     recs = []
     for name, seq in oracle.read_fastx(os.path.join(REF, reads)):
