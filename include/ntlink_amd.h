@@ -102,6 +102,25 @@ uint64_t ntl_batch_bases(const ntl_batch *b);
 int ntl_host_alloc(ntl_ctx *ctx, uint64_t bytes, void **out);
 void ntl_host_free(ntl_ctx *ctx, void *p);
 
+/* ---- synthetic workloads (bench / test harness support; no counterpart in the reference) ---- */
+
+/* BASELINE.json's configurations are synthetic (i.i.d. ACGT genome cut into contigs,
+ * ONT/HiFi-like reads with substitution / insertion / deletion errors).  These entry points build such
+ * batches directly in HBM, in the layout ntl_batch_create leaves, so that a 3 Gbp assembly and 90
+ * Gbases of reads need neither host generation nor PCIe.  All sequences are pure ACGT.
+ *   ntl_synth_genome: nseq sequences of len[i] uniform random bases (deterministic in seed).
+ *   ntl_synth_slices: sequence i = out_len[i] bases read from source sequence src_seq[i] starting at
+ *       src_start[i]; reverse[i] != 0 takes the reverse complement of the slice; sub/ins/del are
+ *       per-base event probabilities (0,0,0 = exact copy: contigs).  With errors the slice may consume up
+ *       to out_len + out_len/8 + 64 source bases, which must fit the source sequence.
+ *   ntl_batch_download: the bases back as ASCII (seqs[offsets[i]..offsets[i+1]), offsets[nseq+1]) --
+ *       what the tests hand to the oracle.  Only for pure-ACGT batches. */
+int ntl_synth_genome(ntl_ctx *ctx, uint64_t seed, const uint32_t *len, uint64_t nseq, ntl_batch **out);
+int ntl_synth_slices(ntl_ctx *ctx, const ntl_batch *src, uint64_t seed, uint64_t n, const uint32_t *src_seq,
+                     const uint32_t *src_start, const uint32_t *out_len, const uint8_t *reverse,
+                     double sub, double ins, double del, ntl_batch **out);
+int ntl_batch_download(const ntl_batch *b, char *seqs, uint64_t *offsets);
+
 /* ---- sketch ---------------------------------------------------------------------------- */
 
 /* Computes the (k,w) minimizers of every sequence of the batch on the device; the result stays

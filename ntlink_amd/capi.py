@@ -19,6 +19,7 @@ SYMBOLS = [
     "ntl_ctx_create", "ntl_ctx_destroy", "ntl_last_error", "ntl_ctx_device_name", "ntl_ctx_sync",
     "ntl_prof_enable", "ntl_prof_reset", "ntl_prof_get",
     "ntl_batch_create", "ntl_batch_destroy", "ntl_batch_nseq", "ntl_batch_bases", "ntl_host_alloc", "ntl_host_free",
+    "ntl_synth_genome", "ntl_synth_slices", "ntl_batch_download",
     "ntl_sketch_run", "ntl_sketch_destroy", "ntl_sketch_nseq", "ntl_sketch_count", "ntl_sketch_download",
     "ntl_sketch_from_host",
     "ntl_index_build", "ntl_index_destroy", "ntl_index_size",
@@ -76,6 +77,10 @@ def load(path=None):
     L.ntl_batch_nseq.restype = C.c_uint64
     L.ntl_batch_bases.argtypes = [vp]
     L.ntl_batch_bases.restype = C.c_uint64
+    L.ntl_synth_genome.argtypes = [vp, C.c_uint64, u32p, C.c_uint64, C.POINTER(vp)]
+    L.ntl_synth_slices.argtypes = [vp, vp, C.c_uint64, C.c_uint64, u32p, u32p, u32p, u8p, C.c_double, C.c_double, C.c_double,
+                                   C.POINTER(vp)]
+    L.ntl_batch_download.argtypes = [vp, vp, u64p]
     L.ntl_sketch_run.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]
     L.ntl_sketch_destroy.argtypes = [vp]
     L.ntl_sketch_destroy.restype = None
@@ -179,6 +184,13 @@ class Batch(_Handle):
     @property
     def bases(self):
         return int(self.dev.L.ntl_batch_bases(self.ptr))
+
+    def download(self):
+        """(ASCII bases uint8, offsets u64[nseq+1]) of a pure-ACGT batch (the synthetic ones)."""
+        buf = np.empty(max(self.bases, 1), np.uint8)
+        off = np.zeros(self.nseq + 1, np.uint64)
+        self.dev._chk(self.dev.L.ntl_batch_download(self.ptr, buf.ctypes.data, _ptr(off, C.c_uint64)))
+        return buf[:self.bases], off
 
 
 class Sketch(_Handle):
@@ -344,6 +356,27 @@ class Device:
         p = C.c_void_p()
         self._chk(self.L.ntl_batch_create(self.ptr, buf.ctypes.data, _ptr(offsets, C.c_uint64), len(offsets) - 1,
                                           C.byref(p)))
+        return Batch(self, p)
+
+    def synth_genome(self, seed, lengths):
+        """Uniform random ACGT sequences generated on the device (bench / test support)."""
+        ln = np.ascontiguousarray(lengths, np.uint32)
+        p = C.c_void_p()
+        self._chk(self.L.ntl_synth_genome(self.ptr, int(seed), _ptr(ln, C.c_uint32), len(ln), C.byref(p)))
+        return Batch(self, p)
+
+    def synth_slices(self, src, seed, src_seq, src_start, out_len, reverse=None, sub=0.0, ins=0.0, dele=0.0):
+        """Slices of the sequences of batch `src` (reverse-complemented where reverse[i]), with per-base
+        error events: contigs cut from chromosomes (no errors), reads sampled from them (with errors)."""
+        sq = np.ascontiguousarray(src_seq, np.uint32); st = np.ascontiguousarray(src_start, np.uint32)
+        ln = np.ascontiguousarray(out_len, np.uint32)
+        rv = None if reverse is None else np.ascontiguousarray(reverse, np.uint8)
+        if not (len(sq) == len(st) == len(ln)) or (rv is not None and len(rv) != len(ln)):
+            raise ValueError("slice arrays must have one entry per output sequence")
+        p = C.c_void_p()
+        self._chk(self.L.ntl_synth_slices(self.ptr, src.ptr, int(seed), len(ln), _ptr(sq, C.c_uint32), _ptr(st, C.c_uint32),
+                                          _ptr(ln, C.c_uint32), None if rv is None else _ptr(rv, C.c_uint8),
+                                          float(sub), float(ins), float(dele), C.byref(p)))
         return Batch(self, p)
 
     def sketch(self, batch, k, w):

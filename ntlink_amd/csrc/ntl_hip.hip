@@ -21,6 +21,7 @@
 #include "sketch_kernels.h"
 #include "map_kernels.h"
 #include "pack_kernels.h"
+#include "synth_kernels.h"
 
 #define NTL_END_PAD 4096u /* bases of padding behind the last sequence (rolling over-reads) */
 #define SK_NT 256
@@ -397,6 +398,127 @@ extern "C" void ntl_host_free(ntl_ctx *c, void *p)
 }
 extern "C" uint64_t ntl_batch_nseq(const ntl_batch *b) { return b ? b->nseq : 0; }
 extern "C" uint64_t ntl_batch_bases(const ntl_batch *b) { return b ? b->bases : 0; }
+
+/* ------------------------------------------------------------------ synthetic batches ----- */
+
+/* device layout of a batch whose sequences are pure ACGT: every sequence is one run */
+static int synth_layout(ntl_ctx *c, const uint32_t *len, uint64_t nseq, std::unique_ptr<ntl_batch> &b, std::vector<uint64_t> &seq_base)
+{
+    if (nseq >= ((uint64_t)1 << 31)) return fail(c, NTL_EINVAL, "too many sequences in one batch");
+    b.reset(new ntl_batch());
+    b->c = c;
+    b->nseq = nseq;
+    seq_base.resize(nseq + 1);
+    b->seq_len.assign(len, len + nseq);
+    uint64_t total = 0;
+    for (uint64_t i = 0; i < nseq; i++) {
+        if (len[i] == 0 || len[i] >= 0xFFFFFFF0u) return fail(c, NTL_EINVAL, "synthetic sequences must hold 1..2^32-17 bases");
+        seq_base[i] = NTL_LEAD_PAD + total;
+        total += len[i];
+    }
+    seq_base[nseq] = NTL_LEAD_PAD + total;
+    b->bases = total;
+    b->total_gpos = NTL_LEAD_PAD + total;
+    b->nruns = nseq;
+    b->nwords_packed = (NTL_LEAD_PAD + total + NTL_END_PAD + 15) / 16 + 2;
+    b->any_multi = false;
+    int rc;
+    if ((rc = b->packed.alloc(c, b->nwords_packed * 4)) || (rc = b->seq_base.alloc(c, (nseq + 1) * 8)) ||
+        (rc = b->seq_run_first.alloc(c, (nseq + 1) * 4)) || (rc = b->run_start.alloc(c, (nseq + 1) * 4)) ||
+        (rc = b->run_len.alloc(c, (nseq + 1) * 4)))
+        return rc;
+    std::vector<uint32_t> iota(nseq + 1);
+    for (uint64_t i = 0; i <= nseq; i++) iota[i] = (uint32_t)i;
+    HIPCHK(c, hipMemcpyAsync(b->seq_base.p, seq_base.data(), (nseq + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(b->seq_run_first.p, iota.data(), (nseq + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(b->run_start.p, 0, (nseq + 1) * 4, c->stream));
+    if (nseq) HIPCHK(c, hipMemcpyAsync(b->run_len.p, len, nseq * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream)); /* iota and seq_base are stack/host temporaries */
+    return NTL_OK;
+}
+
+extern "C" int ntl_synth_genome(ntl_ctx *c, uint64_t seed, const uint32_t *len, uint64_t nseq, ntl_batch **out)
+{
+    if (!c || !out || (!len && nseq)) return NTL_EINVAL;
+    *out = nullptr;
+    (void)hipSetDevice(c->device);
+    std::unique_ptr<ntl_batch> b;
+    std::vector<uint64_t> seq_base;
+    int rc = synth_layout(c, len, nseq, b, seq_base);
+    if (rc) return rc;
+    const uint64_t nw = b->nwords_packed;
+    hipLaunchKernelGGL(synth_genome_kernel, dim3((unsigned)((nw / 2 + 256) / 256)), dim3(256), 0, c->stream, b->packed.as<uint32_t>(), nw, seed);
+    HIPCHK(c, hipGetLastError());
+    *out = b.release();
+    return NTL_OK;
+}
+
+extern "C" int ntl_synth_slices(ntl_ctx *c, const ntl_batch *src, uint64_t seed, uint64_t n, const uint32_t *src_seq,
+                                const uint32_t *src_start, const uint32_t *out_len, const uint8_t *reverse,
+                                double sub, double ins, double del, ntl_batch **out)
+{
+    if (!c || !src || !out || (n && (!src_seq || !src_start || !out_len))) return NTL_EINVAL;
+    *out = nullptr;
+    if (src->nruns != src->nseq || src->any_multi) return fail(c, NTL_EINVAL, "the source batch must be pure ACGT");
+    if (sub < 0 || ins < 0 || del < 0 || sub > 0.5 || ins + del > 0.5) return fail(c, NTL_EINVAL, "error rates out of range");
+    const bool errors = sub > 0 || ins > 0 || del > 0;
+    for (uint64_t i = 0; i < n; i++) {
+        if (src_seq[i] >= src->nseq) return fail(c, NTL_EINVAL, "source sequence index out of range");
+        const uint64_t need = errors ? synth_span(out_len[i]) : (uint64_t)out_len[i];
+        if ((uint64_t)src_start[i] + need > src->seq_len[src_seq[i]]) return fail(c, NTL_EINVAL, "slice does not fit its source sequence");
+    }
+    (void)hipSetDevice(c->device);
+    std::unique_ptr<ntl_batch> b;
+    std::vector<uint64_t> seq_base;
+    int rc = synth_layout(c, out_len, n, b, seq_base);
+    if (rc) return rc;
+    DevBuf d_seq, d_start, d_rev;
+    if ((rc = d_seq.alloc(c, (n + 1) * 4)) || (rc = d_start.alloc(c, (n + 1) * 4)) || (rc = d_rev.alloc(c, n + 1))) return rc;
+    HIPCHK(c, hipMemsetAsync(b->packed.p, 0, b->nwords_packed * 4, c->stream));
+    if (n) {
+        HIPCHK(c, hipMemcpyAsync(d_seq.p, src_seq, n * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d_start.p, src_start, n * 4, hipMemcpyHostToDevice, c->stream));
+        if (reverse) HIPCHK(c, hipMemcpyAsync(d_rev.p, reverse, n, hipMemcpyHostToDevice, c->stream));
+        SliceArgs A;
+        A.src_packed = src->packed.as<uint32_t>(); A.src_seq_base = src->seq_base.as<uint64_t>(); A.n_src = (uint32_t)src->nseq;
+        A.dst_packed = b->packed.as<uint32_t>(); A.dst_seq_base = b->seq_base.as<uint64_t>();
+        A.src_seq = d_seq.as<uint32_t>(); A.src_start = d_start.as<uint32_t>(); A.reverse = reverse ? d_rev.as<uint8_t>() : nullptr;
+        A.n = n; A.seed = seed;
+        const double S = 16777216.0; /* 24-bit draws */
+        A.t_ins = (uint32_t)(ins * S); A.t_del = (uint32_t)((ins + del) * S); A.t_sub = (uint32_t)(sub * S);
+        if (errors && A.t_del == 0 && A.t_sub == 0) A.t_sub = 1; /* keeps the error path (and its source span) selected */
+        hipLaunchKernelGGL(synth_slices_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, A);
+        HIPCHK(c, hipGetLastError());
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream)); /* the caller's arrays are free again */
+    *out = b.release();
+    return NTL_OK;
+}
+
+extern "C" int ntl_batch_download(const ntl_batch *b, char *seqs, uint64_t *off)
+{
+    if (!b || (!seqs && b->bases) || !off) return NTL_EINVAL;
+    ntl_ctx *c = b->c;
+    if (b->nruns != b->nseq || b->any_multi) return fail(c, NTL_EINVAL, "only pure-ACGT batches can be downloaded");
+    (void)hipSetDevice(c->device);
+    uint64_t t = 0;
+    for (uint64_t i = 0; i < b->nseq; i++) { off[i] = t; t += b->seq_len[i]; }
+    off[b->nseq] = t;
+    if (t != b->bases) return fail(c, NTL_EINVAL, "only pure-ACGT batches can be downloaded");
+    const uint64_t CH = (uint64_t)1 << 28; /* 256 Mbases of ASCII per piece */
+    DevBuf tmp;
+    int rc = tmp.alloc(c, std::min<uint64_t>(CH, b->bases) + 16);
+    if (rc) return rc;
+    for (uint64_t p0 = 0; p0 < b->bases; p0 += CH) {
+        const uint64_t m = std::min<uint64_t>(CH, b->bases - p0);
+        hipLaunchKernelGGL(unpack_kernel, dim3((unsigned)((m / 16 + 256) / 256)), dim3(256), 0, c->stream,
+                           (const uint32_t *)b->packed.as<uint32_t>(), (uint64_t)NTL_LEAD_PAD + p0, m, tmp.as<uint8_t>());
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(seqs + p0, tmp.p, m, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return NTL_OK;
+}
 
 /* ------------------------------------------------------------------ sketch --------------- */
 

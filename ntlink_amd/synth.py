@@ -103,3 +103,83 @@ def workload(name, scale=1.0):
         return dict(n_chrom=25, contigs_per_chrom=200, contig_len=int(600_000 * scale), read_bases=int(180_000_000_000 * scale),
                     read_len=20_000, k=24, w=100, sub=0.001, ins=0.0005, dele=0.0005, sensitive=True)
     raise ValueError(name)
+
+
+# ---- device-side generation (capi.Device.synth_genome / synth_slices): the host only plans ----
+
+def plan_assembly(seed, n_chrom, contigs_per_chrom, contig_len, gap_lo=100, gap_hi=5000):
+    """Chromosome lengths and the contig slices (chromosome, start, length) of make_assembly's layout,
+    without generating a base: contigs of contig_len * U[0.7, 1.3] separated by dropped gaps U[gap_lo, gap_hi]."""
+    rng = np.random.default_rng(seed)
+    chrom_len, c_chr, c_start, c_len = [], [], [], []
+    for c in range(n_chrom):
+        gaps = rng.integers(gap_lo, gap_hi + 1, contigs_per_chrom)
+        lens = np.maximum(1000, (contig_len * rng.uniform(0.7, 1.3, contigs_per_chrom)).astype(np.int64))
+        starts = np.concatenate(([0], np.cumsum(lens + gaps)[:-1]))
+        chrom_len.append(int(lens.sum() + gaps.sum()))
+        c_chr.append(np.full(contigs_per_chrom, c, np.uint32))
+        c_start.append(starts.astype(np.uint32))
+        c_len.append(lens.astype(np.uint32))
+    return dict(chrom_len=np.array(chrom_len, np.uint32), ctg_chrom=np.concatenate(c_chr), ctg_start=np.concatenate(c_start),
+                ctg_len=np.concatenate(c_len), names=[f"ctg{i:06d}" for i in range(n_chrom * contigs_per_chrom)])
+
+
+def slice_span(length):
+    """Source bases a read of `length` output bases may consume (ntl_synth_slices, include/ntlink_amd.h)."""
+    return length + length // 8 + 64
+
+
+def plan_reads(seed, chrom_len, total_bases, mean_len, lognormal_sigma=0.4, min_len=1000, max_len=100000):
+    """Read slices (chromosome, start, length, reverse) for about total_bases bases: start uniform on the
+    chromosome, 50/50 strand, log-normal length clipped to [min_len, max_len]."""
+    rng = np.random.default_rng(seed)
+    clen = np.asarray(chrom_len, np.int64)
+    n = max(1, int(np.ceil(total_bases / mean_len)))
+    if lognormal_sigma > 0:
+        ln = np.clip(rng.lognormal(np.log(mean_len) - lognormal_sigma ** 2 / 2, lognormal_sigma, n), min_len, max_len).astype(np.int64)
+    else:
+        ln = np.full(n, int(mean_len), np.int64)
+    c = rng.choice(len(clen), size=n, p=clen / clen.sum()) if len(clen) > 1 else np.zeros(n, np.int64)
+    ln = np.minimum(ln, (clen[c] - 64) * 8 // 9 - 1)
+    room = clen[c] - slice_span(ln)
+    st = (rng.random(n) * (room + 1)).astype(np.int64)
+    rev = (rng.random(n) < 0.5).astype(np.uint8)
+    return dict(chrom=c.astype(np.uint32), start=st.astype(np.uint32), length=ln.astype(np.uint32), reverse=rev)
+
+
+class DeviceWorkload:
+    """A named BASELINE.json configuration resident in HBM: chromosomes, contigs, and the reads as
+    sub-batches of at most batch_bases bases (one ntl_batch each; a batch is bounded by 32-bit base indices)."""
+
+    def __init__(self, dev, name, scale=1.0, read_bases=None, batch_bases=3_950_000_000, read_seed=2, with_reads=True):
+        self.dev, self.name, self.W = dev, name, workload(name, scale)
+        W = self.W
+        self.plan = plan_assembly(1, W["n_chrom"], W["contigs_per_chrom"], W["contig_len"])
+        self.genome = dev.synth_genome(1, self.plan["chrom_len"])
+        self.contigs = dev.synth_slices(self.genome, 0, self.plan["ctg_chrom"], self.plan["ctg_start"], self.plan["ctg_len"])
+        self.ctg_len = self.plan["ctg_len"]
+        self.read_batches, self.read_lens = [], []
+        total = int(W["read_bases"] if read_bases is None else read_bases)
+        self.read_bases = 0
+        if with_reads:
+            nb = max(1, -(-total // int(batch_bases)))
+            for b in range(nb):
+                self.add_reads(total // nb, seed=tuple(np.atleast_1d(read_seed).tolist()) + (b,))
+
+    def make_reads(self, bases, seed):
+        W = self.W
+        rp = plan_reads(seed, self.plan["chrom_len"], bases, W["read_len"])
+        s64 = int(np.random.SeedSequence(seed).generate_state(1, np.uint64)[0])
+        rb = self.dev.synth_slices(self.genome, s64, rp["chrom"], rp["start"], rp["length"], rp["reverse"],
+                                   sub=W["sub"], ins=W["ins"], dele=W["dele"])
+        return rb, rp["length"]
+
+    def add_reads(self, bases, seed):
+        rb, ln = self.make_reads(bases, seed)
+        self.read_batches.append(rb)
+        self.read_lens.append(ln)
+        self.read_bases += int(ln.sum())
+
+    def close(self):
+        for h in self.read_batches + [self.contigs, self.genome]:
+            h.close()
