@@ -1,0 +1,37 @@
+"""bench.py --gpus N must run N ranks when it is started without a launcher (the driver's SCALE command shape
+is `python bench.py --gpus N ...` as well as torch.distributed.run): CPU check of the spawn path with gloo."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_gpus_2_spawns_two_ranks():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--spawn-check"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1  # one JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["world"] == 2
+
+
+def test_bench_line_on_the_simt_mock(tmp_path):
+    """The bench's own logic (device-side workload, contig stage once, steps over resident sub-batches, JSON contract)
+    on the SIMT mock at a tiny scale; the numbers mean nothing here."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from sim import simlib
+    lib = simlib.build()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--lib", lib, "--workload", "C2", "--scale", "0.0004",
+                        "--steps", "1", "--warmup", "1", "--no-e2e", "--batch-bases", "100000"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["config"]["workload"].startswith("C2:") and "2 distinct HBM-resident sub-batches" in out["config"]["workload"]
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "dtype", "roofline", "cpu_baseline"):
+        assert key in out
+    assert out["n_gpus"] == 1 and out["cpu_baseline"]["kind"] == "port" and "stages_s" in out["cpu_baseline"]
+    assert out["config"]["index_size"] > 0 and out["config"]["mappings_hits_pafs_per_step"][0] > 0
