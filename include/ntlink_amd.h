@@ -41,7 +41,8 @@
  * NTL_IO_NO_MMAP=1 (stream every input through zlib on one thread), NTL_IO_NO_LIBDEFLATE=1,
  * NTL_IO_GZ_WHOLE_MAX (compressed bytes up to which a gzip file is inflated in one go, default
  * 1/40 of the physical memory within 1..16 GiB), NTL_IO_TRACE=1 (reader diagnostics on stderr), NTL_SKETCH_C / NTL_SKETCH_NT (k-mers per
- * lane, lanes per strip of the sketch kernel).
+ * lane, lanes per strip of the sketch kernel), NTL_SKETCH_FAST=0 (exact 64-bit window pass only), NTL_SKETCH_FORCE_REDO=1
+ * (every strip takes the 32-bit pass and the exact pass).
  */
 #ifndef NTLINK_AMD_H
 #define NTLINK_AMD_H
@@ -132,6 +133,11 @@ void ntl_sketch_destroy(ntl_sketch *s);
 uint64_t ntl_sketch_nseq(const ntl_sketch *s);
 /* Total number of minimizers. */
 uint64_t ntl_sketch_count(const ntl_sketch *s);
+/* Diagnostics of the window pass: strips (workgroups) it was cut into, and how many of them the 32-bit pass
+ * handed to the exact 64-bit pass (k-mers that share a window and the top 32 hash bits: low-complexity
+ * sequence).  The result is the same either way. */
+uint64_t ntl_sketch_strips(const ntl_sketch *s);
+uint64_t ntl_sketch_redo_strips(const ntl_sketch *s);
 /* mx_off[nseq+1]: minimizers of sequence i are [mx_off[i], mx_off[i+1]); hash/pos/strand hold
  * ntl_sketch_count() entries (the three fields `indexlr` prints as H:pos:strand). */
 int ntl_sketch_download(const ntl_sketch *s, uint64_t *mx_off, uint64_t *hash, uint32_t *pos,

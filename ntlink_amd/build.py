@@ -6,7 +6,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libntlink_hip.so")
-SOURCES = ["ntl_hip.hip", "ntl_io.cpp", "ntl_pairs.cpp", "dev_common.h", "dev_intrin.h", "scan_kernels.h", "sketch_kernels.h", "map_kernels.h", "pack_kernels.h", "synth_kernels.h"]
+SOURCES = ["ntl_hip.hip", "ntl_io.cpp", "ntl_pairs.cpp", "dev_common.h", "dev_intrin.h", "scan_kernels.h", "sketch_kernels.h", "sketch2_kernels.h", "map_kernels.h", "pack_kernels.h", "synth_kernels.h"]
 
 
 def hipcc_path():

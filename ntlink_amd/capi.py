@@ -21,6 +21,7 @@ SYMBOLS = [
     "ntl_batch_create", "ntl_batch_destroy", "ntl_batch_nseq", "ntl_batch_bases", "ntl_host_alloc", "ntl_host_free",
     "ntl_synth_genome", "ntl_synth_slices", "ntl_batch_download",
     "ntl_sketch_run", "ntl_sketch_destroy", "ntl_sketch_nseq", "ntl_sketch_count", "ntl_sketch_download",
+    "ntl_sketch_strips", "ntl_sketch_redo_strips",
     "ntl_sketch_from_host",
     "ntl_index_build", "ntl_index_destroy", "ntl_index_size",
     "ntl_map_run", "ntl_mapres_destroy", "ntl_mapres_n_mappings", "ntl_mapres_n_hits", "ntl_mapres_n_pafs",
@@ -88,6 +89,9 @@ def load(path=None):
     L.ntl_sketch_nseq.restype = C.c_uint64
     L.ntl_sketch_count.argtypes = [vp]
     L.ntl_sketch_count.restype = C.c_uint64
+    for nm in ("ntl_sketch_strips", "ntl_sketch_redo_strips"):
+        getattr(L, nm).argtypes = [vp]
+        getattr(L, nm).restype = C.c_uint64
     L.ntl_sketch_download.argtypes = [vp, u64p, u64p, u32p, u8p]
     L.ntl_sketch_from_host.argtypes = [vp, C.c_uint64, u64p, u64p, u32p, u8p, C.POINTER(vp)]
     L.ntl_index_build.argtypes = [vp, vp, u32p, C.c_uint32, C.POINTER(vp)]
@@ -204,6 +208,14 @@ class Sketch(_Handle):
     @property
     def count(self):
         return int(self.dev.L.ntl_sketch_count(self.ptr))
+
+    @property
+    def strips(self):
+        return int(self.dev.L.ntl_sketch_strips(self.ptr))
+
+    @property
+    def redo_strips(self):
+        return int(self.dev.L.ntl_sketch_redo_strips(self.ptr))
 
     def download(self):
         """(mx_off u64[nseq+1], hash u64, pos u32, strand u8 [1 = '+'])."""

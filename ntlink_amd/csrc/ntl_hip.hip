@@ -19,6 +19,7 @@
 #include "dev_common.h"
 #include "scan_kernels.h"
 #include "sketch_kernels.h"
+#include "sketch2_kernels.h"
 #include "map_kernels.h"
 #include "pack_kernels.h"
 #include "synth_kernels.h"
@@ -525,6 +526,7 @@ extern "C" int ntl_batch_download(const ntl_batch *b, char *seqs, uint64_t *off)
 struct ntl_sketch {
     ntl_ctx *c;
     uint64_t nseq = 0, count = 0;
+    uint64_t strips = 0, redo_strips = 0; /* diagnostics: strips of the window pass, strips that also took the exact pass */
     DevBuf records; /* MxRecord[count] */
     DevBuf mx_off;  /* u32[nseq+1] */
 };
@@ -588,22 +590,35 @@ static void make_g8(std::vector<uint64_t> &g8)
     }
 }
 
+/* exact 64-bit pass: over all strips (multi-run strips when `multi`), or -- redo != NULL -- over the strips the fast pass flagged */
 template <int C, int NT, int R0>
-static void launch_mask_r0(ntl_ctx *c, const SketchArgs &A, unsigned strips, bool multi)
+static void launch_mask_r0(ntl_ctx *c, const SketchArgs &A, unsigned strips, bool single, bool multi)
 {
     if (A.G.r0 == R0) {
-        hipLaunchKernelGGL((sketch_mask_kernel<C, NT, false, R0>), dim3((strips + 7u) & ~7u), dim3(NT), 0, c->stream, A);
+        const unsigned grid = A.redo_list ? 2048u : ((strips + 7u) & ~7u);
+        if (single) hipLaunchKernelGGL((sketch_mask_kernel<C, NT, false, R0>), dim3(grid), dim3(NT), 0, c->stream, A);
         if (multi) hipLaunchKernelGGL((sketch_mask_kernel<C, NT, true, R0>), dim3((strips + 7u) & ~7u), dim3(NT), 0, c->stream, A);
         return;
     }
-    if constexpr (R0 + 1 < C) launch_mask_r0<C, NT, R0 + 1>(c, A, strips, multi);
+    if constexpr (R0 + 1 < C) launch_mask_r0<C, NT, R0 + 1>(c, A, strips, single, multi);
 }
 
 template <int C>
-static void launch_mask(ntl_ctx *c, const SketchArgs &A, unsigned strips, bool multi, int nt)
+static void launch_mask(ntl_ctx *c, const SketchArgs &A, unsigned strips, bool single, bool multi, int nt)
 {
-    if (C == 16 && nt == 128) launch_mask_r0<C, 128, 0>(c, A, strips, multi);
-    else launch_mask_r0<C, SK_NT, 0>(c, A, strips, multi);
+    if (C == 16 && nt == 128) launch_mask_r0<C, 128, 0>(c, A, strips, single, multi);
+    else launch_mask_r0<C, SK_NT, 0>(c, A, strips, single, multi);
+}
+
+/* fast 32-bit pass over the single-run strips (sketch2_kernels.h) */
+template <int NT, int R0>
+static void launch_fast_r0(ntl_ctx *c, const Sketch2Args &B, unsigned strips)
+{
+    if (B.A.G.r0 == R0) {
+        hipLaunchKernelGGL((sketch_fast_kernel<NT, R0>), dim3((strips + 7u) & ~7u), dim3(NT), 0, c->stream, B);
+        return;
+    }
+    if constexpr (R0 + 1 < 16) launch_fast_r0<NT, R0 + 1>(c, B, strips);
 }
 
 extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_sketch **out)
@@ -635,7 +650,9 @@ extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_
     ntl_sketch *s = s_guard.get();
     s->c = c; s->nseq = nseq;
     int rc;
-    DevBuf run_n, run_ord, seq_M, nstrips, strip_first, mask, tile, tot, word_rank;
+    DevBuf run_n, run_ord, seq_M, nstrips, strip_first, mask, tile, tot, word_rank, redo;
+    uint32_t redo_n = 0;
+    bool fast = false;
     /* nstrips / strip_first hold nseq+1 entries: the scan leaves the total behind the last one */
     const uint64_t nmask = (b->total_gpos + 31) / 32 + 1;
     if ((rc = run_n.alloc(c, (b->nruns + 1) * 4)) || (rc = run_ord.alloc(c, (b->nruns + 1) * 4)) ||
@@ -684,11 +701,39 @@ extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_
         make_tables(k, A.roll_tab, A.seed_tab);
         A.g4 = (const uint64_t (*)[2])c->g4;
         A.g8 = (const uint64_t (*)[2])c->g8;
-        ProfSpan sp(c, "sketch_mask");
-        if (C == 16) launch_mask<16>(c, A, (unsigned)ub_strips, b->any_multi, nt);
-        else if (C == 4) launch_mask<4>(c, A, (unsigned)ub_strips, b->any_multi, nt);
-        else launch_mask<1>(c, A, (unsigned)ub_strips, b->any_multi, nt);
-        HIPCHK(c, hipGetLastError());
+        A.redo_list = nullptr; A.redo_count = nullptr;
+        /* 32-bit fast pass + exact pass over what it flags; the exact pass alone for small windows / huge k */
+        fast = C == 16 && k <= 16 * SK2_QMAX;
+        if (const char *e = getenv("NTL_SKETCH_FAST")) fast = fast && atoi(e) != 0; /* 0: exact pass only (A/B, tests) */
+        if (fast) {
+            if ((rc = redo.alloc(c, (ub_strips + 2) * 4))) return rc;
+            HIPCHK(c, hipMemsetAsync(redo.p, 0, 4, c->stream));
+            Sketch2Args B;
+            B.A = A;
+            B.redo_count = redo.as<uint32_t>(); B.redo_list = redo.as<uint32_t>() + 1;
+            B.max_word = b->nwords_packed - 1;
+            B.q16 = k / 16; B.r16 = k % 16;
+            B.force_redo = 0;
+            if (const char *e = getenv("NTL_SKETCH_FORCE_REDO")) B.force_redo = atoi(e); /* tests: every strip takes both passes */
+            {
+                ProfSpan sp(c, "sketch_mask");
+                if (nt == 128) launch_fast_r0<128, 0>(c, B, (unsigned)ub_strips);
+                else launch_fast_r0<SK_NT, 0>(c, B, (unsigned)ub_strips);
+                HIPCHK(c, hipGetLastError());
+            }
+            ProfSpan sp(c, "sketch_redo");
+            SketchArgs R = A;
+            R.redo_count = B.redo_count; R.redo_list = B.redo_list;
+            launch_mask<16>(c, R, (unsigned)ub_strips, true, false, nt);
+            if (b->any_multi) launch_mask<16>(c, A, (unsigned)ub_strips, false, true, nt);
+            HIPCHK(c, hipGetLastError());
+        } else {
+            ProfSpan sp(c, "sketch_mask");
+            if (C == 16) launch_mask<16>(c, A, (unsigned)ub_strips, true, b->any_multi, nt);
+            else if (C == 4) launch_mask<4>(c, A, (unsigned)ub_strips, true, b->any_multi, nt);
+            else launch_mask<1>(c, A, (unsigned)ub_strips, true, b->any_multi, nt);
+            HIPCHK(c, hipGetLastError());
+        }
     }
     {
         ProfSpan sp(c, "sketch_emit");
@@ -721,8 +766,11 @@ extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_
                            (const uint32_t *)word_rank.as<uint32_t>(), nmask, (const uint32_t *)tot.as<uint32_t>(), s->mx_off.as<uint32_t>());
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(&total_mx, tot.p, 4, hipMemcpyDeviceToHost, c->stream));
+        if (fast) HIPCHK(c, hipMemcpyAsync(&redo_n, redo.p, 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         s->count = total_mx;
+        s->strips = ub_strips;
+        s->redo_strips = redo_n;
         if ((uint64_t)total_mx > cap_guess) {
             if ((rc = s->records.alloc(c, (uint64_t)total_mx * sizeof(MxRecord)))) return rc;
             E.out = s->records.as<MxRecord>(); E.out_cap = total_mx;
@@ -739,6 +787,8 @@ extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_
 extern "C" void ntl_sketch_destroy(ntl_sketch *s) { delete s; }
 extern "C" uint64_t ntl_sketch_nseq(const ntl_sketch *s) { return s ? s->nseq : 0; }
 extern "C" uint64_t ntl_sketch_count(const ntl_sketch *s) { return s ? s->count : 0; }
+extern "C" uint64_t ntl_sketch_strips(const ntl_sketch *s) { return s ? s->strips : 0; }
+extern "C" uint64_t ntl_sketch_redo_strips(const ntl_sketch *s) { return s ? s->redo_strips : 0; }
 
 extern "C" int ntl_sketch_download(const ntl_sketch *s, uint64_t *mx_off, uint64_t *hash, uint32_t *pos, uint8_t *strand)
 {

@@ -1,0 +1,344 @@
+/*
+ * sketch_fast_kernel: the window pass of the (k,w) minimizer sketch on 32-bit keys.
+ *
+ * Same contract and strip geometry as sketch_mask_kernel (sketch_kernels.h; btllib `indexlr`, ntLink:199,223,
+ * SURVEY.md 8 rows a1-a2): one workgroup = one strip of NT*16 consecutive valid-k-mer ordinals of one
+ * sequence, lane L owns 16 of them, one bit per emitted minimizer in the global bitmask.  What differs is the
+ * arithmetic between the hash and the bit:
+ *
+ *   key      the window minimum is taken on c = h0 >> 32 (one register, v_min_u32) instead of the 64-bit h0
+ *            plus an index (compare + three selects per combine).  Positions are NOT tracked.
+ *   argmin   a window whose minimum VALUE differs from the previous window's is a "changed" window; only
+ *            those (2/(w+1) of all) are searched for the position of their minimum, by one lane each, over
+ *            the block minima and one block of elements staged in LDS.
+ *   exact    the result equals Indexlr's rightmost 64-bit argmin unless two k-mers that share a window also
+ *            share the top 32 bits of h0 while being that window's minimum (identical k-mers in low-complexity
+ *            sequence, or 2^-32 coincidences).  Every such case is DETECTED -- an entering element equal to
+ *            the previous window's minimum, or a searched window whose minimum occurs twice -- and the strip
+ *            is handed to sketch_mask_kernel (the exact 64-bit pass) through a redo list.  Bits are only ever
+ *            set for proven minimizers, and setting a bit is idempotent, so both kernels may write one strip.
+ *
+ *   Why this is exact (c is a non-decreasing function of h0; "value" = c):
+ *   (1) If a window's minimum value v occurs once in it, that element is the 64-bit argmin, rightmost or not.
+ *   (2) Let windows s-1 and s have the same minimum value v.  Either the element entering at s has value v
+ *       (flagged: `hh == x_prev`), or the occurrences of v in window s are a subset of those in window s-1;
+ *       with (1) holding for the last searched window the argmin is unchanged.
+ *   (3) The first owned window of a strip and every changed window are searched; a search counts the
+ *       occurrences of the minimum inside the window and flags the strip unless there is exactly one.
+ *   (4) v == 2^32-1 (padding, or h0 >= 2^64 - 2^32, which Indexlr never emits when it is 2^64-1) flags.
+ *
+ * The hash of a lane's first k-mer is assembled from 16-base partial hashes that neighbouring lanes compute
+ * for their own 16 bases (two 8-base table lookups each) and exchange through LDS:
+ *   fwd = XOR_i srol^(k-16(i+1))(F16[L+i]) ^ (first k%16 bases of chunk L+k/16),   same for rev with sror.
+ */
+#pragma once
+#include "sketch_kernels.h"
+
+#define SK2_JOBCAP 1024 /* searched windows per strip; more (pathological sequence) hands the strip to the exact pass */
+#define SK2_QMAX 16     /* k <= 16 * SK2_QMAX */
+#define SK2_INF 0xFFFFFFFFu
+
+struct Sketch2Args {
+    SketchArgs A;
+    uint32_t *redo_list;   /* strips for the exact pass */
+    uint32_t *redo_count;
+    uint64_t max_word;     /* last word of `packed` that may be read */
+    int q16, r16;          /* k = 16 * q16 + r16 */
+    int force_redo;        /* tests: flag every strip */
+};
+
+__device__ __forceinline__ uint32_t sk2_bases16(const uint32_t *__restrict__ packed, uint64_t gp, uint64_t max_word)
+{
+    uint64_t wi = gp >> 4;
+    if (wi >= max_word) wi = max_word - 1; /* over-reads behind the last sequence: values never used */
+    const uint32_t a = (uint32_t)gp & 15u;
+    return ntl_alignbit(packed[wi + 1], packed[wi], 2u * a);
+}
+
+/* partial hashes of one 16-base chunk: Horner forms over its 16 bases {F, U} and over its first r bases {PF, PU} */
+__device__ __forceinline__ void sk2_chunk(uint32_t so, int r, const uint64_t (*__restrict__ g8)[2], const uint64_t (*g4)[2],
+                                          const uint64_t (*seed_tab)[2], uint64_t &F, uint64_t &U, uint64_t &PF, uint64_t &PU)
+{
+    const uint32_t w0 = so & 0xFFFFu, w1 = so >> 16;
+    const uint64_t e0f = g8[w0][0], e0u = g8[w0][1], e1f = g8[w1][0], e1u = g8[w1][1];
+    F = srot(e0f, 8, 8) ^ e1f;
+    U = srot(e0u, 25, 23) ^ e1u;
+    uint64_t f = 0, u = 0;
+    int j = 0;
+    if (r >= 8) { f = e0f; u = e0u; j = 8; }
+    if (r - j >= 4) {
+        const uint32_t byte = (so >> (2 * j)) & 255u;
+        f = srot(f, 4, 4) ^ g4[byte][0];
+        u = srot(u, 29, 27) ^ g4[byte][1];
+        j += 4;
+    }
+    for (; j < r; j++) {
+        const uint32_t c = (so >> (2 * j)) & 3u;
+        f = srol1(f) ^ seed_tab[c][0];
+        u = sror1(u) ^ seed_tab[c][1];
+    }
+    PF = f; PU = u;
+}
+
+template <int NT, int R0>
+__global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
+{
+    constexpr int C = 16;
+    constexpr int NBW = (C * NT + 31) / 32;
+    __shared__ uint32_t s_c[C * NT];            /* element (L,t) at [t*NT + L] */
+    __shared__ uint32_t s_t[2][NT + 128];       /* [0]: block minima; doubling levels ping-pong; INF behind NT */
+    __shared__ uint32_t s_pre0[NT + 4];         /* minimum of the first R0 elements of each block */
+    __shared__ uint32_t s_last[NT];             /* minimum of each lane's last window */
+    __shared__ uint64_t s_x[NT + SK2_QMAX + 1][2]; /* {F16, U16} of chunk L */
+    __shared__ uint64_t s_y[NT + SK2_QMAX + 1][2]; /* {PF, PU}: first k%16 bases of chunk L */
+    __shared__ uint32_t s_bits[NBW];
+    __shared__ uint16_t s_jobs[SK2_JOBCAP];
+    __shared__ uint32_t s_njobs, s_flag;
+    __shared__ uint64_t s_roll[16][2], s_seed[4][2];
+
+    const SketchArgs &A = B.A;
+    const int L = threadIdx.x;
+    const SketchGeom G = A.G;
+    const uint32_t per_xcd = gridDim.x >> 3; /* consecutive strips on one XCD (see sketch_mask_kernel) */
+    const uint32_t strip = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (strip >= A.nstrips) return;
+    const StripInfo I = A.strip_tab[strip];
+    if (I.seq == NTL_NONE || I.multi != 0) return; /* strips that cross non-ACGT runs: sketch_mask_kernel<.., MULTI = true> */
+    if (L < 16) { s_roll[L][0] = A.roll_tab[L][0]; s_roll[L][1] = A.roll_tab[L][1]; }
+    if (L < 4) { s_seed[L][0] = A.seed_tab[L][0]; s_seed[L][1] = A.seed_tab[L][1]; }
+    if (L < NBW) s_bits[L] = 0;
+    if (L < 128) { s_t[0][NT + L] = SK2_INF; s_t[1][NT + L] = SK2_INF; }
+    if (L < 4) s_pre0[NT + L] = SK2_INF;
+    if (L == 0) { s_njobs = 0; s_flag = B.force_redo ? 1u : 0u; }
+    __syncthreads();
+
+    const int64_t e_lane = (int64_t)I.E0 + (int64_t)L * C; /* ordinal of this lane's element t = 0 */
+    const uint64_t gp = (uint64_t)((int64_t)I.base + I.P0 + (int64_t)L * C);
+    const int k = G.k;
+
+    /* ---- phase 1a: 16-base partial hashes of the lane's own chunk (and of the chunks behind the strip) ---- */
+    const bool live = e_lane < (int64_t)I.M;            /* the lane has at least one k-mer of the sequence */
+    const bool feeds = e_lane - 16 * (int64_t)(B.q16 + 1) < (int64_t)I.M; /* its chunk is part of a live lane's first k-mer */
+    uint32_t so = 0;
+    if (feeds) {
+        so = sk2_bases16(A.T.packed, gp, B.max_word);
+        uint64_t F, U, PF, PU;
+        sk2_chunk(so, B.r16, A.g8, A.g4, s_seed, F, U, PF, PU);
+        s_x[L][0] = F; s_x[L][1] = U; s_y[L][0] = PF; s_y[L][1] = PU;
+    }
+    if (L <= B.q16) { /* chunks NT .. NT+q16 feed the last lanes */
+        const int64_t ev = (int64_t)I.E0 + (int64_t)(NT + L) * C;
+        if (ev - 16 * (int64_t)(B.q16 + 1) < (int64_t)I.M) {
+            const uint32_t sv = sk2_bases16(A.T.packed, gp + (uint64_t)NT * C, B.max_word);
+            uint64_t F, U, PF, PU;
+            sk2_chunk(sv, B.r16, A.g8, A.g4, s_seed, F, U, PF, PU);
+            s_x[NT + L][0] = F; s_x[NT + L][1] = U; s_y[NT + L][0] = PF; s_y[NT + L][1] = PU;
+        }
+    }
+    __syncthreads();
+
+    /* ---- phase 1b: first k-mer from the partials, then 15 rolling steps; c = h0 >> 32 ---- */
+    uint32_t c[C];
+#pragma unroll
+    for (int t = 0; t < C; t++) c[t] = SK2_INF;
+    if (live) {
+        uint64_t f = 0, u = 0;
+        for (int i = 0; i < B.q16; i++) {
+            if (i) { f = srot(f, 16, 16); u = srot(u, 17, 15); } /* srol^16, sror^16 */
+            f ^= s_x[L + i][0];
+            u ^= s_x[L + i][1];
+        }
+        if (B.r16) {
+            const uint32_t r = (uint32_t)B.r16;
+            if (B.q16) { f = srot(f, r, r); u = srot(u, 33u - r, 31u - r); }
+            f ^= s_y[L + B.q16][0];
+            u ^= s_y[L + B.q16][1];
+        }
+        uint64_t fwd = f;
+        uint64_t rev = srot(u, (uint32_t)(k - 1) % 33u, (uint32_t)(k - 1) % 31u);
+        c[0] = (uint32_t)((fwd + rev) >> 32);
+        const uint32_t si = sk2_bases16(A.T.packed, gp + (uint64_t)k, B.max_word);
+        /* table index of step t: in<<2 | out, two bits each at base t of si / so -> nibbles of two words */
+        const uint32_t zev = (so & 0x33333333u) | ((si & 0x33333333u) << 2);        /* even bases: nibble i <-> base 2i */
+        const uint32_t zod = ((so >> 2) & 0x33333333u) | (si & 0xCCCCCCCCu);         /* odd bases */
+#pragma unroll
+        for (int t = 1; t < C; t++) {
+            const int b = t - 1;
+            const uint32_t z = (b & 1) ? zod : zev;
+            const uint32_t idx = (z >> (4 * (b >> 1))) & 15u;
+            fwd = srol1(fwd) ^ s_roll[idx][0];
+            rev = sror1(rev ^ s_roll[idx][1]);
+            c[t] = (uint32_t)((fwd + rev) >> 32);
+        }
+        if (e_lane < 0 || e_lane + C > (int64_t)I.M) { /* strip edges only */
+#pragma unroll
+            for (int t = 0; t < C; t++) {
+                const int64_t e = e_lane + t;
+                if (e < 0 || e >= (int64_t)I.M) c[t] = SK2_INF;
+            }
+        }
+    }
+
+    /* ---- phase 2: stage, block minimum, minimum of the first R0 elements, suffix minima in place ---- */
+    uint32_t bm = SK2_INF, pre0 = SK2_INF;
+#pragma unroll
+    for (int t = 0; t < C; t++) {
+        s_c[t * NT + L] = c[t];
+        bm = c[t] < bm ? c[t] : bm;
+        if (t == R0 - 1) pre0 = bm;
+    }
+    s_t[0][L] = bm;
+    s_pre0[L] = pre0;
+#pragma unroll
+    for (int j = C - 2; j >= 0; j--) c[j] = c[j] < c[j + 1] ? c[j] : c[j + 1]; /* c[j] = min of elements j..15 */
+    __syncthreads();
+
+    /* ---- phase 3: minimum over the whole blocks L+1 .. L+a by doubling (range of a = two ranges of 2^p) ---- */
+    uint32_t fa = SK2_INF;
+    if (G.a >= 1) {
+        int p = 0;
+        while ((2 << p) <= G.a) p++;
+        int cur = 0;
+        for (int lv = 0; lv < p; lv++) {
+            const uint32_t m0 = s_t[cur][L], m1 = s_t[cur][L + (1 << lv)];
+            s_t[cur ^ 1][L] = m0 < m1 ? m0 : m1;
+            __syncthreads();
+            cur ^= 1;
+        }
+        const uint32_t m0 = s_t[cur][L + 1], m1 = s_t[cur][L + 1 + G.a - (1 << p)];
+        fa = m0 < m1 ? m0 : m1;
+    }
+    /* levels 2, 4, .. overwrote s_t[0]; the search below reads the block minima from it again */
+    __syncthreads();
+    s_t[0][L] = bm;
+    __syncthreads();
+
+    /* ---- phase 4: every window starting in the own block ---- */
+    const bool own = L < G.LW && e_lane + G.w <= (int64_t)I.M;
+    uint32_t chg = 0;    /* bit j: window j has another minimum value than window j-1 */
+    uint32_t x0 = SK2_INF, xl = SK2_INF;
+    bool tie = false;
+    if (own) {
+        const int Lr = L + G.a + 1;
+        uint32_t P = fa;
+        {
+            const uint32_t hh = s_pre0[Lr];
+            P = hh < P ? hh : P;
+        }
+        const bool inside = e_lane >= 0 && e_lane + (C - 1) + G.w <= (int64_t)I.M; /* all 16 windows lie in the sequence */
+        uint32_t xp = 0;
+#pragma unroll
+        for (int j = 0; j < C; j++) {
+            const int rt = R0 + j;
+            uint32_t hh = 0;
+            if (j > 0) {
+                const int tp = rt - 1 < C ? rt - 1 : rt - 1 - C;
+                const int Lb = rt - 1 < C ? Lr : Lr + 1;
+                hh = s_c[tp * NT + Lb];
+                P = hh < P ? hh : P;
+            }
+            const uint32_t x = P < c[j] ? P : c[j];
+            if (j == 0) { x0 = x; xl = x; }
+            else {
+                bool valid = true;
+                if (!inside) valid = e_lane + j + G.w <= (int64_t)I.M && e_lane + j >= 0;
+                if (valid) {
+                    chg |= (x != xp ? 1u : 0u) << j;
+                    tie = tie || hh == xp;
+                    xl = x;
+                }
+            }
+            xp = x;
+        }
+    }
+    s_last[L] = xl;
+    __syncthreads();
+    if (own) {
+        /* window (L,0) against the last window of lane L-1; window (0,0) belongs to the previous strip, so the
+           strip's first owned window (0,1) is always searched */
+        if (L == 0) chg |= 2u;
+        else {
+            const uint32_t xprev = s_last[L - 1];
+            const uint32_t hh0 = s_c[((R0 + 15) & 15) * NT + (R0 ? L + G.a + 1 : L + G.a)]; /* the element that entered at window (L,0) */
+            chg |= (x0 != xprev) ? 1u : 0u;
+            tie = tie || hh0 == xprev;
+        }
+        if (L == 0 && e_lane + 1 + G.w > (int64_t)I.M) chg &= ~2u; /* window (0,1) does not exist */
+        if (tie) s_flag = 2u;
+#ifdef NTL_SIM
+        if (tie && getenv("NTL_SK2_DEBUG")) fprintf(stderr, "strip %u lane %d tie chg=%x x0=%x M=%u E0=%d\n", strip, L, chg, x0, I.M, I.E0);
+#endif
+        /* ---- phase 5: one job per changed window ---- */
+        if (chg) {
+            const uint32_t n = (uint32_t)__popc(chg);
+            uint32_t at = atomicAdd(&s_njobs, n);
+            uint32_t m = chg;
+            while (m) {
+                const int j = __ffs(m) - 1;
+                m &= m - 1;
+                if (at < SK2_JOBCAP) s_jobs[at] = (uint16_t)(L * C + j);
+                at++;
+            }
+        }
+    }
+    __syncthreads();
+
+    /* ---- phase 6: position of the minimum of every changed window ---- */
+    {
+        uint32_t njobs = s_njobs;
+        if (njobs > SK2_JOBCAP) { njobs = SK2_JOBCAP; if (L == 0) s_flag = 1u; }
+        for (uint32_t i = L; i < njobs; i += NT) {
+            const uint32_t g = s_jobs[i], ge = g + (uint32_t)G.w; /* window = strip elements [g, ge) */
+            const uint32_t b0 = g >> 4, b1 = (ge - 1) >> 4;
+            /* minimum over the whole blocks that cover the window: if its only occurrence lies inside the window it
+               is the window's minimum and its only occurrence there */
+            uint32_t m = SK2_INF, bb = 0, nb = 0;
+            for (uint32_t b = b0; b <= b1; b++) {
+                const uint32_t v = s_t[0][b];
+                if (v < m) { m = v; bb = b; nb = 1; }
+                else if (v == m) nb++;
+            }
+            uint32_t pos = 0, ne = 0;
+            if (nb == 1) {
+                for (uint32_t t = 0; t < 16; t++)
+                    if (s_c[t * NT + bb] == m) { pos = bb * 16 + t; ne++; }
+            }
+            bool ok = nb == 1 && ne == 1 && pos >= g && pos < ge && m != SK2_INF;
+            if (!ok) {
+                /* element by element at the two ends, block minima in between */
+                uint32_t v = SK2_INF;
+                for (uint32_t e = g; e < ge; ) {
+                    if ((e & 15u) == 0 && e + 16 <= ge) { const uint32_t q = s_t[0][e >> 4]; v = q < v ? q : v; e += 16; }
+                    else { const uint32_t q = s_c[(e & 15u) * NT + (e >> 4)]; v = q < v ? q : v; e++; }
+                }
+                ne = 0;
+                for (uint32_t e = g; e < ge; ) {
+                    if ((e & 15u) == 0 && e + 16 <= ge && s_t[0][e >> 4] != v) { e += 16; continue; }
+                    if (s_c[(e & 15u) * NT + (e >> 4)] == v) { pos = e; ne++; }
+                    e++;
+                }
+                ok = ne == 1 && v != SK2_INF;
+            }
+            if (ok) atomicOr(&s_bits[pos >> 5], 1u << (pos & 31u));
+            else {
+                s_flag = 8u;
+#ifdef NTL_SIM
+                if (getenv("NTL_SK2_DEBUG")) fprintf(stderr, "strip %u job g=%u search failed nb=%u ne=%u m=%x M=%u E0=%d\n", strip, g, nb, ne, m, I.M, I.E0);
+#endif
+            }
+        }
+    }
+    __syncthreads();
+
+    /* ---- phase 7: proven minimizers to the global bitmask; flagged strips to the exact pass ---- */
+    if (L < NBW) {
+        const uint32_t word = s_bits[L];
+        if (word) {
+            const uint64_t g0 = (uint64_t)((int64_t)I.base + I.P0 + 32 * (int64_t)L);
+            const uint32_t sh = (uint32_t)g0 & 31u;
+            atomicOr(&A.mask[g0 >> 5], word << sh);
+            if (sh && (word >> (32u - sh))) atomicOr(&A.mask[(g0 >> 5) + 1], word >> (32u - sh));
+        }
+    }
+    if (L == 0 && s_flag) B.redo_list[atomicAdd(B.redo_count, 1u)] = strip;
+}

@@ -128,6 +128,8 @@ struct SketchArgs {
     uint64_t seed_tab[4][2];     /* [c] = {seed[c], seed[3-c]} */
     const uint64_t (*g4)[2];     /* [256] four-base init table (dev_common.h hash_init) */
     const uint64_t (*g8)[2];     /* [65536] eight-base init table */
+    const uint32_t *redo_list;   /* not NULL: process exactly these strips (flagged by sketch_fast_kernel), looping */
+    const uint32_t *redo_count;
 };
 
 /* 16-bit strip-local index back to 32 bits (0xFFFF -> NTL_NONE) */
@@ -146,7 +148,7 @@ struct NtlFalse { static constexpr bool value = false; };
  * (which remote block and which whole-block minimum a window uses is then known at compile time).
  */
 template <int C, int NT, bool MULTI, int R0>
-__global__ __launch_bounds__(NT) void sketch_mask_kernel(SketchArgs A)
+__device__ __forceinline__ void sketch_mask_strip(const SketchArgs &A, const uint32_t strip)
 {
     constexpr int NBW = (C * NT + 31) / 32; /* words of the strip-local emission bitmask */
     __shared__ uint64_t s_h[C * NT];  /* element (L,t) at [t*NT + L] */
@@ -159,10 +161,6 @@ __global__ __launch_bounds__(NT) void sketch_mask_kernel(SketchArgs A)
     const int L = threadIdx.x;
     const SketchGeom G = A.G; /* G.r0 == R0 (the host picks the instantiation) */
 
-    /* Workgroups are handed to the eight XCDs round-robin, and each XCD has its own L2: consecutive strips
-       (which share their halo bases and their strip-table lines) go to one XCD, not to eight. */
-    const uint32_t per_xcd = gridDim.x >> 3; /* the grid is a multiple of 8 */
-    const uint32_t strip = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
     if (strip >= A.nstrips) return;
     const StripInfo I = A.strip_tab[strip];
     if (I.seq == NTL_NONE) return; /* the grid is an upper bound of the number of strips */
@@ -376,6 +374,23 @@ __global__ __launch_bounds__(NT) void sketch_mask_kernel(SketchArgs A)
             }
         }
     }
+}
+
+template <int C, int NT, bool MULTI, int R0>
+__global__ __launch_bounds__(NT) void sketch_mask_kernel(SketchArgs A)
+{
+    if (A.redo_list) { /* the exact pass over the strips sketch_fast_kernel could not decide */
+        const uint32_t n = *A.redo_count;
+        for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+            sketch_mask_strip<C, NT, MULTI, R0>(A, A.redo_list[i]);
+            __syncthreads(); /* the strip's LDS arrays are reused */
+        }
+        return;
+    }
+    /* Workgroups are handed to the eight XCDs round-robin, and each XCD has its own L2: consecutive strips
+       (which share their halo bases and their strip-table lines) go to one XCD, not to eight. */
+    const uint32_t per_xcd = gridDim.x >> 3; /* the grid is a multiple of 8 */
+    sketch_mask_strip<C, NT, MULTI, R0>(A, (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3));
 }
 
 /* ---------------------------------------------------------------------------- emit -------- */

@@ -213,3 +213,109 @@ def test_anchor_function_matches_reference(dev):
     """ntlink_amd.anchor.get_accepted_anchor_contigs (gap-fill re-mapping entry point, bin/ntlink_utils.py:200-268)
     against vectors produced by the imported reference."""
     assert pc.check_anchor_cases(dev) == 125
+
+
+# ---------------------------------------------------------------- round 2: the 32-bit window pass and its exact fallback
+
+def _rand_seq(rng, n):
+    return bytes(synth.random_bases(rng, n))
+
+
+def test_fast_window_pass_decides_random_sequence_alone(dev):
+    """sketch_fast_kernel: on random sequence no strip needs the exact pass (and the sketch is the oracle's)."""
+    rng = np.random.default_rng(5)
+    seqs = [_rand_seq(rng, n) for n in (90000, 4200, 170000, 300, 131, 5000, 1_000_000)]
+    for k, w in ((32, 100), (32, 250), (24, 100), (40, 31), (15, 16), (20, 33), (64, 64), (100, 70), (32, 1000), (17, 3000)):
+        with dev.batch(seqs) as b, dev.sketch(b, k, w) as sk:
+            assert sk.strips > 0 and sk.redo_strips == 0, (k, w, sk.strips, sk.redo_strips)
+        pc.check_sketch(dev, seqs, k, w)
+
+
+def test_fast_window_pass_hands_ties_to_the_exact_pass(dev, monkeypatch):
+    """Identical k-mers inside one window tie on the 32-bit key: detected, redone by the exact 64-bit pass."""
+    rng = np.random.default_rng(6)
+    unit = _rand_seq(rng, 37)
+    seqs = [unit * 1500, b"A" * 30000, _rand_seq(rng, 25000) + unit * 40 + _rand_seq(rng, 25000), _rand_seq(rng, 60000),
+            b"AC" * 12000 + _rand_seq(rng, 7000)]
+    for k, w in ((32, 100), (24, 40), (32, 250), (7, 47)):
+        with dev.batch(seqs) as b, dev.sketch(b, k, w) as sk:
+            assert 0 < sk.redo_strips < sk.strips
+        pc.check_sketch(dev, seqs, k, w)
+
+
+@pytest.mark.parametrize("env", [{"NTL_SKETCH_FORCE_REDO": "1"}, {"NTL_SKETCH_FAST": "0"}, {"NTL_SKETCH_NT": "128"}, {"NTL_SKETCH_NT": "256"},
+                                 {"NTL_SKETCH_NT": "128", "NTL_SKETCH_FAST": "0"}, {"NTL_SKETCH_C": "4"}, {"NTL_SKETCH_CAP_GUESS": "1000"}],
+                         ids=lambda e: ",".join(f"{k[11:]}={v}" for k, v in e.items()))
+def test_sketch_variants_on_the_gpu(dev, monkeypatch, env):
+    """Every tuning variant of the window pass and the second emit pass (record array denser than guessed) on the GPU,
+    on the fuzz sequences (ties, N patterns, boundary lengths) and the edge cases."""
+    import fuzz_cases
+    for kk, vv in env.items():
+        monkeypatch.setenv(kk, vv)
+    for seed, k, w in ((1, 32, 100), (2, 32, 250), (3, 24, 100), (7, 40, 16)):
+        pc.check_sketch(dev, fuzz_cases.fuzz_sequences(seed), k, w)
+    pc.check_sketch(dev, pc.edge_sequences(), 32, 100)
+
+
+@pytest.mark.parametrize("name,n_reads", [("C3", 100_000), ("C5", 100_000)])
+def test_full_size_assembly_parity(dev, name, n_reads):
+    """BASELINE configs[2] / configs[4] at FULL assembly size: 3 Gbp in 5000 contigs on the device (same generator as
+    bench.py), every contig minimizer and the index size against the oracle, then 100 k sampled reads (ONT 15 kb at
+    k32 w250; HiFi 20 kb at k24 w100 --sensitive) mapped on both sides, records byte-equal."""
+    wl = synth.DeviceWorkload(dev, name, with_reads=False)
+    W = wl.W
+    k, w = W["k"], W["w"]
+    cbuf, coff = wl.contigs.download()
+    assert int(coff[-1]) > 2_900_000_000 and len(coff) - 1 == 5000
+    with dev.sketch(wl.contigs, k, w) as csk, dev.index(csk, wl.ctg_len) as ix:
+        assert csk.redo_strips == 0
+        c_off, ch, cp, cs = csk.download()
+        o_off, oh, op, os_ = oracle.sketch_batch(cbuf, coff, k, w)
+        assert np.array_equal(c_off, o_off) and np.array_equal(ch, oh) and np.array_equal(cp, op) and np.array_equal(cs, os_)
+        del ch, cp, cs, c_off, cbuf
+        from helpers import contig_ids
+        oix = oracle.Index(oh, contig_ids(o_off), op, os_)
+        assert len(ix) == len(oix) > 20_000_000
+        rb, rlen = wl.make_reads(n_reads * W["read_len"], seed=(5, 1))
+        rbuf, roff = rb.download()
+        params = dict(k=k, z=1000, x=0.0, sensitive=W["sensitive"], repeat_filter=False)
+        with dev.sketch(rb, k, w) as rsk, dev.map(ix, rsk, rlen, **params) as res:
+            got = res.download()
+            r_off, rh, rp, rs = rsk.download()
+        rb.close()
+    q_off, qh, qp, qs = oracle.sketch_batch(rbuf, roff, k, w)
+    assert np.array_equal(r_off, q_off) and np.array_equal(rh, qh) and np.array_equal(rp, qp) and np.array_equal(rs, qs)
+    exp = oracle.map_reads(oix, wl.ctg_len, q_off, rlen, qh, qp, qs, threads=0, **params)
+    pc.assert_same_records(got, exp)
+    assert len(got["maps"]) > 0.9 * len(rlen) and len(rlen) >= n_reads * 0.99
+    wl.close()
+
+
+def test_synth_generator_on_the_gpu(dev):
+    """The device-side workload generator (bench / full-size tests): exact slices, reverse complements, determinism,
+    error rates of the read model."""
+    g = dev.synth_genome(1, [500_000, 300_000, 17])
+    buf, off = g.download()
+    cnt = np.bincount(buf, minlength=128)[[65, 67, 71, 84]]
+    assert cnt.sum() == 800_017 and cnt.min() > 0.24 * cnt.sum()
+    rng = np.random.default_rng(0)
+    n = 300
+    ln = rng.integers(1, 20000, n); sq = rng.integers(0, 2, n); rv = rng.integers(0, 2, n).astype(np.uint8)
+    st = (rng.random(n) * (np.array([500_000, 300_000])[sq] - ln)).astype(np.int64)
+    s = dev.synth_slices(g, 7, sq, st, ln, rv)
+    sb, so = s.download()
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    for i in range(n):
+        src = bytes(buf[int(off[sq[i]]) + st[i]: int(off[sq[i]]) + st[i] + ln[i]])
+        assert bytes(sb[int(so[i]):int(so[i + 1])]) == (src.translate(comp)[::-1] if rv[i] else src)
+    ln2 = np.full(50, 15000); st2 = rng.integers(0, 400_000, 50); sq2 = np.zeros(50, int); rv2 = rng.integers(0, 2, 50).astype(np.uint8)
+    r1 = dev.synth_slices(g, 9, sq2, st2, ln2, rv2, sub=0.02, ins=0.015, dele=0.015)
+    r2 = dev.synth_slices(g, 9, sq2, st2, ln2, rv2, sub=0.02, ins=0.015, dele=0.015)
+    a, ao = r1.download()
+    assert np.array_equal(a, r2.download()[0]) and int(ao[-1]) == 50 * 15000
+    # about (1 - 0.05)^21 of the 21-mers of a read survive: its sketch must still hit the source
+    with dev.sketch(g, 21, 10) as gsk, dev.index(gsk, [500_000, 300_000, 17]) as ix, dev.sketch(r1, 21, 10) as rsk, \
+            dev.map(ix, rsk, ln2, k=21, z=10) as res:
+        assert 0.2 < res.n_index_hits / rsk.count < 0.6
+    for h in (g, s, r1, r2):
+        h.close()

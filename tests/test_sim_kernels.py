@@ -1,6 +1,7 @@
 """The product's kernel source executed under the SIMT mock (tests/sim: one pthread per lane), checked
 against the oracle.  This is a CPU debugging aid for the kernels' logic and for sanitizers -- the parity
 tests proper are tests/test_gpu_parity.py on a real MI355X."""
+import numpy as np
 import pytest
 
 import parity_cases as pc
@@ -177,3 +178,43 @@ def test_sim_fuzz_mapping(dev, seed):
     kw = dict(k=24, z=[1000, 500, 1000, 1][seed % 4], x=[0.0, 0.0, 1.2, 0.4][seed % 4], sensitive=bool(seed & 1),
               repeat_filter=bool(seed & 2))
     pc.check_pair_arrays(dev, *arrs, **kw)
+
+
+def _rand_seq(rng, n):
+    return bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), n))
+
+
+def test_sim_fast_window_pass_decides_random_sequence_alone(dev):
+    """sketch_fast_kernel (32-bit keys, searched change points): on random sequence no strip needs the exact pass,
+    and the result is the oracle's."""
+    rng = np.random.default_rng(5)
+    seqs = [_rand_seq(rng, n) for n in (9000, 4200, 17000, 300, 131, 5000)]
+    for k, w in ((32, 100), (32, 250), (24, 100), (40, 31), (15, 16), (20, 33), (64, 64), (100, 70)):
+        with dev.batch(seqs) as b, dev.sketch(b, k, w) as sk:
+            assert sk.strips > 0 and sk.redo_strips == 0, (k, w, sk.strips, sk.redo_strips)
+        pc.check_sketch(dev, seqs, k, w)
+    with dev.batch(seqs) as b, dev.sketch(b, 7, 47) as sk:  # 4^7 distinct k-mers: identical k-mers do share windows
+        assert 0 < sk.redo_strips < sk.strips
+    pc.check_sketch(dev, seqs, 7, 47)
+
+
+def test_sim_fast_window_pass_hands_ties_to_the_exact_pass(dev, monkeypatch):
+    """Identical k-mers inside one window (tandem repeats, homopolymers) tie on the 32-bit key: those strips must be
+    detected and redone by the exact 64-bit pass; forcing every strip through both passes changes nothing."""
+    rng = np.random.default_rng(6)
+    unit = _rand_seq(rng, 37)
+    seqs = [unit * 150, b"A" * 3000, _rand_seq(rng, 2500) + unit * 40 + _rand_seq(rng, 2500), _rand_seq(rng, 6000),
+            b"AC" * 1200 + _rand_seq(rng, 700)]
+    for k, w in ((32, 100), (24, 40), (32, 250)):
+        with dev.batch(seqs) as b, dev.sketch(b, k, w) as sk:
+            assert 0 < sk.redo_strips < sk.strips
+        pc.check_sketch(dev, seqs, k, w)
+    monkeypatch.setenv("NTL_SKETCH_FORCE_REDO", "1")
+    with dev.batch(seqs) as b, dev.sketch(b, 32, 100) as sk:
+        assert sk.redo_strips == sk.strips
+    pc.check_sketch(dev, seqs, 32, 100)
+    monkeypatch.delenv("NTL_SKETCH_FORCE_REDO")
+    monkeypatch.setenv("NTL_SKETCH_FAST", "0")
+    with dev.batch(seqs) as b, dev.sketch(b, 32, 100) as sk:
+        assert sk.redo_strips == 0
+    pc.check_sketch(dev, seqs, 32, 100)
