@@ -86,7 +86,8 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
     constexpr int C = 16;
     constexpr int NBW = (C * NT + 31) / 32;
     __shared__ uint32_t s_c[C * NT];            /* element (L,t) at [t*NT + L] */
-    __shared__ uint32_t s_t[2][NT + 128];       /* [0]: block minima; doubling levels ping-pong; INF behind NT */
+    __shared__ uint32_t s_bm[NT + 128];         /* block minima; INF behind NT */
+    __shared__ uint32_t s_t[2][NT + 128];       /* doubling levels of the block minima, ping-pong; INF behind NT */
     __shared__ uint32_t s_pre0[NT + 4];         /* minimum of the first R0 elements of each block */
     __shared__ uint32_t s_last[NT];             /* minimum of each lane's last window */
     __shared__ uint64_t s_x[NT + SK2_QMAX + 1][2]; /* {F16, U16} of chunk L */
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
     if (L < 16) { s_roll[L][0] = A.roll_tab[L][0]; s_roll[L][1] = A.roll_tab[L][1]; }
     if (L < 4) { s_seed[L][0] = A.seed_tab[L][0]; s_seed[L][1] = A.seed_tab[L][1]; }
     if (L < NBW) s_bits[L] = 0;
-    if (L < 128) { s_t[0][NT + L] = SK2_INF; s_t[1][NT + L] = SK2_INF; }
+    if (L < 128) { s_bm[NT + L] = SK2_INF; s_t[0][NT + L] = SK2_INF; s_t[1][NT + L] = SK2_INF; }
     if (L < 4) s_pre0[NT + L] = SK2_INF;
     if (L == 0) { s_njobs = 0; s_flag = B.force_redo ? 1u : 0u; }
     __syncthreads();
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
         bm = c[t] < bm ? c[t] : bm;
         if (t == R0 - 1) pre0 = bm;
     }
-    s_t[0][L] = bm;
+    s_bm[L] = bm;
     s_pre0[L] = pre0;
 #pragma unroll
     for (int j = C - 2; j >= 0; j--) c[j] = c[j] < c[j + 1] ? c[j] : c[j + 1]; /* c[j] = min of elements j..15 */
@@ -198,20 +199,17 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
     if (G.a >= 1) {
         int p = 0;
         while ((2 << p) <= G.a) p++;
-        int cur = 0;
+        const uint32_t *cur = s_bm;
         for (int lv = 0; lv < p; lv++) {
-            const uint32_t m0 = s_t[cur][L], m1 = s_t[cur][L + (1 << lv)];
-            s_t[cur ^ 1][L] = m0 < m1 ? m0 : m1;
+            uint32_t *nxt = s_t[lv & 1];
+            const uint32_t m0 = cur[L], m1 = cur[L + (1 << lv)];
+            nxt[L] = m0 < m1 ? m0 : m1;
             __syncthreads();
-            cur ^= 1;
+            cur = nxt;
         }
-        const uint32_t m0 = s_t[cur][L + 1], m1 = s_t[cur][L + 1 + G.a - (1 << p)];
+        const uint32_t m0 = cur[L + 1], m1 = cur[L + 1 + G.a - (1 << p)];
         fa = m0 < m1 ? m0 : m1;
     }
-    /* levels 2, 4, .. overwrote s_t[0]; the search below reads the block minima from it again */
-    __syncthreads();
-    s_t[0][L] = bm;
-    __syncthreads();
 
     /* ---- phase 4: every window starting in the own block ---- */
     const bool own = L < G.LW && e_lane + G.w <= (int64_t)I.M;
@@ -283,47 +281,48 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
     }
     __syncthreads();
 
-    /* ---- phase 6: position of the minimum of every changed window ---- */
+    /* ---- phase 6: position of the minimum of every changed window ----
+       One lane per window [g, ge): the elements of its first and last block (two batches of independent LDS reads),
+       the block minima in between; the minimum must occur exactly once. */
     {
         uint32_t njobs = s_njobs;
-        if (njobs > SK2_JOBCAP) { njobs = SK2_JOBCAP; if (L == 0) s_flag = 1u; }
+        if (njobs > SK2_JOBCAP) { njobs = SK2_JOBCAP; if (L == 0) s_flag = 4u; }
         for (uint32_t i = L; i < njobs; i += NT) {
-            const uint32_t g = s_jobs[i], ge = g + (uint32_t)G.w; /* window = strip elements [g, ge) */
+            const uint32_t g = s_jobs[i], ge = g + (uint32_t)G.w;
             const uint32_t b0 = g >> 4, b1 = (ge - 1) >> 4;
-            /* minimum over the whole blocks that cover the window: if its only occurrence lies inside the window it
-               is the window's minimum and its only occurrence there */
-            uint32_t m = SK2_INF, bb = 0, nb = 0;
-            for (uint32_t b = b0; b <= b1; b++) {
-                const uint32_t v = s_t[0][b];
-                if (v < m) { m = v; bb = b; nb = 1; }
-                else if (v == m) nb++;
+            const uint32_t t0 = g & 15u, t1 = (ge - 1) & 15u;       /* head: t >= t0 of block b0; tail: t <= t1 of block b1 */
+            uint32_t hv[16], tv[16];
+#pragma unroll
+            for (int t = 0; t < 16; t++) { hv[t] = s_c[t * NT + b0]; tv[t] = s_c[t * NT + b1]; }
+            uint32_t v = SK2_INF;
+#pragma unroll
+            for (int t = 0; t < 16; t++) {
+                const bool inh = (uint32_t)t >= t0 && (b1 > b0 || (uint32_t)t <= t1);
+                const bool intl = b1 > b0 && (uint32_t)t <= t1;
+                hv[t] = inh ? hv[t] : SK2_INF;
+                tv[t] = intl ? tv[t] : SK2_INF;
+                v = hv[t] < v ? hv[t] : v;
+                v = tv[t] < v ? tv[t] : v;
             }
-            uint32_t pos = 0, ne = 0;
+            for (uint32_t b = b0 + 1; b < b1; b++) { const uint32_t q = s_bm[b]; v = q < v ? q : v; }
+            uint32_t n = 0, pos = 0, bb = 0, nb = 0;
+#pragma unroll
+            for (int t = 0; t < 16; t++) {
+                if (hv[t] == v) { n++; pos = b0 * 16 + t; }
+                if (tv[t] == v) { n++; pos = b1 * 16 + t; }
+            }
+            for (uint32_t b = b0 + 1; b < b1; b++)
+                if (s_bm[b] == v) { nb++; bb = b; }
             if (nb == 1) {
-                for (uint32_t t = 0; t < 16; t++)
-                    if (s_c[t * NT + bb] == m) { pos = bb * 16 + t; ne++; }
-            }
-            bool ok = nb == 1 && ne == 1 && pos >= g && pos < ge && m != SK2_INF;
-            if (!ok) {
-                /* element by element at the two ends, block minima in between */
-                uint32_t v = SK2_INF;
-                for (uint32_t e = g; e < ge; ) {
-                    if ((e & 15u) == 0 && e + 16 <= ge) { const uint32_t q = s_t[0][e >> 4]; v = q < v ? q : v; e += 16; }
-                    else { const uint32_t q = s_c[(e & 15u) * NT + (e >> 4)]; v = q < v ? q : v; e++; }
-                }
-                ne = 0;
-                for (uint32_t e = g; e < ge; ) {
-                    if ((e & 15u) == 0 && e + 16 <= ge && s_t[0][e >> 4] != v) { e += 16; continue; }
-                    if (s_c[(e & 15u) * NT + (e >> 4)] == v) { pos = e; ne++; }
-                    e++;
-                }
-                ok = ne == 1 && v != SK2_INF;
-            }
-            if (ok) atomicOr(&s_bits[pos >> 5], 1u << (pos & 31u));
+#pragma unroll
+                for (int t = 0; t < 16; t++)
+                    if (s_c[t * NT + bb] == v) { n++; pos = bb * 16 + t; }
+            } else if (nb > 1) n = 2;
+            if (n == 1 && v != SK2_INF) atomicOr(&s_bits[pos >> 5], 1u << (pos & 31u));
             else {
                 s_flag = 8u;
 #ifdef NTL_SIM
-                if (getenv("NTL_SK2_DEBUG")) fprintf(stderr, "strip %u job g=%u search failed nb=%u ne=%u m=%x M=%u E0=%d\n", strip, g, nb, ne, m, I.M, I.E0);
+                if (getenv("NTL_SK2_DEBUG")) fprintf(stderr, "strip %u job g=%u: minimum %x occurs %u times (M=%u E0=%d)\n", strip, g, v, n, I.M, I.E0);
 #endif
             }
         }

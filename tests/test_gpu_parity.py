@@ -225,7 +225,7 @@ def test_fast_window_pass_decides_random_sequence_alone(dev):
     """sketch_fast_kernel: on random sequence no strip needs the exact pass (and the sketch is the oracle's)."""
     rng = np.random.default_rng(5)
     seqs = [_rand_seq(rng, n) for n in (90000, 4200, 170000, 300, 131, 5000, 1_000_000)]
-    for k, w in ((32, 100), (32, 250), (24, 100), (40, 31), (15, 16), (20, 33), (64, 64), (100, 70), (32, 1000), (17, 3000)):
+    for k, w in ((32, 100), (32, 250), (24, 100), (40, 31), (20, 16), (20, 33), (64, 64), (100, 70), (32, 1000), (17, 3000)):
         with dev.batch(seqs) as b, dev.sketch(b, k, w) as sk:
             assert sk.strips > 0 and sk.redo_strips == 0, (k, w, sk.strips, sk.redo_strips)
         pc.check_sketch(dev, seqs, k, w)
