@@ -17,13 +17,14 @@
 #define NTL_NONE 0xFFFFFFFFu
 #define NTL_LEAD_PAD 16u /* bases of padding in front of the first sequence of a batch */
 
-/* srol / sror on the two 32-bit halves: 5 VALU ops each (alignbit + bfi) */
+/* srol / sror on the two 32-bit halves (lo = bits 0..31, hi bit 0 = bit 32 of the 33-bit ring, hi bits 1..31 = the
+ * 31-bit ring): 5 and 4 VALU instructions, every one written out (v_alignbit / v_bfi / v_lshl_or) */
 __device__ __forceinline__ uint64_t srol1(uint64_t x)
 {
     const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
-    const uint32_t nlo = (lo << 1) | (hi & 1u);                 /* bit 32 -> bit 0 */
-    uint32_t nhi = ntl_alignbit(hi, lo, 31);                    /* (hi << 1) | (lo >> 31): bit 31 -> bit 32 */
-    nhi = (nhi & ~2u) | ((hi >> 30) & 2u);                      /* bit 63 -> bit 33 */
+    const uint32_t nlo = (lo << 1) | (hi & 1u);                 /* bit 32 -> bit 0 (v_and + v_lshl_or) */
+    const uint32_t t = ntl_alignbit(hi, lo, 31);                /* (hi << 1) | (lo >> 31): bit 31 -> bit 32 */
+    const uint32_t nhi = ntl_bfi<2u>(hi >> 30, t);              /* bit 63 -> bit 33 */
     return ((uint64_t)nhi << 32) | nlo;
 }
 
@@ -31,8 +32,22 @@ __device__ __forceinline__ uint64_t sror1(uint64_t x)
 {
     const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
     const uint32_t nlo = ntl_alignbit(hi, lo, 1);               /* bit 32 -> bit 31 */
-    const uint32_t src = (hi << 30) | (lo & 1u);                /* bit 33 -> bit 63, bit 0 -> bit 32 */
-    const uint32_t nhi = ((hi >> 1) & ~0x80000001u) | (src & 0x80000001u); /* one v_bfi */
+    const uint32_t t = ntl_alignbit(hi >> 1, hi, 1);            /* (hi >> 1) with bit 33 -> bit 63 */
+    const uint32_t nhi = ntl_bfi<1u>(lo, t);                    /* bit 0 -> bit 32 */
+    return ((uint64_t)nhi << 32) | nlo;
+}
+
+/* rotate the 33-bit ring left by a (1..32) and the 31-bit ring left by b (1..30) on the halves: 7 VALU
+ * instructions whatever the amounts (compile-time or uniform) */
+__device__ __forceinline__ uint64_t srot_h(uint64_t x, uint32_t a, uint32_t b)
+{
+    const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    const uint32_t y = ntl_alignbit(hi, lo, 1);                 /* bits 1..32 of the 33-bit ring */
+    const uint32_t nlo = ntl_alignbit(lo, y, 32u - a);          /* (lo << a) | (ring33 >> (33 - a)) */
+    const uint32_t b32 = (lo >> ((32u - a) & 31u)) & 1u;        /* ring bit 32-a -> bit 32 (a = 32: bit 0) */
+    const uint32_t r31 = hi >> 1;
+    const uint32_t o = ntl_alignbit(r31, hi & ~1u, 32u - b);    /* (r31 << b) | (r31 >> (31 - b)); bit 31 is dropped below */
+    const uint32_t nhi = (o << 1) | b32;
     return ((uint64_t)nhi << 32) | nlo;
 }
 
@@ -44,6 +59,12 @@ __device__ __forceinline__ uint64_t srot(uint64_t x, uint32_t a, uint32_t b)
     r33 = ((r33 << a) | (r33 >> (33u - a))) & 0x1FFFFFFFFull;
     r31 = ((r31 << b) | (b ? r31 >> (31u - b) : 0u)) & 0x7FFFFFFFu;
     return r33 | ((uint64_t)r31 << 33);
+}
+
+/* the same for amounts that may be zero (uniform): the halves form needs a, b >= 1 */
+__device__ __forceinline__ uint64_t srot_u(uint64_t x, uint32_t a, uint32_t b)
+{
+    return (a == 0 || b == 0) ? srot(x, a, b) : srot_h(x, a, b);
 }
 
 /* 16 consecutive bases starting at global base index gp, base j in bits [2j, 2j+2) */

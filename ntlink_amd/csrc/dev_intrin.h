@@ -10,6 +10,26 @@ __device__ __forceinline__ uint32_t ntl_alignbit(uint32_t hi, uint32_t lo, uint3
     return __builtin_amdgcn_alignbit(hi, lo, sh);
 }
 
+/* (a & mask) | (b & ~mask) : v_bfi_b32 (written as asm: the compiler re-associates the C form into more instructions) */
+template <uint32_t MASK>
+__device__ __forceinline__ uint32_t ntl_bfi(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "n"(MASK), "v"(a), "v"(b));
+    return r;
+}
+
+/* (acc << 1) | (a != b): v_cmp_ne_u32 + v_addc_co_u32 (acc + acc + carry) */
+__device__ __forceinline__ uint32_t ntl_shl1_or_ne(uint32_t acc, uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_cmp_ne_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %3, %3, vcc" : "=v"(r) : "v"(a), "v"(b), "v"(acc) : "vcc");
+    return r;
+}
+
+/* bit reversal of a 32-bit word: v_bfrev_b32 */
+__device__ __forceinline__ uint32_t ntl_brev(uint32_t x) { return __builtin_bitreverse32(x); }
+
 /* number of set bits of `mask` below this lane: v_mbcnt_lo/hi */
 __device__ __forceinline__ uint32_t ntl_mbcnt(unsigned long long mask)
 {

@@ -61,15 +61,15 @@ __device__ __forceinline__ void sk2_chunk(uint32_t so, int r, const uint64_t (*_
 {
     const uint32_t w0 = so & 0xFFFFu, w1 = so >> 16;
     const uint64_t e0f = g8[w0][0], e0u = g8[w0][1], e1f = g8[w1][0], e1u = g8[w1][1];
-    F = srot(e0f, 8, 8) ^ e1f;
-    U = srot(e0u, 25, 23) ^ e1u;
+    F = srot_h(e0f, 8, 8) ^ e1f;
+    U = srot_h(e0u, 25, 23) ^ e1u;
     uint64_t f = 0, u = 0;
     int j = 0;
     if (r >= 8) { f = e0f; u = e0u; j = 8; }
     if (r - j >= 4) {
         const uint32_t byte = (so >> (2 * j)) & 255u;
-        f = srot(f, 4, 4) ^ g4[byte][0];
-        u = srot(u, 29, 27) ^ g4[byte][1];
+        f = srot_h(f, 4, 4) ^ g4[byte][0];
+        u = srot_h(u, 29, 27) ^ g4[byte][1];
         j += 4;
     }
     for (; j < r; j++) {
@@ -145,18 +145,18 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
     if (live) {
         uint64_t f = 0, u = 0;
         for (int i = 0; i < B.q16; i++) {
-            if (i) { f = srot(f, 16, 16); u = srot(u, 17, 15); } /* srol^16, sror^16 */
+            if (i) { f = srot_h(f, 16, 16); u = srot_h(u, 17, 15); } /* srol^16, sror^16 */
             f ^= s_x[L + i][0];
             u ^= s_x[L + i][1];
         }
         if (B.r16) {
             const uint32_t r = (uint32_t)B.r16;
-            if (B.q16) { f = srot(f, r, r); u = srot(u, 33u - r, 31u - r); }
+            if (B.q16) { f = srot_h(f, r, r); u = srot_h(u, 33u - r, 31u - r); } /* 1 <= r <= 15 */
             f ^= s_y[L + B.q16][0];
             u ^= s_y[L + B.q16][1];
         }
         uint64_t fwd = f;
-        uint64_t rev = srot(u, (uint32_t)(k - 1) % 33u, (uint32_t)(k - 1) % 31u);
+        uint64_t rev = srot_u(u, (uint32_t)(k - 1) % 33u, (uint32_t)(k - 1) % 31u);
         c[0] = (uint32_t)((fwd + rev) >> 32);
         const uint32_t si = sk2_bases16(A.T.packed, gp + (uint64_t)k, B.max_word);
         /* table index of step t: in<<2 | out, two bits each at base t of si / so -> nibbles of two words */
@@ -180,18 +180,18 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
         }
     }
 
-    /* ---- phase 2: stage, block minimum, minimum of the first R0 elements, suffix minima in place ---- */
-    uint32_t bm = SK2_INF, pre0 = SK2_INF;
+    /* ---- phase 2: stage, minimum of the first R0 elements, suffix minima in place (c[0] = block minimum) ---- */
+    uint32_t pre0 = SK2_INF;
 #pragma unroll
     for (int t = 0; t < C; t++) {
         s_c[t * NT + L] = c[t];
-        bm = c[t] < bm ? c[t] : bm;
-        if (t == R0 - 1) pre0 = bm;
+        if (t < R0) pre0 = c[t] < pre0 ? c[t] : pre0;
     }
-    s_bm[L] = bm;
-    s_pre0[L] = pre0;
 #pragma unroll
     for (int j = C - 2; j >= 0; j--) c[j] = c[j] < c[j + 1] ? c[j] : c[j + 1]; /* c[j] = min of elements j..15 */
+    const uint32_t bm = c[0];
+    s_bm[L] = bm;
+    s_pre0[L] = pre0;
     __syncthreads();
 
     /* ---- phase 3: minimum over the whole blocks L+1 .. L+a by doubling (range of a = two ranges of 2^p) ---- */
@@ -216,37 +216,47 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
     uint32_t chg = 0;    /* bit j: window j has another minimum value than window j-1 */
     uint32_t x0 = SK2_INF, xl = SK2_INF;
     bool tie = false;
-    if (own) {
-        const int Lr = L + G.a + 1;
-        uint32_t P = fa;
-        {
-            const uint32_t hh = s_pre0[Lr];
-            P = hh < P ? hh : P;
-        }
+    {
         const bool inside = e_lane >= 0 && e_lane + (C - 1) + G.w <= (int64_t)I.M; /* all 16 windows lie in the sequence */
-        uint32_t xp = 0;
-#pragma unroll
-        for (int j = 0; j < C; j++) {
-            const int rt = R0 + j;
-            uint32_t hh = 0;
-            if (j > 0) {
-                const int tp = rt - 1 < C ? rt - 1 : rt - 1 - C;
-                const int Lb = rt - 1 < C ? Lr : Lr + 1;
-                hh = s_c[tp * NT + Lb];
+        const bool all_inside = __ballot(own && !inside) == 0ull;                   /* ... for every owning lane of the wavefront */
+        auto window_pass = [&](auto chk) {
+            constexpr bool CHECK = decltype(chk)::value;
+            const int Lr = L + G.a + 1;
+            uint32_t P = fa;
+            {
+                const uint32_t hh = s_pre0[Lr];
                 P = hh < P ? hh : P;
             }
-            const uint32_t x = P < c[j] ? P : c[j];
-            if (j == 0) { x0 = x; xl = x; }
-            else {
-                bool valid = true;
-                if (!inside) valid = e_lane + j + G.w <= (int64_t)I.M && e_lane + j >= 0;
-                if (valid) {
-                    chg |= (x != xp ? 1u : 0u) << j;
-                    tie = tie || hh == xp;
-                    xl = x;
+            uint32_t xp = 0, acc = 0; /* acc: change bits of windows 1..15, newest in bit 0 */
+#pragma unroll
+            for (int j = 0; j < C; j++) {
+                const int rt = R0 + j;
+                uint32_t hh = 0;
+                if (j > 0) {
+                    const int tp = rt - 1 < C ? rt - 1 : rt - 1 - C;
+                    const int Lb = rt - 1 < C ? Lr : Lr + 1;
+                    hh = s_c[tp * NT + Lb];
+                    P = hh < P ? hh : P;
                 }
+                const uint32_t x = P < c[j] ? P : c[j];
+                if (j == 0) { x0 = x; xl = x; }
+                else {
+                    bool valid = true;
+                    if (CHECK) valid = e_lane + j + G.w <= (int64_t)I.M && e_lane + j >= 0;
+                    if (!CHECK) acc = ntl_shl1_or_ne(acc, x, xp);
+                    else if (valid) chg |= (x != xp ? 1u : 0u) << j;
+                    if (valid) {
+                        tie = tie || hh == xp;
+                        xl = x;
+                    }
+                }
+                xp = x;
             }
-            xp = x;
+            if (!CHECK) chg = ntl_brev(acc) >> 16; /* bit 15-j of acc is window j */
+        };
+        if (own) {
+            if (all_inside) window_pass(NtlFalse());
+            else window_pass(NtlTrue());
         }
     }
     s_last[L] = xl;

@@ -8,6 +8,17 @@ inline uint32_t ntl_alignbit(uint32_t hi, uint32_t lo, uint32_t sh)
     return (uint32_t)((((uint64_t)hi << 32) | lo) >> (sh & 31));
 }
 
+template <uint32_t MASK> inline uint32_t ntl_bfi(uint32_t a, uint32_t b) { return (a & MASK) | (b & ~MASK); }
+
+inline uint32_t ntl_shl1_or_ne(uint32_t acc, uint32_t a, uint32_t b) { return (acc << 1) | (a != b ? 1u : 0u); }
+inline uint32_t ntl_brev(uint32_t x)
+{
+    x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+    x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+    x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
+    return __builtin_bswap32(x);
+}
+
 inline uint32_t ntl_mbcnt(unsigned long long mask)
 {
     unsigned l = sim::tid & 63;
