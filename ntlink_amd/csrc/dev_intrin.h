@@ -27,6 +27,25 @@ __device__ __forceinline__ uint32_t ntl_shl1_or_ne(uint32_t acc, uint32_t a, uin
     return r;
 }
 
+/* (acc << 1) | (a <= b) */
+__device__ __forceinline__ uint32_t ntl_shl1_or_le(uint32_t acc, uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_cmp_le_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %3, %3, vcc" : "=v"(r) : "v"(a), "v"(b), "v"(acc) : "vcc");
+    return r;
+}
+
+/* minimum over the 16 lanes of a row (lanes 16i..16i+15), result in every lane: four v_min_u32 with DPP row rotations */
+__device__ __forceinline__ uint32_t ntl_row_min16(uint32_t v)
+{
+    uint32_t t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xF, 0xF, false); v = t < v ? t : v; /* row_ror:8 */
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x124, 0xF, 0xF, false); v = t < v ? t : v; /* row_ror:4 */
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x122, 0xF, 0xF, false); v = t < v ? t : v; /* row_ror:2 */
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x121, 0xF, 0xF, false); v = t < v ? t : v; /* row_ror:1 */
+    return v;
+}
+
 /* bit reversal of a 32-bit word: v_bfrev_b32 */
 __device__ __forceinline__ uint32_t ntl_brev(uint32_t x) { return __builtin_bitreverse32(x); }
 

@@ -8,13 +8,14 @@
  *
  *   key      the window minimum is taken on c = h0 >> 32 (one register, v_min_u32) instead of the 64-bit h0
  *            plus an index (compare + three selects per combine).  Positions are NOT tracked.
- *   argmin   a window whose minimum VALUE differs from the previous window's is a "changed" window; only
- *            those (2/(w+1) of all) are searched for the position of their minimum, by one lane each, over
- *            the block minima and one block of elements staged in LDS.
+ *   argmin   a window whose minimum VALUE differs from the previous window's is a "changed" window (2/(w+1) of
+ *            all).  Where the value dropped, the element that just entered is the new minimum (nothing else can
+ *            be below the old one); where it rose, sixteen lanes search the window for the position of its
+ *            minimum over the block minima and two blocks of elements staged in LDS.
  *   exact    the result equals Indexlr's rightmost 64-bit argmin unless two k-mers that share a window also
  *            share the top 32 bits of h0 while being that window's minimum (identical k-mers in low-complexity
  *            sequence, or 2^-32 coincidences).  Every such case is DETECTED -- an entering element equal to
- *            the previous window's minimum, or a searched window whose minimum occurs twice -- and the strip
+ *            the previous window's minimum while that minimum stays, or a searched window whose minimum occurs twice -- and the strip
  *            is handed to sketch_mask_kernel (the exact 64-bit pass) through a redo list.  Bits are only ever
  *            set for proven minimizers, and setting a bit is idempotent, so both kernels may write one strip.
  *
@@ -214,8 +215,8 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
     /* ---- phase 4: every window starting in the own block ---- */
     const bool own = L < G.LW && e_lane + G.w <= (int64_t)I.M;
     uint32_t chg = 0;    /* bit j: window j has another minimum value than window j-1 */
+    uint32_t le = 0;     /* bit j: the element that entered at window j is <= the minimum of window j-1 */
     uint32_t x0 = SK2_INF, xl = SK2_INF;
-    bool tie = false;
     {
         const bool inside = e_lane >= 0 && e_lane + (C - 1) + G.w <= (int64_t)I.M; /* all 16 windows lie in the sequence */
         const bool all_inside = __ballot(own && !inside) == 0ull;                   /* ... for every owning lane of the wavefront */
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
                 const uint32_t hh = s_pre0[Lr];
                 P = hh < P ? hh : P;
             }
-            uint32_t xp = 0, acc = 0; /* acc: change bits of windows 1..15, newest in bit 0 */
+            uint32_t xp = 0, acc = 0, lacc = 0; /* change bits / "entering element <= previous minimum" bits of windows 1..15, newest in bit 0 */
 #pragma unroll
             for (int j = 0; j < C; j++) {
                 const int rt = R0 + j;
@@ -243,16 +244,13 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
                 else {
                     bool valid = true;
                     if (CHECK) valid = e_lane + j + G.w <= (int64_t)I.M && e_lane + j >= 0;
-                    if (!CHECK) acc = ntl_shl1_or_ne(acc, x, xp);
-                    else if (valid) chg |= (x != xp ? 1u : 0u) << j;
-                    if (valid) {
-                        tie = tie || hh == xp;
-                        xl = x;
-                    }
+                    if (!CHECK) { acc = ntl_shl1_or_ne(acc, x, xp); lacc = ntl_shl1_or_le(lacc, hh, xp); }
+                    else if (valid) { chg |= (x != xp ? 1u : 0u) << j; le |= (hh <= xp ? 1u : 0u) << j; }
+                    if (valid) xl = x;
                 }
                 xp = x;
             }
-            if (!CHECK) chg = ntl_brev(acc) >> 16; /* bit 15-j of acc is window j */
+            if (!CHECK) { chg = ntl_brev(acc) >> 16; le = ntl_brev(lacc) >> 16; } /* bit 15-j of acc is window j */
         };
         if (own) {
             if (all_inside) window_pass(NtlFalse());
@@ -264,23 +262,34 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
     if (own) {
         /* window (L,0) against the last window of lane L-1; window (0,0) belongs to the previous strip, so the
            strip's first owned window (0,1) is always searched */
-        if (L == 0) chg |= 2u;
+        if (L == 0) { chg |= 2u; le &= ~2u; }
         else {
             const uint32_t xprev = s_last[L - 1];
             const uint32_t hh0 = s_c[((R0 + 15) & 15) * NT + (R0 ? L + G.a + 1 : L + G.a)]; /* the element that entered at window (L,0) */
             chg |= (x0 != xprev) ? 1u : 0u;
-            tie = tie || hh0 == xprev;
+            le |= (hh0 <= xprev) ? 1u : 0u;
         }
         if (L == 0 && e_lane + 1 + G.w > (int64_t)I.M) chg &= ~2u; /* window (0,1) does not exist */
-        if (tie) s_flag = 2u;
+        /* entering element <= previous minimum:  minimum unchanged -> the two are equal: a tie (or the old minimum just
+           left: flagged all the same);  minimum changed -> it dropped, and only the entering element can be below the
+           old minimum: it is the new, unique minimum, no search needed */
+        if (le & ~chg) {
+            s_flag = 2u;
 #ifdef NTL_SIM
-        if (tie && getenv("NTL_SK2_DEBUG")) fprintf(stderr, "strip %u lane %d tie chg=%x x0=%x M=%u E0=%d\n", strip, L, chg, x0, I.M, I.E0);
+            if (getenv("NTL_SK2_DEBUG")) fprintf(stderr, "strip %u lane %d tie chg=%x le=%x M=%u E0=%d\n", strip, L, chg, le, I.M, I.E0);
 #endif
-        /* ---- phase 5: one job per changed window ---- */
-        if (chg) {
-            const uint32_t n = (uint32_t)__popc(chg);
-            uint32_t at = atomicAdd(&s_njobs, n);
-            uint32_t m = chg;
+        }
+        uint32_t m = chg & le;
+        while (m) {
+            const int j = __ffs(m) - 1;
+            m &= m - 1;
+            const uint32_t pos = (uint32_t)(L * C + j + G.w - 1);
+            atomicOr(&s_bits[pos >> 5], 1u << (pos & 31u));
+        }
+        /* ---- phase 5: one job per window whose minimum rose (the old minimum left) ---- */
+        m = chg & ~le;
+        if (m) {
+            uint32_t at = atomicAdd(&s_njobs, (uint32_t)__popc(m));
             while (m) {
                 const int j = __ffs(m) - 1;
                 m &= m - 1;
@@ -291,49 +300,56 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
     }
     __syncthreads();
 
-    /* ---- phase 6: position of the minimum of every changed window ----
-       One lane per window [g, ge): the elements of its first and last block (two batches of independent LDS reads),
-       the block minima in between; the minimum must occur exactly once. */
+    /* ---- phase 6: position of the minimum of every such window [g, ge) ----
+       Sixteen lanes per window: lane i takes element i of the window's first block, element i of its last block and
+       every 16th block minimum in between; the minimum (row-wide v_min with DPP) must occur exactly once; if it is a
+       block minimum, the sixteen lanes then look at that block's elements. */
     {
         uint32_t njobs = s_njobs;
         if (njobs > SK2_JOBCAP) { njobs = SK2_JOBCAP; if (L == 0) s_flag = 4u; }
-        for (uint32_t i = L; i < njobs; i += NT) {
-            const uint32_t g = s_jobs[i], ge = g + (uint32_t)G.w;
-            const uint32_t b0 = g >> 4, b1 = (ge - 1) >> 4;
-            const uint32_t t0 = g & 15u, t1 = (ge - 1) & 15u;       /* head: t >= t0 of block b0; tail: t <= t1 of block b1 */
-            uint32_t hv[16], tv[16];
-#pragma unroll
-            for (int t = 0; t < 16; t++) { hv[t] = s_c[t * NT + b0]; tv[t] = s_c[t * NT + b1]; }
-            uint32_t v = SK2_INF;
-#pragma unroll
-            for (int t = 0; t < 16; t++) {
-                const bool inh = (uint32_t)t >= t0 && (b1 > b0 || (uint32_t)t <= t1);
-                const bool intl = b1 > b0 && (uint32_t)t <= t1;
-                hv[t] = inh ? hv[t] : SK2_INF;
-                tv[t] = intl ? tv[t] : SK2_INF;
-                v = hv[t] < v ? hv[t] : v;
-                v = tv[t] < v ? tv[t] : v;
+        const uint32_t gl = (uint32_t)L & 15u, grp = (uint32_t)L >> 4, sh = 16u * (((uint32_t)L >> 4) & 3u);
+        const uint32_t rounds = (njobs + NT / 16 - 1) / (NT / 16);
+        const uint32_t mid_rounds = ((uint32_t)G.a + 1u + 15u) / 16u; /* the middle blocks number a or a+1 */
+        for (uint32_t it = 0; it < rounds; it++) {
+            const uint32_t i = it * (NT / 16) + grp;
+            const bool act = i < njobs;
+            const uint32_t g = act ? s_jobs[i] : 0u, ge = g + (uint32_t)G.w;
+            const uint32_t b0 = g >> 4, b1 = (ge - 1) >> 4, t0 = g & 15u, t1 = (ge - 1) & 15u;
+            const bool inh = act && gl >= t0 && (b1 > b0 || gl <= t1), intl = act && b1 > b0 && gl <= t1;
+            uint32_t hv = s_c[gl * NT + b0], tv = s_c[gl * NT + b1];
+            hv = inh ? hv : SK2_INF;
+            tv = intl ? tv : SK2_INF;
+            uint32_t mv = SK2_INF, mb = 0;      /* smallest middle block minimum this lane has seen, and its block */
+            bool mdup = false;
+            for (uint32_t r = 0; r < mid_rounds; r++) {
+                const uint32_t b = b0 + 1 + gl + 16u * r;
+                const uint32_t q = (act && b < b1) ? s_bm[b] : SK2_INF;
+                mdup = mdup || (q == mv && q != SK2_INF);
+                if (q < mv) { mv = q; mb = b; mdup = false; }
             }
-            for (uint32_t b = b0 + 1; b < b1; b++) { const uint32_t q = s_bm[b]; v = q < v ? q : v; }
-            uint32_t n = 0, pos = 0, bb = 0, nb = 0;
-#pragma unroll
-            for (int t = 0; t < 16; t++) {
-                if (hv[t] == v) { n++; pos = b0 * 16 + t; }
-                if (tv[t] == v) { n++; pos = b1 * 16 + t; }
-            }
-            for (uint32_t b = b0 + 1; b < b1; b++)
-                if (s_bm[b] == v) { nb++; bb = b; }
-            if (nb == 1) {
-#pragma unroll
-                for (int t = 0; t < 16; t++)
-                    if (s_c[t * NT + bb] == v) { n++; pos = bb * 16 + t; }
-            } else if (nb > 1) n = 2;
-            if (n == 1 && v != SK2_INF) atomicOr(&s_bits[pos >> 5], 1u << (pos & 31u));
-            else {
-                s_flag = 8u;
+            uint32_t v = hv < tv ? hv : tv;
+            v = mv < v ? mv : v;
+            v = ntl_row_min16(v);
+            const uint32_t eh = (uint32_t)((__ballot(inh && hv == v) >> sh) & 0xFFFFull);
+            const uint32_t et = (uint32_t)((__ballot(intl && tv == v) >> sh) & 0xFFFFull);
+            const uint32_t em = (uint32_t)((__ballot(act && mv == v && v != SK2_INF) >> sh) & 0xFFFFull);
+            const bool dupm = ((__ballot(act && mv == v && mdup) >> sh) & 0xFFFFull) != 0ull;
+            uint32_t n = (uint32_t)(__popc(eh) + __popc(et) + __popc(em));
+            uint32_t pos = eh ? b0 * 16 + (uint32_t)(__ffs(eh) - 1) : b1 * 16 + (uint32_t)(__ffs(et) - 1);
+            /* the block whose minimum it is (all sixteen lanes need it: row-wide minimum of the candidates' block ids) */
+            const uint32_t bb = ntl_row_min16((act && mv == v && v != SK2_INF) ? mb : SK2_INF);
+            const bool need_blk = act && em != 0;
+            const uint32_t bv = s_c[gl * NT + (need_blk ? bb : 0u)];
+            const uint32_t eb = (uint32_t)((__ballot(need_blk && bv == v) >> sh) & 0xFFFFull);
+            if (need_blk) { n = n - 1u + (uint32_t)__popc(eb); pos = bb * 16 + (uint32_t)(__ffs(eb) - 1); }
+            if (act && gl == 0) {
+                if (n == 1 && !dupm && v != SK2_INF) atomicOr(&s_bits[pos >> 5], 1u << (pos & 31u));
+                else {
+                    s_flag = 8u;
 #ifdef NTL_SIM
-                if (getenv("NTL_SK2_DEBUG")) fprintf(stderr, "strip %u job g=%u: minimum %x occurs %u times (M=%u E0=%d)\n", strip, g, v, n, I.M, I.E0);
+                    if (getenv("NTL_SK2_DEBUG")) fprintf(stderr, "strip %u job g=%u: minimum %x occurs %u times (M=%u E0=%d)\n", strip, g, v, n, I.M, I.E0);
 #endif
+                }
             }
         }
     }

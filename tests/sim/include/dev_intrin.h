@@ -11,6 +11,18 @@ inline uint32_t ntl_alignbit(uint32_t hi, uint32_t lo, uint32_t sh)
 template <uint32_t MASK> inline uint32_t ntl_bfi(uint32_t a, uint32_t b) { return (a & MASK) | (b & ~MASK); }
 
 inline uint32_t ntl_shl1_or_ne(uint32_t acc, uint32_t a, uint32_t b) { return (acc << 1) | (a != b ? 1u : 0u); }
+inline uint32_t ntl_shl1_or_le(uint32_t acc, uint32_t a, uint32_t b) { return (acc << 1) | (a <= b ? 1u : 0u); }
+
+inline uint32_t ntl_row_min16(uint32_t v)
+{
+    const int l = (int)(sim::tid & 63u);
+    for (int d = 8; d >= 1; d >>= 1) {
+        const uint32_t t = __shfl(v, (l & ~15) | ((l + d) & 15));
+        v = t < v ? t : v;
+    }
+    return v;
+}
+
 inline uint32_t ntl_brev(uint32_t x)
 {
     x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
