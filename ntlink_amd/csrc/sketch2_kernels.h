@@ -35,7 +35,7 @@
 #pragma once
 #include "sketch_kernels.h"
 
-#define SK2_JOBCAP 1024 /* searched windows per strip; more (pathological sequence) hands the strip to the exact pass */
+#define SK2_JOBCAP 512 /* searched windows per strip; more (pathological sequence) hands the strip to the exact pass */
 #define SK2_QMAX 16     /* k <= 16 * SK2_QMAX */
 #define SK2_INF 0xFFFFFFFFu
 
@@ -86,17 +86,22 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
 {
     constexpr int C = 16;
     constexpr int NBW = (C * NT + 31) / 32;
-    __shared__ uint32_t s_c[C * NT];            /* element (L,t) at [t*NT + L] */
-    __shared__ uint32_t s_bm[NT + 128];         /* block minima; INF behind NT */
-    __shared__ uint32_t s_t[2][NT + 128];       /* doubling levels of the block minima, ping-pong; INF behind NT */
+    constexpr int ST = NT + 1;                  /* row stride of s_c: element (L,t) at [t*ST + L] -- a block's 16 elements and
+                                                   the elements t of 16 neighbouring blocks both fall into distinct banks */
+    constexpr int NX = NT + SK2_QMAX + 1;
+    __shared__ uint32_t s_c[C * ST];
+    __shared__ uint32_t s_bm[NT + 256];         /* block minima; INF behind NT */
     __shared__ uint32_t s_pre0[NT + 4];         /* minimum of the first R0 elements of each block */
-    __shared__ uint32_t s_last[NT];             /* minimum of each lane's last window */
-    __shared__ uint64_t s_x[NT + SK2_QMAX + 1][2]; /* {F16, U16} of chunk L */
-    __shared__ uint64_t s_y[NT + SK2_QMAX + 1][2]; /* {PF, PU}: first k%16 bases of chunk L */
     __shared__ uint32_t s_bits[NBW];
-    __shared__ uint16_t s_jobs[SK2_JOBCAP];
     __shared__ uint32_t s_njobs, s_flag;
-    __shared__ uint64_t s_roll[16][2], s_seed[4][2];
+    __shared__ uint64_t s_roll[16][2];
+    /* phase 1: {F16, U16} of chunk L at s_xy[L], {PF, PU} (first k%16 bases) at s_xy[NX + L];
+       afterwards the same bytes hold the range-minimum levels and the job list */
+    __shared__ uint64_t s_xy[2 * NX][2];
+    uint32_t *const s_t0 = (uint32_t *)&s_xy[0][0];      /* [NT + 256] */
+    uint32_t *const s_t1 = s_t0 + (NT + 256);            /* [NT + 256] */
+    uint16_t *const s_jobs = (uint16_t *)(s_t1 + (NT + 256)); /* [SK2_JOBCAP] */
+    static_assert(sizeof(uint64_t) * 4 * NX >= 2 * (NT + 256) * 4 + 2 * SK2_JOBCAP, "aliased arrays must fit");
 
     const SketchArgs &A = B.A;
     const int L = threadIdx.x;
@@ -106,13 +111,12 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
     if (strip >= A.nstrips) return;
     const StripInfo I = A.strip_tab[strip];
     if (I.seq == NTL_NONE || I.multi != 0) return; /* strips that cross non-ACGT runs: sketch_mask_kernel<.., MULTI = true> */
+    /* nothing written here is read before the first barrier below */
     if (L < 16) { s_roll[L][0] = A.roll_tab[L][0]; s_roll[L][1] = A.roll_tab[L][1]; }
-    if (L < 4) { s_seed[L][0] = A.seed_tab[L][0]; s_seed[L][1] = A.seed_tab[L][1]; }
     if (L < NBW) s_bits[L] = 0;
-    if (L < 128) { s_bm[NT + L] = SK2_INF; s_t[0][NT + L] = SK2_INF; s_t[1][NT + L] = SK2_INF; }
+    s_bm[NT + L] = SK2_INF;
     if (L < 4) s_pre0[NT + L] = SK2_INF;
     if (L == 0) { s_njobs = 0; s_flag = B.force_redo ? 1u : 0u; }
-    __syncthreads();
 
     const int64_t e_lane = (int64_t)I.E0 + (int64_t)L * C; /* ordinal of this lane's element t = 0 */
     const uint64_t gp = (uint64_t)((int64_t)I.base + I.P0 + (int64_t)L * C);
@@ -125,16 +129,18 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
     if (feeds) {
         so = sk2_bases16(A.T.packed, gp, B.max_word);
         uint64_t F, U, PF, PU;
-        sk2_chunk(so, B.r16, A.g8, A.g4, s_seed, F, U, PF, PU);
-        s_x[L][0] = F; s_x[L][1] = U; s_y[L][0] = PF; s_y[L][1] = PU;
+        sk2_chunk(so, B.r16, A.g8, A.g4, A.seed_tab, F, U, PF, PU);
+        s_xy[L][0] = F; s_xy[L][1] = U;
+        if (B.r16) { s_xy[NX + L][0] = PF; s_xy[NX + L][1] = PU; }
     }
     if (L <= B.q16) { /* chunks NT .. NT+q16 feed the last lanes */
         const int64_t ev = (int64_t)I.E0 + (int64_t)(NT + L) * C;
         if (ev - 16 * (int64_t)(B.q16 + 1) < (int64_t)I.M) {
             const uint32_t sv = sk2_bases16(A.T.packed, gp + (uint64_t)NT * C, B.max_word);
             uint64_t F, U, PF, PU;
-            sk2_chunk(sv, B.r16, A.g8, A.g4, s_seed, F, U, PF, PU);
-            s_x[NT + L][0] = F; s_x[NT + L][1] = U; s_y[NT + L][0] = PF; s_y[NT + L][1] = PU;
+            sk2_chunk(sv, B.r16, A.g8, A.g4, A.seed_tab, F, U, PF, PU);
+            s_xy[NT + L][0] = F; s_xy[NT + L][1] = U;
+            if (B.r16) { s_xy[NX + NT + L][0] = PF; s_xy[NX + NT + L][1] = PU; }
         }
     }
     __syncthreads();
@@ -147,14 +153,14 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
         uint64_t f = 0, u = 0;
         for (int i = 0; i < B.q16; i++) {
             if (i) { f = srot_h(f, 16, 16); u = srot_h(u, 17, 15); } /* srol^16, sror^16 */
-            f ^= s_x[L + i][0];
-            u ^= s_x[L + i][1];
+            f ^= s_xy[L + i][0];
+            u ^= s_xy[L + i][1];
         }
         if (B.r16) {
             const uint32_t r = (uint32_t)B.r16;
             if (B.q16) { f = srot_h(f, r, r); u = srot_h(u, 33u - r, 31u - r); } /* 1 <= r <= 15 */
-            f ^= s_y[L + B.q16][0];
-            u ^= s_y[L + B.q16][1];
+            f ^= s_xy[NX + L + B.q16][0];
+            u ^= s_xy[NX + L + B.q16][1];
         }
         uint64_t fwd = f;
         uint64_t rev = srot_u(u, (uint32_t)(k - 1) % 33u, (uint32_t)(k - 1) % 31u);
@@ -185,41 +191,47 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
     uint32_t pre0 = SK2_INF;
 #pragma unroll
     for (int t = 0; t < C; t++) {
-        s_c[t * NT + L] = c[t];
+        s_c[t * ST + L] = c[t];
         if (t < R0) pre0 = c[t] < pre0 ? c[t] : pre0;
     }
 #pragma unroll
     for (int j = C - 2; j >= 0; j--) c[j] = c[j] < c[j + 1] ? c[j] : c[j + 1]; /* c[j] = min of elements j..15 */
-    const uint32_t bm = c[0];
-    s_bm[L] = bm;
+    s_bm[L] = c[0];
     s_pre0[L] = pre0;
     __syncthreads();
 
-    /* ---- phase 3: minimum over the whole blocks L+1 .. L+a by doubling (range of a = two ranges of 2^p) ---- */
+    /* ---- phase 3: minimum over the whole blocks L+1 .. L+a: range minima of 4^p blocks (one barrier per level),
+       the range of a covered by at most four of them ---- */
     uint32_t fa = SK2_INF;
     if (G.a >= 1) {
-        int p = 0;
-        while ((2 << p) <= G.a) p++;
         const uint32_t *cur = s_bm;
-        for (int lv = 0; lv < p; lv++) {
-            uint32_t *nxt = s_t[lv & 1];
-            const uint32_t m0 = cur[L], m1 = cur[L + (1 << lv)];
-            nxt[L] = m0 < m1 ? m0 : m1;
+        int span = 1;
+        for (int lv = 0; span * 4 <= G.a; lv++) {
+            uint32_t *nxt = (lv & 1) ? s_t1 : s_t0;
+            uint32_t m = cur[L];
+#pragma unroll
+            for (int q = 1; q < 4; q++) { const uint32_t v = cur[L + q * span]; m = v < m ? v : m; }
+            nxt[L] = m;
+            nxt[NT + L] = SK2_INF;
             __syncthreads();
             cur = nxt;
+            span *= 4;
         }
-        const uint32_t m0 = cur[L + 1], m1 = cur[L + 1 + G.a - (1 << p)];
-        fa = m0 < m1 ? m0 : m1;
+        for (int o = 0; o < G.a; o += span) {
+            const int at = o + span <= G.a ? o : G.a - span; /* the last range is pulled back inside */
+            const uint32_t v = cur[L + 1 + at];
+            fa = v < fa ? v : fa;
+        }
     }
 
-    /* ---- phase 4: every window starting in the own block ---- */
+    /* ---- phase 4: the 17 windows starting at elements 0..16 of the own block (window 16 = window 0 of the next lane:
+       this lane decides whether it changed) ---- */
     const bool own = L < G.LW && e_lane + G.w <= (int64_t)I.M;
     uint32_t chg = 0;    /* bit j: window j has another minimum value than window j-1 */
     uint32_t le = 0;     /* bit j: the element that entered at window j is <= the minimum of window j-1 */
-    uint32_t x0 = SK2_INF, xl = SK2_INF;
     {
-        const bool inside = e_lane >= 0 && e_lane + (C - 1) + G.w <= (int64_t)I.M; /* all 16 windows lie in the sequence */
-        const bool all_inside = __ballot(own && !inside) == 0ull;                   /* ... for every owning lane of the wavefront */
+        const bool inside = e_lane >= 0 && e_lane + C + G.w <= (int64_t)I.M;  /* all 17 windows lie in the sequence */
+        const bool all_inside = __ballot(own && !inside) == 0ull;             /* ... for every owning lane of the wavefront */
         auto window_pass = [&](auto chk) {
             constexpr bool CHECK = decltype(chk)::value;
             const int Lr = L + G.a + 1;
@@ -228,48 +240,40 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
                 const uint32_t hh = s_pre0[Lr];
                 P = hh < P ? hh : P;
             }
-            uint32_t xp = 0, acc = 0, lacc = 0; /* change bits / "entering element <= previous minimum" bits of windows 1..15, newest in bit 0 */
+            uint32_t xp = 0, acc = 0, lacc = 0; /* change bits / "entering element <= previous minimum" bits, newest in bit 0 */
 #pragma unroll
-            for (int j = 0; j < C; j++) {
+            for (int j = 0; j <= C; j++) {
                 const int rt = R0 + j;
                 uint32_t hh = 0;
                 if (j > 0) {
                     const int tp = rt - 1 < C ? rt - 1 : rt - 1 - C;
                     const int Lb = rt - 1 < C ? Lr : Lr + 1;
-                    hh = s_c[tp * NT + Lb];
+                    hh = s_c[tp * ST + Lb];
                     P = hh < P ? hh : P;
                 }
-                const uint32_t x = P < c[j] ? P : c[j];
-                if (j == 0) { x0 = x; xl = x; }
-                else {
-                    bool valid = true;
-                    if (CHECK) valid = e_lane + j + G.w <= (int64_t)I.M && e_lane + j >= 0;
+                uint32_t x = P;
+                if (j < C) x = P < c[j] ? P : c[j];
+                if (j > 0) {
                     if (!CHECK) { acc = ntl_shl1_or_ne(acc, x, xp); lacc = ntl_shl1_or_le(lacc, hh, xp); }
-                    else if (valid) { chg |= (x != xp ? 1u : 0u) << j; le |= (hh <= xp ? 1u : 0u) << j; }
-                    if (valid) xl = x;
+                    else if (e_lane + j + G.w <= (int64_t)I.M && e_lane + j >= 0) {
+                        chg |= (x != xp ? 1u : 0u) << j;
+                        le |= (hh <= xp ? 1u : 0u) << j;
+                    }
                 }
                 xp = x;
             }
-            if (!CHECK) { chg = ntl_brev(acc) >> 16; le = ntl_brev(lacc) >> 16; } /* bit 15-j of acc is window j */
+            if (!CHECK) { chg = ntl_brev(acc) >> 15; le = ntl_brev(lacc) >> 15; } /* bit 16-j of acc is window j */
         };
         if (own) {
             if (all_inside) window_pass(NtlFalse());
             else window_pass(NtlTrue());
         }
     }
-    s_last[L] = xl;
-    __syncthreads();
     if (own) {
-        /* window (L,0) against the last window of lane L-1; window (0,0) belongs to the previous strip, so the
-           strip's first owned window (0,1) is always searched */
-        if (L == 0) { chg |= 2u; le &= ~2u; }
-        else {
-            const uint32_t xprev = s_last[L - 1];
-            const uint32_t hh0 = s_c[((R0 + 15) & 15) * NT + (R0 ? L + G.a + 1 : L + G.a)]; /* the element that entered at window (L,0) */
-            chg |= (x0 != xprev) ? 1u : 0u;
-            le |= (hh0 <= xprev) ? 1u : 0u;
-        }
-        if (L == 0 && e_lane + 1 + G.w > (int64_t)I.M) chg &= ~2u; /* window (0,1) does not exist */
+        /* window (0,0) belongs to the previous strip, so the strip's first owned window (0,1) is always searched;
+           window (LW-1,16) is the next strip's */
+        if (L == 0) { if (e_lane + 1 + G.w <= (int64_t)I.M) chg |= 2u; le &= ~2u; }
+        if (L == G.LW - 1) { chg &= 0xFFFFu; le &= 0xFFFFu; }
         /* entering element <= previous minimum:  minimum unchanged -> the two are equal: a tie (or the old minimum just
            left: flagged all the same);  minimum changed -> it dropped, and only the entering element can be below the
            old minimum: it is the new, unique minimum, no search needed */
@@ -316,7 +320,7 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
             const uint32_t g = act ? s_jobs[i] : 0u, ge = g + (uint32_t)G.w;
             const uint32_t b0 = g >> 4, b1 = (ge - 1) >> 4, t0 = g & 15u, t1 = (ge - 1) & 15u;
             const bool inh = act && gl >= t0 && (b1 > b0 || gl <= t1), intl = act && b1 > b0 && gl <= t1;
-            uint32_t hv = s_c[gl * NT + b0], tv = s_c[gl * NT + b1];
+            uint32_t hv = s_c[gl * ST + b0], tv = s_c[gl * ST + b1];
             hv = inh ? hv : SK2_INF;
             tv = intl ? tv : SK2_INF;
             uint32_t mv = SK2_INF, mb = 0;      /* smallest middle block minimum this lane has seen, and its block */
@@ -339,7 +343,7 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
             /* the block whose minimum it is (all sixteen lanes need it: row-wide minimum of the candidates' block ids) */
             const uint32_t bb = ntl_row_min16((act && mv == v && v != SK2_INF) ? mb : SK2_INF);
             const bool need_blk = act && em != 0;
-            const uint32_t bv = s_c[gl * NT + (need_blk ? bb : 0u)];
+            const uint32_t bv = s_c[gl * ST + (need_blk ? bb : 0u)];
             const uint32_t eb = (uint32_t)((__ballot(need_blk && bv == v) >> sh) & 0xFFFFull);
             if (need_blk) { n = n - 1u + (uint32_t)__popc(eb); pos = bb * 16 + (uint32_t)(__ffs(eb) - 1); }
             if (act && gl == 0) {
