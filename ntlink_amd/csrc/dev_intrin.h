@@ -46,6 +46,16 @@ __device__ __forceinline__ uint32_t ntl_row_min16(uint32_t v)
     return v;
 }
 
+__device__ __forceinline__ uint32_t ntl_row_max16(uint32_t v)
+{
+    uint32_t t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xF, 0xF, false); v = t > v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x124, 0xF, 0xF, false); v = t > v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x122, 0xF, 0xF, false); v = t > v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x121, 0xF, 0xF, false); v = t > v ? t : v;
+    return v;
+}
+
 /* bit reversal of a 32-bit word: v_bfrev_b32 */
 __device__ __forceinline__ uint32_t ntl_brev(uint32_t x) { return __builtin_bitreverse32(x); }
 

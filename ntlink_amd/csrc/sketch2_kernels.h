@@ -306,52 +306,60 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
 
     /* ---- phase 6: position of the minimum of every such window [g, ge) ----
        Sixteen lanes per window: lane i takes element i of the window's first block, element i of its last block and
-       every 16th block minimum in between; the minimum (row-wide v_min with DPP) must occur exactly once; if it is a
-       block minimum, the sixteen lanes then look at that block's elements. */
+       every 16th block minimum in between.  v = row-wide minimum (v_min with DPP row rotations).  Every lane that holds
+       v names its candidate -- an element position, or 0x10000 | block for a block minimum -- and the row-wide minimum
+       and maximum of the candidates agree iff v occurs once; a block candidate is resolved by the sixteen lanes reading
+       that block's elements, the same way. */
     {
         uint32_t njobs = s_njobs;
         if (njobs > SK2_JOBCAP) { njobs = SK2_JOBCAP; if (L == 0) s_flag = 4u; }
-        const uint32_t gl = (uint32_t)L & 15u, grp = (uint32_t)L >> 4, sh = 16u * (((uint32_t)L >> 4) & 3u);
+        const uint32_t gl = (uint32_t)L & 15u, grp = (uint32_t)L >> 4;
         const uint32_t rounds = (njobs + NT / 16 - 1) / (NT / 16);
         const uint32_t mid_rounds = ((uint32_t)G.a + 1u + 15u) / 16u; /* the middle blocks number a or a+1 */
         for (uint32_t it = 0; it < rounds; it++) {
             const uint32_t i = it * (NT / 16) + grp;
             const bool act = i < njobs;
-            const uint32_t g = act ? s_jobs[i] : 0u, ge = g + (uint32_t)G.w;
+            if (__ballot(act) == 0ull) break; /* jobs fill the wavefronts in order: nothing left for this one */
+            const uint32_t g = s_jobs[act ? i : 0u], ge = g + (uint32_t)G.w;
             const uint32_t b0 = g >> 4, b1 = (ge - 1) >> 4, t0 = g & 15u, t1 = (ge - 1) & 15u;
-            const bool inh = act && gl >= t0 && (b1 > b0 || gl <= t1), intl = act && b1 > b0 && gl <= t1;
+            const bool inh = gl >= t0 && (b1 > b0 || gl <= t1), intl = b1 > b0 && gl <= t1;
             uint32_t hv = s_c[gl * ST + b0], tv = s_c[gl * ST + b1];
             hv = inh ? hv : SK2_INF;
             tv = intl ? tv : SK2_INF;
             uint32_t mv = SK2_INF, mb = 0;      /* smallest middle block minimum this lane has seen, and its block */
             bool mdup = false;
-            for (uint32_t r = 0; r < mid_rounds; r++) {
+            {
+                const uint32_t b = b0 + 1 + gl;
+                if (b < b1) { mv = s_bm[b]; mb = b; }
+            }
+            for (uint32_t r = 1; r < mid_rounds; r++) { /* w > 271 only */
                 const uint32_t b = b0 + 1 + gl + 16u * r;
-                const uint32_t q = (act && b < b1) ? s_bm[b] : SK2_INF;
+                const uint32_t q = b < b1 ? s_bm[b] : SK2_INF;
                 mdup = mdup || (q == mv && q != SK2_INF);
                 if (q < mv) { mv = q; mb = b; mdup = false; }
             }
             uint32_t v = hv < tv ? hv : tv;
             v = mv < v ? mv : v;
             v = ntl_row_min16(v);
-            const uint32_t eh = (uint32_t)((__ballot(inh && hv == v) >> sh) & 0xFFFFull);
-            const uint32_t et = (uint32_t)((__ballot(intl && tv == v) >> sh) & 0xFFFFull);
-            const uint32_t em = (uint32_t)((__ballot(act && mv == v && v != SK2_INF) >> sh) & 0xFFFFull);
-            const bool dupm = ((__ballot(act && mv == v && mdup) >> sh) & 0xFFFFull) != 0ull;
-            uint32_t n = (uint32_t)(__popc(eh) + __popc(et) + __popc(em));
-            uint32_t pos = eh ? b0 * 16 + (uint32_t)(__ffs(eh) - 1) : b1 * 16 + (uint32_t)(__ffs(et) - 1);
-            /* the block whose minimum it is (all sixteen lanes need it: row-wide minimum of the candidates' block ids) */
-            const uint32_t bb = ntl_row_min16((act && mv == v && v != SK2_INF) ? mb : SK2_INF);
-            const bool need_blk = act && em != 0;
-            const uint32_t bv = s_c[gl * ST + (need_blk ? bb : 0u)];
-            const uint32_t eb = (uint32_t)((__ballot(need_blk && bv == v) >> sh) & 0xFFFFull);
-            if (need_blk) { n = n - 1u + (uint32_t)__popc(eb); pos = bb * 16 + (uint32_t)(__ffs(eb) - 1); }
+            uint32_t lo = SK2_INF, hi = 0;
+            if (hv == v) { lo = b0 * 16 + gl; hi = lo; }
+            if (tv == v) { const uint32_t p = b1 * 16 + gl; lo = p < lo ? p : lo; hi = p > hi ? p : hi; }
+            if (mv == v) { const uint32_t p = mdup ? 0x20000u : (0x10000u | mb); lo = p < lo ? p : lo; hi = p > hi ? p : hi; }
+            lo = ntl_row_min16(lo);
+            hi = ntl_row_max16(hi);
+            const bool blk = lo == hi && lo >= 0x10000u;       /* the only occurrence so far is a block minimum */
+            const uint32_t bb = blk ? (lo & 0xFFFFu) : 0u;
+            const uint32_t bv = s_c[gl * ST + bb];
+            const uint32_t pe = bb * 16 + gl;
+            uint32_t lo2 = blk ? (bv == v ? pe : SK2_INF) : lo, hi2 = blk ? (bv == v ? pe : 0u) : hi;
+            lo2 = ntl_row_min16(lo2);
+            hi2 = ntl_row_max16(hi2);
             if (act && gl == 0) {
-                if (n == 1 && !dupm && v != SK2_INF) atomicOr(&s_bits[pos >> 5], 1u << (pos & 31u));
+                if (lo2 == hi2 && lo2 < 0x10000u && v != SK2_INF) atomicOr(&s_bits[lo2 >> 5], 1u << (lo2 & 31u));
                 else {
                     s_flag = 8u;
 #ifdef NTL_SIM
-                    if (getenv("NTL_SK2_DEBUG")) fprintf(stderr, "strip %u job g=%u: minimum %x occurs %u times (M=%u E0=%d)\n", strip, g, v, n, I.M, I.E0);
+                    if (getenv("NTL_SK2_DEBUG")) fprintf(stderr, "strip %u job g=%u: minimum %x not unique (%x..%x) (M=%u E0=%d)\n", strip, g, v, lo2, hi2, I.M, I.E0);
 #endif
                 }
             }

@@ -23,6 +23,16 @@ inline uint32_t ntl_row_min16(uint32_t v)
     return v;
 }
 
+inline uint32_t ntl_row_max16(uint32_t v)
+{
+    const int l = (int)(sim::tid & 63u);
+    for (int d = 8; d >= 1; d >>= 1) {
+        const uint32_t t = __shfl(v, (l & ~15) | ((l + d) & 15));
+        v = t > v ? t : v;
+    }
+    return v;
+}
+
 inline uint32_t ntl_brev(uint32_t x)
 {
     x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
