@@ -46,6 +46,29 @@ __device__ __forceinline__ uint32_t ntl_row_min16(uint32_t v)
     return v;
 }
 
+/* (acc << 1) | (a == b) */
+__device__ __forceinline__ uint32_t ntl_shl1_or_eq(uint32_t acc, uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_cmp_eq_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %3, %3, vcc" : "=v"(r) : "v"(a), "v"(b), "v"(acc) : "vcc");
+    return r;
+}
+
+/* minimum / sum over the 4 lanes of a quad, result in every lane: DPP quad_perm [1,0,3,2] then [2,3,0,1] */
+__device__ __forceinline__ uint32_t ntl_quad_min(uint32_t v)
+{
+    uint32_t t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false); v = t < v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false); v = t < v ? t : v;
+    return v;
+}
+__device__ __forceinline__ uint32_t ntl_quad_sum(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false);
+    return v;
+}
+
 __device__ __forceinline__ uint32_t ntl_row_max16(uint32_t v)
 {
     uint32_t t;

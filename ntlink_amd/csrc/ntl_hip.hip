@@ -714,6 +714,8 @@ extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_
             B.max_word = b->nwords_packed - 1;
             B.q16 = k / 16; B.r16 = k % 16;
             B.force_redo = 0;
+            B.dbg = 0;
+            if (const char *e = getenv("NTL_SKETCH_ABLATE")) B.dbg = atoi(e); /* tools/sketch_bench.py only: results are wrong */
             if (const char *e = getenv("NTL_SKETCH_FORCE_REDO")) B.force_redo = atoi(e); /* tests: every strip takes both passes */
             {
                 ProfSpan sp(c, "sketch_mask");

@@ -46,6 +46,7 @@ struct Sketch2Args {
     uint64_t max_word;     /* last word of `packed` that may be read */
     int q16, r16;          /* k = 16 * q16 + r16 */
     int force_redo;        /* tests: flag every strip */
+    int dbg;               /* ablation (tools/sketch_bench.py, results WRONG): 1 no search, 2 no window pass, 4 no rolling, 8 no init */
 };
 
 __device__ __forceinline__ uint32_t sk2_bases16(const uint32_t *__restrict__ packed, uint64_t gp, uint64_t max_word)
@@ -126,14 +127,14 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
     const bool live = e_lane < (int64_t)I.M;            /* the lane has at least one k-mer of the sequence */
     const bool feeds = e_lane - 16 * (int64_t)(B.q16 + 1) < (int64_t)I.M; /* its chunk is part of a live lane's first k-mer */
     uint32_t so = 0;
-    if (feeds) {
+    if (feeds && !(B.dbg & 8)) {
         so = sk2_bases16(A.T.packed, gp, B.max_word);
         uint64_t F, U, PF, PU;
         sk2_chunk(so, B.r16, A.g8, A.g4, A.seed_tab, F, U, PF, PU);
         s_xy[L][0] = F; s_xy[L][1] = U;
         if (B.r16) { s_xy[NX + L][0] = PF; s_xy[NX + L][1] = PU; }
     }
-    if (L <= B.q16) { /* chunks NT .. NT+q16 feed the last lanes */
+    if (L <= B.q16 && !(B.dbg & 8)) { /* chunks NT .. NT+q16 feed the last lanes */
         const int64_t ev = (int64_t)I.E0 + (int64_t)(NT + L) * C;
         if (ev - 16 * (int64_t)(B.q16 + 1) < (int64_t)I.M) {
             const uint32_t sv = sk2_bases16(A.T.packed, gp + (uint64_t)NT * C, B.max_word);
@@ -171,6 +172,7 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
         const uint32_t zod = ((so >> 2) & 0x33333333u) | (si & 0xCCCCCCCCu);         /* odd bases */
 #pragma unroll
         for (int t = 1; t < C; t++) {
+            if (B.dbg & 4) { c[t] = c[0] + (uint32_t)t * zev; continue; }
             const int b = t - 1;
             const uint32_t z = (b & 1) ? zod : zev;
             const uint32_t idx = (z >> (4 * (b >> 1))) & 15u;
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
 
     /* ---- phase 4: the 17 windows starting at elements 0..16 of the own block (window 16 = window 0 of the next lane:
        this lane decides whether it changed) ---- */
-    const bool own = L < G.LW && e_lane + G.w <= (int64_t)I.M;
+    const bool own = L < G.LW && e_lane + G.w <= (int64_t)I.M && !(B.dbg & 2);
     uint32_t chg = 0;    /* bit j: window j has another minimum value than window j-1 */
     uint32_t le = 0;     /* bit j: the element that entered at window j is <= the minimum of window j-1 */
     {
@@ -283,20 +285,17 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
             if (getenv("NTL_SK2_DEBUG")) fprintf(stderr, "strip %u lane %d tie chg=%x le=%x M=%u E0=%d\n", strip, L, chg, le, I.M, I.E0);
 #endif
         }
-        uint32_t m = chg & le;
+        /* ---- phase 5: dropped minima are set right away (the entering element); one job per window whose minimum rose ---- */
+        const uint32_t rise = chg & ~le;
+        uint32_t at = rise ? atomicAdd(&s_njobs, (uint32_t)__popc(rise)) : 0u;
+        uint32_t m = chg;
         while (m) {
             const int j = __ffs(m) - 1;
             m &= m - 1;
-            const uint32_t pos = (uint32_t)(L * C + j + G.w - 1);
-            atomicOr(&s_bits[pos >> 5], 1u << (pos & 31u));
-        }
-        /* ---- phase 5: one job per window whose minimum rose (the old minimum left) ---- */
-        m = chg & ~le;
-        if (m) {
-            uint32_t at = atomicAdd(&s_njobs, (uint32_t)__popc(m));
-            while (m) {
-                const int j = __ffs(m) - 1;
-                m &= m - 1;
+            if ((le >> j) & 1u) {
+                const uint32_t pos = (uint32_t)(L * C + j + G.w - 1);
+                atomicOr(&s_bits[pos >> 5], 1u << (pos & 31u));
+            } else {
                 if (at < SK2_JOBCAP) s_jobs[at] = (uint16_t)(L * C + j);
                 at++;
             }
@@ -305,61 +304,75 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
     __syncthreads();
 
     /* ---- phase 6: position of the minimum of every such window [g, ge) ----
-       Sixteen lanes per window: lane i takes element i of the window's first block, element i of its last block and
-       every 16th block minimum in between.  v = row-wide minimum (v_min with DPP row rotations).  Every lane that holds
-       v names its candidate -- an element position, or 0x10000 | block for a block minimum -- and the row-wide minimum
-       and maximum of the candidates agree iff v occurs once; a block candidate is resolved by the sixteen lanes reading
-       that block's elements, the same way. */
+       Four lanes per window: lane q takes elements q, q+4, q+8, q+12 of the window's first block and of its last block
+       and every 4th block minimum in between.  v = minimum over the quad (v_min with DPP quad permutes); a carry chain
+       collects which of a lane's values equal v; v must occur exactly once in the quad.  A block minimum is resolved by
+       the four lanes reading that block's elements, the same way. */
     {
-        uint32_t njobs = s_njobs;
+        uint32_t njobs = (B.dbg & 1) ? 0u : s_njobs;
         if (njobs > SK2_JOBCAP) { njobs = SK2_JOBCAP; if (L == 0) s_flag = 4u; }
-        const uint32_t gl = (uint32_t)L & 15u, grp = (uint32_t)L >> 4;
-        const uint32_t rounds = (njobs + NT / 16 - 1) / (NT / 16);
-        const uint32_t mid_rounds = ((uint32_t)G.a + 1u + 15u) / 16u; /* the middle blocks number a or a+1 */
+        const uint32_t q = (uint32_t)L & 3u, grp = (uint32_t)L >> 2;
+        const uint32_t rounds = (njobs + NT / 4 - 1) / (NT / 4);
+        const uint32_t nmid = (uint32_t)G.a + 1u; /* the middle blocks number a or a+1 */
         for (uint32_t it = 0; it < rounds; it++) {
-            const uint32_t i = it * (NT / 16) + grp;
+            const uint32_t i = it * (NT / 4) + grp;
             const bool act = i < njobs;
             if (__ballot(act) == 0ull) break; /* jobs fill the wavefronts in order: nothing left for this one */
             const uint32_t g = s_jobs[act ? i : 0u], ge = g + (uint32_t)G.w;
             const uint32_t b0 = g >> 4, b1 = (ge - 1) >> 4, t0 = g & 15u, t1 = (ge - 1) & 15u;
-            const bool inh = gl >= t0 && (b1 > b0 || gl <= t1), intl = b1 > b0 && gl <= t1;
-            uint32_t hv = s_c[gl * ST + b0], tv = s_c[gl * ST + b1];
-            hv = inh ? hv : SK2_INF;
-            tv = intl ? tv : SK2_INF;
-            uint32_t mv = SK2_INF, mb = 0;      /* smallest middle block minimum this lane has seen, and its block */
-            bool mdup = false;
-            {
-                const uint32_t b = b0 + 1 + gl;
-                if (b < b1) { mv = s_bm[b]; mb = b; }
+            uint32_t val[12];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const uint32_t t = q + 4u * r, b = b0 + 1 + q + 4u * r;
+                val[r] = s_c[t * ST + b0];
+                val[4 + r] = s_c[t * ST + b1];
+                val[8 + r] = s_bm[b < (uint32_t)NT + 255u ? b : (uint32_t)NT + 255u];
             }
-            for (uint32_t r = 1; r < mid_rounds; r++) { /* w > 271 only */
-                const uint32_t b = b0 + 1 + gl + 16u * r;
-                const uint32_t q = b < b1 ? s_bm[b] : SK2_INF;
-                mdup = mdup || (q == mv && q != SK2_INF);
-                if (q < mv) { mv = q; mb = b; mdup = false; }
+            uint32_t v = SK2_INF;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const uint32_t t = q + 4u * r, b = b0 + 1 + q + 4u * r;
+                val[r] = (t >= t0 && (b1 > b0 || t <= t1)) ? val[r] : SK2_INF;
+                val[4 + r] = (b1 > b0 && t <= t1) ? val[4 + r] : SK2_INF;
+                val[8 + r] = b < b1 ? val[8 + r] : SK2_INF;
+                v = val[r] < v ? val[r] : v;
+                v = val[4 + r] < v ? val[4 + r] : v;
+                v = val[8 + r] < v ? val[8 + r] : v;
             }
-            uint32_t v = hv < tv ? hv : tv;
-            v = mv < v ? mv : v;
-            v = ntl_row_min16(v);
-            uint32_t lo = SK2_INF, hi = 0;
-            if (hv == v) { lo = b0 * 16 + gl; hi = lo; }
-            if (tv == v) { const uint32_t p = b1 * 16 + gl; lo = p < lo ? p : lo; hi = p > hi ? p : hi; }
-            if (mv == v) { const uint32_t p = mdup ? 0x20000u : (0x10000u | mb); lo = p < lo ? p : lo; hi = p > hi ? p : hi; }
-            lo = ntl_row_min16(lo);
-            hi = ntl_row_max16(hi);
-            const bool blk = lo == hi && lo >= 0x10000u;       /* the only occurrence so far is a block minimum */
-            const uint32_t bb = blk ? (lo & 0xFFFFu) : 0u;
-            const uint32_t bv = s_c[gl * ST + bb];
-            const uint32_t pe = bb * 16 + gl;
-            uint32_t lo2 = blk ? (bv == v ? pe : SK2_INF) : lo, hi2 = blk ? (bv == v ? pe : 0u) : hi;
-            lo2 = ntl_row_min16(lo2);
-            hi2 = ntl_row_max16(hi2);
-            if (act && gl == 0) {
-                if (lo2 == hi2 && lo2 < 0x10000u && v != SK2_INF) atomicOr(&s_bits[lo2 >> 5], 1u << (lo2 & 31u));
+            uint32_t xv = SK2_INF, xb = 0;   /* windows of more than 17 blocks (w > 271): the further middle blocks */
+            bool xdup = false;
+            for (uint32_t b = b0 + 17 + q; nmid > 16 && b < b1; b += 4) {
+                const uint32_t u = s_bm[b];
+                xdup = xdup || (u == xv && u != SK2_INF);
+                if (u < xv) { xv = u; xb = b; xdup = false; }
+            }
+            v = xv < v ? xv : v;
+            v = ntl_quad_min(v);
+            uint32_t mk = 0;
+#pragma unroll
+            for (int r = 0; r < 12; r++) mk = ntl_shl1_or_eq(mk, val[r], v); /* bit 11-r: val[r] == v */
+            uint32_t n = (uint32_t)__popc(mk) + (xv == v ? (xdup ? 2u : 1u) : 0u);
+            const uint32_t r1 = 11u - (uint32_t)(__ffs(mk | 0x1000u) - 1); /* the (last) matching value */
+            uint32_t code = r1 < 4 ? b0 * 16 + q + 4u * r1 : (r1 < 8 ? b1 * 16 + q + 4u * (r1 - 4) : (0x10000u | (b0 + 1 + q + 4u * (r1 - 8))));
+            if (mk == 0) code = 0x10000u | xb;
+            n = ntl_quad_sum(v != SK2_INF ? n : 2u);
+            code = ntl_quad_min(n && (mk || xv == v) ? code : SK2_INF);
+            /* a block minimum: its sixteen elements, four per lane */
+            const bool blk = code >= 0x10000u && code != SK2_INF;
+            const uint32_t bb = blk ? (code & 0xFFFFu) : 0u;
+            uint32_t mk2 = 0;
+#pragma unroll
+            for (int r = 0; r < 4; r++) mk2 = ntl_shl1_or_eq(mk2, s_c[(q + 4u * r) * ST + bb], v);
+            const uint32_t n2 = ntl_quad_sum((uint32_t)__popc(mk2));
+            const uint32_t p2 = ntl_quad_min(mk2 ? bb * 16 + q + 4u * (3u - (uint32_t)(__ffs(mk2) - 1)) : SK2_INF);
+            const bool ok = n == 1 && (!blk || n2 == 1);
+            const uint32_t pos = blk ? p2 : code;
+            if (act && q == 0) {
+                if (ok) atomicOr(&s_bits[pos >> 5], 1u << (pos & 31u));
                 else {
                     s_flag = 8u;
 #ifdef NTL_SIM
-                    if (getenv("NTL_SK2_DEBUG")) fprintf(stderr, "strip %u job g=%u: minimum %x not unique (%x..%x) (M=%u E0=%d)\n", strip, g, v, lo2, hi2, I.M, I.E0);
+                    if (getenv("NTL_SK2_DEBUG")) fprintf(stderr, "strip %u job g=%u: minimum %x occurs %u/%u times (M=%u E0=%d)\n", strip, g, v, n, n2, I.M, I.E0);
 #endif
                 }
             }
