@@ -26,6 +26,7 @@
  *                                                      bin/ntlink_pair.py:308-313,382-388,
  *                                                      bin/ntlink_paf_output.py:131-135
  *   ntl_tally_*   contig-pair tally                 <- bin/ntlink_pair.py:416-435,315-334,157-239
+ *   ntl_liftover  verbose mappings through an AGP   <- bin/ntlink_liftover_mappings.py:61-143 (ntLink_rounds:124-125)
  *
  * Conventions: every call returns 0 on success or a negative NTL_E* code; the message is
  * available from ntl_last_error().  All pointers in signatures are HOST pointers unless the
@@ -273,6 +274,24 @@ uint64_t ntl_tally_npairs(const ntl_tally *t);
 uint64_t ntl_tally_ngaps(const ntl_tally *t);
 int ntl_tally_export(const ntl_tally *t, uint32_t *src, uint8_t *src_ori, uint32_t *tgt, uint8_t *tgt_ori,
                      uint32_t *anchor, uint64_t *gap_off, int64_t *gaps);
+
+/* ---- liftover of the verbose mappings (no GPU involved) -------------------------------------- */
+
+/* <prefix>.verbose_mapping.tsv moved to the coordinates of the scaffolds an AGP describes, file to file: the work of
+ * bin/ntlink_liftover_mappings.py (liftover_ctg_mappings :61-87, print_adjusted_mappings :89-121, liftover_mappings
+ * :125-143; called between rounds, ntLink_rounds:124-125).  The AGP's sequence lines (component type not N / P, read_agp
+ * :39-50) come as arrays, one entry per contig id (the last line of an id wins, as in the reference's dict): contig id,
+ * path id, scaf_start, ctg_start, ctg_end (1-based, inclusive) and the orientation byte.  Per line: a contig that is not in
+ * the AGP keeps its name and loses its mappings; mappings outside [ctg_start-1, ctg_end-k] are dropped; `+` / `-`
+ * components of a path with another name are shifted / mirrored (strand flipped).  Per read (consecutive lines with one
+ * read id): lines are grouped by path id, paths strictly between two occurrences of a path's first run and a later run
+ * are subsumed, the surviving lines of a path are concatenated and printed when their contig positions are strictly
+ * monotonic.  A malformed line fails the call (the reference raises) and removes the output file.  lines_in / lines_out
+ * may be NULL. */
+int ntl_liftover(const char *mappings_path, const char *out_path, int k, uint64_t n_agp, const char *ctg_ids,
+                 const uint64_t *ctg_id_off, const char *path_ids, const uint64_t *path_id_off, const int64_t *scaf_start,
+                 const int64_t *ctg_start, const int64_t *ctg_end, const char *orientation, uint64_t *lines_in,
+                 uint64_t *lines_out);
 
 #ifdef __cplusplus
 }

@@ -1,12 +1,22 @@
-"""Builds libntlink_hip.so (the HIP kernels + C ABI) for gfx950 with hipcc, in-tree."""
+"""Builds libntlink_hip.so (the HIP kernels + C ABI) for gfx950 with hipcc, in-tree.
+
+One object per translation unit under ntlink_amd/build/ (rebuilt when the unit or a header it includes is newer), then
+one link: a change in the host-side I/O code does not recompile the kernels."""
 import os
 import shutil
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
 OUT = os.path.join(HERE, "libntlink_hip.so")
-SOURCES = ["ntl_hip.hip", "ntl_io.cpp", "ntl_pairs.cpp", "dev_common.h", "dev_intrin.h", "scan_kernels.h", "sketch_kernels.h", "sketch2_kernels.h", "map_kernels.h", "pack_kernels.h", "synth_kernels.h"]
+HEADER = os.path.join(os.path.dirname(HERE), "include", "ntlink_amd.h")
+KERNEL_HEADERS = ["dev_common.h", "dev_intrin.h", "scan_kernels.h", "sketch_kernels.h", "sketch2_kernels.h", "map_kernels.h",
+                  "pack_kernels.h", "synth_kernels.h", "overlap_kernels.h"]
+# translation unit -> headers it depends on (besides include/ntlink_amd.h)
+UNITS = {"ntl_hip.hip": KERNEL_HEADERS, "ntl_io.cpp": [], "ntl_pairs.cpp": [], "ntl_liftover.cpp": []}
+SOURCES = list(UNITS) + KERNEL_HEADERS
 
 
 def hipcc_path():
@@ -16,13 +26,31 @@ def hipcc_path():
     raise RuntimeError("hipcc not found")
 
 
+def _stale(target, deps):
+    return not os.path.exists(target) or any(os.path.getmtime(target) < os.path.getmtime(d) for d in deps)
+
+
 def build_hip(force=False, extra_flags=()):
-    srcs = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(os.path.dirname(HERE), "include", "ntlink_amd.h")]
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(s) for s in srcs):
-        return OUT
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-result",
-           "-I", CSRC, *extra_flags, os.path.join(CSRC, "ntl_hip.hip"), os.path.join(CSRC, "ntl_io.cpp"), os.path.join(CSRC, "ntl_pairs.cpp"), "-lz", "-ldl", "-lpthread", "-o", OUT]
-    subprocess.check_call(cmd)
+    os.makedirs(OBJ, exist_ok=True)
+    hipcc = hipcc_path()
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-I", CSRC, *extra_flags]
+    tag = os.path.join(OBJ, "flags.txt")
+    if not os.path.exists(tag) or open(tag).read() != " ".join(flags):
+        force = True
+    jobs, objs = [], []
+    for unit, hdrs in UNITS.items():
+        src = os.path.join(CSRC, unit)
+        obj = os.path.join(OBJ, unit.rsplit(".", 1)[0] + ".o")
+        objs.append(obj)
+        deps = [src, HEADER] + [os.path.join(CSRC, h) for h in hdrs if os.path.exists(os.path.join(CSRC, h))]
+        if force or _stale(obj, deps):
+            jobs.append([hipcc, *flags, "-c", src, "-o", obj])
+    if jobs:
+        with ThreadPoolExecutor(len(jobs)) as ex:
+            list(ex.map(subprocess.check_call, jobs))
+        open(tag, "w").write(" ".join(flags))
+    if jobs or _stale(OUT, objs):
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-lz", "-ldl", "-lpthread", "-o", OUT])
     return OUT
 
 

@@ -30,6 +30,7 @@ SYMBOLS = [
     "ntl_fastx_names", "ntl_fastx_name_offsets", "ntl_write_indexlr", "ntl_write_verbose", "ntl_write_paf",
     "ntl_tsv_open", "ntl_tsv_close", "ntl_tsv_error", "ntl_tsv_next", "ntl_tsv_sizes", "ntl_tsv_copy",
     "ntl_tally_create", "ntl_tally_destroy", "ntl_tally_add", "ntl_tally_npairs", "ntl_tally_ngaps", "ntl_tally_export",
+    "ntl_liftover",
 ]
 
 MAPPING_DT = np.dtype([("read", "<u4"), ("ctg", "<u4"), ("n_hits", "<u4"), ("pad", "<u4"), ("hit_off", "<u8")])
@@ -42,6 +43,9 @@ PAF_DT = np.dtype([("read", "<u4"), ("ctg", "<u4"), ("q_start", "<u4"), ("q_end"
 class MapParams(C.Structure):
     _fields_ = [("k", C.c_int32), ("z", C.c_int32), ("x", C.c_double),
                 ("sensitive", C.c_int32), ("repeat_filter", C.c_int32)]
+
+
+NTL_EINVAL, NTL_EDEVICE, NTL_ENOMEM, NTL_EINTERNAL, NTL_ERANGE = -1, -2, -3, -4, -5
 
 
 class NtlError(RuntimeError):
@@ -144,6 +148,7 @@ def load(path=None):
         f.argtypes = [vp]
         f.restype = C.c_uint64
     L.ntl_tally_export.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    L.ntl_liftover.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_uint64, vp, u64p, vp, u64p, vp, vp, vp, vp, u64p, u64p]
     _libs[path] = L
     return L
 

@@ -268,7 +268,7 @@ def test_full_size_assembly_parity(dev, name, n_reads):
     cbuf, coff = wl.contigs.download()
     assert int(coff[-1]) > 2_900_000_000 and len(coff) - 1 == 5000
     with dev.sketch(wl.contigs, k, w) as csk, dev.index(csk, wl.ctg_len) as ix:
-        assert csk.redo_strips == 0
+        assert csk.redo_strips < 64  # 3e9 k-mers x w neighbours x 2^-32: a handful of 32-bit coincidences are expected
         c_off, ch, cp, cs = csk.download()
         o_off, oh, op, os_ = oracle.sketch_batch(cbuf, coff, k, w)
         assert np.array_equal(c_off, o_off) and np.array_equal(ch, oh) and np.array_equal(cp, op) and np.array_equal(cs, os_)
