@@ -12,6 +12,8 @@
  *                                                      -k K -w W` (ntLink:199,223) and
  *                                                      btllib.Indexlr(path,k,w,LONG_MODE,t)
  *                                                      (bin/ntlink_patch_gaps.py:417-441)
+ *   ntl_overlap_filter  valid-region + per-sequence   <- read_minimizer_line (bin/ntlink_overlap_sequences.py:170-190)
+ *                 duplicate filter of the k15 w5 sketch
  *   ntl_index_*   contig minimizer index            <- NtLink.read_minimizers
  *                                                      (bin/ntlink_pair.py:189-211)
  *   ntl_map_*     per-read lookup, hit filtering,   <- NtLink.find_scaffold_pairs body
@@ -148,6 +150,18 @@ int ntl_sketch_download(const ntl_sketch *s, uint64_t *mx_off, uint64_t *hash, u
 int ntl_sketch_from_host(ntl_ctx *ctx, uint64_t nseq, const uint64_t *mx_off, const uint64_t *hash,
                          const uint32_t *pos, const uint8_t *strand, ntl_sketch **out);
 
+/* ---- overlap-stage consumer (k15 w5 sketch) ---------------------------------------------------- */
+
+/* The minimizers the overlap stage keeps per sequence: read_minimizer_line / read_minimizers of
+ * bin/ntlink_overlap_sequences.py:145-190 (ntLink:243-251 pipes `indexlr --long --pos -k 15 -w 5` into it).  Sequence i has the
+ * valid regions region_start[r] .. region_end[r] (inclusive positions, is_in_valid_region :138-143) for r in
+ * region_off[i] .. region_off[i+1]; a sequence without regions (a name that is not in valid_mx_positions) keeps nothing.  Of the
+ * minimizers inside a region, every hash that occurs more than once in the sequence is dropped entirely.  The result is a new
+ * device-resident sketch with the same sequences and the kept minimizers in their original order (ntl_sketch_download gives
+ * the arrays); the input sketch is left alone. */
+int ntl_overlap_filter(ntl_ctx *ctx, const ntl_sketch *s, const uint64_t *region_off, const uint32_t *region_start,
+                       const uint32_t *region_end, ntl_sketch **out);
+
 /* ---- contig index ---------------------------------------------------------------------- */
 
 /* Builds the minimizer -> (contig, position, strand) table from the contig sketch; a hash that
@@ -245,7 +259,8 @@ int ntl_write_paf(int fd, const ntl_paf *pafs, uint64_t n, const char *read_name
  * fills caller-allocated arrays (name_off / mx_off: nrec + 1 entries, lengths may be NULL): record i
  * has the id names[name_off[i]..name_off[i+1]) and the minimizers mx_off[i]..mx_off[i+1]; strand 1 = '+'.
  * A malformed token fails the call (the reference raises ValueError there).  The arrays are what
- * ntl_sketch_from_host takes. */
+ * ntl_sketch_from_host takes.  with_len is a flag word: bit 0 = the `--len` column is present, bit 1 = the tokens are
+ * `H:pos` (indexlr --pos without --strand, the overlap stage's input, ntLink:244,249; strand[] is then filled with 1). */
 typedef struct ntl_tsv ntl_tsv;
 int ntl_tsv_open(const char *path, int with_len, ntl_tsv **out);
 void ntl_tsv_close(ntl_tsv *r);

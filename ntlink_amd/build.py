@@ -33,7 +33,9 @@ def _stale(target, deps):
 def build_hip(force=False, extra_flags=()):
     os.makedirs(OBJ, exist_ok=True)
     hipcc = hipcc_path()
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-I", CSRC, *extra_flags]
+    # NTL_EXTRA_HIPCC_FLAGS: tools only (e.g. -DNTL_SKETCH_ABLATION for tools/gpu_ablate.sh)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-I", CSRC, *extra_flags,
+             *os.environ.get("NTL_EXTRA_HIPCC_FLAGS", "").split()]
     tag = os.path.join(OBJ, "flags.txt")
     if not os.path.exists(tag) or open(tag).read() != " ".join(flags):
         force = True

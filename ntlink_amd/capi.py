@@ -22,7 +22,7 @@ SYMBOLS = [
     "ntl_synth_genome", "ntl_synth_slices", "ntl_batch_download",
     "ntl_sketch_run", "ntl_sketch_destroy", "ntl_sketch_nseq", "ntl_sketch_count", "ntl_sketch_download",
     "ntl_sketch_strips", "ntl_sketch_redo_strips",
-    "ntl_sketch_from_host",
+    "ntl_sketch_from_host", "ntl_overlap_filter",
     "ntl_index_build", "ntl_index_destroy", "ntl_index_size",
     "ntl_map_run", "ntl_mapres_destroy", "ntl_mapres_n_mappings", "ntl_mapres_n_hits", "ntl_mapres_n_pafs",
     "ntl_mapres_n_index_hits", "ntl_mapres_download",
@@ -98,6 +98,7 @@ def load(path=None):
         getattr(L, nm).restype = C.c_uint64
     L.ntl_sketch_download.argtypes = [vp, u64p, u64p, u32p, u8p]
     L.ntl_sketch_from_host.argtypes = [vp, C.c_uint64, u64p, u64p, u32p, u8p, C.POINTER(vp)]
+    L.ntl_overlap_filter.argtypes = [vp, vp, u64p, u32p, u32p, C.POINTER(vp)]
     L.ntl_index_build.argtypes = [vp, vp, u32p, C.c_uint32, C.POINTER(vp)]
     L.ntl_index_destroy.argtypes = [vp]
     L.ntl_index_destroy.restype = None
@@ -408,6 +409,21 @@ class Device:
         p = C.c_void_p()
         self._chk(self.L.ntl_sketch_from_host(self.ptr, len(mx_off) - 1, _ptr(mx_off, C.c_uint64), _ptr(h, C.c_uint64),
                                               _ptr(q, C.c_uint32), _ptr(s, C.c_uint8), C.byref(p)))
+        return Sketch(self, p)
+
+    def overlap_filter(self, sketch, region_off, region_start, region_end):
+        """Valid-region filter + per-sequence duplicate removal of the overlap stage (ntl_overlap_filter) -> new Sketch."""
+        ro = np.ascontiguousarray(region_off, np.uint64)
+        if len(ro) != sketch.nseq + 1:
+            raise ValueError("region_off must have nseq + 1 entries")
+        rs = np.ascontiguousarray(region_start, np.uint32); re = np.ascontiguousarray(region_end, np.uint32)
+        if len(rs) != int(ro[-1]) or len(re) != len(rs):
+            raise ValueError("region arrays must hold region_off[-1] entries")
+        if len(rs) == 0:
+            rs = np.zeros(1, np.uint32); re = np.zeros(1, np.uint32)
+        p = C.c_void_p()
+        self._chk(self.L.ntl_overlap_filter(self.ptr, sketch.ptr, _ptr(ro, C.c_uint64), _ptr(rs, C.c_uint32), _ptr(re, C.c_uint32),
+                                            C.byref(p)))
         return Sketch(self, p)
 
     def index(self, contig_sketch, ctg_len):

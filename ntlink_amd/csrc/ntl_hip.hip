@@ -23,6 +23,7 @@
 #include "map_kernels.h"
 #include "pack_kernels.h"
 #include "synth_kernels.h"
+#include "overlap_kernels.h"
 
 #define NTL_END_PAD 4096u /* bases of padding behind the last sequence (rolling over-reads) */
 #define SK_NT 256
@@ -703,7 +704,7 @@ extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_
         A.g8 = (const uint64_t (*)[2])c->g8;
         A.redo_list = nullptr; A.redo_count = nullptr;
         /* 32-bit fast pass + exact pass over what it flags; the exact pass alone for small windows / huge k */
-        fast = C == 16 && k <= 16 * SK2_QMAX;
+        fast = C == 16 && k <= 16 * SK2_QMAX && G.a + 2 <= SK2_PAD;
         if (const char *e = getenv("NTL_SKETCH_FAST")) fast = fast && atoi(e) != 0; /* 0: exact pass only (A/B, tests) */
         if (fast) {
             if ((rc = redo.alloc(c, (ub_strips + 2) * 4))) return rc;
@@ -713,6 +714,7 @@ extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_
             B.redo_count = redo.as<uint32_t>(); B.redo_list = redo.as<uint32_t>() + 1;
             B.max_word = b->nwords_packed - 1;
             B.q16 = k / 16; B.r16 = k % 16;
+            B.rev_a = (uint32_t)(k - 1) % 33u; B.rev_b = (uint32_t)(k - 1) % 31u;
             B.force_redo = 0;
             B.dbg = 0;
             if (const char *e = getenv("NTL_SKETCH_ABLATE")) B.dbg = atoi(e); /* tools/sketch_bench.py only: results are wrong */
@@ -878,6 +880,73 @@ extern "C" int ntl_sketch_from_host(ntl_ctx *c, uint64_t nseq, const uint64_t *m
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) return fail(c, NTL_EDEVICE, hipGetErrorString(e));
     *out = sk.release();
+    return NTL_OK;
+}
+
+
+/* ------------------------------------------------------------------ overlap-stage consumer -- */
+
+/* read_minimizer_line of bin/ntlink_overlap_sequences.py:170-190 over a device-resident sketch (overlap_kernels.h):
+ * valid-region filter, per-sequence removal of every hash that occurs more than once, dense result in input order. */
+extern "C" int ntl_overlap_filter(ntl_ctx *c, const ntl_sketch *s, const uint64_t *region_off, const uint32_t *region_start,
+                                  const uint32_t *region_end, ntl_sketch **out)
+{
+    if (!c || !s || !region_off || !out) return NTL_EINVAL;
+    *out = nullptr;
+    const uint64_t nseq = s->nseq, n = s->count;
+    const uint64_t nreg = region_off[nseq];
+    if (region_off[0] != 0) return fail(c, NTL_EINVAL, "region_off[0] must be 0");
+    for (uint64_t i = 0; i < nseq; i++)
+        if (region_off[i + 1] < region_off[i]) return fail(c, NTL_EINVAL, "region_off must be non-decreasing");
+    if (nreg >= 0xFFFFFFF0ull) return fail(c, NTL_EINVAL, "too many regions");
+    if (nreg && (!region_start || !region_end)) return NTL_EINVAL;
+    (void)hipSetDevice(c->device);
+    std::unique_ptr<ntl_sketch> o(new ntl_sketch());
+    o->c = c; o->nseq = nseq;
+    int rc;
+    DevBuf roff, rs, re, slots, dup, side, keep, dst;
+    std::vector<uint32_t> roff32(nseq + 1);
+    for (uint64_t i = 0; i <= nseq; i++) roff32[i] = (uint32_t)region_off[i];
+    if ((rc = roff.alloc(c, (nseq + 1) * 4)) || (rc = rs.alloc(c, (nreg + 1) * 4)) || (rc = re.alloc(c, (nreg + 1) * 4)) ||
+        (rc = slots.alloc(c, (2 * n + 1) * 8)) || (rc = dup.alloc(c, (2 * n / 32 + 2) * 4)) || (rc = side.alloc(c, (nseq + 1) * 4)) ||
+        (rc = keep.alloc(c, (n + 1) * 4)) || (rc = dst.alloc(c, (n + 2) * 4)) || (rc = o->mx_off.alloc(c, (nseq + 1) * 4)))
+        return rc;
+    uint32_t total = 0;
+    {
+        ProfSpan sp(c, "overlap_filter");
+        HIPCHK(c, hipMemcpyAsync(roff.p, roff32.data(), (nseq + 1) * 4, hipMemcpyHostToDevice, c->stream));
+        if (nreg) {
+            HIPCHK(c, hipMemcpyAsync(rs.p, region_start, nreg * 4, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(re.p, region_end, nreg * 4, hipMemcpyHostToDevice, c->stream));
+        }
+        HIPCHK(c, hipMemsetAsync(slots.p, 0xFF, (2 * n + 1) * 8, c->stream)); /* NTL_INF = empty */
+        HIPCHK(c, hipMemsetAsync(dup.p, 0, (2 * n / 32 + 2) * 4, c->stream));
+        HIPCHK(c, hipMemsetAsync(side.p, 0, (nseq + 1) * 4, c->stream));
+        HIPCHK(c, hipMemsetAsync(keep.p, 0, (n + 1) * 4, c->stream));
+        OvlArgs A;
+        A.rec = s->records.as<MxRecord>(); A.n = n; A.mx_off = s->mx_off.as<uint32_t>();
+        A.reg_off = roff.as<uint32_t>(); A.reg_start = rs.as<uint32_t>(); A.reg_end = re.as<uint32_t>();
+        A.slots = slots.as<unsigned long long>(); A.dupbits = dup.as<uint32_t>(); A.side = side.as<uint32_t>();
+        A.keep = keep.as<uint32_t>();
+        const unsigned grid = (unsigned)((n + 255) / 256);
+        if (n) {
+            hipLaunchKernelGGL(ovl_insert_kernel, dim3(grid), dim3(256), 0, c->stream, A);
+            hipLaunchKernelGGL(ovl_resolve_kernel, dim3(grid), dim3(256), 0, c->stream, A);
+            HIPCHK(c, hipGetLastError());
+        }
+        /* the one wait of the call: the number of kept records sizes the result */
+        if ((rc = device_scan(c, keep.as<uint32_t>(), dst.as<uint32_t>(), n, &total))) return rc;
+        o->count = total;
+        if ((rc = o->records.alloc(c, (uint64_t)total * sizeof(MxRecord)))) return rc;
+        const uint64_t work = std::max<uint64_t>(n, nseq + 1);
+        hipLaunchKernelGGL(ovl_gather_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, c->stream,
+                           (const MxRecord *)s->records.as<MxRecord>(), n, (const uint32_t *)keep.as<uint32_t>(),
+                           (const uint32_t *)dst.as<uint32_t>(), o->records.as<MxRecord>(), (const uint32_t *)s->mx_off.as<uint32_t>(),
+                           (uint32_t)nseq, o->mx_off.as<uint32_t>());
+        HIPCHK(c, hipGetLastError());
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream)); /* roff32 and the caller's region arrays are free again */
+    *out = o.release();
     return NTL_OK;
 }
 

@@ -918,7 +918,7 @@ struct TsvRange {
 
 struct ntl_tsv {
     int fd = -1;
-    bool with_len = false, eof = false;
+    bool with_len = false, pos_only = false, eof = false;
     char *buf = nullptr;   /* block being parsed + the partial line behind it (from the buffer cache) */
     size_t cap = 0, size_hint = 0;
     size_t have = 0, used = 0; /* buf[0..have) read; buf[0..used) = whole lines of the current batch */
@@ -949,7 +949,7 @@ struct TsvWrite {
 
 /* parses the lines of [p, e) (e at a line end); returns 0 or the 1-based line of the first malformed token */
 template <typename Sink>
-static int tsv_parse(const char *p, const char *e, bool with_len, Sink &out)
+static int tsv_parse(const char *p, const char *e, bool with_len, bool pos_only, Sink &out)
 {
     int line_no = 0;
     while (p < e) {
@@ -990,7 +990,13 @@ static int tsv_parse(const char *p, const char *e, bool with_len, Sink &out)
             uint64_t ps = 0;
             s0 = q;
             while (q < fe && *q >= '0' && *q <= '9') { ps = ps * 10 + (uint64_t)(*q - '0'); q++; }
-            if (q == s0 || q >= fe || *q != ':') return line_no;
+            if (q == s0) return line_no;
+            if (pos_only) { /* `--pos` without `--strand` (ntLink:244,249): the token ends here */
+                out.mx(h, (uint32_t)ps, 1);
+                if (q < fe && *q != ' ') return line_no;
+                continue;
+            }
+            if (q >= fe || *q != ':') return line_no;
             q++;
             if (q >= fe || (*q != '+' && *q != '-')) return line_no;
             out.mx(h, (uint32_t)ps, *q == '+' ? 1 : 0);
@@ -1011,7 +1017,8 @@ extern "C" int ntl_tsv_open(const char *path, int with_len, ntl_tsv **out)
     ntl_tsv *r = new ntl_tsv();
     r->fd = fd;
     widen_pipe(fd);
-    r->with_len = with_len != 0;
+    r->with_len = (with_len & 1) != 0;
+    r->pos_only = (with_len & 2) != 0;
     struct stat st;
     if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode)) r->size_hint = (size_t)st.st_size + 1;
     *out = r;
@@ -1099,11 +1106,11 @@ extern "C" int ntl_tsv_next(ntl_tsv *r, uint64_t max_bytes, uint64_t *nrec)
     run_threads(T, [&](size_t t) {
         TsvRange &g = r->ranges[t];
         TsvCount c;
-        g.bad = tsv_parse(g.b, g.e, r->with_len, c);
+        g.bad = tsv_parse(g.b, g.e, r->with_len, r->pos_only, c);
         g.nrec = c.nrec; g.nmx = c.nmx; g.name_bytes = c.name_bytes;
     });
     for (auto &g : r->ranges)
-        if (g.bad) { r->err = "malformed minimizer token (expected hash:pos:strand)"; return NTL_EINVAL; }
+        if (g.bad) { r->err = r->pos_only ? "malformed minimizer token (expected hash:pos)" : "malformed minimizer token (expected hash:pos:strand)"; return NTL_EINVAL; }
     ntl_tsv_sizes(r, nrec, nullptr, nullptr);
     if (*nrec == 0 && !r->eof) return ntl_tsv_next(r, max_bytes, nrec); /* a block of blank lines */
     return NTL_OK;
@@ -1126,7 +1133,7 @@ extern "C" int ntl_tsv_copy(const ntl_tsv *r, char *names, uint64_t *name_off, u
     run_threads(T, [&](size_t t) {
         const TsvRange &g = r->ranges[t];
         TsvWrite w{names, name_off, lengths, mx_off, hash, pos, strand, r0[t], m0[t], n0[t]};
-        tsv_parse(g.b, g.e, r->with_len, w);
+        tsv_parse(g.b, g.e, r->with_len, r->pos_only, w);
     });
     return NTL_OK;
 }

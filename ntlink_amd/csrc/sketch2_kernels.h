@@ -37,7 +37,15 @@
 
 #define SK2_JOBCAP 512 /* searched windows per strip; more (pathological sequence) hands the strip to the exact pass */
 #define SK2_QMAX 16     /* k <= 16 * SK2_QMAX */
+#define SK2_PAD 72      /* whole blocks right of a window's first block: a + 2 <= SK2_PAD, i.e. w <= 1135; larger windows take the exact pass */
 #define SK2_INF 0xFFFFFFFFu
+/* phase ablation for tools/gpu_ablate.sh (results WRONG): only in builds with -DNTL_SKETCH_ABLATION, so that the product
+   kernel carries no run-time switches inside its unrolled loops */
+#ifdef NTL_SKETCH_ABLATION
+#define SK2_DBG(B, bit) ((B).dbg & (bit))
+#else
+#define SK2_DBG(B, bit) 0
+#endif
 
 struct Sketch2Args {
     SketchArgs A;
@@ -45,6 +53,7 @@ struct Sketch2Args {
     uint32_t *redo_count;
     uint64_t max_word;     /* last word of `packed` that may be read */
     int q16, r16;          /* k = 16 * q16 + r16 */
+    uint32_t rev_a, rev_b; /* (k - 1) % 33, (k - 1) % 31: the rotation that turns the Horner form of the reverse strand into rev */
     int force_redo;        /* tests: flag every strip */
     int dbg;               /* ablation (tools/sketch_bench.py, results WRONG): 1 no search, 2 no window pass, 4 no rolling, 8 no init */
 };
@@ -87,22 +96,24 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
 {
     constexpr int C = 16;
     constexpr int NBW = (C * NT + 31) / 32;
-    constexpr int ST = NT + 1;                  /* row stride of s_c: element (L,t) at [t*ST + L] -- a block's 16 elements and
-                                                   the elements t of 16 neighbouring blocks both fall into distinct banks */
+    constexpr int ST = NT;                      /* row stride of s_c: element (L,t) at [t*ST + L]; rows 1 KB apart, so two rows
+                                                   of one lane are one ds_read2st64 / ds_write2st64 (the rare search phase
+                                                   pays a 4-way conflict for it) */
     constexpr int NX = NT + SK2_QMAX + 1;
+    constexpr int PAD = SK2_PAD;                /* INF entries behind the block minima: a + 2 <= PAD (ntl_sketch_run checks) */
+    /* 23 KB in all: seven workgroups (28 wavefronts) per CU.  s_c doubles as the exchange area of phase 1:
+       {F16, U16} of chunk L at s_xy[L], {PF, PU} (first k%16 bases) at s_xy[NX + L]; a barrier separates the last read of
+       the partial hashes from the first staged element */
     __shared__ uint32_t s_c[C * ST];
-    __shared__ uint32_t s_bm[NT + 256];         /* block minima; INF behind NT */
+    __shared__ uint32_t s_bm[NT + PAD];         /* block minima; INF behind NT */
     __shared__ uint32_t s_pre0[NT + 4];         /* minimum of the first R0 elements of each block */
     __shared__ uint32_t s_bits[NBW];
     __shared__ uint32_t s_njobs, s_flag;
     __shared__ uint64_t s_roll[16][2];
-    /* phase 1: {F16, U16} of chunk L at s_xy[L], {PF, PU} (first k%16 bases) at s_xy[NX + L];
-       afterwards the same bytes hold the range-minimum levels and the job list */
-    __shared__ uint64_t s_xy[2 * NX][2];
-    uint32_t *const s_t0 = (uint32_t *)&s_xy[0][0];      /* [NT + 256] */
-    uint32_t *const s_t1 = s_t0 + (NT + 256);            /* [NT + 256] */
-    uint16_t *const s_jobs = (uint16_t *)(s_t1 + (NT + 256)); /* [SK2_JOBCAP] */
-    static_assert(sizeof(uint64_t) * 4 * NX >= 2 * (NT + 256) * 4 + 2 * SK2_JOBCAP, "aliased arrays must fit");
+    __shared__ uint32_t s_t0[NT + PAD], s_t1[NT + PAD]; /* range-minimum levels */
+    __shared__ uint16_t s_jobs[SK2_JOBCAP];
+    uint64_t (*const s_xy)[2] = (uint64_t (*)[2])s_c;
+    static_assert(sizeof(uint32_t) * C * ST >= sizeof(uint64_t) * 4 * NX, "the exchange area must fit the element array");
 
     const SketchArgs &A = B.A;
     const int L = threadIdx.x;
@@ -115,7 +126,7 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
     /* nothing written here is read before the first barrier below */
     if (L < 16) { s_roll[L][0] = A.roll_tab[L][0]; s_roll[L][1] = A.roll_tab[L][1]; }
     if (L < NBW) s_bits[L] = 0;
-    s_bm[NT + L] = SK2_INF;
+    if (L < PAD) s_bm[NT + L] = SK2_INF;
     if (L < 4) s_pre0[NT + L] = SK2_INF;
     if (L == 0) { s_njobs = 0; s_flag = B.force_redo ? 1u : 0u; }
 
@@ -127,14 +138,14 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
     const bool live = e_lane < (int64_t)I.M;            /* the lane has at least one k-mer of the sequence */
     const bool feeds = e_lane - 16 * (int64_t)(B.q16 + 1) < (int64_t)I.M; /* its chunk is part of a live lane's first k-mer */
     uint32_t so = 0;
-    if (feeds && !(B.dbg & 8)) {
+    if (feeds && !SK2_DBG(B, 8)) {
         so = sk2_bases16(A.T.packed, gp, B.max_word);
         uint64_t F, U, PF, PU;
         sk2_chunk(so, B.r16, A.g8, A.g4, A.seed_tab, F, U, PF, PU);
         s_xy[L][0] = F; s_xy[L][1] = U;
         if (B.r16) { s_xy[NX + L][0] = PF; s_xy[NX + L][1] = PU; }
     }
-    if (L <= B.q16 && !(B.dbg & 8)) { /* chunks NT .. NT+q16 feed the last lanes */
+    if (L <= B.q16 && !SK2_DBG(B, 8)) { /* chunks NT .. NT+q16 feed the last lanes */
         const int64_t ev = (int64_t)I.E0 + (int64_t)(NT + L) * C;
         if (ev - 16 * (int64_t)(B.q16 + 1) < (int64_t)I.M) {
             const uint32_t sv = sk2_bases16(A.T.packed, gp + (uint64_t)NT * C, B.max_word);
@@ -150,6 +161,7 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
     uint32_t c[C];
 #pragma unroll
     for (int t = 0; t < C; t++) c[t] = SK2_INF;
+    uint64_t fwd = 0, rev = 0;
     if (live) {
         uint64_t f = 0, u = 0;
         for (int i = 0; i < B.q16; i++) {
@@ -163,8 +175,11 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
             f ^= s_xy[NX + L + B.q16][0];
             u ^= s_xy[NX + L + B.q16][1];
         }
-        uint64_t fwd = f;
-        uint64_t rev = srot_u(u, (uint32_t)(k - 1) % 33u, (uint32_t)(k - 1) % 31u);
+        fwd = f;
+        rev = srot_u(u, B.rev_a, B.rev_b);
+    }
+    __syncthreads(); /* the partial hashes have been read: s_c may take the elements */
+    if (live) {
         c[0] = (uint32_t)((fwd + rev) >> 32);
         const uint32_t si = sk2_bases16(A.T.packed, gp + (uint64_t)k, B.max_word);
         /* table index of step t: in<<2 | out, two bits each at base t of si / so -> nibbles of two words */
@@ -172,7 +187,7 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
         const uint32_t zod = ((so >> 2) & 0x33333333u) | (si & 0xCCCCCCCCu);         /* odd bases */
 #pragma unroll
         for (int t = 1; t < C; t++) {
-            if (B.dbg & 4) { c[t] = c[0] + (uint32_t)t * zev; continue; }
+            if (SK2_DBG(B, 4)) { c[t] = c[0] + (uint32_t)t * zev; continue; }
             const int b = t - 1;
             const uint32_t z = (b & 1) ? zod : zev;
             const uint32_t idx = (z >> (4 * (b >> 1))) & 15u;
@@ -214,7 +229,7 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
 #pragma unroll
             for (int q = 1; q < 4; q++) { const uint32_t v = cur[L + q * span]; m = v < m ? v : m; }
             nxt[L] = m;
-            nxt[NT + L] = SK2_INF;
+            if (L < PAD) nxt[NT + L] = SK2_INF;
             __syncthreads();
             cur = nxt;
             span *= 4;
@@ -228,7 +243,7 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
 
     /* ---- phase 4: the 17 windows starting at elements 0..16 of the own block (window 16 = window 0 of the next lane:
        this lane decides whether it changed) ---- */
-    const bool own = L < G.LW && e_lane + G.w <= (int64_t)I.M && !(B.dbg & 2);
+    const bool own = L < G.LW && e_lane + G.w <= (int64_t)I.M && !SK2_DBG(B, 2);
     uint32_t chg = 0;    /* bit j: window j has another minimum value than window j-1 */
     uint32_t le = 0;     /* bit j: the element that entered at window j is <= the minimum of window j-1 */
     {
@@ -309,7 +324,7 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
        collects which of a lane's values equal v; v must occur exactly once in the quad.  A block minimum is resolved by
        the four lanes reading that block's elements, the same way. */
     {
-        uint32_t njobs = (B.dbg & 1) ? 0u : s_njobs;
+        uint32_t njobs = SK2_DBG(B, 1) ? 0u : s_njobs;
         if (njobs > SK2_JOBCAP) { njobs = SK2_JOBCAP; if (L == 0) s_flag = 4u; }
         const uint32_t q = (uint32_t)L & 3u, grp = (uint32_t)L >> 2;
         const uint32_t rounds = (njobs + NT / 4 - 1) / (NT / 4);
@@ -326,7 +341,7 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
                 const uint32_t t = q + 4u * r, b = b0 + 1 + q + 4u * r;
                 val[r] = s_c[t * ST + b0];
                 val[4 + r] = s_c[t * ST + b1];
-                val[8 + r] = s_bm[b < (uint32_t)NT + 255u ? b : (uint32_t)NT + 255u];
+                val[8 + r] = s_bm[b < (uint32_t)(NT + PAD - 1) ? b : (uint32_t)(NT + PAD - 1)];
             }
             uint32_t v = SK2_INF;
 #pragma unroll

@@ -87,13 +87,14 @@ def parse_indexlr(fh, with_len):
             np.array(hs, np.uint64), np.array(ps, np.uint32), np.array(ss, np.uint8))
 
 
-def read_indexlr(path, with_len, max_bytes=0):
+def read_indexlr(path, with_len, max_bytes=0, with_strand=True):
     """Native, multi-threaded form of parse_indexlr (csrc/ntl_io.cpp, ntl_tsv_*): yields
     (Names, lengths u32 or None, mx_off u64[n+1], hash u64, pos u32, strand u8) per block of about
-    max_bytes of text (0: the whole input as one block).  path "-" = stdin."""
+    max_bytes of text (0: the whole input as one block).  path "-" = stdin.  with_strand=False reads the `H:pos` tokens of
+    `indexlr --pos` without `--strand` (strand is then all 1)."""
     L = _native()
     h = C.c_void_p()
-    if L.ntl_tsv_open(path.encode(), 1 if with_len else 0, C.byref(h)) != 0:
+    if L.ntl_tsv_open(path.encode(), (1 if with_len else 0) | (0 if with_strand else 2), C.byref(h)) != 0:
         raise OSError(f"cannot open {path}")
     try:
         while True:

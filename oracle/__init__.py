@@ -390,3 +390,26 @@ def format_dot(pairs, ctg_len_by_name, n=1):
     elines = [f"\"{a}\" -> \"{b}\" [d={d} e=100 n={cnt}]\n"
               for a in edges for b, (d, cnt) in edges[a].items() if cnt >= n]
     return head, nodes, elines
+
+
+def overlap_filter(mx_off, mx_hash, pos, regions):
+    """CPU restatement of read_minimizer_line (bin/ntlink_overlap_sequences.py:170-190) on arrays: for sequence i with
+    the valid regions regions[i] (list of inclusive (start, end), or None when the name is not in valid_mx_positions), the
+    minimizers inside a region whose hash occurs once among those (the first occurrence enters the dict :182-185, every
+    later one goes to dup_mxs :181-182, which is deleted after the line :187).  -> (kept mx_off, hash, pos)."""
+    out_off, oh, op = [0], [], []
+    for i in range(len(mx_off) - 1):
+        a, b = int(mx_off[i]), int(mx_off[i + 1])
+        reg = regions[i]
+        if reg:
+            h, p = np.asarray(mx_hash[a:b]), np.asarray(pos[a:b]).astype(np.int64)
+            valid = np.zeros(b - a, bool)
+            for s, e in reg:
+                valid |= (p >= s) & (p <= e)
+            hv = h[valid]
+            uniq, cnt = np.unique(hv, return_counts=True)
+            once = np.isin(hv, uniq[cnt == 1])
+            oh.append(hv[once]); op.append(p[valid][once])
+        out_off.append(out_off[-1] + (len(oh[-1]) if reg and len(oh) else 0) if reg else out_off[-1])
+    cat = lambda xs, dt: np.concatenate(xs).astype(dt) if xs else np.zeros(0, dt)
+    return np.array(out_off, np.uint64), cat(oh, np.uint64), cat(op, np.uint32)

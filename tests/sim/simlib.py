@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 SIM_LIB = os.path.join(HERE, "build", "libntlink_sim.so")
 SRC = [os.path.join(ROOT, "ntlink_amd", "csrc", f) for f in
-       ("ntl_hip.hip", "ntl_io.cpp", "ntl_pairs.cpp", "dev_common.h", "scan_kernels.h", "sketch_kernels.h", "sketch2_kernels.h", "map_kernels.h", "pack_kernels.h", "synth_kernels.h")] + \
+       ("ntl_hip.hip", "ntl_io.cpp", "ntl_pairs.cpp", "ntl_liftover.cpp", "overlap_kernels.h", "dev_common.h", "scan_kernels.h", "sketch_kernels.h", "sketch2_kernels.h", "map_kernels.h", "pack_kernels.h", "synth_kernels.h")] + \
       [os.path.join(HERE, "sim_runtime.cpp"), os.path.join(HERE, "include", "hip", "hip_runtime.h"),
        os.path.join(HERE, "include", "dev_intrin.h")]
 
@@ -21,7 +21,7 @@ def build(sanitize=False):
     cmd = ["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-pthread", "-ffp-contract=off", "-Wall",
            "-Wno-unused-function", "-Wno-unknown-pragmas", "-x", "c++",
            "-I", os.path.join(HERE, "include"), "-I", os.path.join(ROOT, "ntlink_amd", "csrc"),
-           SRC[0], SRC[1], SRC[2], os.path.join(HERE, "sim_runtime.cpp"), "-lz", "-ldl", "-o", out]
+           SRC[0], SRC[1], SRC[2], SRC[3], os.path.join(HERE, "sim_runtime.cpp"), "-lz", "-ldl", "-o", out]
     if sanitize:
         cmd[1:1] = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer"]
     subprocess.check_call(cmd)

@@ -2,7 +2,7 @@
 # phase ablation of sketch_fast_kernel (NTL_SKETCH_ABLATE bits: 1 search, 2 window pass, 4 rolling, 8 init): time + VALU instructions
 TAG=${1:-r02t}
 mkdir -p gpurun_out/$TAG
-python __graft_entry__.py > gpurun_out/$TAG/build.log 2>&1 || { tail -20 gpurun_out/$TAG/build.log; exit 1; }
+NTL_EXTRA_HIPCC_FLAGS=-DNTL_SKETCH_ABLATION python __graft_entry__.py > gpurun_out/$TAG/build.log 2>&1 || { tail -20 gpurun_out/$TAG/build.log; exit 1; }
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 for ab in 0 1 3 7 15; do
