@@ -170,3 +170,81 @@ def check_anchor_cases(dev, max_cases=None):
     for _a, _s, _m, _r, mapper in cache.values():
         mapper.close()
     return n
+
+
+# ---- row f3: overlap-stage consumer ---------------------------------------------------------------
+
+def overlap_cases():
+    import json
+    from helpers import GEN
+    return json.load(open(os.path.join(GEN, "overlap", "cases.json")))
+
+
+def check_overlap_case(dev, case, tmp_path):
+    """ntlink_amd.overlap (native `H:pos` parser + ovl_* kernels) == the imported reference's read_minimizers /
+    read_minimizers_path on the same TSV and valid regions (tests/golden/gen_goldens_overlap.py)."""
+    import gzip
+    import json
+    from helpers import GEN
+    from ntlink_amd import overlap
+    d = os.path.join(GEN, "overlap")
+    c = json.load(gzip.open(os.path.join(d, case + ".json.gz"), "rt"))
+    valid = {n: [tuple(r) for r in v] for n, v in c["valid"].items()}
+    text = gzip.open(os.path.join(d, c["tsv"]), "rt").read()
+    tsv = os.path.join(str(tmp_path), "in.tsv")
+    open(tsv, "w").write(text)
+    mx_info, mxs = overlap.read_minimizers(tsv, valid, dev=dev)
+    assert set(mxs) == set(c["expected"]) and set(k for k in mx_info if k in mxs) == set(mxs)
+    n_kept = 0
+    for n, e in c["expected"].items():
+        assert mxs[n] == [e["mxs"]], n
+        assert list(mx_info[n]) == e["mxs"] and [mx_info[n][m] for m in e["mxs"]] == [(n, p) for p in e["pos"]], n
+        n_kept += len(e["mxs"])
+    # the path form: one call per LAST marker
+    lines = text.splitlines(keepends=True)
+    marked = []
+    for i, line in enumerate(lines):
+        marked.append(line)
+        if i % 3 == 2:
+            marked.append("LASTntLink_%d\t\n" % (i // 3))
+    reader = iter(marked)
+    for chunk in c["path_chunks"]:
+        _info, got = overlap.read_minimizers_path(reader, valid, dev=dev)
+        assert {n: m[0] for n, m in got.items()} == chunk
+    assert next(reader, None) is None
+    return n_kept
+
+
+def check_overlap_random(dev, seed, nseq=40, max_len=30000, k=15, w=5):
+    """Device sketch at the overlap stage's density -> ntl_overlap_filter == the oracle's restatement; sequences with tandem
+    repeats so that duplicated hashes are common, random region lists (none / empty / overlapping / beyond the end)."""
+    rng = np.random.default_rng(seed)
+    seqs, regions = [], []
+    for i in range(nseq):
+        n = int(rng.integers(1, max_len))
+        s = rng.integers(0, 4, n).astype(np.uint8)
+        if i % 3 == 0 and n > 200:
+            unit = int(rng.integers(1, 60)); a = int(rng.integers(0, n - 100)); m = int(rng.integers(50, n - a))
+            s[a:a + m] = np.resize(s[a:a + unit], m)
+        seqs.append(bytes(np.frombuffer(b"ACGT", np.uint8)[s]))
+        r = rng.random()
+        if r < 0.2:
+            regions.append(None)
+        elif r < 0.3:
+            regions.append([])
+        else:
+            regions.append([tuple(sorted(int(x) for x in rng.integers(0, n + 100, 2))) for _ in range(int(rng.integers(1, 4)))])
+    off = np.zeros(nseq + 1, np.uint64)
+    starts, ends = [], []
+    for i, reg in enumerate(regions):
+        for a, b in reg or ():
+            starts.append(a); ends.append(b)
+        off[i + 1] = len(starts)
+    with dev.batch(seqs) as b, dev.sketch(b, k, w) as sk:
+        m_off, h, p, _ = sk.download()
+        with dev.overlap_filter(sk, off, np.array(starts, np.uint32), np.array(ends, np.uint32)) as kept:
+            g_off, gh, gp, _gs = kept.download()
+    e_off, eh, ep = oracle.overlap_filter(m_off, h, p, regions)
+    assert np.array_equal(g_off, e_off) and np.array_equal(gh, eh) and np.array_equal(gp, ep)
+    assert 0 < len(eh) < len(h)
+    return len(eh), len(h)

@@ -319,3 +319,16 @@ def test_synth_generator_on_the_gpu(dev):
         assert 0.2 < res.n_index_hits / rsk.count < 0.6
     for h in (g, s, r1, r2):
         h.close()
+
+
+@pytest.mark.parametrize("case", pc.overlap_cases())
+def test_overlap_consumer_matches_reference(dev, case, tmp_path):
+    """the overlap stage's read_minimizers / read_minimizers_path (valid regions + per-contig duplicate
+    removal, bin/ntlink_overlap_sequences.py:145-190) on the GPU == the imported reference on the same TSV."""
+    assert pc.check_overlap_case(dev, case, tmp_path) > 500
+
+
+@pytest.mark.parametrize("seed,nseq,max_len", [(1, 40, 30000), (2, 400, 5000), (3, 6, 2_000_000)])
+def test_overlap_filter_random(dev, seed, nseq, max_len):
+    kept, total = pc.check_overlap_random(dev, seed, nseq, max_len)
+    assert kept < total

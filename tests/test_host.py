@@ -265,6 +265,16 @@ def test_native_tsv_parser_equals_python_parser(tmp_path):
     bad.write_text("r1\t100\t12:5:+ 13:x:-\n")
     with pytest.raises(ValueError):
         list(formats.read_indexlr(str(bad), True))
+    # `indexlr --pos` without `--strand` (the overlap stage's TSV, ntLink:244,249): H:pos tokens
+    pos = tmp_path / "pos.tsv"
+    pos.write_text("c1\t18446744073709551615:0 7:12 99:4000000000\nc2\t\nc3\t5:6\n")
+    (names, _l, off, h, p, s), = list(formats.read_indexlr(str(pos), False, with_strand=False))
+    assert list(names) == ["c1", "c2", "c3"] and off.tolist() == [0, 3, 3, 4]
+    assert h.tolist() == [18446744073709551615, 7, 99, 5] and p.tolist() == [0, 12, 4000000000, 6] and s.tolist() == [1, 1, 1, 1]
+    for text in ("c1\t5:6:+\n", "c1\t5\n", "c1\t5:\n"):
+        bad.write_text(text)
+        with pytest.raises(ValueError):
+            list(formats.read_indexlr(str(bad), False, with_strand=False))
 
 
 def test_prefetch_and_drain_keep_order_and_propagate_errors():

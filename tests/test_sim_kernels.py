@@ -218,3 +218,15 @@ def test_sim_fast_window_pass_hands_ties_to_the_exact_pass(dev, monkeypatch):
     with dev.batch(seqs) as b, dev.sketch(b, 32, 100) as sk:
         assert sk.redo_strips == 0
     pc.check_sketch(dev, seqs, 32, 100)
+
+
+@pytest.mark.parametrize("case", ["synthetic_k15_w5_s1", "synthetic_k8_w3_s3", "scaffolds_4_k15_w5_s1"])
+def test_sim_overlap_consumer_matches_reference(dev, case, tmp_path):
+    """read_minimizers / read_minimizers_path of the overlap stage (valid regions, per-contig duplicate
+    removal) on the device."""
+    assert pc.check_overlap_case(dev, case, tmp_path) > 500
+
+
+def test_sim_overlap_filter_random(dev):
+    kept, total = pc.check_overlap_random(dev, 3, nseq=12, max_len=6000)
+    assert kept < total
