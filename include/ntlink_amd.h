@@ -233,6 +233,12 @@ const char *ntl_fastx_error(const ntl_fastx *r);
  * names[name_offsets[i]..name_offsets[i+1]).  The pointer accessors return a contiguous copy held
  * by the reader, valid until the next call. */
 int ntl_fastx_next(ntl_fastx *r, uint64_t max_bases, uint64_t *nseq);
+/* A reader over the records of a plain (uncompressed, regular) file whose FIRST byte lies in [lo, hi) -- hi = 0: to the
+ * end -- so that readers opened on [a, b) and [b, c) together see every record once, in order.  NTL_EINVAL for inputs
+ * that cannot be cut (gzip, pipes).  ntl_fastx_range reports the bytes [*lo, *hi) the reader really covers (cut at
+ * record starts).  The multi-GPU driver gives every rank its own range of the concatenated read files (ntLink:222). */
+int ntl_fastx_open_range(const char *path, uint64_t lo, uint64_t hi, ntl_fastx **out);
+void ntl_fastx_range(const ntl_fastx *r, uint64_t *lo, uint64_t *hi);
 void ntl_fastx_sizes(const ntl_fastx *r, uint64_t *nseq, uint64_t *bases, uint64_t *name_bytes);
 int ntl_fastx_copy(const ntl_fastx *r, char *seqs, uint64_t *offsets, char *names, uint64_t *name_offsets);
 const char *ntl_fastx_seqs(ntl_fastx *r);
@@ -289,6 +295,11 @@ uint64_t ntl_tally_npairs(const ntl_tally *t);
 uint64_t ntl_tally_ngaps(const ntl_tally *t);
 int ntl_tally_export(const ntl_tally *t, uint32_t *src, uint8_t *src_ori, uint32_t *tgt, uint8_t *tgt_ori,
                      uint32_t *anchor, uint64_t *gap_off, int64_t *gaps);
+/* Appends an export of ANOTHER tally over the same contigs that covers later reads (pairs first seen there go behind the
+ * known ones, gaps behind the gaps of the same pair, anchors add up): what one tally would hold after both read ranges.
+ * The multi-GPU driver tallies per rank and merges in rank order on rank 0. */
+int ntl_tally_merge(ntl_tally *t, uint64_t npairs, const uint32_t *src, const uint8_t *src_ori, const uint32_t *tgt,
+                    const uint8_t *tgt_ori, const uint32_t *anchor, const uint64_t *gap_off, const int64_t *gaps);
 
 /* ---- liftover of the verbose mappings (no GPU involved) -------------------------------------- */
 

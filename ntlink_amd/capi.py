@@ -26,10 +26,10 @@ SYMBOLS = [
     "ntl_index_build", "ntl_index_destroy", "ntl_index_size",
     "ntl_map_run", "ntl_mapres_destroy", "ntl_mapres_n_mappings", "ntl_mapres_n_hits", "ntl_mapres_n_pafs",
     "ntl_mapres_n_index_hits", "ntl_mapres_download",
-    "ntl_fastx_open", "ntl_fastx_close", "ntl_fastx_error", "ntl_fastx_next", "ntl_fastx_sizes", "ntl_fastx_copy", "ntl_fastx_seqs", "ntl_fastx_offsets",
+    "ntl_fastx_open", "ntl_fastx_open_range", "ntl_fastx_range", "ntl_fastx_close", "ntl_fastx_error", "ntl_fastx_next", "ntl_fastx_sizes", "ntl_fastx_copy", "ntl_fastx_seqs", "ntl_fastx_offsets",
     "ntl_fastx_names", "ntl_fastx_name_offsets", "ntl_write_indexlr", "ntl_write_verbose", "ntl_write_paf",
     "ntl_tsv_open", "ntl_tsv_close", "ntl_tsv_error", "ntl_tsv_next", "ntl_tsv_sizes", "ntl_tsv_copy",
-    "ntl_tally_create", "ntl_tally_destroy", "ntl_tally_add", "ntl_tally_npairs", "ntl_tally_ngaps", "ntl_tally_export",
+    "ntl_tally_create", "ntl_tally_destroy", "ntl_tally_add", "ntl_tally_npairs", "ntl_tally_ngaps", "ntl_tally_export", "ntl_tally_merge",
     "ntl_liftover",
 ]
 
@@ -57,7 +57,8 @@ _libs = {}
 
 def load(path=None):
     """dlopen the C-ABI library and declare its prototypes."""
-    path = path or DEFAULT_LIB
+    # NTLINK_AMD_LIB: another build of the same C ABI (the tests run the kernels' source under a CPU mock of the HIP runtime)
+    path = path or os.environ.get("NTLINK_AMD_LIB") or DEFAULT_LIB
     if path in _libs:
         return _libs[path]
     if not os.path.exists(path):
@@ -116,6 +117,9 @@ def load(path=None):
     L.ntl_host_free.argtypes = [vp, vp]
     L.ntl_host_free.restype = None
     L.ntl_fastx_open.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.ntl_fastx_open_range.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.POINTER(vp)]
+    L.ntl_fastx_range.argtypes = [vp, u64p, u64p]
+    L.ntl_fastx_range.restype = None
     L.ntl_fastx_close.argtypes = [vp]
     L.ntl_fastx_close.restype = None
     L.ntl_fastx_error.argtypes = [vp]
@@ -149,6 +153,7 @@ def load(path=None):
         f.argtypes = [vp]
         f.restype = C.c_uint64
     L.ntl_tally_export.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    L.ntl_tally_merge.argtypes = [vp, C.c_uint64, vp, vp, vp, vp, vp, vp, vp]
     L.ntl_liftover.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_uint64, vp, u64p, vp, u64p, vp, vp, vp, vp, u64p, u64p]
     _libs[path] = L
     return L

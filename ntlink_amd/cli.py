@@ -5,7 +5,9 @@
   ntlink_main       `ntLink pair target= reads= [k= w= ...]` make-style key=value    (ntLink:8-89,165)
 """
 import argparse
+import os
 import sys
+import time
 
 VERSION = "ntLink v1.3.11 pair stage, MI355X build 0.1.0"
 
@@ -88,18 +90,19 @@ _DEFAULTS = dict(target="None", reads="None", w="100", k="32", t="4", z="1000", 
 
 def ntlink_main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
-    targets, kv = [], dict(_DEFAULTS)
+    targets, kv, given = [], dict(_DEFAULTS), set()
     for tok in argv:
         if tok.startswith("-"):
             continue  # make flags such as -B
         if "=" in tok:
             key, val = tok.split("=", 1)
             kv[key] = val
+            given.add(key)
         else:
             targets.append(tok)
     if not targets or "help" in targets:
         print("Usage: ntLink pair target=<target scaffolds> reads='List of long read files' [k= w= z= n= a= f= x= "
-              "paf= verbose= sensitive= repeats= ntlink_pairs_tsv= prefix= device=]\n"
+              "paf= verbose= sensitive= repeats= ntlink_pairs_tsv= prefix= device= t= v=]\n"
               "Only the `pair` stage (minimizer sketch + read-to-contig mapping) runs on the GPU; "
               "scaffold/gap_fill stay with the reference pipeline.")
         return 0
@@ -116,12 +119,58 @@ def ntlink_main(argv=None):
         print("ERROR: Must set target", file=sys.stderr)
         return 2
     from . import pipeline
+    apply_threads(kv, given)
+    t0 = time.perf_counter()
     dev = _device(int(kv["device"]))
     try:
-        pipeline.run_pair(dev, kv["target"], kv["reads"], prefix=kv["prefix"], k=int(kv["k"]), w=int(kv["w"]), n=int(kv["n"]),
-                          a=int(kv["a"]), z=int(kv["z"]), f=int(kv["f"]), x=float(kv["x"]), paf=kv["paf"] == "True",
-                          verbose=kv["verbose"] == "True", sensitive=kv["sensitive"] == "True", repeats=kv["repeats"] == "True",
-                          pairs_tsv=kv["ntlink_pairs_tsv"] == "True")
+        stats = pipeline.run_pair(dev, kv["target"], kv["reads"], prefix=kv["prefix"], k=int(kv["k"]), w=int(kv["w"]), n=int(kv["n"]),
+                                  a=int(kv["a"]), z=int(kv["z"]), f=int(kv["f"]), x=float(kv["x"]), paf=kv["paf"] == "True",
+                                  verbose=kv["verbose"] == "True", sensitive=kv["sensitive"] == "True", repeats=kv["repeats"] == "True",
+                                  pairs_tsv=kv["ntlink_pairs_tsv"] == "True")
     finally:
         dev.close()
+    if kv["v"] != "0":
+        write_time_file(kv, "ntLink " + " ".join(argv), time.perf_counter() - t0, stats)
     return 0
+
+
+def apply_threads(kv, given):
+    """`t=` (ntLink:27: threads of indexlr) sets the parser / emitter thread count of the native I/O when it was given
+    on the command line; without it the library's own default (min(cores, 32)) stays."""
+    if "t" in given and "NTL_IO_THREADS" not in os.environ:
+        try:
+            os.environ["NTL_IO_THREADS"] = str(max(1, int(kv["t"])))
+        except ValueError:
+            raise SystemExit(f"ERROR: t={kv['t']} is not a number")
+
+
+def write_time_file(kv, command, wall_s, stats):
+    """`v=1` (ntLink:100-110): the reference wraps every recipe in `time -v -o $@.time`.  The fused driver runs the
+    two recipes of the pair stage (ntLink:198-199,221-225) in one process, so one file is written next to the last target,
+    <prefix>.n<n>.scaffold.dot.time, with GNU time's -v lines for this process and the stage times of the driver."""
+    import resource
+    ru, rc = resource.getrusage(resource.RUSAGE_SELF), resource.getrusage(resource.RUSAGE_CHILDREN)
+    user, system = ru.ru_utime + rc.ru_utime, ru.ru_stime + rc.ru_stime
+    prefix = kv["prefix"] or f"{kv['target']}.k{kv['k']}.w{kv['w']}.z{kv['z']}"
+    m, sec = divmod(wall_s, 60.0)
+    h, m = divmod(int(m), 60)
+    elapsed = f"{h}:{m:02d}:{sec:05.2f}" if h else f"{m}:{sec:05.2f}"
+    lines = [f"\tCommand being timed: \"{command}\"",
+             f"\tUser time (seconds): {user:.2f}",
+             f"\tSystem time (seconds): {system:.2f}",
+             f"\tPercent of CPU this job got: {int(100 * (user + system) / max(wall_s, 1e-9))}%",
+             f"\tElapsed (wall clock) time (h:mm:ss or m:ss): {elapsed}",
+             f"\tMaximum resident set size (kbytes): {max(ru.ru_maxrss, rc.ru_maxrss)}",
+             f"\tMajor (requiring I/O) page faults: {ru.ru_majflt}",
+             f"\tMinor (reclaiming a frame) page faults: {ru.ru_minflt}",
+             f"\tVoluntary context switches: {ru.ru_nvcsw}",
+             f"\tInvoluntary context switches: {ru.ru_nivcsw}",
+             f"\tFile system inputs: {ru.ru_inblock}",
+             f"\tFile system outputs: {ru.ru_oublock}",
+             "\tExit status: 0"]
+    for key in sorted(stats or {}):
+        if key.startswith("t_") or key in ("read_bases", "reads", "read_minimizers", "index_hits", "index_size", "parsed_bytes",
+                                           "parsed_bytes_per_rank"):
+            lines.append(f"\tntlink_amd {key}: {stats[key]:.3f}" if isinstance(stats[key], float) else f"\tntlink_amd {key}: {stats[key]}")
+    with open(f"{prefix}.n{kv['n']}.scaffold.dot.time", "w") as fh:
+        fh.write("\n".join(lines) + "\n")

@@ -60,7 +60,8 @@ struct ntl_fastx {
     size_t map_size = 0, map_cap = 0;
     int fd = -1;               /* file / serial */
     bool seekable = false;
-    size_t file_size = 0;
+    size_t file_size = 0;      /* file: end of the bytes this reader covers (the file's size, or the end of its range) */
+    size_t range_lo = 0;       /* file: first byte it covers */
     bool gz = false, z_init = false, src_eof = false; /* serial */
     z_stream zs;
     std::vector<unsigned char> zin;
@@ -435,6 +436,66 @@ extern "C" int ntl_fastx_open(const char *path, ntl_fastx **out)
     r->zin.resize(1u << 20);
     *out = r;
     return NTL_OK;
+}
+
+/* First record start at or behind byte `at` of a plain file (a record belongs to the range that holds its first byte:
+ * two readers opened on [a, b) and [b, c) see every record exactly once); the file size when there is none. */
+static bool record_start_at(int fd, size_t file_size, bool fastq, size_t at, size_t *out)
+{
+    if (at == 0) { *out = 0; return true; }
+    if (at >= file_size) { *out = file_size; return true; }
+    size_t win = (size_t)1 << 20;
+    std::vector<char> buf;
+    for (;;) {
+        const size_t from = at - 1; /* the byte before: `at` itself is a record start when it follows a newline */
+        const size_t len = std::min(win, file_size - from);
+        buf.resize(len);
+        size_t have = 0;
+        while (have < len) {
+            const ssize_t n = pread(fd, buf.data() + have, len - have, (off_t)(from + have));
+            if (n <= 0) return false;
+            have += (size_t)n;
+        }
+        const char *b = buf.data(), *e = b + len;
+        const char *p = find_boundary(b, e, fastq);
+        if (p < e) { *out = from + (size_t)(p - b); return true; }
+        if (from + len >= file_size) { *out = file_size; return true; }
+        win *= 4; /* a record (or the look-ahead of the FASTQ test) longer than the window */
+    }
+}
+
+/* A reader over the records of a plain (uncompressed, regular) file whose first byte lies in [lo, hi); hi = 0 or beyond
+ * the end means the end of the file.  NTL_EINVAL for anything that cannot be cut (gzip, pipes): such inputs are read whole
+ * by one reader.  The multi-GPU driver gives every rank its own byte range of the read files. */
+extern "C" int ntl_fastx_open_range(const char *path, uint64_t lo, uint64_t hi, ntl_fastx **out)
+{
+    if (!path || !out) return NTL_EINVAL;
+    *out = nullptr;
+    if (strcmp(path, "-") == 0) return NTL_EINVAL;
+    ntl_fastx *r = nullptr;
+    int rc = ntl_fastx_open(path, &r);
+    if (rc != NTL_OK) return rc;
+    if (!r->seekable) { ntl_fastx_close(r); return NTL_EINVAL; }
+    const size_t size = r->file_size;
+    if (hi == 0 || hi > size) hi = size;
+    if (lo > hi) lo = hi;
+    size_t a = 0, b = 0;
+    if (!record_start_at(r->fd, size, r->fastq, (size_t)lo, &a) || !record_start_at(r->fd, size, r->fastq, (size_t)hi, &b)) {
+        ntl_fastx_close(r);
+        return NTL_EINVAL;
+    }
+    if (b < a) b = a;
+    r->range_lo = a; r->cur = a; r->stage_off = a;
+    r->file_size = b;
+    *out = r;
+    return NTL_OK;
+}
+
+/* The byte range [*lo, *hi) of the file this reader covers (0, 0 for sources that are not plain files). */
+extern "C" void ntl_fastx_range(const ntl_fastx *r, uint64_t *lo, uint64_t *hi)
+{
+    if (lo) *lo = r && r->seekable ? r->range_lo : 0;
+    if (hi) *hi = r && r->seekable ? r->file_size : 0;
 }
 
 extern "C" void ntl_fastx_close(ntl_fastx *r)

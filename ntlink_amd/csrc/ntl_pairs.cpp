@@ -64,7 +64,7 @@ extern "C" int ntl_tally_create(const char *ctg_names, const uint64_t *ctg_name_
 extern "C" void ntl_tally_destroy(ntl_tally *t) { delete t; }
 
 /* One batch of mappings (reads in order; read_len is indexed by ntl_mapping.read).  Returns NTL_ERANGE
- * when an overhang comes out negative -- the reference's "Gap distance estimation less than 0". */
+ * when an overhang of an evaluated pair comes out negative -- the reference's "Gap distance estimation less than 0". */
 extern "C" int ntl_tally_add(ntl_tally *t, const ntl_mapping *maps, uint64_t n_maps, const ntl_hit *hits, const uint32_t *read_len)
 {
     if (!t || (n_maps && (!maps || !hits || !read_len))) return NTL_EINVAL;
@@ -83,7 +83,6 @@ extern "C" int ntl_tally_add(ntl_tally *t, const ntl_mapping *maps, uint64_t n_m
         tp[i] = hf.read_strand == hf.ctg_strand;
         a[i] = sp[i] ? clen - (int64_t)hl.ctg_pos - k : (int64_t)hl.ctg_pos;
         b[i] = tp[i] ? (int64_t)hf.ctg_pos : clen - (int64_t)hf.ctg_pos - k;
-        if (a[i] < 0 || b[i] < 0) return NTL_ERANGE;
     }
     std::unordered_set<uint64_t> added;
     std::vector<uint64_t> strong;
@@ -95,7 +94,10 @@ extern "C" int ntl_tally_add(ntl_tally *t, const ntl_mapping *maps, uint64_t n_m
         if (m > 1) {
             const int64_t rl = read_len[maps[s0].read];
             /* returns the normalized key, or 0 when the pair was not recorded (keys are never 0: see below) */
+            bool negative = false; /* the reference asserts a >= 0 and b >= 0 inside calculate_gap_size (:173-184): only for
+                                      pairs it evaluates, before the |gap| > read length test */
             auto add = [&](uint64_t i, uint64_t j, const std::unordered_set<uint64_t> *check) -> uint64_t {
+                if (a[i] < 0 || b[j] < 0) { negative = true; return 0; }
                 const ntl_hit &hf = hits[maps[j].hit_off], &hl = hits[maps[i].hit_off + maps[i].n_hits - 1];
                 const int64_t gap = (int64_t)hf.read_pos - (int64_t)hl.read_pos - a[i] - b[j];
                 uint32_t ci = maps[i].ctg, cj = maps[j].ctg;
@@ -121,8 +123,8 @@ extern "C" int ntl_tally_add(ntl_tally *t, const ntl_mapping *maps, uint64_t n_m
                 return key;
             };
             if (m <= (uint64_t)t->f) {
-                for (uint64_t i = s0; i < s1; i++)
-                    for (uint64_t j = i + 1; j < s1; j++) add(i, j, nullptr);
+                for (uint64_t i = s0; i < s1 && !negative; i++)
+                    for (uint64_t j = i + 1; j < s1 && !negative; j++) add(i, j, nullptr);
             } else { /* long chains: neighbours, then neighbours among the contigs with more than one hit */
                 added.clear();
                 for (uint64_t i = s0; i + 1 < s1; i++) {
@@ -133,6 +135,7 @@ extern "C" int ntl_tally_add(ntl_tally *t, const ntl_mapping *maps, uint64_t n_m
                 for (uint64_t i = s0; i < s1; i++) if (maps[i].n_hits > 1) strong.push_back(i);
                 for (size_t q = 0; q + 1 < strong.size(); q++) add(strong[q], strong[q + 1], &added);
             }
+            if (negative) return NTL_ERANGE;
         }
         s0 = s1;
     }
@@ -159,6 +162,35 @@ extern "C" int ntl_tally_export(const ntl_tally *t, uint32_t *src, uint8_t *src_
         if (!e.gaps.empty()) memcpy(gaps + g, e.gaps.data(), e.gaps.size() * sizeof(int64_t));
         g += e.gaps.size();
         gap_off[i + 1] = g;
+    }
+    return NTL_OK;
+}
+
+/* Appends the export of another tally (same contigs, same k and f) that covers LATER reads: pairs it saw first come
+ * behind the ones known here, its gaps behind the gaps of the same pair, anchors add up -- the state one tally would
+ * have after walking both read ranges in order.  Multi-GPU driver: every rank tallies its own reads, rank 0 merges the
+ * exports in rank order (= read order). */
+extern "C" int ntl_tally_merge(ntl_tally *t, uint64_t npairs, const uint32_t *src, const uint8_t *src_ori, const uint32_t *tgt,
+                               const uint8_t *tgt_ori, const uint32_t *anchor, const uint64_t *gap_off, const int64_t *gaps)
+{
+    if (!t || (npairs && (!src || !src_ori || !tgt || !tgt_ori || !anchor || !gap_off))) return NTL_EINVAL;
+    for (uint64_t i = 0; i < npairs; i++) {
+        if (src[i] >= t->rank.size() || tgt[i] >= t->rank.size() || gap_off[i + 1] < gap_off[i]) return NTL_EINVAL;
+        const uint64_t key = ((uint64_t)t->rank[src[i]] << 33) | ((uint64_t)(src_ori[i] & 1u) << 32) | ((uint64_t)t->rank[tgt[i]] << 1) |
+                             (uint64_t)(tgt_ori[i] & 1u) | (1ull << 63);
+        auto it = t->slot.find(key);
+        uint32_t e;
+        if (it == t->slot.end()) {
+            e = (uint32_t)t->pairs.size();
+            t->slot.emplace(key, e);
+            t->pairs.emplace_back();
+            t->pairs[e].key = key; t->pairs[e].src = src[i]; t->pairs[e].tgt = tgt[i];
+        } else e = it->second;
+        const uint64_t ng = gap_off[i + 1] - gap_off[i];
+        if (ng && !gaps) return NTL_EINVAL;
+        t->pairs[e].gaps.insert(t->pairs[e].gaps.end(), gaps + gap_off[i], gaps + gap_off[i + 1]);
+        t->ngaps += ng;
+        t->pairs[e].anchor += anchor[i];
     }
     return NTL_OK;
 }

@@ -1,9 +1,10 @@
 """`ntLink pair` on N GPUs of one node: one process per GPU, launched by torch.distributed.run.
 
 Reads shard embarrassingly: the contig index is rebuilt on every GPU
-(deterministic, <= 1 GB), each rank maps a contiguous share of each read batch, rank 0 gathers the
-result RECORDS (host objects, gloo) in rank order and writes the files.  No RCCL collective is on
-the data path; RCCL/gloo only carry the barrier and the result gather.
+(deterministic, <= 1 GB); every rank owns a contiguous byte range of the concatenated read files, parses
+only that, maps it, writes its own text and keeps its own pair tally (pipeline.run_pair).  gloo carries two
+barriers, the byte counts of the part files and the pair-tally deltas; no record array leaves its process
+and no RCCL collective is on the data path.
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
         -m ntlink_amd.dist_pair pair target=asm.fa reads='r1.fq.gz r2.fq.gz' k=32 w=250 paf=True
@@ -25,14 +26,19 @@ class DistComm:
         self.dist.gather_object(obj, out, dst=0)
         return out
 
+    def allgather(self, obj):
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
     def barrier(self):
         self.dist.barrier()
 
 
-def main(argv=None, device_factory=None):
+def main(argv=None):
     from . import cli, pipeline
     argv = list(sys.argv[1:] if argv is None else argv)
-    kv = dict(cli._DEFAULTS)
+    kv, given = dict(cli._DEFAULTS), set()
     targets = []
     for tok in argv:
         if tok.startswith("-"):
@@ -40,23 +46,26 @@ def main(argv=None, device_factory=None):
         if "=" in tok:
             key, val = tok.split("=", 1)
             kv[key] = val
+            given.add(key)
         else:
             targets.append(tok)
     if targets != ["pair"] or kv["target"] == "None" or kv["reads"] == "None":
         print("usage: ... -m ntlink_amd.dist_pair pair target=<fa> reads='<files>' [k= w= ...]", file=sys.stderr)
         return 2
-    comm = DistComm("gloo")  # host objects only; the device work needs no collective
+    cli.apply_threads(kv, given)
+    import time
+    t0 = time.perf_counter()
+    comm = DistComm("gloo")  # a few host objects only; the device work needs no collective
     local = int(os.environ.get("LOCAL_RANK", comm.rank))
-    if device_factory is None:
-        from . import capi
-        dev = capi.Device(local)
-    else:
-        dev = device_factory(local)
+    from . import capi
+    dev = capi.Device(local)
     try:
-        pipeline.run_pair(dev, kv["target"], kv["reads"], prefix=kv["prefix"], k=int(kv["k"]), w=int(kv["w"]), n=int(kv["n"]),
+        stats = pipeline.run_pair(dev, kv["target"], kv["reads"], prefix=kv["prefix"], k=int(kv["k"]), w=int(kv["w"]), n=int(kv["n"]),
                           a=int(kv["a"]), z=int(kv["z"]), f=int(kv["f"]), x=float(kv["x"]), paf=kv["paf"] == "True",
                           verbose=kv["verbose"] == "True", sensitive=kv["sensitive"] == "True", repeats=kv["repeats"] == "True",
                           pairs_tsv=kv["ntlink_pairs_tsv"] == "True", comm=comm)
+        if comm.rank == 0 and kv["v"] != "0":
+            cli.write_time_file(kv, "ntlink_amd.dist_pair " + " ".join(argv), time.perf_counter() - t0, stats)
     finally:
         dev.close()
         comm.dist.destroy_process_group()

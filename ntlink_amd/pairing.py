@@ -63,17 +63,32 @@ class PairTally:
         if rc != 0:
             raise ValueError(f"ntl_tally_add failed with {rc}")
 
+    def export(self):
+        """(src u32, src_ori u8, tgt u32, tgt_ori u8, anchor u32, gap_off u64[n+1], gaps i64): every pair in order of
+        first appearance, contig indices, 1 = '+'.  The form merge() takes -- small enough to send between ranks."""
+        L, h = self._L, self._h
+        n, g = int(L.ntl_tally_npairs(h)), int(L.ntl_tally_ngaps(h))
+        src, tgt, anchor = np.zeros(n, np.uint32), np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+        so, to = np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+        goff, gaps = np.zeros(n + 1, np.uint64), np.zeros(g, np.int64)
+        L.ntl_tally_export(h, src.ctypes.data, so.ctypes.data, tgt.ctypes.data, to.ctypes.data, anchor.ctypes.data,
+                           goff.ctypes.data, gaps.ctypes.data)
+        return src, so, tgt, to, anchor, goff, gaps
+
+    def merge(self, exported):
+        """Appends the export() of a tally that covers LATER reads (multi-GPU driver: rank order = read order)."""
+        src, so, tgt, to, anchor, goff, gaps = (np.ascontiguousarray(x) for x in exported)
+        self._pairs = None
+        rc = self._L.ntl_tally_merge(self._h, len(src), src.ctypes.data, so.ctypes.data, tgt.ctypes.data, to.ctypes.data,
+                                     anchor.ctypes.data, goff.ctypes.data, gaps.ctypes.data if len(gaps) else None)
+        if rc != 0:
+            raise ValueError(f"ntl_tally_merge failed with {rc}")
+
     @property
     def pairs(self):
         """(src, src_ori, tgt, tgt_ori) -> [gaps, anchor] in order of first appearance."""
         if self._pairs is None:
-            L, h = self._L, self._h
-            n, g = int(L.ntl_tally_npairs(h)), int(L.ntl_tally_ngaps(h))
-            src, tgt, anchor = np.zeros(n, np.uint32), np.zeros(n, np.uint32), np.zeros(n, np.uint32)
-            so, to = np.zeros(n, np.uint8), np.zeros(n, np.uint8)
-            goff, gaps = np.zeros(n + 1, np.uint64), np.zeros(g, np.int64)
-            L.ntl_tally_export(h, src.ctypes.data, so.ctypes.data, tgt.ctypes.data, to.ctypes.data, anchor.ctypes.data,
-                               goff.ctypes.data, gaps.ctypes.data)
+            src, so, tgt, to, anchor, goff, gaps = self.export()
             names = self.names.tolist() if hasattr(self.names, "tolist") else list(self.names)
             gl, go = gaps.tolist(), goff.tolist()
             out = {}

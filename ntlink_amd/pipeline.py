@@ -30,11 +30,12 @@ def _log(*a):
 class PairOutputs:
     """<prefix>.verbose_mapping.tsv / .paf writers + the pair tally, fed batch by batch in read order."""
 
-    def __init__(self, prefix, ctg_names, ctg_len, k, f, verbose, paf):
-        self.prefix = prefix
+    def __init__(self, prefix, ctg_names, ctg_len, k, f, verbose, paf, part=""):
+        """part: suffix of this rank's part files in a multi-process run (rank 0 writes the final names)"""
+        self.prefix, self.part = prefix, part
         self.ctg_names, self.ctg_len = ctg_names, ctg_len
-        self.verbose_fh = open(prefix + ".verbose_mapping.tsv", "w") if verbose else None
-        self.paf_fh = open(prefix + ".paf", "w") if paf else None
+        self.verbose_fh = open(prefix + ".verbose_mapping.tsv" + part, "w") if verbose else None
+        self.paf_fh = open(prefix + ".paf" + part, "w") if paf else None
         self.tally = pairing.PairTally(ctg_names, ctg_len, k, f)
         self.t_write = self.t_tally = 0.0
         self._exc = None
@@ -76,8 +77,9 @@ class PairOutputs:
         """Error convention of the reference: partial outputs are deleted (bin/ntlink_pair.py:608-613)."""
         self.close()
         for ext, on in ((".verbose_mapping.tsv", self.verbose_fh), (".paf", self.paf_fh)):
-            if on and os.path.exists(self.prefix + ext):
-                os.remove(self.prefix + ext)
+            for path in {self.prefix + ext + self.part, self.prefix + ext}:
+                if on and os.path.exists(path):
+                    os.remove(path)
 
 
 def finish_pairs(tally, prefix, n, a, write_pairs_tsv):
@@ -119,8 +121,17 @@ def run_indexlr(dev, paths, k, w, out, with_len, batch_bases=DEFAULT_BATCH_BASES
 
 
 def _contig_lengths(fasta):
+    """ids, lengths and id -> record index of the target FASTA.  The reference keeps ONE Scaffold per id, the last
+    record's (dict overwrite, bin/ntlink_utils.py:65-73): every record of a repeated id gets that length (it feeds the
+    z filter, the gap estimates and the PAF target length)."""
     ss = seqio.load_all([fasta])
-    return ss.names.tolist(), ss.lengths
+    names, ctg_len = ss.names.tolist(), ss.lengths
+    index_of = {n: i for i, n in enumerate(names)}
+    if len(index_of) != len(names):
+        last = ctg_len.copy()
+        for i, n in enumerate(names):
+            ctg_len[i] = last[index_of[n]]
+    return names, ctg_len, index_of
 
 
 def run_ntlink_pair(dev, args):
@@ -130,12 +141,7 @@ def run_ntlink_pair(dev, args):
     if os.path.isfile(args.p + ".verbose_mapping.tsv"):
         ckpt = args.p + ".verbose_mapping.tsv"  # bin/ntlink_pair.py:565-567
     _log("Reading fasta file", args.s)
-    names, ctg_len = _contig_lengths(args.s)
-    index_of = {n: i for i, n in enumerate(names)}
-    if len(index_of) != len(names):
-        # the reference keeps the LAST record of a repeated id (dict overwrite, bin/ntlink_utils.py:71)
-        for i, n in enumerate(names):
-            ctg_len[index_of[n]] = ctg_len[i]
+    names, ctg_len, index_of = _contig_lengths(args.s)
     if ckpt:
         print("Found checkpoint file, bypassing read mapping...\n")
         if args.paf:
@@ -270,10 +276,13 @@ class Drain:
 
 class LocalComm:
     """Single process.  The multi-GPU launcher passes a torch.distributed-backed object with the same
-    three members (ntlink_amd/dist_pair.py)."""
+    members (ntlink_amd/dist_pair.py)."""
     rank, world = 0, 1
 
     def gather(self, obj):
+        return [obj]
+
+    def allgather(self, obj):
         return [obj]
 
     def barrier(self):
@@ -282,7 +291,8 @@ class LocalComm:
 
 def shard_range(offsets, rank, world):
     """Contiguous read range [lo, hi) of this rank, balanced by bases; concatenating the ranks' ranges
-    in rank order restores the input order."""
+    in rank order restores the input order.  (Sharding of in-memory batches: the bench and callers that
+    already hold the reads.  The file-to-file driver shards the INPUT BYTES instead: seqio.shard_plan.)"""
     n = len(offsets) - 1
     if world == 1:
         return 0, n
@@ -295,15 +305,41 @@ def shard_range(offsets, rank, world):
     return cuts[rank], cuts[rank + 1]
 
 
+def _append_part(final_path, part_path, offset):
+    """This rank's part file into its place in the final file (in-kernel copy; ranks write disjoint ranges at once)."""
+    size = os.path.getsize(part_path)
+    src = os.open(part_path, os.O_RDONLY)
+    dst = os.open(final_path, os.O_WRONLY | os.O_CREAT, 0o644)
+    try:
+        done = 0
+        while done < size:
+            try:
+                n = os.copy_file_range(src, dst, min(size - done, 1 << 30), done, offset + done)
+            except OSError:
+                n = 0
+            if n <= 0:  # file systems without copy_file_range
+                chunk = os.pread(src, min(size - done, 64 << 20), done)
+                if not chunk:
+                    raise OSError(f"short read from {part_path}")
+                n = os.pwrite(dst, chunk, offset + done)
+            done += n
+    finally:
+        os.close(src)
+        os.close(dst)
+    os.remove(part_path)
+
+
 def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=10, x=0.0, paf=False, verbose=True,
              sensitive=False, repeats=False, pairs_tsv=False, batch_bases=DEFAULT_BATCH_BASES, write_contig_tsv=True,
              comm=None):
     """`ntLink pair target=T reads='R1 R2' k= w= ...`: the fused device path.
 
-    With a communicator of world > 1 (one process per GPU) every rank builds the same contig index on
-    its own GPU and maps a contiguous share of every read batch; rank 0 gathers the records in rank
-    order -- which is read order -- and does all the writing and the pair tally.  No collective touches
-    the data path on the device."""
+    With a communicator of world > 1 (one process per GPU) every rank builds the same contig index on its own GPU and
+    owns a contiguous BYTE RANGE of the concatenated read files (seqio.shard_plan): it parses only that, maps it, formats
+    its own text into part files and keeps its own pair tally.  At the end the ranks exchange three numbers (the byte
+    counts of their parts) and copy their parts, all at once, to their offsets in the final files; rank 0 merges the
+    pair tallies in rank order -- which is read order -- and writes `.pairs.tsv` / `.scaffold.dot`.  No record array
+    leaves the process that produced it and no collective touches the data path on the device."""
     comm = comm or LocalComm()
     root = comm.rank == 0
     prefix = prefix or f"{target}.k{k}.w{w}.z{z}"
@@ -319,12 +355,14 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
     comm.barrier()  # nobody creates the verbose file before everyone has looked for it
     t_start = time.perf_counter()
     read_paths = reads.split() if isinstance(reads, str) else list(reads)
-    # the read files are opened, inflated and parsed from now on, behind the contig stage
-    batches = Prefetch(seqio.load(read_paths, max_bases=batch_bases * comm.world, alloc=dev.pinned_empty))
+    plan = seqio.shard_plan(read_paths, comm.rank, comm.world)
+    io_stats = {}
+    # this rank's share of the read files is opened, inflated and parsed from now on, behind the contig stage
+    batches = Prefetch(seqio.load(plan, max_bases=batch_bases, alloc=dev.pinned_empty, stats=io_stats))
     ctg = seqio.load_all([target])  # used once: page-locking a buffer for it would cost more than the staged copy
     ctg_len = ctg.lengths
-    out = PairOutputs(prefix, ctg.names, ctg_len, k, f, verbose, paf) if root else None
-    pin_out = comm.world == 1  # records land in page-locked pool buffers (not when they are pickled to rank 0)
+    part = "" if root else f".part{comm.rank}"
+    out = PairOutputs(prefix, ctg.names, ctg_len, k, f, verbose, paf, part=part)
 
     def consume(pres, names, lens):
         out.add(pres, names, lens)
@@ -334,7 +372,7 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
         with open(f"{target}.k{k}.w{w}.tsv", "w") as fh:
             formats.write_indexlr(fh, ctg.names, ctg_len, off, h, p, s, False)
 
-    drain = Drain(consume) if root else None  # text emitters + pair tally run behind the device
+    drain = Drain(consume)  # text emitters + pair tally run behind the device
     tsv_drain = Drain(emit_contig_tsv) if root and write_contig_tsv else None
     stats = dict(read_bases=0, reads=0, read_minimizers=0, index_hits=0, t_contigs=0.0, t_ingest=0.0, t_device=0.0, t_handover=0.0)
     try:
@@ -353,48 +391,58 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
                         stats["t_ingest"] += time.perf_counter() - t_mark  # waiting for the reader thread
                         t_dev = time.perf_counter()
                         rl = rs_.lengths
-                        lo, hi = shard_range(rs_.offsets, comm.rank, comm.world)
-                        b0 = int(rs_.offsets[lo])
-                        sub_off = rs_.offsets[lo:hi + 1] - np.uint64(b0)
-                        with dev.batch(rs_.buf[b0:int(rs_.offsets[hi])], sub_off) as rb:
+                        with dev.batch(rs_.buf, rs_.offsets) as rb:
                             dev.pinned_release(rs_.buf)  # the bases are on the device: the reader may refill this buffer
                             rs_.buf = None
                             with dev.sketch(rb, k, w) as rsk, \
-                                    dev.map(ix, rsk, rl[lo:hi], k=k, z=z, x=x, sensitive=sensitive, repeat_filter=repeats) as res:
-                                mine = (lo, hi, res.download(pinned=pin_out), rsk.count, res.n_index_hits)
+                                    dev.map(ix, rsk, rl, k=k, z=z, x=x, sensitive=sensitive, repeat_filter=repeats) as res:
+                                pres = res.download(pinned=True)
+                                stats["read_minimizers"] += rsk.count
+                                stats["index_hits"] += res.n_index_hits
                         stats["t_device"] += time.perf_counter() - t_dev  # H2D + pack + kernels + D2H
                         t_put = time.perf_counter()
-                        parts = comm.gather(mine)
-                        if root:
-                            for plo, phi, pres, pmx, phits in parts:
-                                drain.put(pres, rs_.names[plo:phi], rl[plo:phi])
-                                stats["read_minimizers"] += pmx
-                                stats["index_hits"] += phits
-                            stats["read_bases"] += rs_.bases
-                            stats["reads"] += len(rs_)
+                        drain.put(pres, rs_.names, rl)
+                        stats["read_bases"] += rs_.bases
+                        stats["reads"] += len(rs_)
                         t_mark = time.perf_counter()
-                        stats["t_handover"] += t_mark - t_put  # gather + waiting for the writer thread to take the batch
-        if root:
+                        stats["t_handover"] += t_mark - t_put  # waiting for the writer thread to take the batch
+        t_fin = time.perf_counter()
+        drain.close()
+        if tsv_drain:
+            tsv_drain.close()
+        out.close()
+        stats["t_drain_tail"] = time.perf_counter() - t_fin  # writers still busy after the last device batch
+        stats["parsed_bytes"] = io_stats.get("parsed_bytes", 0)
+        if comm.world > 1:
             t_fin = time.perf_counter()
-            drain.close()
-            if tsv_drain:
-                tsv_drain.close()
-            out.close()
-            stats["t_drain_tail"] = time.perf_counter() - t_fin  # writers still busy after the last device batch
+            exts = [e for e, on in ((".verbose_mapping.tsv", verbose), (".paf", paf)) if on]
+            sizes = comm.allgather([os.path.getsize(prefix + e + part) for e in exts])
+            for j, e in enumerate(exts):
+                if not root:
+                    _append_part(prefix + e, prefix + e + part, sum(sz[j] for sz in sizes[:comm.rank]))
+            mine = (out.tally.export(), {key: stats[key] for key in ("read_bases", "reads", "read_minimizers", "index_hits", "parsed_bytes")})
+            parts = comm.gather(mine)  # pair-tally deltas and five counters per rank
+            if root:
+                stats["parsed_bytes_per_rank"] = [p[1]["parsed_bytes"] for p in parts]
+                for exported, st in parts[1:]:
+                    out.tally.merge(exported)
+                    for key in ("read_bases", "reads", "read_minimizers", "index_hits", "parsed_bytes"):
+                        stats[key] += st[key]
+            stats["t_merge"] = time.perf_counter() - t_fin
+        if root:
             t_fin = time.perf_counter()
             finish_pairs(out.tally, prefix, n, a, pairs_tsv)
             stats["t_graph"] = time.perf_counter() - t_fin
             stats["t_write"], stats["t_tally"] = out.t_write, out.t_tally
         comm.barrier()
     except BaseException:
-        if out:
-            for d in (drain, tsv_drain):
-                try:
-                    if d:
-                        d.close()
-                except BaseException:
-                    pass
-            out.remove_partial()
+        for d in (drain, tsv_drain):
+            try:
+                if d:
+                    d.close()
+            except BaseException:
+                pass
+        out.remove_partial()
         batches.stop()
         raise
     return stats

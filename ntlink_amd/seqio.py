@@ -134,21 +134,76 @@ def _np_empty(nbytes):
     return np.empty(nbytes, np.uint8)
 
 
-def _open_native(L, path):
+def _open_native(L, item):
+    """item: a path, or (path, lo, hi) = the records of a plain file whose first byte lies in [lo, hi)"""
     import ctypes as C
     h = C.c_void_p()
-    if L.ntl_fastx_open(path.encode(), C.byref(h)) != 0:
-        raise OSError(f"cannot open {path}")
+    if isinstance(item, tuple):
+        path, lo, hi = item
+        if L.ntl_fastx_open_range(path.encode(), int(lo), int(hi), C.byref(h)) != 0:
+            raise OSError(f"cannot open bytes {lo}..{hi} of {path}")
+        return h
+    if L.ntl_fastx_open(item.encode(), C.byref(h)) != 0:
+        raise OSError(f"cannot open {item}")
     return h
 
 
-def load(paths, max_bases=None, alloc=None, ahead=None):
+def _splittable(path):
+    """plain regular file (not gzip): byte ranges of it can be read independently"""
+    try:
+        if path == "-" or not os.path.isfile(path) or os.path.getsize(path) == 0:
+            return False
+        with open(path, "rb") as f:
+            return f.read(2) != b"\x1f\x8b"
+    except OSError:
+        return False
+
+
+def shard_plan(paths, rank, world):
+    """The share of rank `rank` of the read files concatenated in the order given (ntLink:222): the bytes
+    [total*rank/world, total*(rank+1)/world) of the concatenation.  Plain files are cut at those offsets (the readers
+    move the cuts to record starts: a record belongs to the range that holds its first byte); a file that cannot be cut
+    (gzip, stdin) goes whole to the rank whose share holds its first byte.  -> list of paths / (path, lo, hi) in input
+    order; the ranks' lists, taken in rank order, cover every record once, in input order."""
+    if isinstance(paths, str):
+        paths = [paths]
+    if world == 1:
+        return list(paths)
+    sizes = []
+    for p in paths:
+        try:
+            sizes.append(os.path.getsize(p) if p != "-" else 0)
+        except OSError:
+            sizes.append(0)
+    total = sum(sizes)
+    lo_r, hi_r = total * rank // world, total * (rank + 1) // world
+    plan, at = [], 0
+    for p, sz in zip(paths, sizes):
+        f0, f1 = at, at + sz
+        at = f1
+        if p == "-":
+            raise ValueError("reads from stdin cannot be shared out between ranks: give the files by name")
+        if sz == 0:
+            continue  # no records
+        if not _splittable(p):
+            if lo_r <= f0 < hi_r:  # whole file to the owner of its first byte
+                plan.append(p)
+            continue
+        a, b = max(lo_r, f0), min(hi_r, f1)
+        if a < b:
+            plan.append((p, a - f0, b - f0))
+    return plan
+
+
+def load(paths, max_bases=None, alloc=None, ahead=None, stats=None):
     """Native reader (ntl_fastx_*, csrc/ntl_io.cpp).  Whole input as one SeqSet, or, with max_bases,
     SeqSets of about that many bases; several files are concatenated in the order given and a batch
     never spans two files.  alloc(nbytes) -> uint8 array supplies the sequence buffers (the pair
     driver passes the device's page-locked pool); default numpy.  Opening a gzip file inflates it, so
     the next `ahead` files (default min(8, cores/4), at most 2 GiB of compressed input) are opened by
-    background threads while the current one is consumed: many .fq.gz files decode in parallel."""
+    background threads while the current one is consumed: many .fq.gz files decode in parallel.  An entry of `paths` may
+    be (path, lo, hi): the records of a plain file that start in that byte range (shard_plan).  stats["parsed_bytes"]
+    accumulates the input bytes consumed (file bytes of plain files and ranges, compressed bytes of gzip files)."""
     import collections
     import ctypes as C
     from concurrent.futures import ThreadPoolExecutor
@@ -169,7 +224,7 @@ def load(paths, max_bases=None, alloc=None, ahead=None):
             if path is None:
                 return
             try:
-                size = os.path.getsize(path)
+                size = os.path.getsize(path) if not isinstance(path, tuple) else int(path[2]) - int(path[1])
             except OSError:
                 size = 0
             pending.append((path, pool.submit(_open_native, L, path), size))
@@ -180,12 +235,16 @@ def load(paths, max_bases=None, alloc=None, ahead=None):
             path, fut, _size = pending.popleft()
             h = fut.result()
             top_up()
+            if stats is not None:
+                lo, hi = C.c_uint64(), C.c_uint64()
+                L.ntl_fastx_range(h, C.byref(lo), C.byref(hi))
+                stats["parsed_bytes"] = stats.get("parsed_bytes", 0) + (hi.value - lo.value if hi.value else _size)
             try:
                 while True:
                     n = C.c_uint64()
                     t_0 = time.perf_counter()
                     if L.ntl_fastx_next(h, int(max_bases or 0), C.byref(n)) != 0:
-                        raise OSError(f"{path}: {L.ntl_fastx_error(h).decode()}")
+                        raise OSError(f"{path if not isinstance(path, tuple) else path[0]}: {L.ntl_fastx_error(h).decode()}")
                     n = n.value
                     if n == 0:
                         break

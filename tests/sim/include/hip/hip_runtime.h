@@ -119,7 +119,7 @@ struct hipDeviceProp_t { char name[64]; int multiProcessorCount; size_t totalGlo
 
 inline const char *hipGetErrorString(hipError_t) { return "sim"; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
-inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+inline hipError_t hipGetDeviceCount(int *n) { *n = 8; return hipSuccess; } /* eight identical mock devices (one per test rank) */
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int)
 {

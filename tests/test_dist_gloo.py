@@ -1,13 +1,17 @@
-"""N > 1 path: reads sharded over ranks (world_size 2, gloo, CPU), records gathered in rank order.
-The sharded run must leave exactly the files of the single-process run."""
+"""N > 1 path of the file-to-file driver: every rank owns a byte range of the concatenated read files (gloo, CPU, the
+SIMT-mock build of the kernels standing in for the GPUs).  The sharded run must leave exactly the files of the
+single-process run, and every rank must have parsed about 1/N of the input bytes."""
+import json
 import os
 import shutil
 import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 from helpers import GEN, REF, TEST7_PAF, read_text
+from ntlink_amd import seqio
 from ntlink_amd.pipeline import shard_range
 from sim import simlib
 
@@ -28,15 +32,72 @@ def test_shard_ranges_cover_in_order():
                 assert max(per) - min(per) < 2 * 30000  # balanced by bases up to one read
 
 
-def test_two_ranks_equal_single_process(tmp_path):
-    simlib.build()
+def _records(plan):
+    out = []
+    for ss in seqio.load(plan, max_bases=50_000):
+        names = ss.names.tolist()
+        for i, n in enumerate(names):
+            out.append((n, bytes(ss.buf[int(ss.offsets[i]):int(ss.offsets[i + 1])])))
+    return out
+
+
+@pytest.mark.parametrize("fastq,wrap", [(False, 0), (False, 60), (True, 0)])
+def test_byte_range_readers_see_every_record_once(tmp_path, fastq, wrap):
+    """seqio.shard_plan + ntl_fastx_open_range: the ranks' record lists, concatenated in rank order, are the records of
+    the serial reader -- for cuts anywhere (inside headers, sequences, quality lines that start with '@')."""
+    rng = np.random.default_rng(7)
+    paths = []
+    for f in range(3):
+        p = tmp_path / f"r{f}.{'fq' if fastq else 'fa'}"
+        with open(p, "w") as fh:
+            for i in range(int(rng.integers(1, 60))):
+                n = int(rng.integers(1, 3000))
+                s = "".join(rng.choice(list("ACGTN"), n))
+                if fastq:
+                    q = "".join(rng.choice(list("@+>I5"), n))  # qualities that look like headers
+                    fh.write(f"@f{f}_{i} c\n{s}\n+\n{q}\n")
+                else:
+                    body = s if not wrap else "\n".join(s[j:j + wrap] for j in range(0, n, wrap))
+                    fh.write(f">f{f}_{i} comment\n{body}\n")
+        paths.append(str(p))
+    gz = tmp_path / "z.fa.gz"
+    import gzip
+    with gzip.open(gz, "wt") as fh:
+        fh.write(">gz1\nACGT\n>gz2\nGGGTTT\n")
+    paths.insert(2, str(gz))  # a file that cannot be cut goes whole to one rank
+    want = _records(paths)
+    total = sum(os.path.getsize(p) for p in paths)
+    for world in (2, 3, 5, 64):
+        got, parsed = [], []
+        for r in range(world):
+            plan = seqio.shard_plan(paths, r, world)
+            st = {}
+            recs = []
+            for ss in seqio.load(plan, max_bases=50_000, stats=st):
+                for i, n in enumerate(ss.names.tolist()):
+                    recs.append((n, bytes(ss.buf[int(ss.offsets[i]):int(ss.offsets[i + 1])])))
+            got += recs
+            parsed.append(st.get("parsed_bytes", 0))
+        assert got == want, world
+        assert sum(parsed) == total
+        if world <= 3:
+            assert max(parsed) < total / world + 8000  # a rank's share + at most one record and the small gzip file
+
+
+def _run_ranks(tmp_path, world, port, args):
+    env = dict(os.environ, OMP_NUM_THREADS="1", NTLINK_AMD_LIB=simlib.build(), NTL_IO_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"), "pair"] + args
+    assert subprocess.call(cmd, cwd=tmp_path, env=env, timeout=900) == 0
+
+
+@pytest.mark.parametrize("world,port", [(2, 29571), (3, 29572)])
+def test_ranks_equal_single_process(tmp_path, world, port):
+    """top-5 reads of test 7 in one plain FASTA: five reads over 2 / 3 ranks, every cut falls inside a read."""
     for n in ("scaffolds_4.fa", "long_reads_4_top5.fa"):
         shutil.copy(os.path.join(REF, n), tmp_path / n)
-    env = dict(os.environ, OMP_NUM_THREADS="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29571", os.path.join(ROOT, "tests", "dist_worker.py"), "pair", "target=scaffolds_4.fa",
-           "reads=long_reads_4_top5.fa", "k=40", "w=100", "paf=True", "ntlink_pairs_tsv=True"]
-    assert subprocess.call(cmd, cwd=tmp_path, env=env, timeout=600) == 0
+    _run_ranks(tmp_path, world, port, ["target=scaffolds_4.fa", "reads=long_reads_4_top5.fa", "k=40", "w=100", "paf=True",
+                                       "ntlink_pairs_tsv=True", "v=1"])
     pre = str(tmp_path / "scaffolds_4.fa.k40.w100.z1000")
     d = os.path.join(GEN, "fixtures", "t7_top5_k40_w100")
     assert read_text(pre + ".verbose_mapping.tsv") == read_text(d + ".verbose_mapping.tsv")
@@ -44,3 +105,33 @@ def test_two_ranks_equal_single_process(tmp_path):
     assert set(read_text(pre + ".paf").splitlines()) == TEST7_PAF
     assert read_text(pre + ".pairs.tsv") == read_text(d + ".pairs.tsv")
     assert os.path.exists(pre + ".n1.scaffold.dot")
+    assert not [f for f in os.listdir(tmp_path) if ".part" in f]
+    # v=1: GNU-time style report with the driver's counters; every rank parsed about its share of the read file
+    rep = dict(line.strip().split(": ", 1) for line in open(pre + ".n1.scaffold.dot.time") if ": " in line)
+    assert rep["Exit status"] == "0" and float(rep["User time (seconds)"]) > 0
+    per = json.loads(rep["ntlink_amd parsed_bytes_per_rank"])
+    total = os.path.getsize(tmp_path / "long_reads_4_top5.fa")
+    assert sum(per) == total == int(rep["ntlink_amd parsed_bytes"]) and len(per) == world
+    longest = max(len(s) for _, s in __import__("oracle").read_fastx(str(tmp_path / "long_reads_4_top5.fa"))) + 200
+    assert all(abs(b - total / world) <= longest for b in per)
+
+
+def test_three_ranks_many_reads_and_files(tmp_path):
+    """test 1 of the reference (plain FASTA reads, k32 w250) cut into two files + a gzip file, three ranks: pairs gathered
+    from all ranks (gap lists in read order), outputs byte-identical to the single-process goldens."""
+    shutil.copy(os.path.join(REF, "scaffolds_1.fa"), tmp_path / "scaffolds_1.fa")
+    recs = list(__import__("oracle").read_fastx(os.path.join(REF, "long_reads_1.fa")))
+    import gzip
+    cuts = [0, len(recs) // 2, len(recs) * 3 // 4, len(recs)]
+    names = ["a.fa", "b.fa.gz", "c.fa"]
+    for (a, b), n in zip(zip(cuts, cuts[1:]), names):
+        opener = gzip.open if n.endswith(".gz") else open
+        with opener(tmp_path / n, "wt") as fh:
+            for name, seq in recs[a:b]:
+                fh.write(f">{name}\n{seq.decode() if isinstance(seq, bytes) else seq}\n")
+    _run_ranks(tmp_path, 3, 29573, ["target=scaffolds_1.fa", "reads=" + " ".join(names), "k=32", "w=250", "paf=True", "ntlink_pairs_tsv=True"])
+    pre = str(tmp_path / "scaffolds_1.fa.k32.w250.z1000")
+    d = os.path.join(GEN, "fixtures", "t1_k32_w250")
+    for ext in (".verbose_mapping.tsv", ".paf", ".pairs.tsv"):
+        assert read_text(pre + ext) == read_text(d + ext), ext
+    assert read_text(pre + ".pairs.tsv") == read_text(os.path.join(REF, "expected_outputs", "scaffolds_1.fa.k32.w250.z1000.pairs.tsv"))

@@ -374,3 +374,47 @@ def test_bgzf_members_inflate_in_parallel(tmp_path):
     cut = text.index(b"\n@", len(text) // 2) + 1
     mixed.write_bytes(_bgzf(text[:cut])[:-28] + gzip.compress(text[cut:]))  # BGZF members, then an ordinary one
     assert _records(list(seqio.load([str(mixed)], max_bases=200_000))) == want
+
+
+def test_duplicate_contig_ids_take_the_last_length(tmp_path):
+    """The reference keeps one Scaffold per id, the last record's (dict overwrite, bin/ntlink_utils.py:65-73)."""
+    from ntlink_amd.pipeline import _contig_lengths
+    fa = tmp_path / "dup.fa"
+    fa.write_text(">a\nACGTACGT\n>b\nAC\n>a\nACG\n>c\nA\n>b\nACGTA\n")
+    names, ctg_len, index_of = _contig_lengths(str(fa))
+    assert names == ["a", "b", "a", "c", "b"] and ctg_len.tolist() == [3, 5, 3, 1, 5]
+    assert index_of == {"a": 2, "b": 4, "c": 3}
+
+
+def test_tally_overhang_check_only_for_evaluated_pairs_and_merge():
+    """calculate_gap_size asserts a >= 0 and b >= 0 for the pairs it evaluates (bin/ntlink_pair.py:173-184): a read with
+    one mapping, however odd, raises nothing.  merge(): two tallies over consecutive read ranges == one tally over both."""
+    from ntlink_amd import capi
+    from ntlink_amd.pairing import PairTally
+    names, lens, k = ["c1", "c2", "c3"], [1000, 2000, 50], 32
+
+    def recs(reads):
+        maps, hits = [], []
+        for r, ms in enumerate(reads):
+            for ctg, hs in ms:
+                maps.append((r, ctg, len(hs), 0, len(hits)))
+                hits += [(cp, rp, cs, rs, (0, 0)) for cp, rp, cs, rs in hs]
+        return {"maps": np.array(maps, capi.MAPPING_DT), "hits": np.array(hits, capi.HIT_DT)}
+    # contig c3 is 50 long: a hit at 40 with k = 32 has a negative overhang behind it
+    lone = [[(2, [(40, 100, 1, 1)])]]
+    t = PairTally(names, lens, k)
+    t.add_batch(recs(lone), [5000])
+    assert t.pairs == {}
+    with pytest.raises(AssertionError):
+        t.add_batch(recs([[(2, [(40, 100, 1, 1)]), (0, [(10, 900, 1, 1)])]]), [5000])
+    reads = [[(0, [(900, 100, 1, 1), (950, 150, 1, 1)]), (1, [(10, 400, 1, 1), (60, 450, 1, 1)])],
+             [(1, [(1900, 100, 1, 1)]), (2, [(5, 300, 1, 1)])],
+             [(0, [(800, 50, 1, 1), (850, 100, 1, 1)]), (1, [(5, 300, 1, 1), (55, 350, 1, 1)])]]
+    rl = [6000, 7000, 8000]
+    whole = PairTally(names, lens, k)
+    whole.add_batch(recs(reads), rl)
+    a, b = PairTally(names, lens, k), PairTally(names, lens, k)
+    a.add_batch(recs(reads[:1]), rl[:1])
+    b.add_batch(recs(reads[1:]), rl[1:])
+    a.merge(b.export())
+    assert list(a.pairs.items()) == list(whole.pairs.items()) and len(whole.pairs) >= 2
