@@ -211,6 +211,7 @@ struct MapArgs {
     uint32_t *scr;                                /* (MAP_NHA + MAP_NRA) arrays of scr_stride u32 */
     uint64_t scr_stride;
     uint32_t *err;
+    uint32_t *over_list, *over_count;             /* reads that do not fit the LDS staging: [nreads], [1] */
 };
 
 struct HitArr { uint32_t *ctg, *cpos, *rpos, *fl, *run, *ord; };
@@ -281,13 +282,14 @@ __device__ __forceinline__ void map_fill_runs(HitArr H, uint32_t n, RunArr RU, u
     __syncthreads();
 }
 
-template <int MAP_CAPH, int MAP_CAPR>
-__global__ __launch_bounds__(MAP_NT) void map_kernel(MapArgs A)
+/* One read on one wavefront.  GLOBAL = false: hits and runs live in the workgroup's LDS arrays -- the pointers are set from
+ * them unconditionally, so every access is a DS instruction; a read that does not fit (more than MAP_CAPH hits or MAP_CAPR
+ * runs) is put on the overflow list and left alone.  GLOBAL = true (map_overflow_kernel): the same code on the read's region
+ * of the global scratch arrays. */
+template <int MAP_CAPH, int MAP_CAPR, bool GLOBAL>
+__device__ __forceinline__ void map_read(const MapArgs &A, const uint32_t r, uint32_t (*s_hit)[MAP_CAPH], uint32_t (*s_run)[MAP_CAPR])
 {
-    __shared__ uint32_t s_hit[MAP_NHA][MAP_CAPH];
-    __shared__ uint32_t s_run[MAP_NRA][MAP_CAPR];
     const uint32_t lane = threadIdx.x;
-    const uint32_t r = blockIdx.x;
     const uint32_t m0 = A.mx_off[r], m1 = A.mx_off[r + 1], nmx = m1 - m0;
     const MapParamsDev P = A.P;
     uint32_t R = 0, n = 0, np = 0;
@@ -295,7 +297,7 @@ __global__ __launch_bounds__(MAP_NT) void map_kernel(MapArgs A)
     /* candidates found in the index: counted only when the read could overflow the LDS staging
        (hits <= minimizers, so short sketches need no counting pass) */
     uint32_t nc = nmx;
-    if (nmx > MAP_CAPH) {
+    if (!GLOBAL && nmx > MAP_CAPH) {
         nc = 0;
         for (uint32_t c = 0; c < nmx; c += MAP_NT) {
             const uint32_t i = c + lane;
@@ -304,7 +306,11 @@ __global__ __launch_bounds__(MAP_NT) void map_kernel(MapArgs A)
         }
     }
     HitArr H;
-    if (nc <= MAP_CAPH) {
+    if (!GLOBAL) {
+        if (nc > MAP_CAPH) { /* wave-uniform */
+            if (lane == 0) A.over_list[atomicAdd(A.over_count, 1u)] = r;
+            return;
+        }
         H.ctg = s_hit[0]; H.cpos = s_hit[1]; H.rpos = s_hit[2]; H.fl = s_hit[3]; H.run = s_hit[4]; H.ord = s_hit[5];
     } else {
         uint32_t *g = A.scr + m0;
@@ -352,7 +358,11 @@ __global__ __launch_bounds__(MAP_NT) void map_kernel(MapArgs A)
     if (n == 0) goto done;
 
     R = map_number_runs(H, n);
-    if (R <= MAP_CAPR) {
+    if (!GLOBAL) {
+        if (R > MAP_CAPR) { /* wave-uniform; nothing has been written for this read yet */
+            if (lane == 0) A.over_list[atomicAdd(A.over_count, 1u)] = r;
+            return;
+        }
         RU.start = s_run[0]; RU.ctg = s_run[1]; RU.leader = s_run[2]; RU.flag = s_run[3]; RU.cnt = s_run[4];
         RU.mn = s_run[5]; RU.mni = s_run[6]; RU.mx = s_run[7]; RU.mxi = s_run[8]; RU.last = s_run[9];
     } else {
@@ -367,7 +377,8 @@ __global__ __launch_bounds__(MAP_NT) void map_kernel(MapArgs A)
     {
         if (R <= 8 && n >= 128) {
             /* few, long runs (HiFi: hundreds of hits on one contig): the lanes share each run and
-               lane 0 merges the 64 partial results; H.ord is free until the PAF stage (>= 256 entries) */
+               lane 0 merges the 64 partial results; H.ord is free until the PAF stage and holds >= 256 entries (MAP_CAPH in LDS;
+               a read is on the global scratch only with more than MAP_CAPH candidates or more than MAP_CAPR > 8 runs) */
             uint32_t *tmp = H.ord;
             for (uint32_t q = 0; q < R; q++) {
                 const uint32_t s = RU.start[q], e = q + 1 < R ? RU.start[q + 1] : n;
@@ -640,6 +651,24 @@ __global__ __launch_bounds__(MAP_NT) void map_kernel(MapArgs A)
 
 done:
     if (lane == 0) { A.n_maps[r] = R; A.n_hits[r] = n; A.n_pafs[r] = np; }
+}
+
+template <int MAP_CAPH, int MAP_CAPR>
+__global__ __launch_bounds__(MAP_NT) void map_kernel(MapArgs A)
+{
+    __shared__ uint32_t s_hit[MAP_NHA][MAP_CAPH];
+    __shared__ uint32_t s_run[MAP_NRA][MAP_CAPR];
+    map_read<MAP_CAPH, MAP_CAPR, false>(A, blockIdx.x, s_hit, s_run);
+}
+
+/* the reads map_kernel could not stage in LDS, on their regions of the global scratch arrays */
+__global__ __launch_bounds__(MAP_NT) void map_overflow_kernel(MapArgs A)
+{
+    const uint32_t n = *A.over_count;
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+        map_read<1, 1, true>(A, A.over_list[i], nullptr, nullptr);
+        __syncthreads();
+    }
 }
 
 /* ---------------------------------------------------------------------------- gather ------ */

@@ -651,7 +651,7 @@ extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_
     ntl_sketch *s = s_guard.get();
     s->c = c; s->nseq = nseq;
     int rc;
-    DevBuf run_n, run_ord, seq_M, nstrips, strip_first, mask, tile, tot, word_rank, redo;
+    DevBuf run_n, run_ord, seq_M, nstrips, strip_first, mask, tile, tot, redo;
     uint32_t redo_n = 0;
     bool fast = false;
     /* nstrips / strip_first hold nseq+1 entries: the scan leaves the total behind the last one */
@@ -742,7 +742,7 @@ extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_
     {
         ProfSpan sp(c, "sketch_emit");
         const uint64_t tiles = (nmask + EMIT_TILE - 1) / EMIT_TILE;
-        if ((rc = tile.alloc(c, tiles * 4)) || (rc = tot.alloc(c, 4)) || (rc = word_rank.alloc(c, nmask * 4))) return rc;
+        if ((rc = tile.alloc(c, tiles * 4)) || (rc = tot.alloc(c, 4))) return rc;
         hipLaunchKernelGGL(mask_count_kernel, dim3((unsigned)tiles), dim3(EMIT_NT), 0, c->stream,
                            (const uint32_t *)mask.as<uint32_t>(), nmask, tile.as<uint32_t>());
         hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(SCAN_NT), 0, c->stream, tile.as<uint32_t>(), tiles, tot.as<uint32_t>(), (uint64_t)0, (uint32_t *)nullptr);
@@ -757,7 +757,7 @@ extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_
         if ((rc = s->records.alloc(c, cap_guess * sizeof(MxRecord)))) return rc;
         EmitArgs E;
         E.packed = T.packed; E.seq_base = T.seq_base; E.nseq = (uint32_t)nseq; E.mask = mask.as<uint32_t>();
-        E.nwords = nmask; E.tile_off = tile.as<uint32_t>(); E.word_rank = word_rank.as<uint32_t>();
+        E.nwords = nmask; E.tile_off = tile.as<uint32_t>(); E.mx_off = s->mx_off.as<uint32_t>();
         E.out = s->records.as<MxRecord>(); E.out_cap = (uint32_t)cap_guess;
         E.k = k; E.mult = 1ull ^ ((uint64_t)k * 0x90b45d39fb6da1faull);
         uint64_t roll[16][2];
@@ -765,9 +765,6 @@ extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_
         E.g4 = (const uint64_t (*)[2])c->g4;
         E.g8 = (const uint64_t (*)[2])c->g8;
         hipLaunchKernelGGL(emit_kernel, dim3((unsigned)tiles), dim3(EMIT_NT), 0, c->stream, E);
-        hipLaunchKernelGGL(mx_offsets_kernel, dim3((unsigned)((nseq + 1 + 255) / 256)), dim3(256), 0, c->stream,
-                           T.seq_base, (uint32_t)nseq, (const uint32_t *)mask.as<uint32_t>(),
-                           (const uint32_t *)word_rank.as<uint32_t>(), nmask, (const uint32_t *)tot.as<uint32_t>(), s->mx_off.as<uint32_t>());
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(&total_mx, tot.p, 4, hipMemcpyDeviceToHost, c->stream));
         if (fast) HIPCHK(c, hipMemcpyAsync(&redo_n, redo.p, 4, hipMemcpyDeviceToHost, c->stream));
@@ -1042,14 +1039,14 @@ extern "C" int ntl_map_run(ntl_ctx *c, const ntl_index *ix, const ntl_sketch *re
     ntl_mapres *R = R_guard.get();
     R->c = c;
     int rc;
-    DevBuf cand, rlen, smaps, shits, spafs, n3, off3, scr, sums;
-    struct MapSums { unsigned long long nfound; uint32_t err; uint32_t tot[3]; uint32_t pad[2]; }; /* one memset, one read-back */
+    DevBuf cand, rlen, smaps, shits, spafs, n3, off3, scr, sums, over;
+    struct MapSums { unsigned long long nfound; uint32_t err; uint32_t tot[3]; uint32_t n_over; uint32_t pad; }; /* one memset, one read-back */
     const uint64_t cap = nmx ? nmx : 1;
     if ((rc = cand.alloc(c, cap * sizeof(Cand))) || (rc = rlen.alloc(c, (nreads + 1) * 4)) ||
         (rc = smaps.alloc(c, cap * sizeof(MapRec))) || (rc = shits.alloc(c, cap * sizeof(HitRec))) ||
         (rc = spafs.alloc(c, cap * sizeof(PafRec))) || (rc = n3.alloc(c, 3 * (nreads + 1) * 4)) ||
         (rc = off3.alloc(c, 3 * (nreads + 1) * 4)) || (rc = scr.alloc(c, (uint64_t)(MAP_NHA + MAP_NRA) * cap * 4)) ||
-        (rc = sums.alloc(c, sizeof(MapSums)))) return rc;
+        (rc = sums.alloc(c, sizeof(MapSums))) || (rc = over.alloc(c, (nreads + 1) * 4))) return rc;
     MapSums *dsums = sums.as<MapSums>();
     if (nreads) HIPCHK(c, hipMemcpyAsync(rlen.p, read_len, nreads * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(sums.p, 0, sizeof(MapSums), c->stream));
@@ -1070,6 +1067,7 @@ extern "C" int ntl_map_run(ntl_ctx *c, const ntl_index *ix, const ntl_sketch *re
     A.maps = smaps.as<MapRec>(); A.hits = shits.as<HitRec>(); A.pafs = spafs.as<PafRec>();
     A.n_maps = n3.as<uint32_t>(); A.n_hits = A.n_maps + (nreads + 1); A.n_pafs = A.n_hits + (nreads + 1);
     A.scr = scr.as<uint32_t>(); A.scr_stride = cap; A.err = &dsums->err;
+    A.over_list = over.as<uint32_t>(); A.over_count = &dsums->n_over;
     MapSums hs;
     memset(&hs, 0, sizeof hs);
     if (nreads) {
@@ -1078,6 +1076,8 @@ extern "C" int ntl_map_run(ntl_ctx *c, const ntl_index *ix, const ntl_sketch *re
             /* LDS staging sized by the average sketch length of the batch */
             if (nmx <= 256 * nreads) hipLaunchKernelGGL((map_kernel<256, 64>), dim3((unsigned)nreads), dim3(MAP_NT), 0, c->stream, A);
             else hipLaunchKernelGGL((map_kernel<512, 128>), dim3((unsigned)nreads), dim3(MAP_NT), 0, c->stream, A);
+            /* reads with more hits / runs than the LDS staging holds (rare): same code on global scratch */
+            hipLaunchKernelGGL(map_overflow_kernel, dim3((unsigned)std::min<uint64_t>(nreads, 1024)), dim3(MAP_NT), 0, c->stream, A);
             HIPCHK(c, hipGetLastError());
         }
         ProfSpan sp(c, "compact");

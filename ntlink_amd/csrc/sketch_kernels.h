@@ -427,7 +427,7 @@ struct EmitArgs {
     const uint32_t *mask;
     uint64_t nwords;
     const uint32_t *tile_off; /* exclusive scan of tile_cnt */
-    uint32_t *word_rank;      /* [nwords] set bits before each word */
+    uint32_t *mx_off;         /* [nseq+1] minimizers before each sequence start = offsets of the per-sequence lists */
     MxRecord *out;
     uint32_t out_cap;         /* records `out` can hold (it is sized before the count is known) */
     int k;
@@ -453,6 +453,7 @@ __global__ __launch_bounds__(EMIT_NT) void emit_kernel(EmitArgs A)
 {
     __shared__ uint32_t s_tmp[EMIT_NT];
     __shared__ uint16_t s_list[EMIT_CAP];
+    __shared__ uint16_t s_wrank[EMIT_TILE]; /* set bits of the tile before each of its words */
     __shared__ uint64_t s_seed[4][2];
     __shared__ uint64_t s_base[EMIT_SEQ_CAP];
     __shared__ uint32_t s_range[2];
@@ -513,11 +514,25 @@ __global__ __launch_bounds__(EMIT_NT) void emit_kernel(EmitArgs A)
     const uint32_t s_hi = cached ? s_lo + s_range[1] : A.nseq; /* candidates [s_lo, s_hi) */
     const uint32_t tile_base = A.tile_off[blockIdx.x];
     {
-        uint32_t r = tile_base + excl;
+        uint32_t r = excl;
 #pragma unroll
         for (int i = 0; i < EMIT_WPT; i++) {
-            if (w0 + i < A.nwords) A.word_rank[w0 + i] = r;
+            s_wrank[t * EMIT_WPT + i] = (uint16_t)r; /* < 65536: at most 65504 bits precede a word of the tile */
             r += (uint32_t)__popc(words[i]);
+        }
+    }
+    __syncthreads();
+    /* offsets of the per-sequence lists: the rank of every sequence start that lies in this tile (the end of the last
+       sequence, seq_base[nseq], counts as one: it receives the total) */
+    {
+        const uint64_t gp0 = tile_w0 * 32;
+        for (uint32_t s = s_lo + (uint32_t)t; s <= A.nseq; s += EMIT_NT) {
+            const uint64_t g = s - s_lo < ncache ? s_base[s - s_lo] : A.seq_base[s];
+            if (g > gp_last) break; /* starts are sorted: nothing further for this thread */
+            if (g < gp0) continue;  /* s_lo itself may start before the tile */
+            const uint32_t wl = (uint32_t)((g >> 5) - tile_w0), b = (uint32_t)g & 31u;
+            const uint32_t word = tile_w0 + wl < A.nwords ? A.mask[tile_w0 + wl] : 0u;
+            A.mx_off[s] = tile_base + s_wrank[wl] + (uint32_t)__popc(word & ((1u << b) - 1u));
         }
     }
     for (uint32_t r0 = 0; r0 < total; r0 += EMIT_CAP) {
@@ -550,20 +565,4 @@ __global__ __launch_bounds__(EMIT_NT) void emit_kernel(EmitArgs A)
         }
         __syncthreads();
     }
-}
-
-/* minimizers before each sequence start = offsets of the per-sequence lists */
-__global__ void mx_offsets_kernel(const uint64_t *seq_base, uint32_t nseq, const uint32_t *mask,
-                                  const uint32_t *word_rank, uint64_t nwords, const uint32_t *total_dev,
-                                  uint32_t *mx_off)
-{
-    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s > nseq) return;
-    const uint32_t total = *total_dev;
-    if (s == nseq) { mx_off[s] = total; return; }
-    const uint64_t g = seq_base[s];
-    const uint64_t wi = g >> 5;
-    if (wi >= nwords) { mx_off[s] = total; return; }
-    const uint32_t b = (uint32_t)g & 31u;
-    mx_off[s] = word_rank[wi] + (uint32_t)__popc(mask[wi] & ((1u << b) - 1u));
 }

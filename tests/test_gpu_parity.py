@@ -113,8 +113,11 @@ def test_long_read_uses_global_scratch(dev):
     contigs = [bytes(synth.random_bases(rng, 3000)) for _ in range(400)]
     order = rng.permutation(400)
     read = b"".join(contigs[i] for i in order[:300])
-    reads = [read, contigs[5] + contigs[5], b"ACGT"]
-    pc.check_full_pipeline(dev, contigs, reads, 24, 20, z=1000)
+    # few hits on many contigs: the hits fit the LDS staging, the runs (> 128) do not -> map_overflow_kernel as well
+    patchy = b"".join(contigs[i][1000:1048] for i in order[:250])
+    reads = [read, contigs[5] + contigs[5], b"ACGT", patchy, contigs[7][:500]]
+    got = pc.check_full_pipeline(dev, contigs, reads, 24, 20, z=1000)
+    assert 128 < int((got["maps"]["read"] == 3).sum()) and int(got["maps"]["n_hits"][got["maps"]["read"] == 3].sum()) <= 512
     pc.check_full_pipeline(dev, contigs, reads, 24, 20, z=1000, sensitive=True)
 
 

@@ -230,3 +230,17 @@ def test_sim_overlap_consumer_matches_reference(dev, case, tmp_path):
 def test_sim_overlap_filter_random(dev):
     kept, total = pc.check_overlap_random(dev, 3, nseq=12, max_len=6000)
     assert kept < total
+
+
+def test_sim_map_overflow_reads_take_the_global_scratch_kernel(dev):
+    """More hits than the LDS staging holds, and few hits on more contigs than it has runs: map_overflow_kernel."""
+    from ntlink_amd import synth
+    rng = np.random.default_rng(3)
+    contigs = [bytes(synth.random_bases(rng, 1500)) for _ in range(120)]
+    order = rng.permutation(120)
+    dense = b"".join(contigs[i] for i in order[:40])                  # > 256 hits
+    patchy = b"".join(contigs[i][700:748] for i in order[:110])       # < 256 hits, > 64 runs
+    got = pc.check_full_pipeline(dev, contigs, [dense, patchy, contigs[3][:400]], 24, 20, z=1000)
+    maps = got["maps"]
+    assert int(maps["n_hits"][maps["read"] == 0].sum()) > 256
+    assert int((maps["read"] == 1).sum()) > 64 and int(maps["n_hits"][maps["read"] == 1].sum()) <= 256
