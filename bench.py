@@ -46,7 +46,7 @@ def parse_args(argv=None):
     ap.add_argument("--batch-bases", type=float, default=3.95e9, help="read bases per device batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
-    ap.add_argument("--e2e-bases", type=float, default=8e9, help="read bases of the end-to-end (file to file) leg")
+    ap.add_argument("--e2e-bases", type=float, default=32e9, help="read bases of the end-to-end (file to file) leg")
     ap.add_argument("--lib", default=None, help="C-ABI library to load (tests point this at the SIMT-mock build)")
     ap.add_argument("--spawn-check", action="store_true", help="ranks only report the world size (CPU test of the launcher)")
     return ap.parse_args(argv)
@@ -414,7 +414,7 @@ def end_to_end(dev, wl, W, args):
         return {"value": round(st["read_bases"] / dt / 1e9, 3), "unit": "Gbases/s", "seconds": round(dt, 3),
                 "read_bases": st["read_bases"], "reads": st["reads"], "input": f"plain FASTA, {len(files)} read file(s), page cache ({d})",
                 "output_bytes": out_bytes, "prepare_inputs_s": round(prep_s, 1),
-                "t_contig_stage": round(st["t_contigs"], 3), "t_wait_for_ingest": round(st["t_ingest"], 3),
+                "t_contig_stage": round(st["t_contigs"], 3), "t_contig_stage_parts": st.get("t_contigs_parts"), "t_wait_for_ingest": round(st["t_ingest"], 3),
                 "t_device_incl_pack_pcie": round(st["t_device"], 3), "t_handover": round(st["t_handover"], 3),
                 "t_drain_tail": round(st.get("t_drain_tail", 0), 3), "t_graph": round(st.get("t_graph", 0), 3)}
     finally:

@@ -27,6 +27,7 @@
 
 #define NTL_END_PAD 4096u /* bases of padding behind the last sequence (rolling over-reads) */
 #define SK_NT 256
+#define NTL_MAX_W (16 * (SK_NT - 4) + 31) /* 16 k-mers per lane, a + 2 <= SK_NT - 2 halo lanes: w <= 4063 */
 
 /* ------------------------------------------------------------------ context ------------- */
 
@@ -48,6 +49,7 @@ struct ntl_ctx {
     void *g8 = nullptr;                 /* device copy of the eight-base init table (1 MB) */
     std::multimap<size_t, void *> pool; /* cached device blocks by size */
     size_t pool_bytes = 0;
+    size_t pool_cap = (size_t)32 << 30; /* upper bound of pool_bytes */
     void *host_tmp = nullptr;           /* page-locked bounce buffer for record downloads (grows, never shrinks) */
     size_t host_tmp_cap = 0;
 };
@@ -125,7 +127,18 @@ struct DevBuf {
     }
     void release()
     {
-        if (p && c) { c->pool.insert({bytes, p}); c->pool_bytes += bytes; }
+        if (p && c) {
+            c->pool.insert({bytes, p}); c->pool_bytes += bytes;
+            /* the cache is bounded (half of the device memory unless NTL_POOL_MAX_BYTES says otherwise; a bound below the
+               working set of a batch -- tens of GB for 4-Gbases HiFi batches -- turns every release into a hipFree): the
+               largest blocks go first, they are the least likely to be asked for again at exactly their size */
+            while (c->pool_bytes > c->pool_cap && !c->pool.empty()) {
+                auto it = std::prev(c->pool.end());
+                (void)hipFree(it->second);
+                c->pool_bytes -= it->first;
+                c->pool.erase(it);
+            }
+        }
         p = nullptr; bytes = 0;
     }
     ~DevBuf() { release(); }
@@ -188,6 +201,8 @@ extern "C" int ntl_ctx_create(int device, ntl_ctx **out)
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+        c->pool_cap = std::max<size_t>((size_t)prop.totalGlobalMem / 2, (size_t)256 << 20);
+        if (const char *e = getenv("NTL_POOL_MAX_BYTES")) { const long long v = atoll(e); if (v >= 0) c->pool_cap = (size_t)v; }
         char buf[256];
         snprintf(buf, sizeof buf, "%s %s %d CUs %.0f GiB", prop.name, prop.gcnArchName, prop.multiProcessorCount,
                  (double)prop.totalGlobalMem / (1024.0 * 1024.0 * 1024.0));
@@ -639,13 +654,24 @@ extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_
     /* lanes per strip: 128-lane strips waste fewer lanes on the last strip of a ~10 kb read; the halo
        (a+2 lanes) makes them a loss for large windows (measured: +5 % at w=100, -3 % at w=250) */
     int nt = (C == 16 && (w - C) / C + 2 <= 10) ? 128 : SK_NT;
-    if (const char *e = getenv("NTL_SKETCH_NT")) { /* tuning knob */
+    if (const char *e = getenv("NTL_SKETCH_NT")) { /* tuning knob; ignored where it leaves no lane to own a window */
         const int v = atoi(e);
-        if (v == 256 || (v == 128 && C == 16)) nt = v;
+        if ((v == 256 || (v == 128 && C == 16)) && v - (G.a + 2) >= 2) nt = v;
     }
     G.LW = nt - (G.a + 2);
+    if (G.LW < 2 && C != 16) { /* a tuning knob (NTL_SKETCH_C) made the strip too short for this window: back to the default */
+        C = 16;
+        G.a = (w - C) / C; G.r0 = (w - C) % C;
+        nt = SK_NT;
+        G.LW = nt - (G.a + 2);
+    }
     G.NWO = G.LW * C - 1;
-    if (G.LW < 2 || G.NWO < 1) return fail(c, NTL_EINVAL, "window size too large for this build (w <= ~4000)");
+    if (G.LW < 2 || G.NWO < 1) {
+        char msg[160];
+        snprintf(msg, sizeof msg, "window size w=%d is beyond this build's limit of w <= %d (a strip of %d x 16 k-mers must hold two windows' lanes)",
+                 w, NTL_MAX_W, SK_NT);
+        return fail(c, NTL_EINVAL, msg);
+    }
     const uint64_t nseq = b->nseq;
     std::unique_ptr<ntl_sketch> s_guard(new ntl_sketch());
     ntl_sketch *s = s_guard.get();
@@ -1077,7 +1103,7 @@ extern "C" int ntl_map_run(ntl_ctx *c, const ntl_index *ix, const ntl_sketch *re
             if (nmx <= 256 * nreads) hipLaunchKernelGGL((map_kernel<256, 64>), dim3((unsigned)nreads), dim3(MAP_NT), 0, c->stream, A);
             else hipLaunchKernelGGL((map_kernel<512, 128>), dim3((unsigned)nreads), dim3(MAP_NT), 0, c->stream, A);
             /* reads with more hits / runs than the LDS staging holds (rare): same code on global scratch */
-            hipLaunchKernelGGL(map_overflow_kernel, dim3((unsigned)std::min<uint64_t>(nreads, 1024)), dim3(MAP_NT), 0, c->stream, A);
+            hipLaunchKernelGGL(map_overflow_kernel, dim3((unsigned)std::min<uint64_t>(nreads, 32768)), dim3(MAP_NT), 0, c->stream, A); /* no LDS: 32 wavefronts per CU resident, four rounds of them */
             HIPCHK(c, hipGetLastError());
         }
         ProfSpan sp(c, "compact");

@@ -23,11 +23,15 @@
 #include <string.h>
 #include <dlfcn.h>
 #include <fcntl.h>
+#include <pthread.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
 #include <algorithm>
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -62,6 +66,8 @@ struct ntl_fastx {
     bool seekable = false;
     size_t file_size = 0;      /* file: end of the bytes this reader covers (the file's size, or the end of its range) */
     size_t range_lo = 0;       /* file: first byte it covers */
+    const char *mm = nullptr;  /* file: mapping of the whole file (whole-input batches only) */
+    size_t mm_len = 0;
     bool gz = false, z_init = false, src_eof = false; /* serial */
     z_stream zs;
     std::vector<unsigned char> zin;
@@ -99,13 +105,100 @@ static unsigned io_threads()
     return n == 0 ? 1 : std::min(n, 32u);
 }
 
+/*
+ * Parallel regions run on a process-wide pool of worker threads that is created once: starting and joining 32
+ * std::threads costs 3-4 ms per region on a 256-core host (measured: tools/io_diag.py), three regions per read batch, which
+ * was most of the reader's time per 256-Mbase batch.  Several callers may be inside run_threads at once (the reader thread
+ * and the two text emitters of the pair driver); a caller works through the queue itself while it waits, so regions
+ * never wait for each other's workers.  A forked child starts with an empty pool of its own.
+ */
+struct WorkPool {
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<std::function<void()>> q;
+    std::vector<std::thread> workers;
+    bool stop = false;
+
+    explicit WorkPool(unsigned n)
+    {
+        for (unsigned i = 0; i < n; i++) workers.emplace_back([this] { loop(); });
+    }
+    void loop()
+    {
+        for (;;) {
+            std::function<void()> job;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [this] { return stop || !q.empty(); });
+                if (stop && q.empty()) return;
+                job = std::move(q.front());
+                q.pop_front();
+            }
+            job();
+        }
+    }
+    bool help() /* the caller of a region runs queued jobs too */
+    {
+        std::function<void()> job;
+        {
+            std::lock_guard<std::mutex> lk(m);
+            if (q.empty()) return false;
+            job = std::move(q.front());
+            q.pop_front();
+        }
+        job();
+        return true;
+    }
+};
+
+static WorkPool *g_pool = nullptr;
+static std::mutex g_pool_mutex;
+
+static WorkPool *work_pool()
+{
+    std::lock_guard<std::mutex> lk(g_pool_mutex);
+    if (!g_pool) {
+        static bool atfork_set = false;
+        if (!atfork_set) {
+            atfork_set = true;
+            pthread_atfork(nullptr, nullptr, [] { g_pool = nullptr; new (&g_pool_mutex) std::mutex(); }); /* threads do not survive fork() */
+        }
+        unsigned hc = std::thread::hardware_concurrency();
+        if (hc == 0) hc = 4;
+        g_pool = new WorkPool(std::min(hc, std::max(2 * io_threads(), 8u))); /* never destroyed: workers idle on the condition variable */
+    }
+    return g_pool;
+}
+
 template <typename F>
 static void run_threads(size_t n, F work)
 {
     if (n <= 1) { if (n) work((size_t)0); return; }
-    std::vector<std::thread> th;
-    for (size_t t = 0; t < n; t++) th.emplace_back(work, t);
-    for (auto &x : th) x.join();
+    WorkPool *P = work_pool();
+    struct Region { std::mutex m; std::condition_variable cv; size_t left; } R;
+    R.left = n - 1;
+    {
+        std::lock_guard<std::mutex> lk(P->m);
+        for (size_t t = 1; t < n; t++)
+            P->q.emplace_back([&work, &R, t] {
+                work(t);
+                std::lock_guard<std::mutex> lk2(R.m);
+                if (--R.left == 0) R.cv.notify_all();
+            });
+    }
+    P->cv.notify_all();
+    work((size_t)0);
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> lk(R.m);
+            if (R.left == 0) break;
+        }
+        if (!P->help()) { /* everything left of this region is running on workers */
+            std::unique_lock<std::mutex> lk(R.m);
+            R.cv.wait(lk, [&R] { return R.left == 0; });
+            break;
+        }
+    }
 }
 
 static inline bool id_blank(char ch) { return ch == ' ' || ch == '\t' || ch == '\r' || ch == '\f' || ch == '\v'; }
@@ -503,6 +596,7 @@ extern "C" void ntl_fastx_close(ntl_fastx *r)
     if (!r) return;
     if (r->z_init) inflateEnd(&r->zs);
     if (r->map) buf_cache().give((char *)r->map, r->map_cap);
+    if (r->mm) munmap((void *)r->mm, r->mm_len);
     if (r->fd >= 0) close(r->fd);
     if (r->stage) buf_cache().give(r->stage, r->stage_cap);
     delete r;
@@ -600,6 +694,18 @@ static const char *view(ntl_fastx *r, size_t need, size_t *avail, bool *at_eof)
     }
     if (r->seekable) {
         const size_t remain = r->file_size - r->cur;
+        /* the whole rest of a large file in one batch (the assembly): parsed straight from a mapping of the page cache --
+           a staging buffer of that size would be fresh memory, zeroed page by page and then filled by a copy */
+        size_t map_min = (size_t)64 << 20;
+        if (const char *e = getenv("NTL_IO_MAP_WHOLE_MIN")) map_min = (size_t)atoll(e); /* tests; a huge value switches it off */
+        if (!r->mm && need == (size_t)-1 && remain >= map_min) {
+            void *m = mmap(nullptr, r->file_size, PROT_READ, MAP_PRIVATE, r->fd, 0);
+            if (m != MAP_FAILED) { r->mm = (const char *)m; r->mm_len = r->file_size; }
+        }
+        if (r->mm) {
+            *avail = remain;
+            return r->mm + r->cur;
+        }
         const size_t target = std::min(need, remain);
         if (r->stage_have < target) {
             if (!stage_reserve(r, target)) return r->stage;

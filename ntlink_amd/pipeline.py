@@ -361,6 +361,7 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
     batches = Prefetch(seqio.load(plan, max_bases=batch_bases, alloc=dev.pinned_empty, stats=io_stats))
     ctg = seqio.load_all([target])  # used once: page-locking a buffer for it would cost more than the staged copy
     ctg_len = ctg.lengths
+    t_ctg_parsed = time.perf_counter()
     part = "" if root else f".part{comm.rank}"
     out = PairOutputs(prefix, ctg.names, ctg_len, k, f, verbose, paf, part=part)
 
@@ -378,13 +379,19 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
     try:
         with dev.batch(ctg.buf, ctg.offsets) as cb:
             ctg.buf = None
+            t_ctg_up = time.perf_counter()
             with dev.sketch(cb, k, w) as csk:
+                t_ctg_sk = time.perf_counter()
                 if tsv_drain:
                     tsv_drain.put(*csk.download())  # <target>.k<k>.w<w>.tsv is written while the reads are mapped
+                t_ctg_dl = time.perf_counter()
                 with dev.index(csk, ctg_len) as ix:
                     stats["index_size"] = len(ix)
                     t_mark = time.perf_counter()
                     stats["t_contigs"] = t_mark - t_start
+                    stats["t_contigs_parts"] = {"parse": round(t_ctg_parsed - t_start, 4), "upload_pack": round(t_ctg_up - t_ctg_parsed, 4),
+                                                "sketch": round(t_ctg_sk - t_ctg_up, 4), "download_for_tsv": round(t_ctg_dl - t_ctg_sk, 4),
+                                                "index": round(t_mark - t_ctg_dl, 4)}
                     for rs_ in batches:
                         if not len(rs_):
                             continue

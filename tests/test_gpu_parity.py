@@ -114,7 +114,7 @@ def test_long_read_uses_global_scratch(dev):
     order = rng.permutation(400)
     read = b"".join(contigs[i] for i in order[:300])
     # few hits on many contigs: the hits fit the LDS staging, the runs (> 128) do not -> map_overflow_kernel as well
-    patchy = b"".join(contigs[i][1000:1048] for i in order[:250])
+    patchy = b"".join(contigs[i][1000:1048] for i in order[:200])
     reads = [read, contigs[5] + contigs[5], b"ACGT", patchy, contigs[7][:500]]
     got = pc.check_full_pipeline(dev, contigs, reads, 24, 20, z=1000)
     assert 128 < int((got["maps"]["read"] == 3).sum()) and int(got["maps"]["n_hits"][got["maps"]["read"] == 3].sum()) <= 512

@@ -418,3 +418,22 @@ def test_tally_overhang_check_only_for_evaluated_pairs_and_merge():
     b.add_batch(recs(reads[1:]), rl[1:])
     a.merge(b.export())
     assert list(a.pairs.items()) == list(whole.pairs.items()) and len(whole.pairs) >= 2
+
+
+def test_whole_file_batches_parse_from_a_mapping(tmp_path, monkeypatch):
+    """A plain file taken as one batch (the assembly) is parsed from a mapping of the page cache; same records."""
+    rng = np.random.default_rng(11)
+    p = tmp_path / "asm.fa"
+    with open(p, "w") as fh:
+        for i in range(300):
+            s = "".join(rng.choice(list("ACGTNacgt"), int(rng.integers(1, 5000))))
+            fh.write(f">c{i} x\n" + "\n".join(s[j:j + 70] for j in range(0, len(s), 70)) + "\n")
+    monkeypatch.setenv("NTL_IO_MAP_WHOLE_MIN", str(1 << 60))
+    a = seqio.load_all([str(p)])
+    monkeypatch.setenv("NTL_IO_MAP_WHOLE_MIN", "1")
+    monkeypatch.setenv("NTL_IO_THREADS", "5")
+    monkeypatch.setenv("NTL_IO_MIN_CHUNK", "3000")
+    b = seqio.load_all([str(p)])
+    assert a.names == b.names and np.array_equal(a.offsets, b.offsets) and np.array_equal(a.buf, b.buf) and len(a) == 300
+    want = list(seqio.read_fastx(str(p)))
+    assert [n for n, _ in want] == b.names.tolist() and b"".join(s for _, s in want) == b.buf.tobytes()

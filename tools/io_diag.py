@@ -32,14 +32,14 @@ def main():
     # raw memory numbers
     a = np.empty(nbytes, np.uint8); t = time.perf_counter(); a[:] = 1; out["touch_np_empty_s"] = round(time.perf_counter() - t, 4)
     t = time.perf_counter(); a[:] = 2; out["retouch_s"] = round(time.perf_counter() - t, 4)
-    b = seqio.big_empty(nbytes); t = time.perf_counter(); b[:] = 1; out["touch_big_empty_s"] = round(time.perf_counter() - t, 4)
+    b = np.empty(nbytes, np.uint8); b[:] = 1
     t = time.perf_counter(); b[:] = a; out["memcpy_1thr_s"] = round(time.perf_counter() - t, 4)
     del a, b
     L = capi.load()
     rows = []
     for thr in ("1", "4", "8", "16", "32", "64", "128"):
         os.environ["NTL_IO_THREADS"] = thr
-        for dest in ("np", "big", "reuse"):
+        for dest in ("np", "reuse"):
             best = None
             keep = None
             for rep in range(3):
@@ -50,7 +50,7 @@ def main():
                 if dest == "reuse" and keep is not None:
                     buf = keep
                 else:
-                    buf = np.empty(nb.value, np.uint8) if dest == "np" else seqio.big_empty(nb.value)
+                    buf = np.empty(nb.value, np.uint8)
                 keep = buf
                 names = np.empty(nn.value, np.uint8)
                 off, noff = np.empty(n.value + 1, np.uint64), np.empty(n.value + 1, np.uint64)
