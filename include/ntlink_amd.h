@@ -41,7 +41,8 @@
  *
  * Environment (tuning and tests; none is needed): NTL_IO_THREADS (parser threads, default
  * min(cores, 32)), NTL_IO_MIN_CHUNK (bytes per parser thread below which fewer threads are used),
- * NTL_IO_NO_MMAP=1 (stream every input through zlib on one thread), NTL_IO_NO_LIBDEFLATE=1,
+ * NTL_IO_NO_MMAP=1 (stream every input through zlib on one thread), NTL_IO_PREAD=1 (plain files through staged preads
+ * instead of a mapping), NTL_IO_NO_LIBDEFLATE=1, NTL_POOL_MAX_BYTES (bound of the cache of device blocks, default half the device memory),
  * NTL_IO_GZ_WHOLE_MAX (compressed bytes up to which a gzip file is inflated in one go, default
  * 1/40 of the physical memory within 1..16 GiB), NTL_IO_TRACE=1 (reader diagnostics on stderr), NTL_SKETCH_C / NTL_SKETCH_NT (k-mers per
  * lane, lanes per strip of the sketch kernel), NTL_SKETCH_FAST=0 (exact 64-bit window pass only), NTL_SKETCH_FORCE_REDO=1

@@ -420,20 +420,23 @@ def test_tally_overhang_check_only_for_evaluated_pairs_and_merge():
     assert list(a.pairs.items()) == list(whole.pairs.items()) and len(whole.pairs) >= 2
 
 
-def test_whole_file_batches_parse_from_a_mapping(tmp_path, monkeypatch):
-    """A plain file taken as one batch (the assembly) is parsed from a mapping of the page cache; same records."""
+def test_plain_files_parse_from_a_mapping_or_staged_preads(tmp_path, monkeypatch):
+    """A plain file is parsed from a mapping of the page cache, or (NTL_IO_PREAD=1) from staged preads; same records."""
     rng = np.random.default_rng(11)
     p = tmp_path / "asm.fa"
     with open(p, "w") as fh:
         for i in range(300):
             s = "".join(rng.choice(list("ACGTNacgt"), int(rng.integers(1, 5000))))
             fh.write(f">c{i} x\n" + "\n".join(s[j:j + 70] for j in range(0, len(s), 70)) + "\n")
-    monkeypatch.setenv("NTL_IO_MAP_WHOLE_MIN", str(1 << 60))
+    monkeypatch.setenv("NTL_IO_PREAD", "1")
     a = seqio.load_all([str(p)])
-    monkeypatch.setenv("NTL_IO_MAP_WHOLE_MIN", "1")
+    a2 = seqio.concat(list(seqio.load([str(p)], max_bases=40_000)))
+    monkeypatch.delenv("NTL_IO_PREAD")
     monkeypatch.setenv("NTL_IO_THREADS", "5")
     monkeypatch.setenv("NTL_IO_MIN_CHUNK", "3000")
     b = seqio.load_all([str(p)])
-    assert a.names == b.names and np.array_equal(a.offsets, b.offsets) and np.array_equal(a.buf, b.buf) and len(a) == 300
+    b2 = seqio.concat(list(seqio.load([str(p)], max_bases=40_000)))
+    for x in (a2, b, b2):
+        assert a.names == x.names and np.array_equal(a.offsets, x.offsets) and np.array_equal(a.buf, x.buf) and len(a) == 300
     want = list(seqio.read_fastx(str(p)))
     assert [n for n, _ in want] == b.names.tolist() and b"".join(s for _, s in want) == b.buf.tobytes()
