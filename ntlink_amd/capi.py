@@ -272,7 +272,7 @@ class MapResult(_Handle):
             hits = base[offs[1]:offs[1] + sizes[1]].view(HIT_DT)
             pafs = base[offs[2]:offs[2] + sizes[2]].view(PAF_DT)
             self.dev._chk(self.dev.L.ntl_mapres_download(self.ptr, maps.ctypes.data, hits.ctypes.data, pafs.ctypes.data))
-            return {"maps": maps, "hits": hits, "pafs": pafs, "_pinned": base}
+            return {"maps": maps, "hits": hits, "pafs": pafs, "_pinned": base, "_owner": self.dev}
         maps = np.empty(nm, MAPPING_DT); hits = np.empty(nh, HIT_DT); pafs = np.empty(npf, PAF_DT)
         self.dev._chk(self.dev.L.ntl_mapres_download(self.ptr, maps.ctypes.data, hits.ctypes.data, pafs.ctypes.data))
         return {"maps": maps, "hits": hits, "pafs": pafs}
@@ -283,6 +283,7 @@ class Device:
 
     def __init__(self, device=0, lib_path=None):
         self.L = load(lib_path)
+        self.ordinal, self.lib_path = int(device), lib_path
         p = C.c_void_p()
         rc = self.L.ntl_ctx_create(int(device), C.byref(p))
         if rc != 0:
@@ -292,6 +293,11 @@ class Device:
         self._live = weakref.WeakSet()
         self._pinned_free, self._pinned_all, self._pinned_out = [], [], {}  # (address, capacity) of page-locked buffers
         self._pinned_lock = threading.Lock()  # the reader thread takes buffers, the device thread returns them
+
+    def clone(self):
+        """Another context (stream, block cache, staging pool) on the same GPU: a second worker thread of the pair driver
+        uploads its batch while this one's kernels run.  Device objects of one context may be used by the other."""
+        return Device(self.ordinal, self.lib_path)
 
     def close(self):
         if self.ptr:

@@ -329,6 +329,90 @@ def _append_part(final_path, part_path, offset):
     os.remove(part_path)
 
 
+def _map_batches(dev, ix, batches, drain, stats, t_mark, **map_kw):
+    """The device stage of the pair driver: read batches -> records, handed to `drain` in input order.
+
+    NTL_DEVICE_STREAMS (default 2) worker threads, each with its own context on the GPU (stream, block cache, page-locked
+    result buffers), take batches in turn: while one batch's kernels and record download run, the next batch's bases
+    cross PCIe.  The batches' results are committed in input order."""
+    import threading
+    n_workers = max(1, int(os.environ.get("NTL_DEVICE_STREAMS", "2")))
+    devs = [dev] + [dev.clone() for _ in range(n_workers - 1)]
+    it = iter(batches)
+    lock, commit = threading.Lock(), threading.Condition()
+    state = {"next_seq": 0, "commit_seq": 0, "error": None, "t_mark": t_mark}
+
+    def take():
+        with lock:
+            while True:
+                if state["error"] is not None:
+                    return None
+                rs_ = next(it, None)
+                if rs_ is None:
+                    return None
+                if len(rs_):
+                    seq = state["next_seq"]
+                    state["next_seq"] += 1
+                    now = time.perf_counter()
+                    stats["t_ingest"] += max(0.0, now - state["t_mark"])  # the device stage waited for the reader thread
+                    state["t_mark"] = now
+                    return seq, rs_
+
+    def work(wdev):
+        try:
+            while True:
+                got = take()
+                if got is None:
+                    return
+                seq, rs_ = got
+                t_dev = time.perf_counter()
+                rl = rs_.lengths
+                with wdev.batch(rs_.buf, rs_.offsets) as rb:
+                    dev.pinned_release(rs_.buf)  # the bases are on the device: the reader may refill this buffer
+                    rs_.buf = None
+                    with wdev.sketch(rb, map_kw["k"], stats["w"]) as rsk, wdev.map(ix, rsk, rl, **map_kw) as res:
+                        pres = res.download(pinned=True)
+                        n_mx, n_hit = rsk.count, res.n_index_hits
+                t_done = time.perf_counter()
+                with commit:
+                    while state["commit_seq"] != seq and state["error"] is None:
+                        commit.wait(0.05)
+                    if state["error"] is not None:
+                        return
+                    t_put = time.perf_counter()
+                    drain.put(pres, rs_.names, rl)
+                    now = time.perf_counter()
+                    stats["t_device"] += t_done - t_dev      # H2D + pack + kernels + D2H, summed over the worker threads
+                    stats["t_handover"] += now - t_put       # waiting for the writer thread to take the batch
+                    stats["read_minimizers"] += n_mx
+                    stats["index_hits"] += n_hit
+                    stats["read_bases"] += rs_.bases
+                    stats["reads"] += len(rs_)
+                    state["commit_seq"] += 1
+                    state["t_mark"] = max(state["t_mark"], now)
+                    commit.notify_all()
+        except BaseException as exc:
+            with commit:
+                if state["error"] is None:
+                    state["error"] = exc
+                commit.notify_all()
+
+    threads = [threading.Thread(target=work, args=(d,), daemon=True) for d in devs[1:]]
+    for t in threads:
+        t.start()
+    work(devs[0])
+    for t in threads:
+        t.join()
+    for d in devs[1:]:
+        if state["error"] is None:
+            # results of this context may still sit in the writer's queue: their page-locked buffers go back to it later
+            stats.setdefault("_extra_devices", []).append(d)
+        else:
+            d.close()
+    if state["error"] is not None:
+        raise state["error"]
+
+
 def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=10, x=0.0, paf=False, verbose=True,
              sensitive=False, repeats=False, pairs_tsv=False, batch_bases=DEFAULT_BATCH_BASES, write_contig_tsv=True,
              comm=None):
@@ -367,7 +451,7 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
 
     def consume(pres, names, lens):
         out.add(pres, names, lens)
-        dev.pinned_release(pres.get("_pinned"))
+        pres.get("_owner", dev).pinned_release(pres.get("_pinned"))
 
     def emit_contig_tsv(off, h, p, s):
         with open(f"{target}.k{k}.w{w}.tsv", "w") as fh:
@@ -375,7 +459,7 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
 
     drain = Drain(consume)  # text emitters + pair tally run behind the device
     tsv_drain = Drain(emit_contig_tsv) if root and write_contig_tsv else None
-    stats = dict(read_bases=0, reads=0, read_minimizers=0, index_hits=0, t_contigs=0.0, t_ingest=0.0, t_device=0.0, t_handover=0.0)
+    stats = dict(read_bases=0, reads=0, read_minimizers=0, index_hits=0, t_contigs=0.0, t_ingest=0.0, t_device=0.0, t_handover=0.0, w=w)
     try:
         with dev.batch(ctg.buf, ctg.offsets) as cb:
             ctg.buf = None
@@ -392,29 +476,11 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
                     stats["t_contigs_parts"] = {"parse": round(t_ctg_parsed - t_start, 4), "upload_pack": round(t_ctg_up - t_ctg_parsed, 4),
                                                 "sketch": round(t_ctg_sk - t_ctg_up, 4), "download_for_tsv": round(t_ctg_dl - t_ctg_sk, 4),
                                                 "index": round(t_mark - t_ctg_dl, 4)}
-                    for rs_ in batches:
-                        if not len(rs_):
-                            continue
-                        stats["t_ingest"] += time.perf_counter() - t_mark  # waiting for the reader thread
-                        t_dev = time.perf_counter()
-                        rl = rs_.lengths
-                        with dev.batch(rs_.buf, rs_.offsets) as rb:
-                            dev.pinned_release(rs_.buf)  # the bases are on the device: the reader may refill this buffer
-                            rs_.buf = None
-                            with dev.sketch(rb, k, w) as rsk, \
-                                    dev.map(ix, rsk, rl, k=k, z=z, x=x, sensitive=sensitive, repeat_filter=repeats) as res:
-                                pres = res.download(pinned=True)
-                                stats["read_minimizers"] += rsk.count
-                                stats["index_hits"] += res.n_index_hits
-                        stats["t_device"] += time.perf_counter() - t_dev  # H2D + pack + kernels + D2H
-                        t_put = time.perf_counter()
-                        drain.put(pres, rs_.names, rl)
-                        stats["read_bases"] += rs_.bases
-                        stats["reads"] += len(rs_)
-                        t_mark = time.perf_counter()
-                        stats["t_handover"] += t_mark - t_put  # waiting for the writer thread to take the batch
+                    _map_batches(dev, ix, batches, drain, stats, t_mark, k=k, z=z, x=x, sensitive=sensitive, repeat_filter=repeats)
         t_fin = time.perf_counter()
         drain.close()
+        for d in stats.pop("_extra_devices", []):
+            d.close()
         if tsv_drain:
             tsv_drain.close()
         out.close()
@@ -449,6 +515,8 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
                     d.close()
             except BaseException:
                 pass
+        for d in stats.pop("_extra_devices", []):
+            d.close()
         out.remove_partial()
         batches.stop()
         raise

@@ -16,6 +16,7 @@
 #include <stdio.h>
 #include <chrono>
 #include <functional>
+#include <mutex>
 #include <vector>
 
 #define NTL_SIM 1
@@ -45,6 +46,7 @@ struct Block {
     unsigned long long slot[16][64];
 };
 extern Block *cur;
+std::mutex &launch_mutex();
 extern unsigned grid_y; /* blockIdx.y of the running launch (2-D grids run one row at a time) */
 extern thread_local unsigned tid;
 void launch(unsigned grid, unsigned block, const std::function<void()> &fn);
@@ -152,6 +154,7 @@ inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b)
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...)                         \
     do {                                                                                  \
         dim3 g_ = (grid), b_ = (block);                                                   \
+        std::lock_guard<std::mutex> launch_lock_(sim::launch_mutex()); /* one launch at a time, whatever host thread */ \
         for (unsigned y_ = 0; y_ < g_.y; y_++) {                                          \
             sim::grid_y = y_;                                                             \
             sim::launch_k(g_.x, b_.x, kern, __VA_ARGS__);                                 \

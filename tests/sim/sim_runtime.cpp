@@ -4,6 +4,7 @@
 namespace sim {
 Block *cur = nullptr;
 unsigned grid_y = 0;
+std::mutex &launch_mutex() { static std::mutex m; return m; }
 thread_local unsigned tid = 0;
 
 struct Job {

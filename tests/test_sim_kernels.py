@@ -71,10 +71,20 @@ def test_sim_pair_driver_files(dev, tmp_path):
     os.chdir(tmp_path)
     try:
         pipeline.run_pair(dev, "scaffolds_4.fa", "long_reads_4_top5.fa", k=40, w=100, paf=True, pairs_tsv=True)
+        # one read per batch, three device worker threads (contexts) taking batches in turn: results still in read order
+        os.environ["NTL_DEVICE_STREAMS"] = "3"
+        try:
+            st = pipeline.run_pair(dev, "scaffolds_4.fa", "long_reads_4_top5.fa", k=40, w=100, paf=True, pairs_tsv=True,
+                                   batch_bases=1000, prefix="streams3", write_contig_tsv=False)
+        finally:
+            del os.environ["NTL_DEVICE_STREAMS"]
+        assert st["reads"] == 5
     finally:
         os.chdir(cwd)
     pre = str(tmp_path / "scaffolds_4.fa.k40.w100.z1000")
     d = os.path.join(GEN, "fixtures", "t7_top5_k40_w100")
+    for ext in (".verbose_mapping.tsv", ".paf", ".pairs.tsv"):
+        assert read_text(str(tmp_path / "streams3") + ext) == read_text(d + ext), ext
     assert read_text(pre + ".verbose_mapping.tsv") == read_text(d + ".verbose_mapping.tsv")
     assert set(read_text(pre + ".paf").splitlines()) == TEST7_PAF
     assert read_text(pre + ".pairs.tsv") == read_text(d + ".pairs.tsv")
