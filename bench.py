@@ -415,7 +415,7 @@ def end_to_end(dev, wl, W, args):
                 "read_bases": st["read_bases"], "reads": st["reads"], "input": f"plain FASTA, {len(files)} read file(s), page cache ({d})",
                 "output_bytes": out_bytes, "prepare_inputs_s": round(prep_s, 1),
                 "t_contig_stage": round(st["t_contigs"], 3), "t_contig_stage_parts": st.get("t_contigs_parts"), "t_wait_for_ingest": round(st["t_ingest"], 3),
-                "t_device_incl_pack_pcie": round(st["t_device"], 3), "t_handover": round(st["t_handover"], 3),
+                "t_device_incl_pack_pcie": round(st["t_device"], 3), "t_device_parts": st.get("t_device_parts"), "t_handover": round(st["t_handover"], 3),
                 "t_drain_tail": round(st.get("t_drain_tail", 0), 3), "t_graph": round(st.get("t_graph", 0), 3),
                 "t_write": round(st.get("t_write", 0), 3), "t_tally": round(st.get("t_tally", 0), 3),
                 "device_streams": int(os.environ.get("NTL_DEVICE_STREAMS", "2"))}

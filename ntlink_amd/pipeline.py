@@ -368,12 +368,17 @@ def _map_batches(dev, ix, batches, drain, stats, t_mark, **map_kw):
                 t_dev = time.perf_counter()
                 rl = rs_.lengths
                 with wdev.batch(rs_.buf, rs_.offsets) as rb:
+                    t_up = time.perf_counter()
                     dev.pinned_release(rs_.buf)  # the bases are on the device: the reader may refill this buffer
                     rs_.buf = None
-                    with wdev.sketch(rb, map_kw["k"], stats["w"]) as rsk, wdev.map(ix, rsk, rl, **map_kw) as res:
-                        pres = res.download(pinned=True)
-                        n_mx, n_hit = rsk.count, res.n_index_hits
+                    with wdev.sketch(rb, map_kw["k"], stats["w"]) as rsk:
+                        t_sk = time.perf_counter()
+                        with wdev.map(ix, rsk, rl, **map_kw) as res:
+                            t_mp = time.perf_counter()
+                            pres = res.download(pinned=True)
+                            n_mx, n_hit = rsk.count, res.n_index_hits
                 t_done = time.perf_counter()
+                parts = (t_up - t_dev, t_sk - t_up, t_mp - t_sk, t_done - t_mp)
                 with commit:
                     while state["commit_seq"] != seq and state["error"] is None:
                         commit.wait(0.05)
@@ -383,6 +388,8 @@ def _map_batches(dev, ix, batches, drain, stats, t_mark, **map_kw):
                     drain.put(pres, rs_.names, rl)
                     now = time.perf_counter()
                     stats["t_device"] += t_done - t_dev      # H2D + pack + kernels + D2H, summed over the worker threads
+                    for key, v in zip(("upload_pack", "sketch", "map", "download_free"), parts):
+                        stats["t_device_parts"][key] = round(stats["t_device_parts"].get(key, 0.0) + v, 4)
                     stats["t_handover"] += now - t_put       # waiting for the writer thread to take the batch
                     stats["read_minimizers"] += n_mx
                     stats["index_hits"] += n_hit
@@ -459,7 +466,7 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
 
     drain = Drain(consume)  # text emitters + pair tally run behind the device
     tsv_drain = Drain(emit_contig_tsv) if root and write_contig_tsv else None
-    stats = dict(read_bases=0, reads=0, read_minimizers=0, index_hits=0, t_contigs=0.0, t_ingest=0.0, t_device=0.0, t_handover=0.0, w=w)
+    stats = dict(read_bases=0, reads=0, read_minimizers=0, index_hits=0, t_contigs=0.0, t_ingest=0.0, t_device=0.0, t_handover=0.0, w=w, t_device_parts={})
     try:
         with dev.batch(ctg.buf, ctg.offsets) as cb:
             ctg.buf = None
