@@ -99,6 +99,15 @@ int ntl_prof_get(ntl_ctx *ctx, const char *name, double *total_ms, uint64_t *lau
 int ntl_batch_create(ntl_ctx *ctx, const char *seqs, const uint64_t *offsets, uint64_t nseq,
                      ntl_batch **out);
 void ntl_batch_destroy(ntl_batch *b);
+/* The same from bases that are already in the device's layout -- what ntl_fastx_copy_packed + ntl_fastx_runs produce while
+ * they parse: packed[ntl_packed_words(bases)] holds 2 bits per base (A/a 0, C/c 1, G/g 2, T/t 3, anything else 0), sixteen per
+ * word, base b of the batch at bit position 2 * (16 + b) (sixteen bases of zero padding in front, 4096 behind); offsets[0] = 0;
+ * sequence i has the maximal ACGT/acgt runs seq_run_first[i] .. seq_run_first[i+1], run r = run_len[r] bases from offset
+ * run_start[r] of its sequence.  A quarter of the bytes of ntl_batch_create cross PCIe and no pack kernel runs. */
+uint64_t ntl_packed_words(uint64_t bases);
+int ntl_batch_create_packed(ntl_ctx *ctx, const uint32_t *packed, const uint64_t *offsets, uint64_t nseq,
+                            const uint32_t *seq_run_first, const uint32_t *run_start, const uint32_t *run_len, uint64_t nruns,
+                            ntl_batch **out);
 uint64_t ntl_batch_nseq(const ntl_batch *b);
 uint64_t ntl_batch_bases(const ntl_batch *b);
 
@@ -242,6 +251,10 @@ int ntl_fastx_open_range(const char *path, uint64_t lo, uint64_t hi, ntl_fastx *
 void ntl_fastx_range(const ntl_fastx *r, uint64_t *lo, uint64_t *hi);
 void ntl_fastx_sizes(const ntl_fastx *r, uint64_t *nseq, uint64_t *bases, uint64_t *name_bytes);
 int ntl_fastx_copy(const ntl_fastx *r, char *seqs, uint64_t *offsets, char *names, uint64_t *name_offsets);
+/* The current batch in the layout of ntl_batch_create_packed instead of ASCII: packed[ntl_packed_words(bases)], offsets and names
+ * as above, *nruns = number of ACGT runs; ntl_fastx_runs then fills seq_run_first[nseq + 1], run_start[nruns], run_len[nruns]. */
+int ntl_fastx_copy_packed(ntl_fastx *r, uint32_t *packed, uint64_t *offsets, char *names, uint64_t *name_offsets, uint64_t *nruns);
+int ntl_fastx_runs(const ntl_fastx *r, uint32_t *seq_run_first, uint32_t *run_start, uint32_t *run_len);
 const char *ntl_fastx_seqs(ntl_fastx *r);
 const uint64_t *ntl_fastx_offsets(ntl_fastx *r);
 const char *ntl_fastx_names(ntl_fastx *r);

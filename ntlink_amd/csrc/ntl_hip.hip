@@ -396,6 +396,60 @@ extern "C" int ntl_batch_create(ntl_ctx *c, const char *seqs, const uint64_t *of
     return NTL_OK;
 }
 
+/* The same batch from bases that are already packed (ntl_fastx_copy_packed + ntl_fastx_runs: the parser threads pack
+ * while they copy): a quarter of the bytes cross PCIe and the pack / run-table kernels are not needed. */
+extern "C" int ntl_batch_create_packed(ntl_ctx *c, const uint32_t *packed, const uint64_t *off, uint64_t nseq,
+                                       const uint32_t *seq_run_first, const uint32_t *run_start, const uint32_t *run_len,
+                                       uint64_t nruns, ntl_batch **out)
+{
+    if (!c || !out || !packed || !off || !seq_run_first || (nruns && (!run_start || !run_len))) return NTL_EINVAL;
+    *out = nullptr;
+    if (nseq >= ((uint64_t)1 << 31)) return fail(c, NTL_EINVAL, "too many sequences in one batch");
+    if (nruns >= 0xFFFFFFF0ull) return fail(c, NTL_EINVAL, "too many ACGT runs in one batch");
+    if (off[0] != 0) return fail(c, NTL_EINVAL, "offsets[0] must be 0 for a packed batch");
+    std::unique_ptr<ntl_batch> b(new ntl_batch());
+    b->c = c;
+    b->nseq = nseq;
+    b->seq_len.resize(nseq);
+    std::vector<uint64_t> seq_base(nseq + 1);
+    bool multi = false;
+    for (uint64_t i = 0; i < nseq; i++) {
+        if (off[i + 1] < off[i]) return fail(c, NTL_EINVAL, "offsets must be non-decreasing");
+        if (off[i + 1] - off[i] >= 0xFFFFFFF0ull) return fail(c, NTL_EINVAL, "sequence longer than 2^32 bases");
+        if (seq_run_first[i + 1] < seq_run_first[i]) return fail(c, NTL_EINVAL, "seq_run_first must be non-decreasing");
+        multi |= seq_run_first[i + 1] - seq_run_first[i] > 1u;
+        b->seq_len[i] = (uint32_t)(off[i + 1] - off[i]);
+        seq_base[i] = NTL_LEAD_PAD + off[i];
+    }
+    if (seq_run_first[0] != 0 || seq_run_first[nseq] != nruns) return fail(c, NTL_EINVAL, "seq_run_first does not match the run count");
+    const uint64_t total = off[nseq];
+    seq_base[nseq] = NTL_LEAD_PAD + total;
+    b->bases = total;
+    b->total_gpos = NTL_LEAD_PAD + total;
+    b->nruns = nruns;
+    b->any_multi = multi;
+    b->nwords_packed = (NTL_LEAD_PAD + total + NTL_END_PAD + 15) / 16 + 2;
+    (void)hipSetDevice(c->device);
+    int rc;
+    if ((rc = b->packed.alloc(c, b->nwords_packed * 4)) || (rc = b->seq_base.alloc(c, (nseq + 1) * 8)) ||
+        (rc = b->seq_run_first.alloc(c, (nseq + 1) * 4)) || (rc = b->run_start.alloc(c, (nruns + 1) * 4)) ||
+        (rc = b->run_len.alloc(c, (nruns + 1) * 4)))
+        return rc;
+    {
+        ProfSpan span(c, "batch_pack");
+        HIPCHK(c, hipMemcpyAsync(b->packed.p, packed, b->nwords_packed * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(b->seq_base.p, seq_base.data(), (nseq + 1) * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(b->seq_run_first.p, seq_run_first, (nseq + 1) * 4, hipMemcpyHostToDevice, c->stream));
+        if (nruns) {
+            HIPCHK(c, hipMemcpyAsync(b->run_start.p, run_start, nruns * 4, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(b->run_len.p, run_len, nruns * 4, hipMemcpyHostToDevice, c->stream));
+        }
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream)); /* the caller's arrays and seq_base are free again */
+    *out = b.release();
+    return NTL_OK;
+}
+
 extern "C" void ntl_batch_destroy(ntl_batch *b) { delete b; }
 
 extern "C" int ntl_host_alloc(ntl_ctx *c, uint64_t bytes, void **out)

@@ -82,6 +82,7 @@ struct ntl_fastx {
     std::vector<char> m_seqs, m_names;
     std::vector<uint64_t> m_off, m_name_off;
     bool materialized = false;
+    std::vector<std::vector<uint32_t>> pk_seq, pk_start, pk_len; /* ACGT runs of the current batch, per range (ntl_fastx_copy_packed) */
     std::string err;
 };
 
@@ -227,6 +228,94 @@ struct WriteSink {
     void id(const char *p, size_t n) { memcpy(names + n0 + nn, p, n); nn += n; name_off[i + 1] = n0 + nn; }
     void seq(const char *p, size_t n) { memcpy(seqs + b0 + nb, p, n); nb += n; }
     void end_record() { off[i + 1] = b0 + nb; i++; }
+    uint64_t bases() const { return nb; }
+};
+
+/* The second pass with the device's layout as its output: 2 bits per base (A/a 0, C/c 1, G/g 2, T/t 3, anything else 0),
+ * sixteen bases per 32-bit word, base b of the batch at global position NTL_PACK_LEAD + b -- and the table of maximal
+ * ACGT runs per sequence that keeps every other byte out of the k-mers.  Exactly what pack_kernel / run_*_kernel
+ * (pack_kernels.h) derive from the ASCII bytes on the device; done here, a quarter of the bytes cross PCIe.
+ * Eight bases per step: validity and codes with byte-parallel arithmetic, then the eight 2-bit codes are gathered into
+ * sixteen bits.  A thread owns the words that lie wholly inside its range; the first and the last word of a range may be
+ * shared with its neighbours and are OR-ed in atomically (the caller zeroes those words first). */
+#define NTL_PACK_LEAD 16u   /* = NTL_LEAD_PAD of the device code (dev_common.h) */
+#define NTL_PACK_END 4096u  /* = NTL_END_PAD (ntl_hip.hip) */
+
+struct PackSink {
+    uint32_t *packed; uint64_t *off; char *names; uint64_t *name_off;
+    uint64_t b0, n0;
+    std::vector<uint32_t> *run_seq, *run_start, *run_len; /* runs of this range: record (range-local), offset in it, length */
+    uint64_t nb = 0, nn = 0, i = 0;
+    uint64_t acc = 0, widx = 0, first_widx = 0;
+    unsigned fill = 0;
+    bool first_partial = false, in_run = false;
+    uint64_t seq_nb0 = 0, run_nb0 = 0;
+
+    void begin()
+    {
+        const uint64_t g0 = NTL_PACK_LEAD + b0;
+        widx = first_widx = g0 >> 4;
+        fill = 2u * (unsigned)(g0 & 15u);
+        first_partial = fill != 0;
+    }
+    inline void push(uint64_t bits, unsigned nbits)
+    {
+        acc |= bits << fill;
+        fill += nbits;
+        while (fill >= 32) {
+            const uint32_t w = (uint32_t)acc;
+            if (widx == first_widx && first_partial) __atomic_fetch_or(&packed[widx], w, __ATOMIC_RELAXED);
+            else packed[widx] = w;
+            acc >>= 32; fill -= 32; widx++;
+        }
+    }
+    void finish()
+    {
+        if (fill) __atomic_fetch_or(&packed[widx], (uint32_t)acc, __ATOMIC_RELAXED);
+    }
+    inline void close_run(uint64_t at)
+    {
+        if (!in_run) return;
+        run_seq->push_back((uint32_t)i);
+        run_start->push_back((uint32_t)(run_nb0 - seq_nb0));
+        run_len->push_back((uint32_t)(at - run_nb0));
+        in_run = false;
+    }
+    void id(const char *p, size_t n) { memcpy(names + n0 + nn, p, n); nn += n; name_off[i + 1] = n0 + nn; }
+    void seq(const char *p, size_t n)
+    {
+        const uint64_t K1 = 0x0101010101010101ull, K7F = 0x7F7F7F7F7F7F7F7Full, K80 = 0x8080808080808080ull;
+        size_t k = 0;
+        while (k < n) {
+            if (n - k >= 8) {
+                uint64_t x;
+                memcpy(&x, p + k, 8);
+                const uint64_t u = x & 0xDFDFDFDFDFDFDFDFull; /* fold the case */
+                auto zero_bytes = [&](uint64_t z) { return ~(((z & K7F) + K7F) | z | K7F); }; /* 0x80 in every zero byte, exact */
+                const uint64_t ok = zero_bytes(u ^ (0x41 * K1)) | zero_bytes(u ^ (0x43 * K1)) | zero_bytes(u ^ (0x47 * K1)) | zero_bytes(u ^ (0x54 * K1));
+                if (ok == K80) {
+                    uint64_t v = (x >> 1) & (3 * K1);
+                    v ^= (v >> 1) & K1;                                   /* 0 1 3 2 -> 0 1 2 3 */
+                    v = (v | (v >> 6)) & 0x000F000F000F000Full;
+                    v = (v | (v >> 12)) & 0x000000FF000000FFull;
+                    v = (v | (v >> 24)) & 0xFFFFull;
+                    if (!in_run) { in_run = true; run_nb0 = nb + k; }
+                    push(v, 16);
+                    k += 8;
+                    continue;
+                }
+            }
+            const uint32_t c = (uint8_t)p[k], uc = c & 0xDFu;
+            const bool okc = uc == 0x41u || uc == 0x43u || uc == 0x47u || uc == 0x54u;
+            const uint32_t t = (c >> 1) & 3u;
+            push(okc ? ((t ^ (t >> 1)) & 3u) : 0u, 2);
+            if (okc) { if (!in_run) { in_run = true; run_nb0 = nb + k; } }
+            else close_run(nb + k);
+            k++;
+        }
+        nb += n;
+    }
+    void end_record() { close_run(nb); off[i + 1] = b0 + nb; i++; seq_nb0 = nb; }
     uint64_t bases() const { return nb; }
 };
 
@@ -863,6 +952,73 @@ extern "C" int ntl_fastx_copy(const ntl_fastx *r, char *seqs, uint64_t *offsets,
         WriteSink ws{seqs, offsets + rec0[t], names, name_offsets + rec0[t], b0[t], n0[t]};
         parse_range(g.b, g.e, g.stop_bases, g.at_eof, ws, nullptr);
     });
+    return NTL_OK;
+}
+
+/* Words of the packed array of a batch of `bases` bases (lead pad, bases, end pad; what ntl_batch_create_packed uploads). */
+extern "C" uint64_t ntl_packed_words(uint64_t bases)
+{
+    return (NTL_PACK_LEAD + bases + NTL_PACK_END + 15) / 16 + 2;
+}
+
+/* The current batch in the device's layout: packed[ntl_packed_words(bases)], offsets / names as ntl_fastx_copy; *nruns = number
+ * of ACGT runs (ntl_fastx_runs then fills seq_run_first[nseq + 1], run_start[nruns], run_len[nruns]). */
+extern "C" int ntl_fastx_copy_packed(ntl_fastx *r, uint32_t *packed, uint64_t *offsets, char *names, uint64_t *name_offsets, uint64_t *nruns)
+{
+    if (!r || !packed || !offsets || !name_offsets || !nruns) return NTL_EINVAL;
+    uint64_t n, b, nb;
+    ntl_fastx_sizes(r, &n, &b, &nb);
+    if (nb && !names) return NTL_EINVAL;
+    offsets[0] = 0; name_offsets[0] = 0;
+    const size_t T = r->ranges.size();
+    std::vector<uint64_t> rec0(T + 1, 0), b0(T + 1, 0), n0(T + 1, 0);
+    for (size_t t = 0; t < T; t++) {
+        rec0[t + 1] = rec0[t] + r->ranges[t].nrec;
+        b0[t + 1] = b0[t] + r->ranges[t].bases;
+        n0[t + 1] = n0[t] + r->ranges[t].name_bytes;
+    }
+    const uint64_t nwords = ntl_packed_words(b);
+    /* words that are OR-ed into or never written by a range: the lead pad, the first word of every range, everything from the
+       word that holds the last base on */
+    packed[0] = 0;
+    for (size_t t = 0; t <= T; t++) packed[(NTL_PACK_LEAD + b0[t]) >> 4] = 0;
+    for (uint64_t wd = (NTL_PACK_LEAD + b) >> 4; wd < nwords; wd++) packed[wd] = 0;
+    r->pk_seq.assign(T, {}); r->pk_start.assign(T, {}); r->pk_len.assign(T, {});
+    run_threads(T, [&](size_t t) {
+        const Range &g = r->ranges[t];
+        PackSink ps{packed, offsets + rec0[t], names, name_offsets + rec0[t], b0[t], n0[t], &r->pk_seq[t], &r->pk_start[t], &r->pk_len[t]};
+        ps.begin();
+        parse_range(g.b, g.e, g.stop_bases, g.at_eof, ps, nullptr);
+        ps.finish();
+    });
+    uint64_t nr = 0;
+    for (size_t t = 0; t < T; t++) nr += r->pk_seq[t].size();
+    *nruns = nr;
+    return NTL_OK;
+}
+
+extern "C" int ntl_fastx_runs(const ntl_fastx *r, uint32_t *seq_run_first, uint32_t *run_start, uint32_t *run_len)
+{
+    if (!r || !seq_run_first) return NTL_EINVAL;
+    const size_t T = r->ranges.size();
+    if (r->pk_seq.size() != T) return NTL_EINVAL; /* ntl_fastx_copy_packed comes first */
+    uint64_t rec = 0, run = 0;
+    for (size_t t = 0; t < T; t++) {
+        const auto &sq = r->pk_seq[t];
+        size_t j = 0;
+        for (uint64_t i = 0; i < r->ranges[t].nrec; i++) {
+            seq_run_first[rec + i] = (uint32_t)(run + j);
+            while (j < sq.size() && sq[j] == (uint32_t)i) j++;
+        }
+        if (!sq.empty()) {
+            if (!run_start || !run_len) return NTL_EINVAL;
+            memcpy(run_start + run, r->pk_start[t].data(), sq.size() * 4);
+            memcpy(run_len + run, r->pk_len[t].data(), sq.size() * 4);
+        }
+        rec += r->ranges[t].nrec;
+        run += sq.size();
+    }
+    seq_run_first[rec] = (uint32_t)run;
     return NTL_OK;
 }
 

@@ -367,10 +367,10 @@ def _map_batches(dev, ix, batches, drain, stats, t_mark, **map_kw):
                 seq, rs_ = got
                 t_dev = time.perf_counter()
                 rl = rs_.lengths
-                with wdev.batch(rs_.buf, rs_.offsets) as rb:
+                with (wdev.batch_packed(rs_) if rs_.packed is not None else wdev.batch(rs_.buf, rs_.offsets)) as rb:
                     t_up = time.perf_counter()
-                    dev.pinned_release(rs_.buf)  # the bases are on the device: the reader may refill this buffer
-                    rs_.buf = None
+                    dev.pinned_release(rs_.pinned if rs_.packed is not None else rs_.buf)  # on the device: the reader may refill it
+                    rs_.buf = rs_.packed = rs_.pinned = None
                     with wdev.sketch(rb, map_kw["k"], stats["w"]) as rsk:
                         t_sk = time.perf_counter()
                         with wdev.map(ix, rsk, rl, **map_kw) as res:
@@ -449,8 +449,9 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
     plan = seqio.shard_plan(read_paths, comm.rank, comm.world)
     io_stats = {}
     # this rank's share of the read files is opened, inflated and parsed from now on, behind the contig stage
-    batches = Prefetch(seqio.load(plan, max_bases=batch_bases, alloc=dev.pinned_empty, stats=io_stats))
-    ctg = seqio.load_all([target])  # used once: page-locking a buffer for it would cost more than the staged copy
+    packed = os.environ.get("NTL_HOST_PACK", "1") != "0"  # the parser threads pack to 2 bits per base: a quarter of the PCIe bytes
+    batches = Prefetch(seqio.load(plan, max_bases=batch_bases, alloc=dev.pinned_empty, stats=io_stats, packed=packed))
+    ctg = seqio.load_all([target], packed=packed)  # used once: page-locking a buffer for it would cost more than the staged copy
     ctg_len = ctg.lengths
     t_ctg_parsed = time.perf_counter()
     part = "" if root else f".part{comm.rank}"
@@ -468,8 +469,8 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
     tsv_drain = Drain(emit_contig_tsv) if root and write_contig_tsv else None
     stats = dict(read_bases=0, reads=0, read_minimizers=0, index_hits=0, t_contigs=0.0, t_ingest=0.0, t_device=0.0, t_handover=0.0, w=w, t_device_parts={})
     try:
-        with dev.batch(ctg.buf, ctg.offsets) as cb:
-            ctg.buf = None
+        with (dev.batch_packed(ctg) if ctg.packed is not None else dev.batch(ctg.buf, ctg.offsets)) as cb:
+            ctg.buf = ctg.packed = ctg.pinned = None
             t_ctg_up = time.perf_counter()
             with dev.sketch(cb, k, w) as csk:
                 t_ctg_sk = time.perf_counter()

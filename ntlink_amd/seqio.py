@@ -113,10 +113,14 @@ class Names:
 
 
 class SeqSet:
-    """Names + one contiguous uint8 buffer + offsets: the form ntl_batch_create takes."""
+    """Names + one contiguous uint8 buffer + offsets: the form ntl_batch_create takes.  A set read with packed=True has
+    buf = None and carries the device's layout instead (ntl_batch_create_packed): `packed` (uint32 words, 2 bits per base,
+    in the buffer `pinned` that came from alloc) and the ACGT-run table seq_run_first / run_start / run_len."""
 
-    def __init__(self, names, buf, offsets):
+    def __init__(self, names, buf, offsets, packed=None, runs=None, pinned=None):
         self.names, self.buf, self.offsets = Names.of(names), buf, offsets
+        self.packed, self.pinned = packed, pinned
+        self.seq_run_first, self.run_start, self.run_len = runs if runs is not None else (None, None, None)
 
     def __len__(self):
         return len(self.names)
@@ -195,7 +199,7 @@ def shard_plan(paths, rank, world):
     return plan
 
 
-def load(paths, max_bases=None, alloc=None, ahead=None, stats=None):
+def load(paths, max_bases=None, alloc=None, ahead=None, stats=None, packed=False):
     """Native reader (ntl_fastx_*, csrc/ntl_io.cpp).  Whole input as one SeqSet, or, with max_bases,
     SeqSets of about that many bases; several files are concatenated in the order given and a batch
     never spans two files.  alloc(nbytes) -> uint8 array supplies the sequence buffers (the pair
@@ -203,7 +207,9 @@ def load(paths, max_bases=None, alloc=None, ahead=None, stats=None):
     the next `ahead` files (default min(8, cores/4), at most 2 GiB of compressed input) are opened by
     background threads while the current one is consumed: many .fq.gz files decode in parallel.  An entry of `paths` may
     be (path, lo, hi): the records of a plain file that start in that byte range (shard_plan).  stats["parsed_bytes"]
-    accumulates the input bytes consumed (file bytes of plain files and ranges, compressed bytes of gzip files)."""
+    accumulates the input bytes consumed (file bytes of plain files and ranges, compressed bytes of gzip files).
+    packed=True: the parser threads write 2-bit bases and the ACGT-run table instead of ASCII (SeqSet.packed; a quarter of
+    the bytes for the device to fetch); a batch never mixes the two forms."""
     import collections
     import ctypes as C
     from concurrent.futures import ThreadPoolExecutor
@@ -251,15 +257,30 @@ def load(paths, max_bases=None, alloc=None, ahead=None, stats=None):
                     t_1 = time.perf_counter()
                     nb, nn = C.c_uint64(), C.c_uint64()
                     L.ntl_fastx_sizes(h, None, C.byref(nb), C.byref(nn))
-                    buf, names = (alloc or _np_empty)(nb.value), np.empty(nn.value, np.uint8)
+                    names = np.empty(nn.value, np.uint8)
                     off, noff = np.empty(n + 1, np.uint64), np.empty(n + 1, np.uint64)
-                    t_2 = time.perf_counter()
-                    if L.ntl_fastx_copy(h, buf.ctypes.data, off.ctypes.data, names.ctypes.data, noff.ctypes.data) != 0:
-                        raise OSError(f"{path}: gather failed")
+                    if packed:
+                        nw = int(L.ntl_packed_words(nb.value))
+                        pinned = (alloc or _np_empty)(nw * 4)
+                        words = pinned.view(np.uint32)
+                        t_2 = time.perf_counter()
+                        nr = C.c_uint64()
+                        if L.ntl_fastx_copy_packed(h, words.ctypes.data, off.ctypes.data, names.ctypes.data, noff.ctypes.data, C.byref(nr)) != 0:
+                            raise OSError(f"{path}: gather failed")
+                        srf, rst, rln = np.empty(n + 1, np.uint32), np.empty(nr.value, np.uint32), np.empty(nr.value, np.uint32)
+                        if L.ntl_fastx_runs(h, srf.ctypes.data, rst.ctypes.data, rln.ctypes.data) != 0:
+                            raise OSError(f"{path}: run table failed")
+                        buf = None
+                    else:
+                        buf = (alloc or _np_empty)(nb.value)
+                        t_2 = time.perf_counter()
+                        if L.ntl_fastx_copy(h, buf.ctypes.data, off.ctypes.data, names.ctypes.data, noff.ctypes.data) != 0:
+                            raise OSError(f"{path}: gather failed")
                     if trace:
                         print(f"ntl_fastx batch: read+count {t_1 - t_0:.4f}s alloc {t_2 - t_1:.4f}s parse {time.perf_counter() - t_2:.4f}s "
                               f"bases {nb.value} t={time.perf_counter():.4f}", file=sys.stderr)
-                    ss = SeqSet(Names(names, noff), buf, off)
+                    ss = SeqSet(Names(names, noff), buf, off) if not packed else \
+                        SeqSet(Names(names, noff), None, off, packed=words, runs=(srf, rst, rln), pinned=pinned)
                     if max_bases is None:
                         whole.append(ss)
                         break
@@ -280,6 +301,8 @@ def load(paths, max_bases=None, alloc=None, ahead=None, stats=None):
 def concat(sets):
     if len(sets) == 1:
         return sets[0]
+    if any(s.packed is not None for s in sets):
+        raise ValueError("packed sequence sets cannot be concatenated: read the files one at a time")
     if not sets:
         return SeqSet(Names(np.zeros(0, np.uint8), np.zeros(1, np.uint64)), np.zeros(0, np.uint8), np.zeros(1, np.uint64))
     bufs = [s.buf for s in sets]
@@ -292,5 +315,5 @@ def concat(sets):
     return SeqSet(Names(np.concatenate([s.names.blob for s in sets]), np.concatenate(noffs)), np.concatenate(bufs), np.concatenate(offs))
 
 
-def load_all(paths, alloc=None):
-    return next(load(paths, alloc=alloc))
+def load_all(paths, alloc=None, packed=False):
+    return next(load(paths, alloc=alloc, packed=packed))

@@ -440,3 +440,55 @@ def test_plain_files_parse_from_a_mapping_or_staged_preads(tmp_path, monkeypatch
         assert a.names == x.names and np.array_equal(a.offsets, x.offsets) and np.array_equal(a.buf, x.buf) and len(a) == 300
     want = list(seqio.read_fastx(str(p)))
     assert [n for n, _ in want] == b.names.tolist() and b"".join(s for _, s in want) == b.buf.tobytes()
+
+
+def _expected_pack(buf, off):
+    """numpy restatement of pack_kernel / run_*_kernel (csrc/pack_kernels.h): 2-bit codes at global position 16 + b, ACGT runs"""
+    total = int(off[-1])
+    nwords = (16 + total + 4096 + 15) // 16 + 2
+    code = np.zeros(256, np.uint64); ok = np.zeros(256, bool)
+    for ch, v in zip(b"ACGTacgt", (0, 1, 2, 3, 0, 1, 2, 3)):
+        code[ch] = v; ok[ch] = True
+    vals = np.zeros(nwords * 16, np.uint64)
+    vals[16:16 + total] = code[buf[:total]]
+    words = (vals.reshape(-1, 16) << (2 * np.arange(16, dtype=np.uint64))).sum(axis=1).astype(np.uint32)
+    valid = ok[buf[:total]]
+    srf, rst, rln = [0], [], []
+    for i in range(len(off) - 1):
+        v = valid[int(off[i]):int(off[i + 1])]
+        d = np.diff(np.concatenate(([0], v.astype(np.int8), [0])))
+        st, en = np.flatnonzero(d == 1), np.flatnonzero(d == -1)
+        rst += st.tolist(); rln += (en - st).tolist()
+        srf.append(len(rst))
+    return words, np.array(srf, np.uint32), np.array(rst, np.uint32), np.array(rln, np.uint32)
+
+
+@pytest.mark.parametrize("threads,chunk", [("1", "1000000"), ("7", "900")])
+def test_parser_packs_bases_and_runs_like_the_device(tmp_path, monkeypatch, threads, chunk):
+    """seqio.load(packed=True): 2-bit words and ACGT-run table made by the parser threads == what the device-side pack kernels
+    derive from the ASCII bytes (range cuts at any 2-bit offset, N / IUPAC / lower case, wrapped lines, empty records)."""
+    rng = np.random.default_rng(int(threads))
+    p = tmp_path / "x.fa"
+    with open(p, "w") as fh:
+        for i in range(400):
+            n = int(rng.integers(0, 700)) if i % 9 else int(rng.integers(0, 4))
+            s = "".join(rng.choice(list("ACGTACGTACGTacgtNnRYK-"), n)) if i % 3 else "".join(rng.choice(list("ACGT"), n))
+            if i % 11 == 0:
+                s = "N" * n
+            fh.write(f">s{i}\n" + ("\n".join(s[j:j + 61] for j in range(0, n, 61)) if i % 2 else s) + "\n")
+    monkeypatch.setenv("NTL_IO_THREADS", threads)
+    monkeypatch.setenv("NTL_IO_MIN_CHUNK", chunk)
+    plain = seqio.load_all([str(p)])
+    for max_bases in (None, 5000):
+        sets = list(seqio.load([str(p)], max_bases=max_bases, packed=True))
+        at = 0
+        for ss in sets:
+            n = len(ss)
+            o0 = int(plain.offsets[at])
+            sub_off = plain.offsets[at:at + n + 1] - np.uint64(o0)
+            assert np.array_equal(ss.offsets, sub_off) and ss.names.tolist() == plain.names.tolist()[at:at + n] and ss.buf is None
+            words, srf, rst, rln = _expected_pack(plain.buf[o0:int(plain.offsets[at + n])], sub_off)
+            assert np.array_equal(ss.packed, words)
+            assert np.array_equal(ss.seq_run_first, srf) and np.array_equal(ss.run_start, rst) and np.array_equal(ss.run_len, rln)
+            at += n
+        assert at == len(plain) == 400

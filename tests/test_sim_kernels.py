@@ -254,3 +254,22 @@ def test_sim_map_overflow_reads_take_the_global_scratch_kernel(dev):
     maps = got["maps"]
     assert int(maps["n_hits"][maps["read"] == 0].sum()) > 256
     assert int((maps["read"] == 1).sum()) > 64 and int(maps["n_hits"][maps["read"] == 1].sum()) <= 256
+
+
+def test_sim_packed_batches_sketch_like_ascii_batches(dev, tmp_path):
+    """ntl_batch_create_packed (bases packed and ACGT runs found by the parser threads) == ntl_batch_create on the same
+    records: sketches of both equal the oracle's (N runs, lower case, IUPAC, empty and tiny records)."""
+    import oracle
+    from ntlink_amd import seqio
+    seqs = pc.edge_sequences() + [b"ACGTNNNNNACGTTGCAATGC" * 40, b"acgtacgtac" * 90 + b"R" + b"GATTACA" * 70]
+    p = tmp_path / "e.fa"
+    with open(p, "wb") as fh:
+        for i, s in enumerate(seqs):
+            fh.write(b">q%d\n" % i + s + b"\n")
+    ss = seqio.load_all([str(p)], packed=True)
+    assert len(ss) == len(seqs)
+    for k, w in ((32, 100), (12, 8)):
+        with dev.batch_packed(ss) as b, dev.sketch(b, k, w) as sk:
+            off, h, q, s = sk.download()
+        ooff, oh, op, os_ = oracle.sketch_batch(b"".join(seqs), pc.offsets_of(seqs), k, w)
+        assert np.array_equal(off, ooff) and np.array_equal(h, oh) and np.array_equal(q, op) and np.array_equal(s, os_)
