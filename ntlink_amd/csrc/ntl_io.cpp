@@ -152,23 +152,32 @@ struct WorkPool {
     }
 };
 
-static WorkPool *g_pool = nullptr;
+/* Two pools: the parsers (FASTA/FASTQ reader, TSV parser) and the text emitters each queue their regions on their own, so a
+ * batch of long formatting jobs never sits in front of the reader's short passes (the caller of a region helps only its own pool). */
+static WorkPool *g_pool[2] = {nullptr, nullptr};
 static std::mutex g_pool_mutex;
+static thread_local int t_pool_kind = 0; /* 0 parse, 1 emit */
+struct PoolKind {
+    int saved;
+    explicit PoolKind(int k) : saved(t_pool_kind) { t_pool_kind = k; }
+    ~PoolKind() { t_pool_kind = saved; }
+};
 
 static WorkPool *work_pool()
 {
     std::lock_guard<std::mutex> lk(g_pool_mutex);
-    if (!g_pool) {
+    WorkPool *&P = g_pool[t_pool_kind];
+    if (!P) {
         static bool atfork_set = false;
         if (!atfork_set) {
             atfork_set = true;
-            pthread_atfork(nullptr, nullptr, [] { g_pool = nullptr; new (&g_pool_mutex) std::mutex(); }); /* threads do not survive fork() */
+            pthread_atfork(nullptr, nullptr, [] { g_pool[0] = g_pool[1] = nullptr; new (&g_pool_mutex) std::mutex(); }); /* threads do not survive fork() */
         }
         unsigned hc = std::thread::hardware_concurrency();
         if (hc == 0) hc = 4;
-        g_pool = new WorkPool(std::min(hc, std::max(2 * io_threads(), 8u))); /* never destroyed: workers idle on the condition variable */
+        P = new WorkPool(std::min(hc, std::max(io_threads(), 4u))); /* never destroyed: workers idle on the condition variable */
     }
-    return g_pool;
+    return P;
 }
 
 template <typename F>
@@ -931,6 +940,17 @@ extern "C" int ntl_fastx_next(ntl_fastx *r, uint64_t max_bases, uint64_t *nseq)
     }
 }
 
+/* The page-table entries of a parsed byte range of the file mapping are given back right away, by the thread that parsed it
+ * (whole pages inside the range; the data stays in the page cache).  Left to munmap() at the end, a 4-GB file costs one
+ * ~0.1 s tear-down under the address-space write lock, during which every page fault of the next file's parser threads waits. */
+static void drop_mapped(const ntl_fastx *r, const char *b, const char *e)
+{
+    if (!r->mm || b >= e) return;
+    static const uintptr_t page = (uintptr_t)sysconf(_SC_PAGESIZE);
+    const uintptr_t lo = ((uintptr_t)b + page - 1) & ~(page - 1), hi = (uintptr_t)e & ~(page - 1);
+    if (lo < hi && (const char *)lo >= r->mm && (const char *)hi <= r->mm + r->mm_len) (void)madvise((void *)lo, hi - lo, MADV_DONTNEED);
+}
+
 /* Puts the current batch into caller-allocated arrays (sizes from ntl_fastx_sizes; offsets and
  * name_offsets have nseq + 1 entries): every range is parsed straight into place by its own thread. */
 extern "C" int ntl_fastx_copy(const ntl_fastx *r, char *seqs, uint64_t *offsets, char *names, uint64_t *name_offsets)
@@ -951,6 +971,7 @@ extern "C" int ntl_fastx_copy(const ntl_fastx *r, char *seqs, uint64_t *offsets,
         const Range &g = r->ranges[t];
         WriteSink ws{seqs, offsets + rec0[t], names, name_offsets + rec0[t], b0[t], n0[t]};
         parse_range(g.b, g.e, g.stop_bases, g.at_eof, ws, nullptr);
+        drop_mapped(r, g.b, g.e);
     });
     return NTL_OK;
 }
@@ -990,6 +1011,7 @@ extern "C" int ntl_fastx_copy_packed(ntl_fastx *r, uint32_t *packed, uint64_t *o
         ps.begin();
         parse_range(g.b, g.e, g.stop_bases, g.at_eof, ps, nullptr);
         ps.finish();
+        drop_mapped(r, g.b, g.e);
     });
     uint64_t nr = 0;
     for (size_t t = 0; t < T; t++) nr += r->pk_seq[t].size();
@@ -1112,6 +1134,7 @@ static int pwrite_all(int fd, const std::string &s, off_t at)
 template <typename F>
 static int format_parallel(int fd, uint64_t n, uint64_t weight_hint, F fmt)
 {
+    PoolKind emit_pool(1);
     unsigned nthr = std::thread::hardware_concurrency();
     if (nthr == 0) nthr = 1;
     if (nthr > 32) nthr = 32;

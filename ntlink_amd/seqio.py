@@ -286,7 +286,7 @@ def load(paths, max_bases=None, alloc=None, ahead=None, stats=None, packed=False
                         break
                     yield ss
             finally:
-                L.ntl_fastx_close(h)
+                pool.submit(L.ntl_fastx_close, h)  # unmapping a multi-GB file takes ~0.1 s: not on the reader's path
     finally:
         for _path, fut, _size in pending:  # abandoned early: close what the background threads opened
             try:
