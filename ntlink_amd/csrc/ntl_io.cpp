@@ -940,17 +940,6 @@ extern "C" int ntl_fastx_next(ntl_fastx *r, uint64_t max_bases, uint64_t *nseq)
     }
 }
 
-/* The page-table entries of a parsed byte range of the file mapping are given back right away, by the thread that parsed it
- * (whole pages inside the range; the data stays in the page cache).  Left to munmap() at the end, a 4-GB file costs one
- * ~0.1 s tear-down under the address-space write lock, during which every page fault of the next file's parser threads waits. */
-static void drop_mapped(const ntl_fastx *r, const char *b, const char *e)
-{
-    if (!r->mm || b >= e) return;
-    static const uintptr_t page = (uintptr_t)sysconf(_SC_PAGESIZE);
-    const uintptr_t lo = ((uintptr_t)b + page - 1) & ~(page - 1), hi = (uintptr_t)e & ~(page - 1);
-    if (lo < hi && (const char *)lo >= r->mm && (const char *)hi <= r->mm + r->mm_len) (void)madvise((void *)lo, hi - lo, MADV_DONTNEED);
-}
-
 /* Puts the current batch into caller-allocated arrays (sizes from ntl_fastx_sizes; offsets and
  * name_offsets have nseq + 1 entries): every range is parsed straight into place by its own thread. */
 extern "C" int ntl_fastx_copy(const ntl_fastx *r, char *seqs, uint64_t *offsets, char *names, uint64_t *name_offsets)
@@ -971,7 +960,6 @@ extern "C" int ntl_fastx_copy(const ntl_fastx *r, char *seqs, uint64_t *offsets,
         const Range &g = r->ranges[t];
         WriteSink ws{seqs, offsets + rec0[t], names, name_offsets + rec0[t], b0[t], n0[t]};
         parse_range(g.b, g.e, g.stop_bases, g.at_eof, ws, nullptr);
-        drop_mapped(r, g.b, g.e);
     });
     return NTL_OK;
 }
@@ -1011,7 +999,6 @@ extern "C" int ntl_fastx_copy_packed(ntl_fastx *r, uint32_t *packed, uint64_t *o
         ps.begin();
         parse_range(g.b, g.e, g.stop_bases, g.at_eof, ps, nullptr);
         ps.finish();
-        drop_mapped(r, g.b, g.e);
     });
     uint64_t nr = 0;
     for (size_t t = 0; t < T; t++) nr += r->pk_seq[t].size();
