@@ -47,6 +47,7 @@ struct ntl_ctx {
     std::vector<hipEvent_t> ev_free;
     void *g4 = nullptr;                 /* device copy of the four-base init table */
     void *g8 = nullptr;                 /* device copy of the eight-base init table (1 MB) */
+    std::map<int, void *> g8k;          /* k -> the two k-dependent forms of g8 the fast window pass reads (2 MB each, sketch2_kernels.h) */
     std::multimap<size_t, void *> pool; /* cached device blocks by size */
     size_t pool_bytes = 0;
     size_t pool_cap = (size_t)32 << 30; /* upper bound of pool_bytes */
@@ -220,6 +221,7 @@ extern "C" void ntl_ctx_destroy(ntl_ctx *c)
     for (auto &kv : c->pool) (void)hipFree(kv.second);
     (void)hipFree(c->g4);
     (void)hipFree(c->g8);
+    for (auto &kv : c->g8k) (void)hipFree(kv.second);
     if (c->host_tmp) (void)hipHostFree(c->host_tmp);
     for (auto &kv : c->profs)
         for (auto &sp : kv.second.spans) { (void)hipEventDestroy(sp.first); (void)hipEventDestroy(sp.second); }
@@ -795,6 +797,23 @@ extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_
             B.max_word = b->nwords_packed - 1;
             B.q16 = k / 16; B.r16 = k % 16;
             B.rev_a = (uint32_t)(k - 1) % 33u; B.rev_b = (uint32_t)(k - 1) % 31u;
+            {
+                auto it = c->g8k.find(k);
+                if (it == c->g8k.end()) { /* built once per k and context, on the stream in front of its first user */
+                    if (c->g8k.size() >= 8) { /* a caller that sweeps k: start over (the stream orders the free behind earlier users) */
+                        HIPCHK(c, hipStreamSynchronize(c->stream));
+                        for (auto &kv : c->g8k) (void)hipFree(kv.second);
+                        c->g8k.clear();
+                    }
+                    void *t = nullptr;
+                    if (hipMalloc(&t, (size_t)2 * 65536 * 16) != hipSuccess) return fail(c, NTL_ENOMEM, "hipMalloc failed");
+                    hipLaunchKernelGGL(g8k_build_kernel, dim3(256), dim3(256), 0, c->stream, (const uint64_t (*)[2])c->g8, (uint64_t (*)[2])t,
+                                       B.rev_a, B.rev_b);
+                    HIPCHK(c, hipGetLastError());
+                    it = c->g8k.emplace(k, t).first;
+                }
+                B.g8k = (const uint64_t (*)[2])it->second;
+            }
             B.force_redo = 0;
             B.dbg = 0;
             if (const char *e = getenv("NTL_SKETCH_ABLATE")) B.dbg = atoi(e); /* tools/sketch_bench.py only: results are wrong */

@@ -52,6 +52,7 @@ struct Sketch2Args {
     uint32_t *redo_list;   /* strips for the exact pass */
     uint32_t *redo_count;
     uint64_t max_word;     /* last word of `packed` that may be read */
+    const uint64_t (*g8k)[2]; /* k-dependent eight-base tables (g8k_build_kernel): [w] first half of a chunk, [65536 + w] second half */
     int q16, r16;          /* k = 16 * q16 + r16 */
     uint32_t rev_a, rev_b; /* (k - 1) % 33, (k - 1) % 31: the rotation that turns the Horner form of the reverse strand into rev */
     int force_redo;        /* tests: flag every strip */
@@ -66,29 +67,51 @@ __device__ __forceinline__ uint32_t sk2_bases16(const uint32_t *__restrict__ pac
     return ntl_alignbit(packed[wi + 1], packed[wi], 2u * a);
 }
 
-/* partial hashes of one 16-base chunk: Horner forms over its 16 bases {F, U} and over its first r bases {PF, PU} */
-__device__ __forceinline__ void sk2_chunk(uint32_t so, int r, const uint64_t (*__restrict__ g8)[2], const uint64_t (*g4)[2],
-                                          const uint64_t (*seed_tab)[2], uint64_t &F, uint64_t &U, uint64_t &PF, uint64_t &PU)
+/* The eight-base table g8 (k-independent: {XOR_j srol^(7-j)(seed[b_j]), XOR_j sror^(7-j)(seed[3-b_j])}) in the two forms a
+ * 16-base chunk needs, so that a chunk's partial hash is two loads and two XORs without any rotation:
+ *   T0[w] = {srol^8(f), R(sror^8(u))}   the first eight bases of a chunk       (entry w)
+ *   T1[w] = {f,         R(u)}           its second eight bases                 (entry 65536 + w)
+ * R = srol^(k-1) on the reverse strand: the rotation that turns the Horner form into rev commutes with every other
+ * rotation and XOR, so it is applied to the table once per k instead of to every lane's result. */
+__global__ __launch_bounds__(256) void g8k_build_kernel(const uint64_t (*__restrict__ g8)[2], uint64_t (*__restrict__ g8k)[2],
+                                                        uint32_t rev_a, uint32_t rev_b)
+{
+    const uint32_t w = blockIdx.x * 256 + threadIdx.x;
+    if (w >= 65536u) return;
+    const uint64_t f = g8[w][0], u = g8[w][1];
+    g8k[w][0] = srot_h(f, 8, 8);
+    g8k[w][1] = srot_u(srot_h(u, 25, 23), rev_a, rev_b);
+    g8k[65536u + w][0] = f;
+    g8k[65536u + w][1] = srot_u(u, rev_a, rev_b);
+}
+
+/* partial hashes of one 16-base chunk: Horner forms over its 16 bases {F, R(U)} and over its first r bases {PF, R(PU)} */
+__device__ __forceinline__ void sk2_chunk(uint32_t so, int r, const Sketch2Args &B, uint64_t &F, uint64_t &U, uint64_t &PF, uint64_t &PU)
 {
     const uint32_t w0 = so & 0xFFFFu, w1 = so >> 16;
-    const uint64_t e0f = g8[w0][0], e0u = g8[w0][1], e1f = g8[w1][0], e1u = g8[w1][1];
-    F = srot_h(e0f, 8, 8) ^ e1f;
-    U = srot_h(e0u, 25, 23) ^ e1u;
-    uint64_t f = 0, u = 0;
-    int j = 0;
-    if (r >= 8) { f = e0f; u = e0u; j = 8; }
-    if (r - j >= 4) {
-        const uint32_t byte = (so >> (2 * j)) & 255u;
-        f = srot_h(f, 4, 4) ^ g4[byte][0];
-        u = srot_h(u, 29, 27) ^ g4[byte][1];
-        j += 4;
+    const uint64_t a0 = B.g8k[w0][0], a1 = B.g8k[w0][1], b0 = B.g8k[65536u + w1][0], b1 = B.g8k[65536u + w1][1];
+    F = a0 ^ b0;
+    U = a1 ^ b1;
+    PF = 0; PU = 0;
+    if (r == 8) { PF = B.g8k[65536u + w0][0]; PU = B.g8k[65536u + w0][1]; }
+    else if (r) { /* k % 16 not in {0, 8}: four-base and single-base steps on the plain tables, then R */
+        const SketchArgs &A = B.A;
+        uint64_t f = 0, u = 0;
+        int j = 0;
+        if (r >= 8) { f = A.g8[w0][0]; u = A.g8[w0][1]; j = 8; }
+        if (r - j >= 4) {
+            const uint32_t byte = (so >> (2 * j)) & 255u;
+            f = srot_h(f, 4, 4) ^ A.g4[byte][0];
+            u = srot_h(u, 29, 27) ^ A.g4[byte][1];
+            j += 4;
+        }
+        for (; j < r; j++) {
+            const uint32_t c = (so >> (2 * j)) & 3u;
+            f = srol1(f) ^ A.seed_tab[c][0];
+            u = sror1(u) ^ A.seed_tab[c][1];
+        }
+        PF = f; PU = srot_u(u, B.rev_a, B.rev_b);
     }
-    for (; j < r; j++) {
-        const uint32_t c = (so >> (2 * j)) & 3u;
-        f = srol1(f) ^ seed_tab[c][0];
-        u = sror1(u) ^ seed_tab[c][1];
-    }
-    PF = f; PU = u;
 }
 
 template <int NT, int R0>
@@ -113,7 +136,8 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
     __shared__ uint32_t s_t0[NT + PAD], s_t1[NT + PAD]; /* range-minimum levels */
     __shared__ uint16_t s_jobs[SK2_JOBCAP];
     uint64_t (*const s_xy)[2] = (uint64_t (*)[2])s_c;
-    static_assert(sizeof(uint32_t) * C * ST >= sizeof(uint64_t) * 4 * NX, "the exchange area must fit the element array");
+    uint32_t *const s_so = (uint32_t *)&s_xy[2 * NX][0]; /* [NX + 1] the chunks' base words, behind the partial hashes */
+    static_assert(sizeof(uint32_t) * C * ST >= sizeof(uint64_t) * 4 * NX + sizeof(uint32_t) * (NX + 1), "the exchange area must fit the element array");
 
     const SketchArgs &A = B.A;
     const int L = threadIdx.x;
@@ -141,8 +165,9 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
     if (feeds && !SK2_DBG(B, 8)) {
         so = sk2_bases16(A.T.packed, gp, B.max_word);
         uint64_t F, U, PF, PU;
-        sk2_chunk(so, B.r16, A.g8, A.g4, A.seed_tab, F, U, PF, PU);
+        sk2_chunk(so, B.r16, B, F, U, PF, PU);
         s_xy[L][0] = F; s_xy[L][1] = U;
+        s_so[L] = so;
         if (B.r16) { s_xy[NX + L][0] = PF; s_xy[NX + L][1] = PU; }
     }
     if (L <= B.q16 && !SK2_DBG(B, 8)) { /* chunks NT .. NT+q16 feed the last lanes */
@@ -150,8 +175,9 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
         if (ev - 16 * (int64_t)(B.q16 + 1) < (int64_t)I.M) {
             const uint32_t sv = sk2_bases16(A.T.packed, gp + (uint64_t)NT * C, B.max_word);
             uint64_t F, U, PF, PU;
-            sk2_chunk(sv, B.r16, A.g8, A.g4, A.seed_tab, F, U, PF, PU);
+            sk2_chunk(sv, B.r16, B, F, U, PF, PU);
             s_xy[NT + L][0] = F; s_xy[NT + L][1] = U;
+            s_so[NT + L] = sv;
             if (B.r16) { s_xy[NX + NT + L][0] = PF; s_xy[NX + NT + L][1] = PU; }
         }
     }
@@ -162,7 +188,12 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
 #pragma unroll
     for (int t = 0; t < C; t++) c[t] = SK2_INF;
     uint64_t fwd = 0, rev = 0;
+    uint32_t si = 0; /* the sixteen bases behind the lane's first k-mer: the chunks q16 (and q16 + 1) further on */
     if (live) {
+        {
+            const uint32_t lo = s_so[L + B.q16];
+            si = B.r16 ? ntl_alignbit(s_so[L + B.q16 + 1], lo, 2u * (uint32_t)B.r16) : lo;
+        }
         uint64_t f = 0, u = 0;
         for (int i = 0; i < B.q16; i++) {
             if (i) { f = srot_h(f, 16, 16); u = srot_h(u, 17, 15); } /* srol^16, sror^16 */
@@ -176,12 +207,11 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
             u ^= s_xy[NX + L + B.q16][1];
         }
         fwd = f;
-        rev = srot_u(u, B.rev_a, B.rev_b);
+        rev = u; /* the tables carry the reverse strand's final rotation */
     }
     __syncthreads(); /* the partial hashes have been read: s_c may take the elements */
     if (live) {
         c[0] = (uint32_t)((fwd + rev) >> 32);
-        const uint32_t si = sk2_bases16(A.T.packed, gp + (uint64_t)k, B.max_word);
         /* table index of step t: in<<2 | out, two bits each at base t of si / so -> nibbles of two words */
         const uint32_t zev = (so & 0x33333333u) | ((si & 0x33333333u) << 2);        /* even bases: nibble i <-> base 2i */
         const uint32_t zod = ((so >> 2) & 0x33333333u) | (si & 0xCCCCCCCCu);         /* odd bases */
