@@ -687,7 +687,10 @@ template <int NT, int R0>
 static void launch_fast_r0(ntl_ctx *c, const Sketch2Args &B, unsigned strips)
 {
     if (B.A.G.r0 == R0) {
-        hipLaunchKernelGGL((sketch_fast_kernel<NT, R0>), dim3((strips + 7u) & ~7u), dim3(NT), 0, c->stream, B);
+        const dim3 grid((strips + 7u) & ~7u);
+        /* the 20-KB variant holds 128 searched windows per strip: about NWO / (w + 1) are expected (38 at w = 100) */
+        if (B.A.G.a + 2 <= 16 && B.A.G.w >= 64) hipLaunchKernelGGL((sketch_fast_kernel<NT, R0, false>), grid, dim3(NT), 0, c->stream, B);
+        else hipLaunchKernelGGL((sketch_fast_kernel<NT, R0, true>), grid, dim3(NT), 0, c->stream, B);
         return;
     }
     if constexpr (R0 + 1 < 16) launch_fast_r0<NT, R0 + 1>(c, B, strips);

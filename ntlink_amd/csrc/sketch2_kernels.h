@@ -114,7 +114,7 @@ __device__ __forceinline__ void sk2_chunk(uint32_t so, int r, const Sketch2Args 
     }
 }
 
-template <int NT, int R0>
+template <int NT, int R0, bool BIG>
 __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
 {
     constexpr int C = 16;
@@ -123,8 +123,12 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
                                                    of one lane are one ds_read2st64 / ds_write2st64 (the rare search phase
                                                    pays a 4-way conflict for it) */
     constexpr int NX = NT + SK2_QMAX + 1;
-    constexpr int PAD = SK2_PAD;                /* INF entries behind the block minima: a + 2 <= PAD (ntl_sketch_run checks) */
-    /* 23 KB in all: seven workgroups (28 wavefronts) per CU.  s_c doubles as the exchange area of phase 1:
+    /* BIG = false (a + 2 <= 16, i.e. w <= 255: the windows ntLink runs with): one range-minimum level, a short job list in the
+       bytes of the rolling table (dead after phase 1), 16 INF entries -> 20.4 KB: EIGHT workgroups (32 wavefronts) per CU.
+       BIG = true (w <= 1135): two levels, 72 INF entries, 512 jobs -> 23.2 KB, seven workgroups. */
+    constexpr int PAD = BIG ? SK2_PAD : 16;     /* INF entries behind the block minima: a + 2 <= PAD (ntl_sketch_run checks) */
+    constexpr int JOBCAP = BIG ? SK2_JOBCAP : 128;
+    /* s_c doubles as the exchange area of phase 1:
        {F16, U16} of chunk L at s_xy[L], {PF, PU} (first k%16 bases) at s_xy[NX + L]; a barrier separates the last read of
        the partial hashes from the first staged element */
     __shared__ uint32_t s_c[C * ST];
@@ -133,8 +137,10 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
     __shared__ uint32_t s_bits[NBW];
     __shared__ uint32_t s_njobs, s_flag;
     __shared__ uint64_t s_roll[16][2];
-    __shared__ uint32_t s_t0[NT + PAD], s_t1[NT + PAD]; /* range-minimum levels */
-    __shared__ uint16_t s_jobs[SK2_JOBCAP];
+    __shared__ uint32_t s_t0[NT + PAD];         /* range-minimum levels */
+    __shared__ uint32_t s_t1[BIG ? NT + PAD : 1];
+    __shared__ uint16_t s_jobs_big[BIG ? SK2_JOBCAP : 1];
+    uint16_t *const s_jobs = BIG ? s_jobs_big : (uint16_t *)&s_roll[0][0]; /* 256 B = 128 jobs: written two barriers after the last roll */
     uint64_t (*const s_xy)[2] = (uint64_t (*)[2])s_c;
     uint32_t *const s_so = (uint32_t *)&s_xy[2 * NX][0]; /* [NX + 1] the chunks' base words, behind the partial hashes */
     static_assert(sizeof(uint32_t) * C * ST >= sizeof(uint64_t) * 4 * NX + sizeof(uint32_t) * (NX + 1), "the exchange area must fit the element array");
@@ -341,7 +347,7 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
                 const uint32_t pos = (uint32_t)(L * C + j + G.w - 1);
                 atomicOr(&s_bits[pos >> 5], 1u << (pos & 31u));
             } else {
-                if (at < SK2_JOBCAP) s_jobs[at] = (uint16_t)(L * C + j);
+                if (at < (uint32_t)JOBCAP) s_jobs[at] = (uint16_t)(L * C + j);
                 at++;
             }
         }
@@ -355,7 +361,7 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
        the four lanes reading that block's elements, the same way. */
     {
         uint32_t njobs = SK2_DBG(B, 1) ? 0u : s_njobs;
-        if (njobs > SK2_JOBCAP) { njobs = SK2_JOBCAP; if (L == 0) s_flag = 4u; }
+        if (njobs > (uint32_t)JOBCAP) { njobs = JOBCAP; if (L == 0) s_flag = 4u; }
         const uint32_t q = (uint32_t)L & 3u, grp = (uint32_t)L >> 2;
         const uint32_t rounds = (njobs + NT / 4 - 1) / (NT / 4);
         const uint32_t nmid = (uint32_t)G.a + 1u; /* the middle blocks number a or a+1 */
