@@ -666,19 +666,22 @@ static void make_g8(std::vector<uint64_t> &g8)
 template <int C, int NT, int R0>
 static void launch_mask_r0(ntl_ctx *c, const SketchArgs &A, unsigned strips, bool single, bool multi)
 {
-    if (A.G.r0 == R0) {
+    if (R0 < 0 || A.G.r0 == R0) {
         const unsigned grid = A.redo_list ? 2048u : ((strips + 7u) & ~7u);
         if (single) hipLaunchKernelGGL((sketch_mask_kernel<C, NT, false, R0>), dim3(grid), dim3(NT), 0, c->stream, A);
         if (multi) hipLaunchKernelGGL((sketch_mask_kernel<C, NT, true, R0>), dim3((strips + 7u) & ~7u), dim3(NT), 0, c->stream, A);
         return;
     }
-    if constexpr (R0 + 1 < C) launch_mask_r0<C, NT, R0 + 1>(c, A, strips, single, multi);
+    if constexpr (R0 >= 0 && R0 + 1 < C) launch_mask_r0<C, NT, R0 + 1>(c, A, strips, single, multi);
 }
 
 template <int C>
 static void launch_mask(ntl_ctx *c, const SketchArgs &A, unsigned strips, bool single, bool multi, int nt)
 {
-    if (C == 16 && nt == 128) launch_mask_r0<C, 128, 0>(c, A, strips, single, multi);
+    /* 16 k-mers per lane: one instantiation per strip width, R0 at run time (this is the redo / multi-run pass since the 32-bit
+       window pass took over the common case); 4 and 1 k-mers per lane (w < 16): R0 as a template parameter */
+    if (C == 16 && nt == 128) launch_mask_r0<C, 128, -1>(c, A, strips, single, multi);
+    else if (C == 16) launch_mask_r0<C, SK_NT, -1>(c, A, strips, single, multi);
     else launch_mask_r0<C, SK_NT, 0>(c, A, strips, single, multi);
 }
 

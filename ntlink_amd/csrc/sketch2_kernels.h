@@ -162,7 +162,6 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
 
     const int64_t e_lane = (int64_t)I.E0 + (int64_t)L * C; /* ordinal of this lane's element t = 0 */
     const uint64_t gp = (uint64_t)((int64_t)I.base + I.P0 + (int64_t)L * C);
-    const int k = G.k;
 
     /* ---- phase 1a: 16-base partial hashes of the lane's own chunk (and of the chunks behind the strip) ---- */
     const bool live = e_lane < (int64_t)I.M;            /* the lane has at least one k-mer of the sequence */

@@ -147,7 +147,7 @@ struct NtlFalse { static constexpr bool value = false; };
  * R0 = (w - C) % C is a template parameter so that the window pass unrolls into straight-line code
  * (which remote block and which whole-block minimum a window uses is then known at compile time).
  */
-template <int C, int NT, bool MULTI, int R0>
+template <int C, int NT, bool MULTI, int R0T>
 __device__ __forceinline__ void sketch_mask_strip(const SketchArgs &A, const uint32_t strip)
 {
     constexpr int NBW = (C * NT + 31) / 32; /* words of the strip-local emission bitmask */
@@ -159,7 +159,10 @@ __device__ __forceinline__ void sketch_mask_strip(const SketchArgs &A, const uin
     __shared__ uint64_t s_roll[16][2], s_seed[4][2];
 
     const int L = threadIdx.x;
-    const SketchGeom G = A.G; /* G.r0 == R0 (the host picks the instantiation) */
+    const SketchGeom G = A.G;
+    /* R0T >= 0: G.r0 == R0T, the host picks the instantiation (straight-line window pass).  R0T < 0: R0 is read at run time -- the
+       16-k-mer form, which is the redo / multi-run / huge-window pass now, is compiled once per strip width instead of sixteen times */
+    const int R0 = R0T >= 0 ? R0T : G.r0;
 
     if (strip >= A.nstrips) return;
     const StripInfo I = A.strip_tab[strip];
@@ -261,8 +264,8 @@ __device__ __forceinline__ void sketch_mask_strip(const SketchArgs &A, const uin
         uint64_t ph = NTL_INF;
         uint32_t pi = NTL_NONE;
 #pragma unroll
-        for (int t = 0; t < R0; t++) {
-            if (h[t] <= ph) { ph = h[t]; pi = (uint32_t)(L * C + t); }
+        for (int t = 0; t < C; t++) {
+            if (t < R0 && h[t] <= ph) { ph = h[t]; pi = (uint32_t)(L * C + t); }
         }
         s_pr_h[L] = ph;
         s_pr_i[L] = (uint16_t)pi;
@@ -376,13 +379,13 @@ __device__ __forceinline__ void sketch_mask_strip(const SketchArgs &A, const uin
     }
 }
 
-template <int C, int NT, bool MULTI, int R0>
+template <int C, int NT, bool MULTI, int R0T>
 __global__ __launch_bounds__(NT) void sketch_mask_kernel(SketchArgs A)
 {
     if (A.redo_list) { /* the exact pass over the strips sketch_fast_kernel could not decide */
         const uint32_t n = *A.redo_count;
         for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
-            sketch_mask_strip<C, NT, MULTI, R0>(A, A.redo_list[i]);
+            sketch_mask_strip<C, NT, MULTI, R0T>(A, A.redo_list[i]);
             __syncthreads(); /* the strip's LDS arrays are reused */
         }
         return;
@@ -390,7 +393,7 @@ __global__ __launch_bounds__(NT) void sketch_mask_kernel(SketchArgs A)
     /* Workgroups are handed to the eight XCDs round-robin, and each XCD has its own L2: consecutive strips
        (which share their halo bases and their strip-table lines) go to one XCD, not to eight. */
     const uint32_t per_xcd = gridDim.x >> 3; /* the grid is a multiple of 8 */
-    sketch_mask_strip<C, NT, MULTI, R0>(A, (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3));
+    sketch_mask_strip<C, NT, MULTI, R0T>(A, (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3));
 }
 
 /* ---------------------------------------------------------------------------- emit -------- */
