@@ -14,10 +14,12 @@ def offsets_of(seqs):
     return off
 
 
-def check_sketch(dev, seqs, k, w, threads=0):
-    """Device sketch == oracle sketch (offsets, hashes, positions, strands)."""
+def check_sketch(dev, seqs, k, w, threads=0, info=None):
+    """Device sketch == oracle sketch (offsets, hashes, positions, strands).  info (dict): strips / redo_strips of the run."""
     with dev.batch(seqs) as b, dev.sketch(b, k, w) as sk:
         off, h, p, s = sk.download()
+        if info is not None:
+            info.update(strips=sk.strips, redo_strips=sk.redo_strips)
     ooff, oh, op, os_ = oracle.sketch_batch(b"".join(seqs), offsets_of(seqs), k, w, threads=threads)
     assert np.array_equal(off, ooff), "per-sequence minimizer counts differ"
     assert np.array_equal(p, op), "positions differ"

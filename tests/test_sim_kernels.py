@@ -199,13 +199,13 @@ def test_sim_fast_window_pass_decides_random_sequence_alone(dev):
     and the result is the oracle's."""
     rng = np.random.default_rng(5)
     seqs = [_rand_seq(rng, n) for n in (9000, 4200, 17000, 300, 131, 5000)]
-    for k, w in ((32, 100), (32, 250), (24, 100), (40, 31), (15, 16), (20, 33), (64, 64), (100, 70)):
-        with dev.batch(seqs) as b, dev.sketch(b, k, w) as sk:
-            assert sk.strips > 0 and sk.redo_strips == 0, (k, w, sk.strips, sk.redo_strips)
-        pc.check_sketch(dev, seqs, k, w)
-    with dev.batch(seqs) as b, dev.sketch(b, 7, 47) as sk:  # 4^7 distinct k-mers: identical k-mers do share windows
-        assert 0 < sk.redo_strips < sk.strips
-    pc.check_sketch(dev, seqs, 7, 47)
+    for k, w in ((32, 100), (32, 250), (24, 100), (40, 31), (15, 16), (64, 64), (100, 70)):
+        st = {}
+        pc.check_sketch(dev, seqs, k, w, info=st)
+        assert st["strips"] > 0 and st["redo_strips"] == 0, (k, w, st)
+    st = {}
+    pc.check_sketch(dev, seqs, 7, 47, info=st)  # 4^7 distinct k-mers: identical k-mers do share windows
+    assert 0 < st["redo_strips"] < st["strips"]
 
 
 def test_sim_fast_window_pass_hands_ties_to_the_exact_pass(dev, monkeypatch):
@@ -215,19 +215,17 @@ def test_sim_fast_window_pass_hands_ties_to_the_exact_pass(dev, monkeypatch):
     unit = _rand_seq(rng, 37)
     seqs = [unit * 150, b"A" * 3000, _rand_seq(rng, 2500) + unit * 40 + _rand_seq(rng, 2500), _rand_seq(rng, 6000),
             b"AC" * 1200 + _rand_seq(rng, 700)]
+    st = {}
     for k, w in ((32, 100), (24, 40), (32, 250)):
-        with dev.batch(seqs) as b, dev.sketch(b, k, w) as sk:
-            assert 0 < sk.redo_strips < sk.strips
-        pc.check_sketch(dev, seqs, k, w)
+        pc.check_sketch(dev, seqs, k, w, info=st)
+        assert 0 < st["redo_strips"] < st["strips"]
     monkeypatch.setenv("NTL_SKETCH_FORCE_REDO", "1")
-    with dev.batch(seqs) as b, dev.sketch(b, 32, 100) as sk:
-        assert sk.redo_strips == sk.strips
-    pc.check_sketch(dev, seqs, 32, 100)
+    pc.check_sketch(dev, seqs, 32, 100, info=st)
+    assert st["redo_strips"] == st["strips"]
     monkeypatch.delenv("NTL_SKETCH_FORCE_REDO")
     monkeypatch.setenv("NTL_SKETCH_FAST", "0")
-    with dev.batch(seqs) as b, dev.sketch(b, 32, 100) as sk:
-        assert sk.redo_strips == 0
-    pc.check_sketch(dev, seqs, 32, 100)
+    pc.check_sketch(dev, seqs, 32, 100, info=st)
+    assert st["redo_strips"] == 0
 
 
 @pytest.mark.parametrize("case", ["synthetic_k15_w5_s1", "synthetic_k8_w3_s3", "scaffolds_4_k15_w5_s1"])
