@@ -713,9 +713,10 @@ extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_
     SketchGeom G;
     G.k = k; G.w = w;
     G.a = (w - C) / C; G.r0 = (w - C) % C;
-    /* lanes per strip: 128-lane strips waste fewer lanes on the last strip of a ~10 kb read; the halo
-       (a+2 lanes) makes them a loss for large windows (measured: +5 % at w=100, -3 % at w=250) */
-    int nt = (C == 16 && (w - C) / C + 2 <= 10) ? 128 : SK_NT;
+    /* lanes per strip: 128-lane strips waste fewer lanes on the last strip of a ~10 kb read, 256-lane strips fewer on the halo
+       (a+2 lanes) and fit eight workgroups of the 32-bit window pass on a CU.  Measured with that pass: 256 lanes +6 % at w=100
+       (10 kb reads 675 -> 714 Gbases/s, 20 kb reads 696 -> 747); 128 lanes stay for the small windows (w < 64) */
+    int nt = (C == 16 && w < 64) ? 128 : SK_NT;
     if (const char *e = getenv("NTL_SKETCH_NT")) { /* tuning knob; ignored where it leaves no lane to own a window */
         const int v = atoi(e);
         if ((v == 256 || (v == 128 && C == 16)) && v - (G.a + 2) >= 2) nt = v;

@@ -15,11 +15,10 @@ from sim import simlib  # noqa: E402
 capi.DEFAULT_LIB = simlib.build(sanitize=True)  # the host-side entry points (reader, parsers, writers, tally) too
 dev = capi.Device(0)
 pc.check_sketch(dev, pc.edge_sequences(), 32, 100)
-pc.check_sketch(dev, fuzz_cases.fuzz_sequences(3, n=12, max_len=4000), 20, 10)
+pc.check_sketch(dev, fuzz_cases.fuzz_sequences(3, n=6, max_len=2500), 20, 10)
 pc.check_sketch(dev, fuzz_cases.fuzz_sequences(4, n=6, max_len=3000), 70, 3)
 pc.check_scenario(dev, "syn_sens_repeat")
 pc.check_pair_arrays(dev, *fuzz_cases.fuzz_mapping(2, n_reads=40), k=24, z=1000, x=1.2)
-pc.check_full_pipeline(dev, pc.fixture_seqs("scaffolds_4.fa"), pc.fixture_seqs("long_reads_4_top5.fa"), 40, 100, z=1000)
 
 # host side of the C ABI: parallel FASTA/FASTQ reader (cuts inside wrapped quality lines included), gzip,
 # TSV parser, emitters, pair tally, the fused driver and the two-operator path

@@ -125,3 +125,67 @@ def test_btllib_compatible_indexlr_class():
         assert [m.out_hash for m in r.minimizers] == h.tolist() and [m.pos for m in r.minimizers] == p.tolist()
         assert [m.forward for m in r.minimizers] == [bool(v) for v in s]
     got[0].id = "renamed"  # records are mutable in the reference's use
+
+
+def test_file_to_file_at_scale_equals_oracle(tmp_path, monkeypatch):
+    """The fused driver on a scaled C3 workload, file to file -- 90 Mbp assembly, 0.6 Gbases of ONT-like reads spread over
+    plain FASTA, FASTQ and gzip files, 13 read batches, two device worker threads, bases packed by the parser threads --
+    leaves the text the oracle derives from the same sequences: `.tsv`, `.verbose_mapping.tsv`, `.paf`, `.pairs.tsv` byte for
+    byte, `.dot` edge for edge."""
+    import gzip
+    import numpy as np
+    import oracle
+    from ntlink_amd import capi, pipeline, synth
+    dev = capi.Device(0)
+    wl = synth.DeviceWorkload(dev, "C3", scale=0.03, with_reads=False)
+    W = wl.W
+    k, w = W["k"], W["w"]
+    cbuf, coff = wl.contigs.download()
+    ctg_names = ["ctg%06d" % i for i in range(len(coff) - 1)]
+    with open(tmp_path / "asm.fa", "wb") as fh:
+        for i, n in enumerate(ctg_names):
+            s = cbuf[int(coff[i]):int(coff[i + 1])].tobytes()
+            fh.write(b">" + n.encode() + b" len=%d\n" % len(s) + b"\n".join(s[j:j + 80] for j in range(0, len(s), 80)) + b"\n")
+    files, read_names, rbufs, roffs = [], [], [], []
+    for f, kind in enumerate(("fa", "fq", "fa.gz", "fa")):
+        rb, _ = wl.make_reads(150_000_000, seed=(9, f))
+        buf, off = rb.download()
+        rb.close()
+        name = f"reads{f}.{kind}"
+        opener = gzip.open if kind.endswith(".gz") else open
+        with opener(tmp_path / name, "wb") as fh:
+            for i in range(len(off) - 1):
+                s = buf[int(off[i]):int(off[i + 1])].tobytes()
+                rn = b"r%d_%d" % (f, i)
+                fh.write((b"@" + rn + b" x\n" + s + b"\n+\n" + b"I" * len(s) + b"\n") if kind == "fq" else (b">" + rn + b"\n" + s + b"\n"))
+                read_names.append(rn.decode())
+        files.append(name)
+        rbufs.append(buf[:int(off[-1])]); roffs.append(off)
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("NTL_DEVICE_STREAMS", "2")
+    st = pipeline.run_pair(dev, "asm.fa", " ".join(files), k=k, w=w, paf=True, pairs_tsv=True, batch_bases=50_000_000)
+    wl.close()
+    dev.close()
+    assert st["reads"] == len(read_names) and st["read_bases"] == sum(int(o[-1]) for o in roffs)
+    # the oracle on the same sequences
+    rbuf = np.concatenate(rbufs)
+    roff = np.concatenate([[0]] + [o[1:].astype(np.int64) + sum(int(x[-1]) for x in roffs[:i]) for i, o in enumerate(roffs)]).astype(np.uint64)
+    c_off, ch, cp, cs = oracle.sketch_batch(cbuf, coff, k, w)
+    from helpers import contig_ids
+    oix = oracle.Index(ch, contig_ids(c_off), cp, cs)
+    r_off, rh, rp, rs = oracle.sketch_batch(rbuf, roff, k, w)
+    rlen = np.diff(roff).astype(np.uint32)
+    ctg_len = np.diff(coff).astype(np.uint32)
+    res = oracle.map_reads(oix, ctg_len, r_off, rlen, rh, rp, rs, k=k, z=1000, x=0.0, sensitive=False, repeat_filter=False, threads=0)
+    pre = f"asm.fa.k{k}.w{w}.z1000"
+    assert read_text(pre + ".verbose_mapping.tsv") == oracle.format_verbose(res, read_names, ctg_names)
+    assert read_text(pre + ".paf") == oracle.format_paf(res, read_names, rlen, ctg_names, ctg_len)
+    by_name = dict(zip(ctg_names, ctg_len.tolist()))
+    pairs = oracle.filter_pairs(oracle.tally_pairs(res, rlen, ctg_names, ctg_len, k), by_name)
+    assert len(pairs) > 100 and read_text(pre + ".pairs.tsv") == oracle.format_pairs(pairs)
+    head, nodes, edges = oracle.format_dot(pairs, by_name)
+    got = read_text(pre + ".n1.scaffold.dot").splitlines(keepends=True)
+    assert got[:2] == head and [l for l in got if "->" in l] == edges and set(l for l in got[2:-1] if "->" not in l) == set(nodes)
+    recs = [(n, 0, ch[int(c_off[i]):int(c_off[i + 1])], cp[int(c_off[i]):int(c_off[i + 1])], cs[int(c_off[i]):int(c_off[i + 1])])
+            for i, n in enumerate(ctg_names)]
+    assert read_text(f"asm.fa.k{k}.w{w}.tsv") == oracle.format_indexlr(recs)
