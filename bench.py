@@ -155,18 +155,42 @@ def main():
     contig_prof = {nm: dev.prof_get(nm) for nm in ("sketch_meta", "sketch_mask", "sketch_redo", "sketch_emit", "index")}
     contig_mx = csk.count
 
+    # NTL_BENCH_STREAMS worker threads, each with its own context (stream) on the GPU, take the sub-batches in turn: while one
+    # waits on the host for a size (two waits per sub-batch), the other's kernels keep the device busy.  Same work per step.
+    n_streams = max(1, int(os.environ.get("NTL_BENCH_STREAMS", "1")))
+    devs = [dev] + [dev.clone() for _ in range(n_streams - 1)]
+    for d in devs[1:]:
+        d.prof_enable(True)
+
+    def run_batches(d, items, collect, acc):
+        for rb, rl in items:
+            rsk = d.sketch(rb, k, w)
+            res = d.map(ix, rsk, rl, **params)
+            if collect:
+                acc["read_mx"] += rsk.count
+                acc["index_hits"] += res.n_index_hits
+                acc["counts"] = [a + b for a, b in zip(acc["counts"], res.counts())]
+            res.close()
+            rsk.close()
+
     def step(collect=False):
         if collect:
             stats.update(read_mx=0, index_hits=0, counts=[0, 0, 0])
-        for rb, rl in zip(wl.read_batches, wl.read_lens):
-            rsk = dev.sketch(rb, k, w)
-            res = dev.map(ix, rsk, rl, **params)
-            if collect:
-                stats["read_mx"] += rsk.count
-                stats["index_hits"] += res.n_index_hits
-                stats["counts"] = [a + b for a, b in zip(stats["counts"], res.counts())]
-            res.close()
-            rsk.close()
+        items = list(zip(wl.read_batches, wl.read_lens))
+        if n_streams == 1:
+            run_batches(dev, items, collect, stats)
+            return
+        import threading
+        accs = [dict(read_mx=0, index_hits=0, counts=[0, 0, 0]) for _ in devs]
+        ths = [threading.Thread(target=run_batches, args=(d, items[i::n_streams], collect, accs[i])) for i, d in enumerate(devs)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        if collect:
+            for a in accs:
+                stats["read_mx"] += a["read_mx"]; stats["index_hits"] += a["index_hits"]
+                stats["counts"] = [x + y for x, y in zip(stats["counts"], a["counts"])]
 
     def barrier():
         if dist is not None:
@@ -176,13 +200,15 @@ def main():
                 dist.barrier()
         if use_cuda:
             torch.cuda.synchronize()
-        dev.sync()
+        for d in devs:
+            d.sync()
 
     for i in range(args.warmup):
         step(collect=(i == 0))
     if args.warmup == 0:
         stats["read_mx"] = None
-    dev.prof_reset()
+    for d in devs:
+        d.prof_reset()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -190,8 +216,9 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     names = ("sketch_meta", "sketch_mask", "sketch_redo", "sketch_emit", "probe", "map", "compact")
-    prof = {nm: dev.prof_get(nm) for nm in names}
-    dev.prof_enable(False)
+    prof = {nm: tuple(sum(x) for x in zip(*[d.prof_get(nm) for d in devs])) for nm in names}
+    for d in devs:
+        d.prof_enable(False)
     if stats["read_mx"] is None:
         step(collect=True)
     if dist is not None:
@@ -259,6 +286,8 @@ def main():
     ix.close()
     csk.close()
     wl.close()
+    for d in devs[1:]:
+        d.close()
     dev.close()
     if dist is not None:
         dist.destroy_process_group()
