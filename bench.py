@@ -38,7 +38,7 @@ N_SIMD = 1024
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--steps", type=int, default=14)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="C3", help="C3 (default: 3 Gbp + 90 Gbases ONT, k32 w250), C2, C5")
     ap.add_argument("--strong", action="store_true", help="strong scaling: the workload's read set is split over the ranks")
