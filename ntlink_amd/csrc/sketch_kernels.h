@@ -405,7 +405,7 @@ struct MxRecord {
 };
 
 #define EMIT_NT 256
-#define EMIT_WPT 8                       /* mask words per thread */
+#define EMIT_WPT 8                       /* mask words per thread (two 16-byte loads) */
 #define EMIT_TILE (EMIT_NT * EMIT_WPT)   /* mask words per workgroup */
 #define EMIT_CAP 2048                    /* positions staged in LDS per round (16-bit offsets inside the tile) */
 
@@ -416,8 +416,13 @@ __global__ __launch_bounds__(EMIT_NT) void mask_count_kernel(const uint32_t *mas
     __shared__ uint32_t s_tmp[EMIT_NT];
     const uint64_t w0 = (uint64_t)blockIdx.x * EMIT_TILE + (uint64_t)threadIdx.x * EMIT_WPT;
     uint32_t c = 0;
-    for (int i = 0; i < EMIT_WPT; i++)
-        if (w0 + i < nwords) c += (uint32_t)__popc(mask[w0 + i]);
+    if (w0 + EMIT_WPT <= nwords) { /* the thread's eight words as two 16-byte loads (the array is 16-byte aligned, w0 a multiple of 8) */
+        const uint4 a = *reinterpret_cast<const uint4 *>(mask + w0), b = *reinterpret_cast<const uint4 *>(mask + w0 + 4);
+        c = (uint32_t)(__popc(a.x) + __popc(a.y) + __popc(a.z) + __popc(a.w) + __popc(b.x) + __popc(b.y) + __popc(b.z) + __popc(b.w));
+    } else {
+        for (int i = 0; i < EMIT_WPT; i++)
+            if (w0 + i < nwords) c += (uint32_t)__popc(mask[w0 + i]);
+    }
     uint32_t total;
     block_excl_scan<EMIT_NT>(c, s_tmp, total);
     if (threadIdx.x == 0) tile_cnt[blockIdx.x] = total;
@@ -493,11 +498,15 @@ __global__ __launch_bounds__(EMIT_NT) void emit_kernel(EmitArgs A)
     const uint64_t w0 = tile_w0 + (uint64_t)t * EMIT_WPT;
     uint32_t words[EMIT_WPT];
     uint32_t c = 0;
+    if (w0 + EMIT_WPT <= A.nwords) {
+        const uint4 a = *reinterpret_cast<const uint4 *>(A.mask + w0), b = *reinterpret_cast<const uint4 *>(A.mask + w0 + 4);
+        words[0] = a.x; words[1] = a.y; words[2] = a.z; words[3] = a.w; words[4] = b.x; words[5] = b.y; words[6] = b.z; words[7] = b.w;
+    } else {
 #pragma unroll
-    for (int i = 0; i < EMIT_WPT; i++) {
-        words[i] = w0 + i < A.nwords ? A.mask[w0 + i] : 0u;
-        c += (uint32_t)__popc(words[i]);
+        for (int i = 0; i < EMIT_WPT; i++) words[i] = w0 + i < A.nwords ? A.mask[w0 + i] : 0u;
     }
+#pragma unroll
+    for (int i = 0; i < EMIT_WPT; i++) c += (uint32_t)__popc(words[i]);
     uint32_t total;
     const uint32_t excl = block_excl_scan<EMIT_NT>(c, s_tmp, total);
     /* last sequence: count the cached starts that lie inside the tile; more than EMIT_SEQ_CAP of them
