@@ -18,7 +18,7 @@ def build(sanitize=False):
     if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(s) for s in SRC):
         return out
     os.makedirs(os.path.dirname(out), exist_ok=True)
-    cmd = ["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-pthread", "-ffp-contract=off", "-Wall",
+    cmd = ["g++", "-O1", "-g1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-ffp-contract=off", "-Wall",
            "-Wno-unused-function", "-Wno-unknown-pragmas", "-x", "c++",
            "-I", os.path.join(HERE, "include"), "-I", os.path.join(ROOT, "ntlink_amd", "csrc"),
            SRC[0], SRC[1], SRC[2], SRC[3], os.path.join(HERE, "sim_runtime.cpp"), "-lz", "-ldl", "-o", out]
