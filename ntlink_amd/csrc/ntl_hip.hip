@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <chrono>
 #include <map>
 #include <memory>
 #include <string>
@@ -84,6 +85,24 @@ static int fail(ntl_ctx *c, int code, const std::string &msg)
         if (e_ != hipSuccess)                                                                     \
             return fail(ctx, NTL_EDEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));     \
     } while (0)
+
+/* Wait for the stream on the two size read-backs of the hot path (minimizer total of a sketch, result totals of a map call):
+ * polls the stream for a while before it blocks -- a blocking wait is woken by an interrupt some tens of microseconds after
+ * the last kernel ended, and until the host has queued the next kernels the device idles (two such gaps per read batch). */
+static hipError_t sync_hot(ntl_ctx *c)
+{
+    static const int spin_us = [] { const char *e = getenv("NTL_SYNC_SPIN_US"); return e ? atoi(e) : 20000; }();
+    if (spin_us > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            const hipError_t q = hipStreamQuery(c->stream);
+            if (q == hipSuccess) return hipSuccess;
+            if (q != hipErrorNotReady) return q;
+            if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > spin_us) break;
+        }
+    }
+    return hipStreamSynchronize(c->stream);
+}
 
 static int dev_alloc(ntl_ctx *c, size_t bytes, void **out)
 {
@@ -874,7 +893,7 @@ extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(&total_mx, tot.p, 4, hipMemcpyDeviceToHost, c->stream));
         if (fast) HIPCHK(c, hipMemcpyAsync(&redo_n, redo.p, 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, sync_hot(c));
         s->count = total_mx;
         s->strips = ub_strips;
         s->redo_strips = redo_n;
@@ -1191,7 +1210,7 @@ extern "C" int ntl_map_run(ntl_ctx *c, const ntl_index *ix, const ntl_sketch *re
         if ((rc = device_scan(c, n3.as<uint32_t>(), o, nreads, nullptr, 3, dsums->tot))) return rc;
         /* the only wait of the call: three totals (to size the dense arrays), hit count, invariant flag */
         HIPCHK(c, hipMemcpyAsync(&hs, sums.p, sizeof(MapSums), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, sync_hot(c));
         R->n_maps = hs.tot[0]; R->n_hits = hs.tot[1]; R->n_pafs = hs.tot[2];
         if ((rc = R->maps.alloc(c, (uint64_t)hs.tot[0] * sizeof(MapRec))) || (rc = R->hits.alloc(c, (uint64_t)hs.tot[1] * sizeof(HitRec))) ||
             (rc = R->pafs.alloc(c, (uint64_t)hs.tot[2] * sizeof(PafRec)))) return rc;

@@ -114,6 +114,7 @@ template <typename T> inline T atomicCAS(T *p, T cmp, T val)
 /* ---------------------------------------------------------------- host runtime */
 typedef int hipError_t;
 #define hipSuccess 0
+#define hipErrorNotReady 600
 typedef struct sim_stream *hipStream_t;
 typedef struct sim_event { std::chrono::steady_clock::time_point t; } *hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
@@ -140,6 +141,7 @@ inline hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return 
 inline hipError_t hipStreamCreate(hipStream_t *s) { *s = nullptr; return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new sim_event; return hipSuccess; }
 inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
