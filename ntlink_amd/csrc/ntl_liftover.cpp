@@ -289,46 +289,55 @@ extern "C" int ntl_liftover(const char *mappings_path, const char *out_path, int
         size_t min_chunk = 1u << 20;
         if (const char *ev = getenv("NTL_IO_MIN_CHUNK")) { long v = atol(ev); if (v > 0) min_chunk = (size_t)v; }
         T = (unsigned)std::min<size_t>(T, std::max<size_t>(1, size / min_chunk));
-        /* cuts: a line start where the read id differs from the line before */
-        std::vector<const char *> cut(T + 1, end);
-        cut[0] = base;
-        for (unsigned t = 1; t < T; t++) {
-            const char *g = base + size / T * t;
-            if (g < cut[t - 1]) g = cut[t - 1];
+        /* The file is lifted block by block (about 256 MB of input, so that the text held in memory stays bounded); a block is
+           cut into T pieces; every cut is a line start where the read id differs from the line before. */
+        auto next_cut = [&](const char *g, const char *lo) -> const char * {
+            if (g <= lo) g = lo;
+            if (g >= end) return end;
             const char *nl = (const char *)memchr(g, '\n', (size_t)(end - g));
             const char *ls = nl ? nl + 1 : end;
-            /* previous line's id */
             while (ls < end) {
-                const char *pe = ls - 1; /* the '\n' ending the previous line */
-                const char *pb = pe;
+                const char *pb = ls - 1; /* the '\n' ending the previous line */
                 while (pb > base && pb[-1] != '\n') pb--;
                 if (read_id_of(pb, end) != read_id_of(ls, end)) break;
                 const char *nx = (const char *)memchr(ls, '\n', (size_t)(end - ls));
                 ls = nx ? nx + 1 : end;
             }
-            cut[t] = ls;
-        }
-        std::vector<std::string> outs(T);
-        std::vector<uint64_t> li(T, 0), lo(T, 0);
-        std::vector<int> rcs(T, NTL_OK);
-        std::vector<std::thread> th;
-        for (unsigned t = 0; t < T; t++)
-            th.emplace_back([&, t]() {
-                Lifter L{agp, k};
-                rcs[t] = lift_range(cut[t], cut[t + 1], L, outs[t], li[t]);
-                lo[t] = L.lines_out;
-            });
-        for (auto &x : th) x.join();
-        for (unsigned t = 0; t < T && rc == NTL_OK; t++) {
-            if (rcs[t] != NTL_OK) { rc = rcs[t]; break; }
-            nin += li[t]; nout += lo[t];
-            const char *w = outs[t].data();
-            size_t left = outs[t].size();
-            while (left) {
-                ssize_t n = write(ofd, w, left);
-                if (n <= 0) { rc = NTL_EINVAL; break; }
-                w += n; left -= (size_t)n;
+            return ls;
+        };
+        size_t block = (size_t)256 << 20;
+        if (const char *ev = getenv("NTL_LIFTOVER_BLOCK")) { long v = atol(ev); if (v > 0) block = (size_t)v; }
+        const char *at = base;
+        while (at < end && rc == NTL_OK) {
+            const char *bend = (size_t)(end - at) <= block ? end : next_cut(at + block, at);
+            const size_t bsize = (size_t)(bend - at);
+            const unsigned Tb = (unsigned)std::min<size_t>(T, std::max<size_t>(1, bsize / min_chunk));
+            std::vector<const char *> cut(Tb + 1, bend);
+            cut[0] = at;
+            for (unsigned t = 1; t < Tb; t++) cut[t] = std::min(bend, next_cut(at + bsize / Tb * t, cut[t - 1]));
+            std::vector<std::string> outs(Tb);
+            std::vector<uint64_t> li(Tb, 0), lo(Tb, 0);
+            std::vector<int> rcs(Tb, NTL_OK);
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < Tb; t++)
+                th.emplace_back([&, t]() {
+                    Lifter L{agp, k};
+                    rcs[t] = lift_range(cut[t], cut[t + 1], L, outs[t], li[t]);
+                    lo[t] = L.lines_out;
+                });
+            for (auto &x : th) x.join();
+            for (unsigned t = 0; t < Tb && rc == NTL_OK; t++) {
+                if (rcs[t] != NTL_OK) { rc = rcs[t]; break; }
+                nin += li[t]; nout += lo[t];
+                const char *w = outs[t].data();
+                size_t left = outs[t].size();
+                while (left) {
+                    ssize_t n = write(ofd, w, left);
+                    if (n <= 0) { rc = NTL_EINVAL; break; }
+                    w += n; left -= (size_t)n;
+                }
             }
+            at = bend;
         }
         munmap((void *)base, size);
     }

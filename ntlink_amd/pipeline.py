@@ -329,7 +329,7 @@ def _append_part(final_path, part_path, offset):
     os.remove(part_path)
 
 
-def _map_batches(dev, ix, batches, drain, stats, t_mark, **map_kw):
+def _map_batches(dev, ix, batches, drain, stats, t_mark, w, **map_kw):
     """The device stage of the pair driver: read batches -> records, handed to `drain` in input order.
 
     NTL_DEVICE_STREAMS (default 2) worker threads, each with its own context on the GPU (stream, block cache, page-locked
@@ -371,7 +371,7 @@ def _map_batches(dev, ix, batches, drain, stats, t_mark, **map_kw):
                     t_up = time.perf_counter()
                     dev.pinned_release(rs_.pinned if rs_.packed is not None else rs_.buf)  # on the device: the reader may refill it
                     rs_.buf = rs_.packed = rs_.pinned = None
-                    with wdev.sketch(rb, map_kw["k"], stats["w"]) as rsk:
+                    with wdev.sketch(rb, map_kw["k"], w) as rsk:
                         t_sk = time.perf_counter()
                         with wdev.map(ix, rsk, rl, **map_kw) as res:
                             t_mp = time.perf_counter()
@@ -467,7 +467,7 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
 
     drain = Drain(consume)  # text emitters + pair tally run behind the device
     tsv_drain = Drain(emit_contig_tsv) if root and write_contig_tsv else None
-    stats = dict(read_bases=0, reads=0, read_minimizers=0, index_hits=0, t_contigs=0.0, t_ingest=0.0, t_device=0.0, t_handover=0.0, w=w, t_device_parts={})
+    stats = dict(read_bases=0, reads=0, read_minimizers=0, index_hits=0, t_contigs=0.0, t_ingest=0.0, t_device=0.0, t_handover=0.0, t_device_parts={})
     try:
         with (dev.batch_packed(ctg) if ctg.packed is not None else dev.batch(ctg.buf, ctg.offsets)) as cb:
             ctg.buf = ctg.packed = ctg.pinned = None
@@ -484,7 +484,7 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
                     stats["t_contigs_parts"] = {"parse": round(t_ctg_parsed - t_start, 4), "upload_pack": round(t_ctg_up - t_ctg_parsed, 4),
                                                 "sketch": round(t_ctg_sk - t_ctg_up, 4), "download_for_tsv": round(t_ctg_dl - t_ctg_sk, 4),
                                                 "index": round(t_mark - t_ctg_dl, 4)}
-                    _map_batches(dev, ix, batches, drain, stats, t_mark, k=k, z=z, x=x, sensitive=sensitive, repeat_filter=repeats)
+                    _map_batches(dev, ix, batches, drain, stats, t_mark, w, k=k, z=z, x=x, sensitive=sensitive, repeat_filter=repeats)
         t_fin = time.perf_counter()
         drain.close()
         for d in stats.pop("_extra_devices", []):

@@ -35,3 +35,27 @@ def test_bench_line_on_the_simt_mock(tmp_path):
         assert key in out
     assert out["n_gpus"] == 1 and out["cpu_baseline"]["kind"] == "port" and "stages_s" in out["cpu_baseline"]
     assert out["config"]["index_size"] > 0 and out["config"]["mappings_hits_pafs_per_step"][0] > 0
+
+
+def test_two_ranks_strong_scaling_line_on_the_simt_mock():
+    """`bench.py --gpus 2 --strong` end to end on CPU: the launcher starts two gloo ranks, each maps its half of the read
+    set on the SIMT mock, rank 0 prints one line with n_gpus = 2, the max-over-ranks time and the summed bases."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from sim import simlib
+    lib = simlib.build()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--lib", lib, "--workload", "C2", "--scale", "0.0004", "--steps", "1",
+            "--warmup", "1", "--no-e2e", "--no-cpu-baseline", "--batch-bases", "100000"]
+    outs = {}
+    for tag, extra in (("one", []), ("two", ["--gpus", "2", "--strong"])):
+        p = subprocess.run(base + extra, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-2000:]
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1
+        outs[tag] = json.loads(lines[0])
+    one, two = outs["one"], outs["two"]
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and one["n_gpus"] == 1 and one["scaling"] == "weak"
+    per_rank = int(two["config"]["workload"].split(" read bases per GPU")[0].split("+ ")[-1])
+    whole = int(one["config"]["workload"].split(" read bases per GPU")[0].split("+ ")[-1])
+    assert abs(2 * per_rank - whole) < 0.15 * whole  # the same read volume, split two ways (a few 10-kb reads at this scale)
+    assert two["value"] > 0 and two["config"]["index_size"] == one["config"]["index_size"]

@@ -30,6 +30,8 @@ def _mappings_file(case, tmp_path):
 def test_liftover_equals_reference(case, threads, tmp_path, monkeypatch):
     monkeypatch.setenv("NTL_IO_THREADS", threads)
     monkeypatch.setenv("NTL_IO_MIN_CHUNK", "2000")  # several pieces even on these small files: cuts at read boundaries
+    if threads == "5":
+        monkeypatch.setenv("NTL_LIFTOVER_BLOCK", "7000")  # ... and several blocks of pieces
     out = tmp_path / "lifted.tsv"
     agp = liftover.read_agp(os.path.join(GOLD, case["agp"]))
     nin, nout = liftover.liftover_mappings(_mappings_file(case, tmp_path), agp, str(out), case["k"])
