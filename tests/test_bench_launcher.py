@@ -58,4 +58,4 @@ def test_two_ranks_strong_scaling_line_on_the_simt_mock():
     per_rank = int(two["config"]["workload"].split(" read bases per GPU")[0].split("+ ")[-1])
     whole = int(one["config"]["workload"].split(" read bases per GPU")[0].split("+ ")[-1])
     assert abs(2 * per_rank - whole) < 0.15 * whole  # the same read volume, split two ways (a few 10-kb reads at this scale)
-    assert two["value"] > 0 and two["config"]["index_size"] == one["config"]["index_size"]
+    assert two["ms_per_step"] > 0 and two["config"]["index_size"] == one["config"]["index_size"]
