@@ -336,16 +336,19 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
 #endif
         }
         /* ---- phase 5: dropped minima are set right away (the entering element); one job per window whose minimum rose ---- */
-        const uint32_t rise = chg & ~le;
-        uint32_t at = rise ? atomicAdd(&s_njobs, (uint32_t)__popc(rise)) : 0u;
-        uint32_t m = chg;
-        while (m) {
-            const int j = __ffs(m) - 1;
-            m &= m - 1;
-            if ((le >> j) & 1u) {
-                const uint32_t pos = (uint32_t)(L * C + j + G.w - 1);
-                atomicOr(&s_bits[pos >> 5], 1u << (pos & 31u));
-            } else {
+        const uint32_t drop = chg & le, rise = chg & ~le;
+        if (drop) { /* window j's entering element sits at strip position L*C + j + w - 1: the lane's drop bits, shifted, are its mask bits */
+            const uint32_t p0 = (uint32_t)(L * C + G.w - 1);
+            const uint64_t v = (uint64_t)drop << (p0 & 31u);
+            atomicOr(&s_bits[p0 >> 5], (uint32_t)v);
+            if (v >> 32) atomicOr(&s_bits[(p0 >> 5) + 1], (uint32_t)(v >> 32));
+        }
+        if (rise) {
+            uint32_t at = atomicAdd(&s_njobs, (uint32_t)__popc(rise));
+            uint32_t m = rise;
+            while (m) {
+                const int j = __ffs(m) - 1;
+                m &= m - 1;
                 if (at < (uint32_t)JOBCAP) s_jobs[at] = (uint16_t)(L * C + j);
                 at++;
             }
