@@ -128,6 +128,10 @@ struct Cand {
 
 #define PROBE_U 4 /* minimizers per thread and round: their loads are issued together (memory-level parallelism) */
 
+/* TAGS = true: the one-byte tag of the home slot decides first (most lookups end there when few minimizers are in the index:
+ * ONT reads, h ~ 0.15).  TAGS = false: the slots are read directly -- when most lookups hit (HiFi reads, h ~ 0.9) the tag is one more
+ * random cache line per lookup for nothing.  The host picks by the hit fraction of the previous batch on the same index. */
+template <bool TAGS>
 __global__ void probe_kernel(const MxRecord *mx, uint64_t n, const IndexSlot *slots, int bits,
                              const IndexSpecial *special, Cand *cand, unsigned long long *nfound, const uint8_t *tags)
 {
@@ -137,6 +141,7 @@ __global__ void probe_kernel(const MxRecord *mx, uint64_t n, const IndexSlot *sl
     for (uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x * PROBE_U + threadIdx.x; i0 < n; i0 += stride) {
         uint64_t key[PROBE_U], s[PROBE_U];
         uint8_t t[PROBE_U];
+        IndexSlot e0[PROBE_U];
         bool live[PROBE_U];
 #pragma unroll
         for (int u = 0; u < PROBE_U; u++) {
@@ -147,7 +152,8 @@ __global__ void probe_kernel(const MxRecord *mx, uint64_t n, const IndexSlot *sl
 #pragma unroll
         for (int u = 0; u < PROBE_U; u++) {
             s[u] = index_home(key[u], bits);
-            t[u] = live[u] && key[u] != NTL_INF ? tags[s[u]] : (uint8_t)0;
+            if (TAGS) t[u] = live[u] && key[u] != NTL_INF ? tags[s[u]] : (uint8_t)0;
+            else if (live[u] && key[u] != NTL_INF) e0[u] = slots[s[u]];
         }
 #pragma unroll
         for (int u = 0; u < PROBE_U; u++) {
@@ -156,7 +162,7 @@ __global__ void probe_kernel(const MxRecord *mx, uint64_t n, const IndexSlot *sl
             c.cpos = 0; c.meta = 0;
             if (key[u] == NTL_INF) {
                 if (special->cnt == 1) { c.cpos = special->pos; c.meta = (special->meta & ~1u) | 1u; }
-            } else {
+            } else if (TAGS) {
                 const uint8_t tg = index_tag(key[u]);
                 uint64_t q = s[u];
                 uint8_t tq = t[u];
@@ -171,6 +177,18 @@ __global__ void probe_kernel(const MxRecord *mx, uint64_t n, const IndexSlot *sl
                     }
                     q = (q + 1) & mask;
                     tq = tags[q];
+                }
+            } else {
+                uint64_t q = s[u];
+                IndexSlot e = e0[u];
+                for (;;) {
+                    if (e.key == NTL_INF) break; /* empty slot ends the probe sequence */
+                    if (e.key == key[u]) {
+                        if (!(e.meta & 1u)) { c.cpos = e.pos; c.meta = e.meta | 1u; }
+                        break;
+                    }
+                    q = (q + 1) & mask;
+                    e = slots[q];
                 }
             }
             ntl_stream_store((uint64_t *)&cand[i0 + (uint64_t)u * blockDim.x], (uint64_t)c.cpos | ((uint64_t)c.meta << 32));

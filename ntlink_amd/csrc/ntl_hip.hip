@@ -1080,6 +1080,7 @@ struct ntl_index {
     uint64_t nslots = 0;
     mutable uint64_t size = 0;
     mutable bool size_known = false;
+    mutable double hit_fraction = 0.0;   /* of the last batch mapped against this index: picks the probe form */
     uint32_t n_ctg = 0;
     DevBuf slots, special, ctg_len, cnt; /* cnt: device-side count of kept keys, fetched on demand */
     DevBuf tags;                         /* one byte per slot (map_kernels.h index_tag) */
@@ -1177,11 +1178,20 @@ extern "C" int ntl_map_run(ntl_ctx *c, const ntl_index *ix, const ntl_sketch *re
     HIPCHK(c, hipMemsetAsync(sums.p, 0, sizeof(MapSums), c->stream));
     {
         ProfSpan sp(c, "probe");
-        if (nmx)
-            hipLaunchKernelGGL(probe_kernel, dim3((unsigned)std::min<uint64_t>((nmx + 256 * PROBE_U - 1) / (256 * PROBE_U), 4096)), dim3(256), 0, c->stream,
-                               (const MxRecord *)reads->records.as<MxRecord>(), nmx, (const IndexSlot *)ix->slots.as<IndexSlot>(),
-                               ix->bits, (const IndexSpecial *)ix->special.as<IndexSpecial>(), cand.as<Cand>(),
-                               &dsums->nfound, (const uint8_t *)ix->tags.as<uint8_t>());
+        if (nmx) {
+            const dim3 grid((unsigned)std::min<uint64_t>((nmx + 256 * PROBE_U - 1) / (256 * PROBE_U), 4096));
+            /* tags first unless the previous batch on this index found more than half of its minimizers (same result either way) */
+            if (ix->hit_fraction <= 0.5)
+                hipLaunchKernelGGL(probe_kernel<true>, grid, dim3(256), 0, c->stream,
+                                   (const MxRecord *)reads->records.as<MxRecord>(), nmx, (const IndexSlot *)ix->slots.as<IndexSlot>(),
+                                   ix->bits, (const IndexSpecial *)ix->special.as<IndexSpecial>(), cand.as<Cand>(),
+                                   &dsums->nfound, (const uint8_t *)ix->tags.as<uint8_t>());
+            else
+                hipLaunchKernelGGL(probe_kernel<false>, grid, dim3(256), 0, c->stream,
+                                   (const MxRecord *)reads->records.as<MxRecord>(), nmx, (const IndexSlot *)ix->slots.as<IndexSlot>(),
+                                   ix->bits, (const IndexSpecial *)ix->special.as<IndexSpecial>(), cand.as<Cand>(),
+                                   &dsums->nfound, (const uint8_t *)ix->tags.as<uint8_t>());
+        }
         HIPCHK(c, hipGetLastError());
     }
     MapArgs A;
@@ -1220,6 +1230,7 @@ extern "C" int ntl_map_run(ntl_ctx *c, const ntl_index *ix, const ntl_sketch *re
         HIPCHK(c, hipGetLastError());
     }
     R->n_index_hits = hs.nfound;
+    if (nmx) ix->hit_fraction = (double)hs.nfound / (double)nmx;
     if (hs.err) return fail(c, NTL_EINTERNAL, "an accepted contig appeared twice in one read (bin/ntlink_utils.py:262-266)");
     *out = R_guard.release();
     return NTL_OK;

@@ -250,3 +250,22 @@ def check_overlap_random(dev, seed, nseq=40, max_len=30000, k=15, w=5):
     assert np.array_equal(g_off, e_off) and np.array_equal(gh, eh) and np.array_equal(gp, ep)
     assert 0 < len(eh) < len(h)
     return len(eh), len(h)
+
+
+def check_probe_forms(dev, contigs, reads, k, w, **kw):
+    """Both forms of the index lookup on one index: the first batch goes through the slot tags, a batch after one that found
+    most of its minimizers reads the slots directly (probe_kernel<false>); both must equal the oracle."""
+    ctg_len = np.array([len(s) for s in contigs], np.uint32)
+    with dev.batch(contigs) as cb, dev.sketch(cb, k, w) as csk, dev.index(csk, ctg_len) as ix:
+        coff, ch, cp, cs = csk.download()
+        oix = oracle.Index(ch, contig_ids(coff), cp, cs)
+        fractions = []
+        for rs in (reads, reads, list(reversed(reads))):
+            rlen = np.array([len(s) for s in rs], np.uint32)
+            with dev.batch(rs) as rb, dev.sketch(rb, k, w) as rsk, dev.map(ix, rsk, rlen, k=k, **kw) as res:
+                got = res.download()
+                roff, rh, rp, rstr = rsk.download()
+                fractions.append(res.n_index_hits / max(rsk.count, 1))
+            exp = oracle.map_reads(oix, ctg_len, roff, rlen, rh, rp, rstr, threads=0, k=k, **kw)
+            assert_same_records(got, exp)
+    return fractions

@@ -335,3 +335,15 @@ def test_overlap_consumer_matches_reference(dev, case, tmp_path):
 def test_overlap_filter_random(dev, seed, nseq, max_len):
     kept, total = pc.check_overlap_random(dev, seed, nseq, max_len)
     assert kept < total
+
+
+def test_probe_with_and_without_tags(dev):
+    """probe_kernel<true> (first batch on an index) and probe_kernel<false> (after a batch that found most of its minimizers,
+    the HiFi case): both equal the oracle, specific and sensitive."""
+    rng = np.random.default_rng(12)
+    contigs = [bytes(synth.random_bases(rng, n)) for n in (300_000, 120_000, 80_000, 999)]
+    reads = [contigs[0][5000:45000], contigs[1][100:39000] + contigs[2][:20000], bytes(synth.random_bases(rng, 30000)),
+             contigs[0][100_000:160_000], contigs[3] + contigs[2][40000:70000]] * 20
+    for sens in (False, True):
+        fr = pc.check_probe_forms(dev, contigs, reads, 24, 100, z=1000, sensitive=sens)
+        assert min(fr) > 0.5

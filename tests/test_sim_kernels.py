@@ -271,3 +271,12 @@ def test_sim_packed_batches_sketch_like_ascii_batches(dev, tmp_path):
             off, h, q, s = sk.download()
         ooff, oh, op, os_ = oracle.sketch_batch(b"".join(seqs), pc.offsets_of(seqs), k, w)
         assert np.array_equal(off, ooff) and np.array_equal(h, oh) and np.array_equal(q, op) and np.array_equal(s, os_)
+
+
+def test_sim_probe_with_and_without_tags(dev):
+    """probe_kernel<true> (first batch) and probe_kernel<false> (after a batch that found most minimizers): same records."""
+    rng = np.random.default_rng(12)
+    contigs = [_rand_seq(rng, n) for n in (9000, 4000, 2500)]
+    reads = [contigs[0][500:4000], contigs[1][100:3900] + contigs[2][:2000], _rand_seq(rng, 3000), contigs[0][3000:8000]]
+    fr = pc.check_probe_forms(dev, contigs, reads, 24, 30, z=1000)
+    assert min(fr) > 0.5
