@@ -164,7 +164,7 @@ def main():
 
     def run_batches(d, items, collect, acc):
         for rb, rl in items:
-            rsk = d.sketch(rb, k, w)
+            rsk = d.sketch(rb, k, w, index=ix)  # looked up in the index while emitted: no separate probe pass
             res = d.map(ix, rsk, rl, **params)
             if collect:
                 acc["read_mx"] += rsk.count

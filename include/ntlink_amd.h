@@ -142,6 +142,11 @@ int ntl_batch_download(const ntl_batch *b, char *seqs, uint64_t *offsets);
  * ntHash canonical hash for the window minimum, second hash as the emitted value, window over
  * valid k-mers, rightmost minimum on ties. */
 int ntl_sketch_run(ntl_ctx *ctx, const ntl_batch *b, int k, int w, ntl_sketch **out);
+/* The same sketch made FOR one contig index (read batches of the pair stage): every minimizer is looked up in `ix` while it is
+ * emitted, and ntl_map_run(ix, this sketch) skips its own lookup pass over the 16-byte records -- per-read lookup of
+ * bin/ntlink_pair.py:364-367 fused into the emitter of `indexlr`.  Minimizers and mappings are those of the two-call form;
+ * the index must outlive the sketch. */
+int ntl_sketch_run_indexed(ntl_ctx *ctx, const ntl_batch *b, int k, int w, const ntl_index *ix, ntl_sketch **out);
 void ntl_sketch_destroy(ntl_sketch *s);
 uint64_t ntl_sketch_nseq(const ntl_sketch *s);
 /* Total number of minimizers. */

@@ -20,7 +20,7 @@ SYMBOLS = [
     "ntl_prof_enable", "ntl_prof_reset", "ntl_prof_get",
     "ntl_batch_create", "ntl_batch_create_packed", "ntl_packed_words", "ntl_batch_destroy", "ntl_batch_nseq", "ntl_batch_bases", "ntl_host_alloc", "ntl_host_free",
     "ntl_synth_genome", "ntl_synth_slices", "ntl_batch_download",
-    "ntl_sketch_run", "ntl_sketch_destroy", "ntl_sketch_nseq", "ntl_sketch_count", "ntl_sketch_download",
+    "ntl_sketch_run", "ntl_sketch_run_indexed", "ntl_sketch_destroy", "ntl_sketch_nseq", "ntl_sketch_count", "ntl_sketch_download",
     "ntl_sketch_strips", "ntl_sketch_redo_strips",
     "ntl_sketch_from_host", "ntl_overlap_filter",
     "ntl_index_build", "ntl_index_destroy", "ntl_index_size",
@@ -91,6 +91,7 @@ def load(path=None):
                                    C.POINTER(vp)]
     L.ntl_batch_download.argtypes = [vp, vp, u64p]
     L.ntl_sketch_run.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]
+    L.ntl_sketch_run_indexed.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
     L.ntl_sketch_destroy.argtypes = [vp]
     L.ntl_sketch_destroy.restype = None
     L.ntl_sketch_nseq.argtypes = [vp]
@@ -421,9 +422,14 @@ class Device:
                                           float(sub), float(ins), float(dele), C.byref(p)))
         return Batch(self, p)
 
-    def sketch(self, batch, k, w):
+    def sketch(self, batch, k, w, index=None):
+        """index: the contig Index the sketch will be mapped against -- its minimizers are then looked up while they are emitted
+        and Device.map(index, sketch, ...) skips its lookup pass (same records either way)."""
         p = C.c_void_p()
-        self._chk(self.L.ntl_sketch_run(self.ptr, batch.ptr, int(k), int(w), C.byref(p)))
+        if index is None:
+            self._chk(self.L.ntl_sketch_run(self.ptr, batch.ptr, int(k), int(w), C.byref(p)))
+        else:
+            self._chk(self.L.ntl_sketch_run_indexed(self.ptr, batch.ptr, int(k), int(w), index.ptr, C.byref(p)))
         return Sketch(self, p)
 
     def sketch_from_arrays(self, mx_off, mx_hash, pos, strand):

@@ -18,23 +18,9 @@
 #pragma once
 #include "dev_common.h"
 #include "sketch_kernels.h"
+#include "index_common.h"
 
 /* ------------------------------------------------------------------------------ index ---- */
-
-struct IndexSlot {
-    uint64_t key;  /* NTL_INF = empty */
-    uint32_t pos;
-    uint32_t meta; /* bit 0: duplicate, bit 1: strand, bits 2..31: contig */
-};
-
-struct IndexSpecial { /* the one key that equals the empty marker */
-    uint32_t cnt, pos, meta, pad;
-};
-
-__device__ __forceinline__ uint64_t index_home(uint64_t key, int bits)
-{
-    return (key * 0x9E3779B97F4A7C15ull) >> (64 - bits);
-}
 
 /* also zeroes what the build accumulates into: the duplicate bitmap (one word per 32 slots; nslots is a
  * multiple of 32), the side slot and the kept-key counter */
@@ -48,11 +34,6 @@ __global__ void index_clear_kernel(IndexSlot *slots, uint64_t nslots, uint32_t *
     if (i == 0) { special->cnt = 0; special->pos = 0; special->meta = 0; special->pad = 0; *count = 0; }
 }
 
-/* One-byte tags in front of the 16-byte slots: 0 = empty slot, otherwise 7 bits of the key | 1.  The tag
- * array is 16x smaller than the table, so it stays in L2 / Infinity Cache while the table does not; ~85 %
- * of read minimizers are absent from the index and are rejected on tags alone. */
-__device__ __forceinline__ uint8_t index_tag(uint64_t key) { return (uint8_t)(((key >> 20) & 0xFEu) | 1u); }
-
 /* one atomic per workgroup: sum of per-thread counts (all threads must call) */
 __device__ __forceinline__ void block_count_add(unsigned long long mine, unsigned long long *counter)
 {
@@ -63,6 +44,34 @@ __device__ __forceinline__ void block_count_add(unsigned long long mine, unsigne
     __syncthreads();
     if (threadIdx.x == 0 && s_cnt) atomicAdd(counter, s_cnt);
 }
+
+/* After the inserts, one streaming pass over the table: folds the duplicate bits into the slots, writes the
+ * tag byte of every slot (four slots, one 32-bit store per thread and round) and counts the keys that are
+ * kept.  nslots is a multiple of 32.  Grid-stride: launch a bounded number of workgroups. */
+__global__ void index_finish_kernel(IndexSlot *slots, uint64_t nslots, const IndexSpecial *special, const uint32_t *dup,
+                                    uint8_t *tags, unsigned long long *count)
+{
+    unsigned long long u = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nslots / 4; q += stride) {
+        const uint32_t d = (dup[q >> 3] >> ((q & 7u) * 4u)) & 0xFu;
+        uint32_t four = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint64_t key = slots[4 * q + j].key;
+            if (key != NTL_INF) {
+                four |= (uint32_t)index_tag(key) << (8 * j);
+                if ((d >> j) & 1u) slots[4 * q + j].meta |= 1u;
+                else u++;
+            }
+        }
+        reinterpret_cast<uint32_t *>(tags)[q] = four;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && special->cnt == 1) u++;
+    block_count_add(u, count);
+}
+
+
 
 /* One atomic per minimizer: the compare-and-swap that claims the slot.  The winner then stores its payload
  * with a plain 64-bit write (pos and meta are one aligned word); a later arrival of the same key only sets
@@ -95,36 +104,6 @@ __global__ void index_insert_kernel(const MxRecord *mx, uint64_t n, IndexSlot *s
     }
 }
 
-/* After the inserts, one streaming pass over the table: folds the duplicate bits into the slots, writes the
- * tag byte of every slot (four slots, one 32-bit store per thread and round) and counts the keys that are
- * kept.  nslots is a multiple of 32.  Grid-stride: launch a bounded number of workgroups. */
-__global__ void index_finish_kernel(IndexSlot *slots, uint64_t nslots, const IndexSpecial *special, const uint32_t *dup,
-                                    uint8_t *tags, unsigned long long *count)
-{
-    unsigned long long u = 0;
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nslots / 4; q += stride) {
-        const uint32_t d = (dup[q >> 3] >> ((q & 7u) * 4u)) & 0xFu;
-        uint32_t four = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const uint64_t key = slots[4 * q + j].key;
-            if (key != NTL_INF) {
-                four |= (uint32_t)index_tag(key) << (8 * j);
-                if ((d >> j) & 1u) slots[4 * q + j].meta |= 1u;
-                else u++;
-            }
-        }
-        reinterpret_cast<uint32_t *>(tags)[q] = four;
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0 && special->cnt == 1) u++;
-    block_count_add(u, count);
-}
-
-struct Cand {
-    uint32_t cpos;
-    uint32_t meta; /* bit 0: found and unique, bit 1: contig strand, bits 2..31: contig */
-};
 
 #define PROBE_U 4 /* minimizers per thread and round: their loads are issued together (memory-level parallelism) */
 
@@ -139,9 +118,8 @@ __global__ void probe_kernel(const MxRecord *mx, uint64_t n, const IndexSlot *sl
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x * PROBE_U;
     const uint64_t mask = ((uint64_t)1 << bits) - 1;
     for (uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x * PROBE_U + threadIdx.x; i0 < n; i0 += stride) {
-        uint64_t key[PROBE_U], s[PROBE_U];
-        uint8_t t[PROBE_U];
-        IndexSlot e0[PROBE_U];
+        uint64_t key[PROBE_U];
+        IndexProbe<TAGS> pr[PROBE_U];
         bool live[PROBE_U];
 #pragma unroll
         for (int u = 0; u < PROBE_U; u++) {
@@ -150,47 +128,12 @@ __global__ void probe_kernel(const MxRecord *mx, uint64_t n, const IndexSlot *sl
             key[u] = live[u] ? ntl_stream_load(&mx[i].hash) : 0; /* streamed once: keep L2 for the tags */
         }
 #pragma unroll
-        for (int u = 0; u < PROBE_U; u++) {
-            s[u] = index_home(key[u], bits);
-            if (TAGS) t[u] = live[u] && key[u] != NTL_INF ? tags[s[u]] : (uint8_t)0;
-            else if (live[u] && key[u] != NTL_INF) e0[u] = slots[s[u]];
-        }
+        for (int u = 0; u < PROBE_U; u++)
+            if (live[u]) pr[u].start(key[u], slots, tags, bits); /* the first (random) loads of all four are in flight together */
 #pragma unroll
         for (int u = 0; u < PROBE_U; u++) {
             if (!live[u]) continue;
-            Cand c;
-            c.cpos = 0; c.meta = 0;
-            if (key[u] == NTL_INF) {
-                if (special->cnt == 1) { c.cpos = special->pos; c.meta = (special->meta & ~1u) | 1u; }
-            } else if (TAGS) {
-                const uint8_t tg = index_tag(key[u]);
-                uint64_t q = s[u];
-                uint8_t tq = t[u];
-                for (;;) {
-                    if (tq == 0) break; /* empty slot ends the probe sequence */
-                    if (tq == tg) {
-                        const IndexSlot e = slots[q];
-                        if (e.key == key[u]) {
-                            if (!(e.meta & 1u)) { c.cpos = e.pos; c.meta = e.meta | 1u; }
-                            break;
-                        }
-                    }
-                    q = (q + 1) & mask;
-                    tq = tags[q];
-                }
-            } else {
-                uint64_t q = s[u];
-                IndexSlot e = e0[u];
-                for (;;) {
-                    if (e.key == NTL_INF) break; /* empty slot ends the probe sequence */
-                    if (e.key == key[u]) {
-                        if (!(e.meta & 1u)) { c.cpos = e.pos; c.meta = e.meta | 1u; }
-                        break;
-                    }
-                    q = (q + 1) & mask;
-                    e = slots[q];
-                }
-            }
+            const Cand c = pr[u].finish(key[u], slots, tags, special, mask);
             ntl_stream_store((uint64_t *)&cand[i0 + (uint64_t)u * blockDim.x], (uint64_t)c.cpos | ((uint64_t)c.meta << 32));
             found += c.meta & 1u;
         }

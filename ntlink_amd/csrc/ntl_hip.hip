@@ -614,12 +614,31 @@ extern "C" int ntl_batch_download(const ntl_batch *b, char *seqs, uint64_t *off)
 
 /* ------------------------------------------------------------------ sketch --------------- */
 
+/* ------------------------------------------------------------------ index (type) --------- */
+
+struct ntl_index {
+    ntl_ctx *c;
+    int bits = 0;
+    uint64_t nslots = 0;
+    mutable uint64_t size = 0;
+    mutable bool size_known = false;
+    mutable double hit_fraction = 0.0;   /* of the last batch mapped against this index: picks the probe form */
+    uint32_t n_ctg = 0;
+    DevBuf slots, special, ctg_len, cnt; /* cnt: device-side count of kept keys, fetched on demand */
+    DevBuf tags;                         /* one byte per slot (map_kernels.h index_tag) */
+    std::vector<uint32_t> h_ctg_len;     /* source of the asynchronous upload: must outlive it */
+};
+
 struct ntl_sketch {
     ntl_ctx *c;
     uint64_t nseq = 0, count = 0;
     uint64_t strips = 0, redo_strips = 0; /* diagnostics: strips of the window pass, strips that also took the exact pass */
     DevBuf records; /* MxRecord[count] */
     DevBuf mx_off;  /* u32[nseq+1] */
+    /* ntl_sketch_run_indexed: the minimizers were looked up in cand_ix while they were emitted */
+    const ntl_index *cand_ix = nullptr;
+    DevBuf cand;    /* Cand[count] */
+    DevBuf nfound;  /* u64: lookups that found a unique key */
 };
 
 static uint64_t h_srol1(uint64_t x)
@@ -718,7 +737,7 @@ static void launch_fast_r0(ntl_ctx *c, const Sketch2Args &B, unsigned strips)
     if constexpr (R0 + 1 < 16) launch_fast_r0<NT, R0 + 1>(c, B, strips);
 }
 
-extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_sketch **out)
+static int sketch_run_impl(ntl_ctx *c, const ntl_batch *b, int k, int w, const ntl_index *ix, ntl_sketch **out)
 {
     if (!c || !b || !out) return NTL_EINVAL;
     *out = nullptr;
@@ -880,6 +899,17 @@ extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_
         if (cap_guess > 0xFFFFFFF0ull) cap_guess = 0xFFFFFFF0ull;
         if (const char *e = getenv("NTL_SKETCH_CAP_GUESS")) cap_guess = (uint64_t)atoll(e); /* tests: force the second pass */
         if ((rc = s->records.alloc(c, cap_guess * sizeof(MxRecord)))) return rc;
+        const int probe = !ix ? 0 : (ix->hit_fraction <= 0.5 ? 1 : 2); /* tags first unless the last batch on this index mostly hit */
+        if (ix) {
+            if ((rc = s->cand.alloc(c, cap_guess * sizeof(Cand))) || (rc = s->nfound.alloc(c, 8))) return rc;
+            HIPCHK(c, hipMemsetAsync(s->nfound.p, 0, 8, c->stream));
+            s->cand_ix = ix;
+        }
+        auto launch_emit = [&](const EmitArgs &EA, unsigned ntiles) {
+            if (probe == 0) hipLaunchKernelGGL(emit_kernel<0>, dim3(ntiles), dim3(EMIT_NT), 0, c->stream, EA);
+            else if (probe == 1) hipLaunchKernelGGL(emit_kernel<1>, dim3(ntiles), dim3(EMIT_NT), 0, c->stream, EA);
+            else hipLaunchKernelGGL(emit_kernel<2>, dim3(ntiles), dim3(EMIT_NT), 0, c->stream, EA);
+        };
         EmitArgs E;
         E.packed = T.packed; E.seq_base = T.seq_base; E.nseq = (uint32_t)nseq; E.mask = mask.as<uint32_t>();
         E.nwords = nmask; E.tile_off = tile.as<uint32_t>(); E.mx_off = s->mx_off.as<uint32_t>();
@@ -889,7 +919,12 @@ extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_
         make_tables(k, roll, E.seed_tab);
         E.g4 = (const uint64_t (*)[2])c->g4;
         E.g8 = (const uint64_t (*)[2])c->g8;
-        hipLaunchKernelGGL(emit_kernel, dim3((unsigned)tiles), dim3(EMIT_NT), 0, c->stream, E);
+        E.slots = nullptr; E.tags = nullptr; E.special = nullptr; E.ix_bits = 0; E.cand = nullptr; E.nfound = nullptr;
+        if (ix) {
+            E.slots = ix->slots.as<IndexSlot>(); E.tags = ix->tags.as<uint8_t>(); E.special = ix->special.as<IndexSpecial>();
+            E.ix_bits = ix->bits; E.cand = s->cand.as<Cand>(); E.nfound = s->nfound.as<unsigned long long>();
+        }
+        launch_emit(E, (unsigned)tiles);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(&total_mx, tot.p, 4, hipMemcpyDeviceToHost, c->stream));
         if (fast) HIPCHK(c, hipMemcpyAsync(&redo_n, redo.p, 4, hipMemcpyDeviceToHost, c->stream));
@@ -900,7 +935,12 @@ extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_
         if ((uint64_t)total_mx > cap_guess) {
             if ((rc = s->records.alloc(c, (uint64_t)total_mx * sizeof(MxRecord)))) return rc;
             E.out = s->records.as<MxRecord>(); E.out_cap = total_mx;
-            hipLaunchKernelGGL(emit_kernel, dim3((unsigned)tiles), dim3(EMIT_NT), 0, c->stream, E);
+            if (ix) {
+                if ((rc = s->cand.alloc(c, (uint64_t)total_mx * sizeof(Cand)))) return rc;
+                E.cand = s->cand.as<Cand>();
+                HIPCHK(c, hipMemsetAsync(s->nfound.p, 0, 8, c->stream)); /* the first pass counted a part */
+            }
+            launch_emit(E, (unsigned)tiles);
             HIPCHK(c, hipGetLastError());
         }
     }
@@ -908,6 +948,20 @@ extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_
        same stream behind the kernels above, so no wait is needed */
     *out = s_guard.release();
     return NTL_OK;
+}
+
+extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_sketch **out)
+{
+    return sketch_run_impl(c, b, k, w, nullptr, out);
+}
+
+/* The same sketch made FOR one contig index: every minimizer is looked up in `ix` while it is emitted, and ntl_map_run on
+ * (ix, this sketch) skips its own lookup pass over the records.  The minimizers are those of ntl_sketch_run. */
+extern "C" int ntl_sketch_run_indexed(ntl_ctx *c, const ntl_batch *b, int k, int w, const ntl_index *ix, ntl_sketch **out)
+{
+    if (!ix) return NTL_EINVAL;
+    if (ix->c->device != c->device) return fail(c, NTL_EINVAL, "the index lives on another device");
+    return sketch_run_impl(c, b, k, w, ix, out);
 }
 
 extern "C" void ntl_sketch_destroy(ntl_sketch *s) { delete s; }
@@ -1074,18 +1128,6 @@ extern "C" int ntl_overlap_filter(ntl_ctx *c, const ntl_sketch *s, const uint64_
 
 /* ------------------------------------------------------------------ index ---------------- */
 
-struct ntl_index {
-    ntl_ctx *c;
-    int bits = 0;
-    uint64_t nslots = 0;
-    mutable uint64_t size = 0;
-    mutable bool size_known = false;
-    mutable double hit_fraction = 0.0;   /* of the last batch mapped against this index: picks the probe form */
-    uint32_t n_ctg = 0;
-    DevBuf slots, special, ctg_len, cnt; /* cnt: device-side count of kept keys, fetched on demand */
-    DevBuf tags;                         /* one byte per slot (map_kernels.h index_tag) */
-    std::vector<uint32_t> h_ctg_len;     /* source of the asynchronous upload: must outlive it */
-};
 
 extern "C" int ntl_index_build(ntl_ctx *c, const ntl_sketch *ctg, const uint32_t *ctg_len, uint32_t n_ctg, ntl_index **out)
 {
@@ -1176,7 +1218,9 @@ extern "C" int ntl_map_run(ntl_ctx *c, const ntl_index *ix, const ntl_sketch *re
     MapSums *dsums = sums.as<MapSums>();
     if (nreads) HIPCHK(c, hipMemcpyAsync(rlen.p, read_len, nreads * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(sums.p, 0, sizeof(MapSums), c->stream));
-    {
+    const bool have_cand = reads->cand_ix == ix && reads->cand.p != nullptr;
+    if (have_cand) HIPCHK(c, hipMemcpyAsync(&dsums->nfound, reads->nfound.p, 8, hipMemcpyDeviceToDevice, c->stream));
+    if (!have_cand) {
         ProfSpan sp(c, "probe");
         if (nmx) {
             const dim3 grid((unsigned)std::min<uint64_t>((nmx + 256 * PROBE_U - 1) / (256 * PROBE_U), 4096));
@@ -1195,7 +1239,8 @@ extern "C" int ntl_map_run(ntl_ctx *c, const ntl_index *ix, const ntl_sketch *re
         HIPCHK(c, hipGetLastError());
     }
     MapArgs A;
-    A.mx = reads->records.as<MxRecord>(); A.mx_off = reads->mx_off.as<uint32_t>(); A.cand = cand.as<Cand>();
+    A.mx = reads->records.as<MxRecord>(); A.mx_off = reads->mx_off.as<uint32_t>();
+    A.cand = have_cand ? reads->cand.as<Cand>() : cand.as<Cand>();
     A.read_len = rlen.as<uint32_t>(); A.ctg_len = ix->ctg_len.as<uint32_t>(); A.nreads = (uint32_t)nreads;
     A.P.k = params->k; A.P.z = params->z; A.P.x = params->x; A.P.sensitive = params->sensitive;
     A.P.repeat_filter = params->repeat_filter;

@@ -24,6 +24,7 @@
  */
 #pragma once
 #include "dev_common.h"
+#include "index_common.h"
 
 struct SeqTables {
     const uint32_t *packed;        /* 2-bit bases, 16 per word, NTL_LEAD_PAD bases of front padding */
@@ -443,6 +444,14 @@ struct EmitArgs {
     uint64_t seed_tab[4][2];
     const uint64_t (*g4)[2];
     const uint64_t (*g8)[2];
+    /* PROBE != 0: the sketch is made for one contig index and every minimizer is looked up as it is emitted (what probe_kernel
+       would do in a pass of its own over the 16-byte records): candidate i belongs to record i */
+    const IndexSlot *slots;
+    const uint8_t *tags;
+    const IndexSpecial *special;
+    int ix_bits;
+    Cand *cand;
+    unsigned long long *nfound;
 };
 
 #define EMIT_SEQ_CAP 512 /* sequence starts of one tile cached in LDS */
@@ -457,8 +466,11 @@ __device__ __forceinline__ uint32_t seq_of(const uint64_t *base, uint32_t lo, ui
     return lo;
 }
 
+/* PROBE: 0 = records only, 1 = + index lookup through the slot tags, 2 = + index lookup on the slots directly (index_common.h) */
+template <int PROBE>
 __global__ __launch_bounds__(EMIT_NT) void emit_kernel(EmitArgs A)
 {
+    unsigned long long found = 0;
     __shared__ uint32_t s_tmp[EMIT_NT];
     __shared__ uint16_t s_list[EMIT_CAP];
     __shared__ uint16_t s_wrank[EMIT_TILE]; /* set bits of the tile before each of its words */
@@ -573,8 +585,25 @@ __global__ __launch_bounds__(EMIT_NT) void emit_kernel(EmitArgs A)
             R.hash = tt;
             R.pos = (uint32_t)(gp - sb);
             R.meta = (sq << 1) | (fwd <= rev ? 1u : 0u);
-            if (tile_base + r0 + i < A.out_cap) A.out[tile_base + r0 + i] = R;
+            if (tile_base + r0 + i < A.out_cap) {
+                A.out[tile_base + r0 + i] = R;
+                if (PROBE) {
+                    IndexProbe<PROBE == 1> pr;
+                    pr.start(tt, A.slots, A.tags, A.ix_bits);
+                    const Cand cd = pr.finish(tt, A.slots, A.tags, A.special, ((uint64_t)1 << A.ix_bits) - 1);
+                    A.cand[tile_base + r0 + i] = cd;
+                    found += cd.meta & 1u;
+                }
+            }
         }
         __syncthreads();
+    }
+    if (PROBE) { /* one atomic per workgroup */
+        __syncthreads();
+        if (t == 0) s_range[0] = 0;
+        __syncthreads();
+        if (found) atomicAdd(&s_range[0], (uint32_t)found);
+        __syncthreads();
+        if (t == 0 && s_range[0]) atomicAdd(A.nfound, (unsigned long long)s_range[0]);
     }
 }

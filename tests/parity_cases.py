@@ -266,6 +266,13 @@ def check_probe_forms(dev, contigs, reads, k, w, **kw):
                 got = res.download()
                 roff, rh, rp, rstr = rsk.download()
                 fractions.append(res.n_index_hits / max(rsk.count, 1))
+                # the sketch made for the index (lookups inside emit_kernel, no probe pass): same minimizers, same records
+                with dev.sketch(rb, k, w, index=ix) as isk, dev.map(ix, isk, rlen, k=k, **kw) as ires:
+                    got2 = ires.download()
+                    ioff, ih, ip, istr = isk.download()
+                    assert ires.n_index_hits == res.n_index_hits
+                assert np.array_equal(ioff, roff) and np.array_equal(ih, rh) and np.array_equal(ip, rp) and np.array_equal(istr, rstr)
             exp = oracle.map_reads(oix, ctg_len, roff, rlen, rh, rp, rstr, threads=0, k=k, **kw)
             assert_same_records(got, exp)
+            assert_same_records(got2, exp)
     return fractions
