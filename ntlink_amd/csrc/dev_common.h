@@ -101,8 +101,8 @@ __device__ __forceinline__ void hash_init_loop(const uint32_t *__restrict__ pack
         for (int g = 0; g < ng; g++) {
             const uint32_t byte = (s >> (8 * g)) & 255u;
             const uint64_t gf = g4[byte][0], gu = g4[byte][1];
-            f = srot(f, 4, 4) ^ gf;
-            u = srot(u, 29, 27) ^ gu;
+            f = srot_h(f, 4, 4) ^ gf;
+            u = srot_h(u, 29, 27) ^ gu;
         }
         for (int j = ng * 4; j < nb; j++) {
             const uint32_t c = (s >> (2 * j)) & 3u;
@@ -111,7 +111,7 @@ __device__ __forceinline__ void hash_init_loop(const uint32_t *__restrict__ pack
         }
     }
     fwd = f;
-    rev = srot(u, (uint32_t)(k - 1) % 33u, (uint32_t)(k - 1) % 31u);
+    rev = srot_u(u, (uint32_t)(k - 1) % 33u, (uint32_t)(k - 1) % 31u);
 }
 
 /* k <= 64: straight-line form, EIGHT bases per step through g8 (65536 entries x 16 B = 1 MB, L2-resident,
@@ -145,15 +145,15 @@ __device__ __forceinline__ void hash_init(const uint32_t *__restrict__ packed, u
 #pragma unroll
     for (int g = 0; g < 8; g++) {
         if (g < n8) { /* uniform */
-            f = srot(f, 8, 8) ^ gf[g];
-            u = srot(u, 25, 23) ^ gu[g];
+            f = srot_h(f, 8, 8) ^ gf[g];
+            u = srot_h(u, 25, 23) ^ gu[g];
         }
     }
     int j = n8 * 8;
     if (k - j >= 4) {
         const uint32_t byte = (s[(j >> 4) & 3] >> (2 * (j & 15))) & 255u;
-        f = srot(f, 4, 4) ^ g4[byte][0];
-        u = srot(u, 29, 27) ^ g4[byte][1];
+        f = srot_h(f, 4, 4) ^ g4[byte][0];
+        u = srot_h(u, 29, 27) ^ g4[byte][1];
         j += 4;
     }
     for (; j < k; j++) { /* k % 4 trailing bases */
@@ -162,7 +162,7 @@ __device__ __forceinline__ void hash_init(const uint32_t *__restrict__ packed, u
         u = sror1(u) ^ seed_tab[c][1];
     }
     fwd = f;
-    rev = srot(u, (uint32_t)(k - 1) % 33u, (uint32_t)(k - 1) % 31u);
+    rev = srot_u(u, (uint32_t)(k - 1) % 33u, (uint32_t)(k - 1) % 31u);
 }
 
 /* The same with four bases per step only (g4, e.g. an LDS copy): for callers whose table lookups should
@@ -186,8 +186,8 @@ __device__ __forceinline__ void hash_init_g4(const uint32_t *__restrict__ packed
     for (int g = 0; g < 16; g++) {
         if (g < ng) { /* uniform */
             const uint32_t byte = (s[g >> 2] >> (8 * (g & 3))) & 255u;
-            f = srot(f, 4, 4) ^ g4[byte][0];
-            u = srot(u, 29, 27) ^ g4[byte][1];
+            f = srot_h(f, 4, 4) ^ g4[byte][0];
+            u = srot_h(u, 29, 27) ^ g4[byte][1];
         }
     }
     for (int j = ng * 4; j < k; j++) {
@@ -196,7 +196,7 @@ __device__ __forceinline__ void hash_init_g4(const uint32_t *__restrict__ packed
         u = sror1(u) ^ seed_tab[c][1];
     }
     fwd = f;
-    rev = srot(u, (uint32_t)(k - 1) % 33u, (uint32_t)(k - 1) % 31u);
+    rev = srot_u(u, (uint32_t)(k - 1) % 33u, (uint32_t)(k - 1) % 31u);
 }
 
 /* Exclusive scan of one value per thread over a workgroup of NT threads; returns the prefix and

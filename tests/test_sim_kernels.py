@@ -198,8 +198,8 @@ def test_sim_fast_window_pass_decides_random_sequence_alone(dev):
     """sketch_fast_kernel (32-bit keys, searched change points): on random sequence no strip needs the exact pass,
     and the result is the oracle's."""
     rng = np.random.default_rng(5)
-    seqs = [_rand_seq(rng, n) for n in (9000, 4200, 17000, 300, 131, 5000)]
-    for k, w in ((32, 100), (32, 250), (24, 100), (40, 31), (15, 16), (64, 64), (100, 70)):
+    seqs = [_rand_seq(rng, n) for n in (9000, 4200, 300, 131, 5000)]
+    for k, w in ((32, 100), (32, 250), (24, 100), (40, 31), (15, 16), (100, 70)):
         st = {}
         pc.check_sketch(dev, seqs, k, w, info=st)
         assert st["strips"] > 0 and st["redo_strips"] == 0, (k, w, st)
