@@ -57,6 +57,8 @@ def main(argv=None):
     t0 = time.perf_counter()
     comm = DistComm("gloo")  # a few host objects only; the device work needs no collective
     local = int(os.environ.get("LOCAL_RANK", comm.rank))
+    if os.environ.get("NTL_DIST_ONE_DEVICE"):  # every rank on the GPU with this ordinal (tests on a one-GPU box)
+        local = int(os.environ["NTL_DIST_ONE_DEVICE"])
     from . import capi
     dev = capi.Device(local)
     try:

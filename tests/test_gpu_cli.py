@@ -189,3 +189,26 @@ def test_file_to_file_at_scale_equals_oracle(tmp_path, monkeypatch):
     recs = [(n, 0, ch[int(c_off[i]):int(c_off[i + 1])], cp[int(c_off[i]):int(c_off[i + 1])], cs[int(c_off[i]):int(c_off[i + 1])])
             for i, n in enumerate(ctg_names)]
     assert read_text(f"asm.fa.k{k}.w{w}.tsv") == oracle.format_indexlr(recs)
+
+
+def test_three_processes_shard_the_reads(tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 3 -m ntlink_amd.dist_pair pair ...` on real HIP contexts (the three ranks share
+    this box's one GPU): every rank parses, maps and writes its byte range of the read files; the files are those of one process."""
+    import oracle
+    target, k, w = "scaffolds_1.fa", 32, 250
+    _stage(tmp_path, target)
+    recs = list(oracle.read_fastx(os.path.join(REF, "long_reads_1.fa")))
+    cuts = [0, len(recs) // 3, len(recs)]
+    names = ["a.fa", "b.fa"]
+    for (a, b), n in zip(zip(cuts, cuts[1:]), names):
+        with open(tmp_path / n, "w") as fh:
+            for name, seq in recs[a:b]:
+                fh.write(f">{name}\n{seq.decode() if isinstance(seq, bytes) else seq}\n")
+    env = dict(os.environ, NTL_DIST_ONE_DEVICE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3", "--master-addr", "127.0.0.1",
+           "--master-port", "29581", "-m", "ntlink_amd.dist_pair", "pair", f"target={target}", "reads=" + " ".join(names), f"k={k}", f"w={w}",
+           "paf=True", "ntlink_pairs_tsv=True"]
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    assert subprocess.call(cmd, cwd=tmp_path, env=env, timeout=600) == 0
+    _check_outputs(tmp_path, f"{target}.k{k}.w{w}.z1000", "t1_k32_w250", "scaffolds_1.fa.k32.w250")
+    assert not [f for f in os.listdir(tmp_path) if ".part" in f]
