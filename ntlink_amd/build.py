@@ -31,7 +31,15 @@ def _stale(target, deps):
 
 
 def build_hip(force=False, extra_flags=()):
+    """Serialised across processes (several test workers may ask for the library at once): a file lock around the build."""
+    import fcntl
     os.makedirs(OBJ, exist_ok=True)
+    with open(os.path.join(OBJ, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        return _build_hip_locked(force, extra_flags)
+
+
+def _build_hip_locked(force, extra_flags):
     hipcc = hipcc_path()
     # NTL_EXTRA_HIPCC_FLAGS: tools only (e.g. -DNTL_SKETCH_ABLATION for tools/gpu_ablate.sh)
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-I", CSRC, *extra_flags,

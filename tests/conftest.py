@@ -15,3 +15,13 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_xdist_auto_num_workers(config):
+    """`-n auto` of pytest.ini: one process where a GPU is present (the -m gpu tests share the device and their native library is
+    what the run is about), a few workers otherwise (NTL_PYTEST_WORKERS overrides; 0 = serial)."""
+    if "NTL_PYTEST_WORKERS" in os.environ:
+        return int(os.environ["NTL_PYTEST_WORKERS"])
+    if os.path.exists("/dev/kfd"):
+        return 0
+    return max(1, min(4, (os.cpu_count() or 2) // 2))

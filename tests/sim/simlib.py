@@ -14,6 +14,15 @@ SRC = [os.path.join(ROOT, "ntlink_amd", "csrc", f) for f in
 
 
 def build(sanitize=False):
+    """Serialised across processes (pytest-xdist workers, the ranks of the multi-process tests): a file lock around the build."""
+    import fcntl
+    os.makedirs(os.path.dirname(SIM_LIB), exist_ok=True)
+    with open(os.path.join(os.path.dirname(SIM_LIB), ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        return _build_locked(sanitize)
+
+
+def _build_locked(sanitize):
     out = SIM_LIB if not sanitize else SIM_LIB.replace(".so", "_asan.so")
     if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(s) for s in SRC):
         return out
