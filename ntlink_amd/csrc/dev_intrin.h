@@ -10,6 +10,9 @@ __device__ __forceinline__ uint32_t ntl_alignbit(uint32_t hi, uint32_t lo, uint3
     return __builtin_amdgcn_alignbit(hi, lo, sh);
 }
 
+/* (x >> off) & ((1 << width) - 1) : v_bfe_u32 */
+__device__ __forceinline__ uint32_t ntl_bfe(uint32_t x, uint32_t off, uint32_t width) { return __builtin_amdgcn_ubfe(x, off, width); }
+
 /* (a & mask) | (b & ~mask) : v_bfi_b32 (written as asm: the compiler re-associates the C form into more instructions) */
 template <uint32_t MASK>
 __device__ __forceinline__ uint32_t ntl_bfi(uint32_t a, uint32_t b)
@@ -32,6 +35,15 @@ __device__ __forceinline__ uint32_t ntl_shl1_or_le(uint32_t acc, uint32_t a, uin
 {
     uint32_t r;
     asm("v_cmp_le_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %3, %3, vcc" : "=v"(r) : "v"(a), "v"(b), "v"(acc) : "vcc");
+    return r;
+}
+
+/* (acc << 1) | (a < b), and d = a - b (wrapping): v_sub_co_u32 (the borrow is the comparison) + v_addc_co_u32 */
+__device__ __forceinline__ uint32_t ntl_shl1_or_lt_diff(uint32_t acc, uint32_t a, uint32_t b, uint32_t &d)
+{
+    uint32_t r, dd;
+    asm("v_sub_co_u32 %1, vcc, %2, %3\n\tv_addc_co_u32 %0, vcc, %4, %4, vcc" : "=v"(r), "=&v"(dd) : "v"(a), "v"(b), "v"(acc) : "vcc");
+    d = dd;
     return r;
 }
 

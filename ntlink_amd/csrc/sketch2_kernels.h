@@ -1,32 +1,36 @@
 /*
- * sketch_fast_kernel: the window pass of the (k,w) minimizer sketch on 32-bit keys.
+ * sketch_fast_kernel: the window pass of the (k,w) minimizer sketch on 32-bit keys made from the hashes' 31-bit rings.
  *
  * Same contract and strip geometry as sketch_mask_kernel (sketch_kernels.h; btllib `indexlr`, ntLink:199,223,
  * SURVEY.md 8 rows a1-a2): one workgroup = one strip of NT*16 consecutive valid-k-mer ordinals of one
  * sequence, lane L owns 16 of them, one bit per emitted minimizer in the global bitmask.  What differs is the
  * arithmetic between the hash and the bit:
  *
- *   key      the window minimum is taken on c = h0 >> 32 (one register, v_min_u32) instead of the 64-bit h0
- *            plus an index (compare + three selects per combine).  Positions are NOT tracked.
+ *   key      ntHash's split rotation never mixes bits 33..63 of a hash (a 31-bit ring) with bits 0..32, so the rolling update
+ *            of that ring alone is closed: rotate, XOR the ring part of the seeds.  The window minimum is taken on
+ *            key = 2 * ((F + R) mod 2^31) + junk bit, F and R the rings of fwd and rev: one register (v_min_u32) instead of
+ *            the 64-bit h0 plus an index, and 8 instructions per k-mer instead of 16 for the roll.  With c = h0 >> 33:
+ *            c = (F + R + carry of the low 33 bits) mod 2^31, so  key >> 1 <= c <= (key >> 1) + 1  (mod 2^31), and
+ *            key_i + 4 <= key_j  implies  c_i < c_j  implies  h0_i < h0_j.  Positions are NOT tracked.
  *   argmin   a window whose minimum VALUE differs from the previous window's is a "changed" window (2/(w+1) of
  *            all).  Where the value dropped, the element that just entered is the new minimum (nothing else can
- *            be below the old one); where it rose, sixteen lanes search the window for the position of its
+ *            be below the old one); where it rose, four lanes search the window for the position of its
  *            minimum over the block minima and two blocks of elements staged in LDS.
- *   exact    the result equals Indexlr's rightmost 64-bit argmin unless two k-mers that share a window also
- *            share the top 32 bits of h0 while being that window's minimum (identical k-mers in low-complexity
- *            sequence, or 2^-32 coincidences).  Every such case is DETECTED -- an entering element equal to
- *            the previous window's minimum while that minimum stays, or a searched window whose minimum occurs twice -- and the strip
- *            is handed to sketch_mask_kernel (the exact 64-bit pass) through a redo list.  Bits are only ever
- *            set for proven minimizers, and setting a bit is idempotent, so both kernels may write one strip.
+ *   exact    the result equals Indexlr's rightmost 64-bit argmin unless two k-mers that share a window have keys within
+ *            SK2_NEAR = 3 of each other while one of them is that window's minimum (identical k-mers in low-complexity
+ *            sequence, or 2^-29 coincidences).  Every such case is DETECTED and the strip is handed to sketch_mask_kernel
+ *            (the exact 64-bit pass) through a redo list.  Bits are only ever set for proven minimizers, and setting a
+ *            bit is idempotent, so both kernels may write one strip.
  *
- *   Why this is exact (c is a non-decreasing function of h0; "value" = c):
- *   (1) If a window's minimum value v occurs once in it, that element is the 64-bit argmin, rightmost or not.
- *   (2) Let windows s-1 and s have the same minimum value v.  Either the element entering at s has value v
- *       (flagged: `hh == x_prev`), or the occurrences of v in window s are a subset of those in window s-1;
- *       with (1) holding for the last searched window the argmin is unchanged.
- *   (3) The first owned window of a strip and every changed window are searched; a search counts the
- *       occurrences of the minimum inside the window and flags the strip unless there is exactly one.
- *   (4) v == 2^32-1 (padding, or h0 >= 2^64 - 2^32, which Indexlr never emits when it is 2^64-1) flags.
+ *   Why this is exact.  Invariant: the minimum key v of window s is attained by an element m and every other element of
+ *   the window has a key > v + SK2_NEAR; then m is the 64-bit argmin, rightmost or not.
+ *   (1) Searched windows (the first owned window of a strip, and every window whose minimum rose): the search counts the
+ *       elements with key <= v + SK2_NEAR and flags the strip unless there is exactly one.
+ *   (2) Every other window s compares the entering element e with the minimum v' of window s-1, for which the invariant
+ *       holds.  |e - v'| <= SK2_NEAR flags the strip.  e < v' - SK2_NEAR: everything else in the window was in window s-1,
+ *       so it is >= v' > e + SK2_NEAR: e is the new m.  e > v' + SK2_NEAR and the minimum unchanged: the old m is still
+ *       there (had it left, the minimum would have risen past v' + SK2_NEAR) and still alone.
+ *   (3) A real k-mer with key >= 2^32 - 2 flags the strip: its c may have wrapped to 0.  v == 2^32-1 (padding) flags.
  *
  * The hash of a lane's first k-mer is assembled from 16-base partial hashes that neighbouring lanes compute
  * for their own 16 bases (two 8-base table lookups each) and exchange through LDS:
@@ -39,6 +43,7 @@
 #define SK2_QMAX 16     /* k <= 16 * SK2_QMAX */
 #define SK2_PAD 72      /* whole blocks right of a window's first block: a + 2 <= SK2_PAD, i.e. w <= 1135; larger windows take the exact pass */
 #define SK2_INF 0xFFFFFFFFu
+#define SK2_NEAR 3u     /* keys closer than this + 1 do not order their k-mers (see "exact") */
 /* phase ablation for tools/gpu_ablate.sh (results WRONG): only in builds with -DNTL_SKETCH_ABLATION, so that the product
    kernel carries no run-time switches inside its unrolled loops */
 #ifdef NTL_SKETCH_ABLATION
@@ -136,11 +141,11 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
     __shared__ uint32_t s_pre0[NT + 4];         /* minimum of the first R0 elements of each block */
     __shared__ uint32_t s_bits[NBW];
     __shared__ uint32_t s_njobs, s_flag;
-    __shared__ uint64_t s_roll[16][2];
+    __shared__ uint32_t s_roll[64];             /* [2 * (in<<2|out)] = the 31-bit-ring parts {fwd seed >> 33, rev seed >> 32} of roll_tab */
     __shared__ uint32_t s_t0[NT + PAD];         /* range-minimum levels */
     __shared__ uint32_t s_t1[BIG ? NT + PAD : 1];
     __shared__ uint16_t s_jobs_big[BIG ? SK2_JOBCAP : 1];
-    uint16_t *const s_jobs = BIG ? s_jobs_big : (uint16_t *)&s_roll[0][0]; /* 256 B = 128 jobs: written two barriers after the last roll */
+    uint16_t *const s_jobs = BIG ? s_jobs_big : (uint16_t *)&s_roll[0]; /* 256 B = 128 jobs: written two barriers after the last roll */
     uint64_t (*const s_xy)[2] = (uint64_t (*)[2])s_c;
     uint32_t *const s_so = (uint32_t *)&s_xy[2 * NX][0]; /* [NX + 1] the chunks' base words, behind the partial hashes */
     static_assert(sizeof(uint32_t) * C * ST >= sizeof(uint64_t) * 4 * NX + sizeof(uint32_t) * (NX + 1), "the exchange area must fit the element array");
@@ -154,7 +159,7 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
     const StripInfo I = A.strip_tab[strip];
     if (I.seq == NTL_NONE || I.multi != 0) return; /* strips that cross non-ACGT runs: sketch_mask_kernel<.., MULTI = true> */
     /* nothing written here is read before the first barrier below */
-    if (L < 16) { s_roll[L][0] = A.roll_tab[L][0]; s_roll[L][1] = A.roll_tab[L][1]; }
+    if (L < 16) { s_roll[2 * L] = (uint32_t)(A.roll_tab[L][0] >> 33); s_roll[2 * L + 1] = (uint32_t)(A.roll_tab[L][1] >> 32); }
     if (L < NBW) s_bits[L] = 0;
     if (L < PAD) s_bm[NT + L] = SK2_INF;
     if (L < 4) s_pre0[NT + L] = SK2_INF;
@@ -216,20 +221,32 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
     }
     __syncthreads(); /* the partial hashes have been read: s_c may take the elements */
     if (live) {
-        c[0] = (uint32_t)((fwd + rev) >> 32);
-        /* table index of step t: in<<2 | out, two bits each at base t of si / so -> nibbles of two words */
-        const uint32_t zev = (so & 0x33333333u) | ((si & 0x33333333u) << 2);        /* even bases: nibble i <-> base 2i */
-        const uint32_t zod = ((so >> 2) & 0x33333333u) | (si & 0xCCCCCCCCu);         /* odd bases */
+        /* Only the 31-bit rings (bits 33..63) are rolled: fx holds fwd's ring in bits 0..30 (bit 31: junk), ry holds rev's in
+           bits 1..31 (bit 0: junk), so that a rotation is two instructions and key = 2 * (F + R) + junk is one. */
+        uint32_t fx = (uint32_t)(fwd >> 33), ry = (uint32_t)(rev >> 32);
+        c[0] = (fx << 1) + ry;
+        uint32_t mx = c[0];
+        /* byte offset into s_roll of step t = b + 1: 8 * (in<<2 | out) for base b of si / so, as byte b/4 of word b%4 */
+        uint32_t wz[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const uint32_t o2 = r < 2 ? so << (3 - 2 * r) : so >> (2 * r - 3);
+            const uint32_t i2 = r < 3 ? si << (5 - 2 * r) : si >> (2 * r - 5);
+            wz[r] = (o2 & 0x18181818u) | (i2 & 0x60606060u);
+        }
 #pragma unroll
         for (int t = 1; t < C; t++) {
-            if (SK2_DBG(B, 4)) { c[t] = c[0] + (uint32_t)t * zev; continue; }
+            if (SK2_DBG(B, 4)) { c[t] = c[0] + (uint32_t)t * wz[0]; continue; }
             const int b = t - 1;
-            const uint32_t z = (b & 1) ? zod : zev;
-            const uint32_t idx = (z >> (4 * (b >> 1))) & 15u;
-            fwd = srol1(fwd) ^ s_roll[idx][0];
-            rev = sror1(rev ^ s_roll[idx][1]);
-            c[t] = (uint32_t)((fwd + rev) >> 32);
+            const uint32_t off = ntl_bfe(wz[b & 3], 8u * (uint32_t)(b >> 2), 8u);
+            const uint2 sd = *(const uint2 *)((const char *)s_roll + off);
+            fx = ((fx << 1) | ((fx >> 30) & 1u)) ^ sd.x;        /* srol1 on the ring: v_bfe + v_lshl_or */
+            const uint32_t a = ry ^ sd.y;
+            ry = ntl_alignbit(a >> 1, a, 1);                    /* sror1: ring bit 0 (bit 1 of a) -> bit 31 */
+            c[t] = (fx << 1) + ry;                              /* v_lshl_add_u32 */
+            mx = c[t] > mx ? c[t] : mx;
         }
+        if (mx >= 0xFFFFFFFEu) s_flag = 16u; /* the ring sum 2^31 - 1: h0 >> 33 may have wrapped to 0 (rule 4) */
         if (e_lane < 0 || e_lane + C > (int64_t)I.M) { /* strip edges only */
 #pragma unroll
             for (int t = 0; t < C; t++) {
@@ -292,7 +309,8 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
                 const uint32_t hh = s_pre0[Lr];
                 P = hh < P ? hh : P;
             }
-            uint32_t xp = 0, acc = 0, lacc = 0; /* change bits / "entering element <= previous minimum" bits, newest in bit 0 */
+            uint32_t xp = 0, acc = 0, lacc = 0; /* change bits / "entering element < previous minimum" bits, newest in bit 0 */
+            uint32_t dlo = SK2_INF, dhi = 0;    /* extremes of (entering element - previous minimum), wrapping */
 #pragma unroll
             for (int j = 0; j <= C; j++) {
                 const int rt = R0 + j;
@@ -306,19 +324,29 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
                 uint32_t x = P;
                 if (j < C) x = P < c[j] ? P : c[j];
                 if (j > 0) {
-                    if (!CHECK) { acc = ntl_shl1_or_ne(acc, x, xp); lacc = ntl_shl1_or_le(lacc, hh, xp); }
+                    uint32_t d = hh - xp;
+                    if (!CHECK) { acc = ntl_shl1_or_ne(acc, x, xp); lacc = ntl_shl1_or_lt_diff(lacc, hh, xp, d); }
                     else if (e_lane + j + G.w <= (int64_t)I.M && e_lane + j >= 0) {
                         chg |= (x != xp ? 1u : 0u) << j;
-                        le |= (hh <= xp ? 1u : 0u) << j;
-                    }
+                        le |= (hh < xp ? 1u : 0u) << j;
+                    } else d = 0x80000000u;
+                    dlo = d < dlo ? d : dlo;
+                    dhi = d > dhi ? d : dhi;
                 }
                 xp = x;
             }
             if (!CHECK) { chg = ntl_brev(acc) >> 15; le = ntl_brev(lacc) >> 15; } /* bit 16-j of acc is window j */
+            return dlo <= SK2_NEAR || dhi >= 0u - SK2_NEAR;
         };
         if (own) {
-            if (all_inside) window_pass(NtlFalse());
-            else window_pass(NtlTrue());
+            const bool near = all_inside ? window_pass(NtlFalse()) : window_pass(NtlTrue());
+            /* an entering element within SK2_NEAR of the previous window's minimum, on either side: their order is open */
+            if (near) {
+                s_flag = 2u;
+#ifdef NTL_SIM
+                if (getenv("NTL_SK2_DEBUG")) fprintf(stderr, "strip %u lane %d near tie M=%u E0=%d\n", strip, L, I.M, I.E0);
+#endif
+            }
         }
     }
     if (own) {
@@ -326,15 +354,8 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
            window (LW-1,16) is the next strip's */
         if (L == 0) { if (e_lane + 1 + G.w <= (int64_t)I.M) chg |= 2u; le &= ~2u; }
         if (L == G.LW - 1) { chg &= 0xFFFFu; le &= 0xFFFFu; }
-        /* entering element <= previous minimum:  minimum unchanged -> the two are equal: a tie (or the old minimum just
-           left: flagged all the same);  minimum changed -> it dropped, and only the entering element can be below the
-           old minimum: it is the new, unique minimum, no search needed */
-        if (le & ~chg) {
-            s_flag = 2u;
-#ifdef NTL_SIM
-            if (getenv("NTL_SK2_DEBUG")) fprintf(stderr, "strip %u lane %d tie chg=%x le=%x M=%u E0=%d\n", strip, L, chg, le, I.M, I.E0);
-#endif
-        }
+        /* entering element < previous minimum (and not near it): the minimum dropped, and only the entering element can be
+           below the old minimum: it is the new minimum, alone within SK2_NEAR, no search needed */
         /* ---- phase 5: dropped minima are set right away (the entering element); one job per window whose minimum rose ---- */
         const uint32_t drop = chg & le, rise = chg & ~le;
         if (drop) { /* window j's entering element sits at strip position L*C + j + w - 1: the lane's drop bits, shifted, are its mask bits */
@@ -392,30 +413,30 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
                 v = val[4 + r] < v ? val[4 + r] : v;
                 v = val[8 + r] < v ? val[8 + r] : v;
             }
-            uint32_t xv = SK2_INF, xb = 0;   /* windows of more than 17 blocks (w > 271): the further middle blocks */
-            bool xdup = false;
-            for (uint32_t b = b0 + 17 + q; nmid > 16 && b < b1; b += 4) {
+            for (uint32_t b = b0 + 17 + q; nmid > 16 && b < b1; b += 4) { /* windows of more than 17 blocks (w > 271): the further middle blocks */
                 const uint32_t u = s_bm[b];
-                xdup = xdup || (u == xv && u != SK2_INF);
-                if (u < xv) { xv = u; xb = b; xdup = false; }
+                v = u < v ? u : v;
             }
-            v = xv < v ? xv : v;
             v = ntl_quad_min(v);
+            const uint32_t vn = v + SK2_NEAR; /* a wrap (v within SK2_NEAR of 2^32) leaves no match: flagged */
             uint32_t mk = 0;
 #pragma unroll
-            for (int r = 0; r < 12; r++) mk = ntl_shl1_or_eq(mk, val[r], v); /* bit 11-r: val[r] == v */
-            uint32_t n = (uint32_t)__popc(mk) + (xv == v ? (xdup ? 2u : 1u) : 0u);
+            for (int r = 0; r < 12; r++) mk = ntl_shl1_or_le(mk, val[r], vn); /* bit 11-r: val[r] within SK2_NEAR of the minimum */
+            uint32_t xn = 0, xb = 0;
+            for (uint32_t b = b0 + 17 + q; nmid > 16 && b < b1; b += 4)
+                if (s_bm[b] <= vn) { xn++; xb = b; }
+            uint32_t n = (uint32_t)__popc(mk) + xn;
             const uint32_t r1 = 11u - (uint32_t)(__ffs(mk | 0x1000u) - 1); /* the (last) matching value */
             uint32_t code = r1 < 4 ? b0 * 16 + q + 4u * r1 : (r1 < 8 ? b1 * 16 + q + 4u * (r1 - 4) : (0x10000u | (b0 + 1 + q + 4u * (r1 - 8))));
             if (mk == 0) code = 0x10000u | xb;
             n = ntl_quad_sum(v != SK2_INF ? n : 2u);
-            code = ntl_quad_min(n && (mk || xv == v) ? code : SK2_INF);
+            code = ntl_quad_min(n && (mk || xn) ? code : SK2_INF);
             /* a block minimum: its sixteen elements, four per lane */
             const bool blk = code >= 0x10000u && code != SK2_INF;
             const uint32_t bb = blk ? (code & 0xFFFFu) : 0u;
             uint32_t mk2 = 0;
 #pragma unroll
-            for (int r = 0; r < 4; r++) mk2 = ntl_shl1_or_eq(mk2, s_c[(q + 4u * r) * ST + bb], v);
+            for (int r = 0; r < 4; r++) mk2 = ntl_shl1_or_le(mk2, s_c[(q + 4u * r) * ST + bb], vn);
             const uint32_t n2 = ntl_quad_sum((uint32_t)__popc(mk2));
             const uint32_t p2 = ntl_quad_min(mk2 ? bb * 16 + q + 4u * (3u - (uint32_t)(__ffs(mk2) - 1)) : SK2_INF);
             const bool ok = n == 1 && (!blk || n2 == 1);

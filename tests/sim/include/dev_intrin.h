@@ -8,10 +8,18 @@ inline uint32_t ntl_alignbit(uint32_t hi, uint32_t lo, uint32_t sh)
     return (uint32_t)((((uint64_t)hi << 32) | lo) >> (sh & 31));
 }
 
+inline uint32_t ntl_bfe(uint32_t x, uint32_t off, uint32_t width) { return (x >> off) & ((1u << width) - 1u); }
+
 template <uint32_t MASK> inline uint32_t ntl_bfi(uint32_t a, uint32_t b) { return (a & MASK) | (b & ~MASK); }
 
 inline uint32_t ntl_shl1_or_ne(uint32_t acc, uint32_t a, uint32_t b) { return (acc << 1) | (a != b ? 1u : 0u); }
 inline uint32_t ntl_shl1_or_le(uint32_t acc, uint32_t a, uint32_t b) { return (acc << 1) | (a <= b ? 1u : 0u); }
+
+inline uint32_t ntl_shl1_or_lt_diff(uint32_t acc, uint32_t a, uint32_t b, uint32_t &d)
+{
+    d = a - b;
+    return (acc << 1) | (a < b ? 1u : 0u);
+}
 
 inline uint32_t ntl_row_min16(uint32_t v)
 {

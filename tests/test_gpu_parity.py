@@ -230,7 +230,8 @@ def test_fast_window_pass_decides_random_sequence_alone(dev):
     seqs = [_rand_seq(rng, n) for n in (90000, 4200, 170000, 300, 131, 5000, 1_000_000)]
     for k, w in ((32, 100), (32, 250), (24, 100), (40, 31), (20, 16), (20, 33), (64, 64), (100, 70), (32, 1000), (17, 3000)):
         with dev.batch(seqs) as b, dev.sketch(b, k, w) as sk:
-            assert sk.strips > 0 and sk.redo_strips == 0, (k, w, sk.strips, sk.redo_strips)
+            # 1.3 M windows x 7 / 2^32 chances of an entering key within SK2_NEAR of the minimum: none expected
+            assert sk.strips > 0 and sk.redo_strips <= 1, (k, w, sk.strips, sk.redo_strips)
         pc.check_sketch(dev, seqs, k, w)
 
 
@@ -244,6 +245,18 @@ def test_fast_window_pass_hands_ties_to_the_exact_pass(dev, monkeypatch):
         with dev.batch(seqs) as b, dev.sketch(b, k, w) as sk:
             assert 0 < sk.redo_strips < sk.strips
         pc.check_sketch(dev, seqs, k, w)
+
+
+def test_fast_window_pass_flags_keys_it_cannot_order(dev):
+    """The window pass rolls only the hashes' 31-bit rings (bits 33..63): two different k-mers whose hashes agree in those
+    bits have keys it cannot order.  Sequences in which such a pair competes for a window's minimum (one strip each) must all
+    go to the exact pass, and the sketch is the oracle's whichever of the two is smaller."""
+    for k, n in ((16, 48), (21, 24)):
+        seqs = pc.near_tie_sequences(k, n, seed=11 + k)
+        for w in (40, 64):
+            st = {}
+            pc.check_sketch(dev, seqs, k, w, info=st)
+            assert st["redo_strips"] == st["strips"] == len(seqs), (k, w, st)
 
 
 @pytest.mark.parametrize("env", [{"NTL_SKETCH_FORCE_REDO": "1"}, {"NTL_SKETCH_FAST": "0"}, {"NTL_SKETCH_NT": "128"}, {"NTL_SKETCH_NT": "256"},
@@ -271,7 +284,7 @@ def test_full_size_assembly_parity(dev, name, n_reads):
     cbuf, coff = wl.contigs.download()
     assert int(coff[-1]) > 2_900_000_000 and len(coff) - 1 == 5000
     with dev.sketch(wl.contigs, k, w) as csk, dev.index(csk, wl.ctg_len) as ix:
-        assert csk.redo_strips < 64  # 3e9 k-mers x w neighbours x 2^-32: a handful of 32-bit coincidences are expected
+        assert csk.redo_strips < 64  # 3e9 windows x 7 / 2^32 near-ties of the ring keys + as many among the searched windows: about a dozen
         c_off, ch, cp, cs = csk.download()
         o_off, oh, op, os_ = oracle.sketch_batch(cbuf, coff, k, w)
         assert np.array_equal(c_off, o_off) and np.array_equal(ch, oh) and np.array_equal(cp, op) and np.array_equal(cs, os_)

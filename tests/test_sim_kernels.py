@@ -228,6 +228,18 @@ def test_sim_fast_window_pass_hands_ties_to_the_exact_pass(dev, monkeypatch):
     assert st["redo_strips"] == 0
 
 
+def test_sim_fast_window_pass_flags_keys_it_cannot_order(dev):
+    """The window pass rolls only the hashes' 31-bit rings: two different k-mers whose hashes agree in bits 33..63 have keys
+    it cannot order.  When such a pair competes for a window's minimum the strip must go to the exact pass (every sequence
+    here is one strip), and the result is the oracle's whichever of the two comes first."""
+    k = 16
+    seqs = pc.near_tie_sequences(k, 24)
+    for w in (40, 64):
+        st = {}
+        pc.check_sketch(dev, seqs, k, w, info=st)
+        assert st["redo_strips"] == st["strips"] == len(seqs), st
+
+
 @pytest.mark.parametrize("case", ["synthetic_k15_w5_s1", "synthetic_k8_w3_s3", "scaffolds_4_k15_w5_s1"])
 def test_sim_overlap_consumer_matches_reference(dev, case, tmp_path):
     """read_minimizers / read_minimizers_path of the overlap stage (valid regions, per-contig duplicate
