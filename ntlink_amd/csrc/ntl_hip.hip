@@ -647,6 +647,13 @@ static uint64_t h_srol1(uint64_t x)
     return ((x << 1) & 0xFFFFFFFDFFFFFFFFull) | m;
 }
 
+/* sketch_fast_kernel's keys (sketch2_kernels.h, "exact" (3)) rely on this property of the ntHash seeds: a base and its
+   complement have 31-bit rings (bits 33..63) whose set bits add up to an even number */
+constexpr int ring31_bits(uint64_t s) { int n = 0; for (uint64_t r = s >> 33; r; r >>= 1) n += (int)(r & 1); return n; }
+static_assert((ring31_bits(0x3c8bfbb395c60474ull) + ring31_bits(0x295549f54be24456ull)) % 2 == 0 &&
+              (ring31_bits(0x3193c18562a02b4cull) + ring31_bits(0x20323ed082572324ull)) % 2 == 0,
+              "the ring sum of fwd and rev could be 2^31 - 1: the 32-bit window pass would need a wrap check");
+
 static void make_tables(int k, uint64_t roll[16][2], uint64_t seed[4][2])
 {
     const uint64_t S[4] = {0x3c8bfbb395c60474ull, 0x3193c18562a02b4cull, 0x20323ed082572324ull, 0x295549f54be24456ull};

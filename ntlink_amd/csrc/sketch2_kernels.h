@@ -19,8 +19,7 @@
  *   exact    the result equals Indexlr's rightmost 64-bit argmin unless two k-mers that share a window have keys within
  *            SK2_NEAR = 3 of each other while one of them is that window's minimum (identical k-mers in low-complexity
  *            sequence, or 2^-29 coincidences).  Every such case is DETECTED and the strip is handed to sketch_mask_kernel
- *            (the exact 64-bit pass) through a redo list.  Bits are only ever set for proven minimizers, and setting a
- *            bit is idempotent, so both kernels may write one strip.
+ *            (the exact 64-bit pass) through a redo list, and none of what this pass found for it is written.
  *
  *   Why this is exact.  Invariant: the minimum key v of window s is attained by an element m and every other element of
  *   the window has a key > v + SK2_NEAR; then m is the 64-bit argmin, rightmost or not.
@@ -30,7 +29,14 @@
  *       holds.  |e - v'| <= SK2_NEAR flags the strip.  e < v' - SK2_NEAR: everything else in the window was in window s-1,
  *       so it is >= v' > e + SK2_NEAR: e is the new m.  e > v' + SK2_NEAR and the minimum unchanged: the old m is still
  *       there (had it left, the minimum would have risen past v' + SK2_NEAR) and still alone.
- *   (3) A real k-mer with key >= 2^32 - 2 flags the strip: its c may have wrapped to 0.  v == 2^32-1 (padding) flags.
+ *   (3) (F + R + carry) mod 2^31 could wrap -- ring sum 2^31 - 1, true c = 0: the largest key for the smallest hash -- but
+ *       F + R = 2^31 - 1 means R = ~F, i.e. F ^ R has 31 set bits, and F ^ R always has an EVEN number: it is the XOR, over
+ *       the k bases, of a rotation of seed[b]'s ring and a rotation of seed[complement b]'s ring, and for the ntHash seeds
+ *       the rings of A and T have 19 and 15 set bits, those of C and G 12 and 12 (static_assert next to the seed table in
+ *       ntl_hip.hip; tests/test_host.py checks it on the oracle's hashes).  So no real k-mer has key >= 2^32 - 2, and the
+ *       padding value 2^32 - 1 is nobody's key.
+ *   (4) A flagged strip writes NONE of its bits (a lane that saw a near tie may have taken the wrong side of it for a
+ *       drop); the exact pass redoes the whole strip.  v == 2^32-1 (a window of padding) flags.
  *
  * The hash of a lane's first k-mer is assembled from 16-base partial hashes that neighbouring lanes compute
  * for their own 16 bases (two 8-base table lookups each) and exchange through LDS:
@@ -225,7 +231,6 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
            bits 1..31 (bit 0: junk), so that a rotation is two instructions and key = 2 * (F + R) + junk is one. */
         uint32_t fx = (uint32_t)(fwd >> 33), ry = (uint32_t)(rev >> 32);
         c[0] = (fx << 1) + ry;
-        uint32_t mx = c[0];
         /* byte offset into s_roll of step t = b + 1: 8 * (in<<2 | out) for base b of si / so, as byte b/4 of word b%4 */
         uint32_t wz[4];
 #pragma unroll
@@ -244,9 +249,7 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
             const uint32_t a = ry ^ sd.y;
             ry = ntl_alignbit(a >> 1, a, 1);                    /* sror1: ring bit 0 (bit 1 of a) -> bit 31 */
             c[t] = (fx << 1) + ry;                              /* v_lshl_add_u32 */
-            mx = c[t] > mx ? c[t] : mx;
         }
-        if (mx >= 0xFFFFFFFEu) s_flag = 16u; /* the ring sum 2^31 - 1: h0 >> 33 may have wrapped to 0 (rule 4) */
         if (e_lane < 0 || e_lane + C > (int64_t)I.M) { /* strip edges only */
 #pragma unroll
             for (int t = 0; t < C; t++) {
@@ -455,7 +458,8 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
     __syncthreads();
 
     /* ---- phase 7: proven minimizers to the global bitmask; flagged strips to the exact pass ---- */
-    if (L < NBW) {
+    const uint32_t flagged = s_flag; /* written before the barrier above */
+    if (L < NBW && !flagged) {
         const uint32_t word = s_bits[L];
         if (word) {
             const uint64_t g0 = (uint64_t)((int64_t)I.base + I.P0 + 32 * (int64_t)L);
@@ -464,5 +468,5 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
             if (sh && (word >> (32u - sh))) atomicOr(&A.mask[(g0 >> 5) + 1], word >> (32u - sh));
         }
     }
-    if (L == 0 && s_flag) B.redo_list[atomicAdd(B.redo_count, 1u)] = strip;
+    if (L == 0 && flagged) B.redo_list[atomicAdd(B.redo_count, 1u)] = strip;
 }

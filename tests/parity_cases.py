@@ -28,10 +28,12 @@ def check_sketch(dev, seqs, k, w, threads=0, info=None):
     return len(h)
 
 
-def near_tie_sequences(k, n_pairs, seed=11, pool=1 << 22, flank=30):
+def near_tie_sequences(k, n_pairs, seed=11, pool=1 << 22, flank=30, third=False):
     """Sequences in which two DIFFERENT k-mers whose hashes agree in bits 33..63 (so the window pass's ring keys are within
     one of each other: it cannot order them) are the two smallest k-mers of one window: A + filler + B.  Found by brute force
-    over the k-mers of a random sequence; the lowest such pairs, so that random filler rarely goes below them."""
+    over the k-mers of a random sequence; the lowest such pairs, so that random filler rarely goes below them.
+    third: a still smaller k-mer Z follows closely (A + B + Z inside one window of 40), so that the later one of the pair is a
+    minimizer only if it is the smaller of the two -- an early, unproven bit for it would show."""
     rng = np.random.default_rng(seed)
     text = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), pool))
     h0, _, pos, _ = oracle.hash_seq(text, k)
@@ -39,18 +41,24 @@ def near_tie_sequences(k, n_pairs, seed=11, pool=1 << 22, flank=30):
     order = np.argsort(c, kind="stable")
     cs, hs = c[order], h0[order]
     same = np.flatnonzero((cs[1:] == cs[:-1]) & (hs[1:] != hs[:-1]))
+    z0 = int(pos[order[0]])
+    Z = text[z0:z0 + k]
+    fill = lambda n: bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), n))
     seqs = []
     for i in same:
+        if third and cs[i] == cs[0]:
+            continue
         a, b = int(pos[order[i]]), int(pos[order[i + 1]])
         A, B = text[a:a + k], text[b:b + k]
         lim = int(min(hs[i], hs[i + 1]))
-        for _ in range(200):
-            f = int(rng.integers(3, 12))
-            fill = lambda n: bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), n))
-            seq = fill(flank) + (A if rng.integers(2) else B) + fill(f)
-            seq += (B if seq[flank:flank + k] == A else A) + fill(flank)
+        for _ in range(300):
+            first, second = (A, B) if rng.integers(2) else (B, A)
+            if third:
+                seq = fill(flank) + first + fill(int(rng.integers(1, 4))) + second + fill(int(rng.integers(1, 4))) + Z + fill(flank)
+            else:
+                seq = fill(flank) + first + fill(int(rng.integers(3, 12))) + second + fill(flank)
             hh = oracle.hash_seq(seq, k)[0]
-            if int(np.sum(hh < np.uint64(lim))) == 0 and int(np.sum(hh >> np.uint64(33) == cs[i])) == 2:
+            if int(np.sum(hh < np.uint64(lim))) == (1 if third else 0) and int(np.sum(hh >> np.uint64(33) == cs[i])) == 2:
                 seqs.append(seq)
                 break
         if len(seqs) == n_pairs:

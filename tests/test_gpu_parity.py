@@ -257,6 +257,10 @@ def test_fast_window_pass_flags_keys_it_cannot_order(dev):
             st = {}
             pc.check_sketch(dev, seqs, k, w, info=st)
             assert st["redo_strips"] == st["strips"] == len(seqs), (k, w, st)
+        seqs = pc.near_tie_sequences(k, n, seed=11 + k, third=True)  # a smaller k-mer right behind the pair: see parity_cases
+        st = {}
+        pc.check_sketch(dev, seqs, k, 40, info=st)
+        assert st["redo_strips"] == st["strips"] == len(seqs), (k, st)
 
 
 @pytest.mark.parametrize("env", [{"NTL_SKETCH_FORCE_REDO": "1"}, {"NTL_SKETCH_FAST": "0"}, {"NTL_SKETCH_NT": "128"}, {"NTL_SKETCH_NT": "256"},

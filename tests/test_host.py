@@ -492,3 +492,32 @@ def test_parser_packs_bases_and_runs_like_the_device(tmp_path, monkeypatch, thre
             assert np.array_equal(ss.seq_run_first, srf) and np.array_equal(ss.run_start, rst) and np.array_equal(ss.run_len, rln)
             at += n
         assert at == len(plain) == 400
+
+
+def test_nthash_ring_sums_cannot_wrap():
+    """sketch_fast_kernel orders k-mers by the sum of the 31-bit rings (bits 33..63) of fwd and rev and needs that sum never to
+    be 2^31 - 1 (the carry of the low 33 bits would wrap it to 0).  F + R = 2^31 - 1 means F ^ R is all ones: 31 bits, odd.
+    F ^ R is the XOR of rotated seed rings, one of a base and one of its complement per position, and those pairs have an even
+    number of set bits between them; checked on the seeds and, through the oracle's hashes, on random k-mers."""
+    seeds = {"A": 0x3c8bfbb395c60474, "C": 0x3193c18562a02b4c, "G": 0x20323ed082572324, "T": 0x295549f54be24456}
+    ring = {b: s >> 33 for b, s in seeds.items()}
+    assert (bin(ring["A"]).count("1") + bin(ring["T"]).count("1")) % 2 == 0
+    assert (bin(ring["C"]).count("1") + bin(ring["G"]).count("1")) % 2 == 0
+
+    def rot31(x, n):
+        n %= 31
+        return ((x << n) | (x >> (31 - n))) & 0x7FFFFFFF
+
+    rng = np.random.default_rng(4)
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    for k in (7, 16, 24, 32, 33, 100):
+        text = "".join(rng.choice(list("ACGT"), k + 300))
+        h0 = oracle.hash_seq(text.encode(), k)[0]
+        for p in range(0, 300, 7):
+            f = r = 0
+            for i, b in enumerate(text[p:p + k]):
+                f ^= rot31(ring[b], k - 1 - i)
+                r ^= rot31(ring[comp[b]], i)
+            assert bin(f ^ r).count("1") % 2 == 0
+            c = int(h0[p]) >> 33
+            assert c in ((f + r) & 0x7FFFFFFF, (f + r + 1) & 0x7FFFFFFF) and (f + r) & 0x7FFFFFFF != 0x7FFFFFFF

@@ -238,6 +238,12 @@ def test_sim_fast_window_pass_flags_keys_it_cannot_order(dev):
         st = {}
         pc.check_sketch(dev, seqs, k, w, info=st)
         assert st["redo_strips"] == st["strips"] == len(seqs), st
+    # ... and nothing the 32-bit pass decided for such a strip is kept: with a smaller k-mer right behind the pair, the later
+    # one of the pair is a minimizer only if it is the smaller one
+    seqs = pc.near_tie_sequences(k, 24, third=True)
+    st = {}
+    pc.check_sketch(dev, seqs, k, 40, info=st)
+    assert st["redo_strips"] == st["strips"] == len(seqs), st
 
 
 @pytest.mark.parametrize("case", ["synthetic_k15_w5_s1", "synthetic_k8_w3_s3", "scaffolds_4_k15_w5_s1"])
