@@ -48,7 +48,7 @@ struct ntl_ctx {
     std::vector<hipEvent_t> ev_free;
     void *g4 = nullptr;                 /* device copy of the four-base init table */
     void *g8 = nullptr;                 /* device copy of the eight-base init table (1 MB) */
-    std::map<int, void *> g8k;          /* k -> the two k-dependent forms of g8 the fast window pass reads (2 MB each, sketch2_kernels.h) */
+    std::map<int, void *> g8k;          /* k -> the two k-dependent ring forms of g8 the fast window pass reads (1 MB per k, sketch2_kernels.h) */
     std::multimap<size_t, void *> pool; /* cached device blocks by size */
     size_t pool_bytes = 0;
     size_t pool_cap = (size_t)32 << 30; /* upper bound of pool_bytes */
@@ -858,13 +858,13 @@ static int sketch_run_impl(ntl_ctx *c, const ntl_batch *b, int k, int w, const n
                         c->g8k.clear();
                     }
                     void *t = nullptr;
-                    if (hipMalloc(&t, (size_t)2 * 65536 * 16) != hipSuccess) return fail(c, NTL_ENOMEM, "hipMalloc failed");
-                    hipLaunchKernelGGL(g8k_build_kernel, dim3(256), dim3(256), 0, c->stream, (const uint64_t (*)[2])c->g8, (uint64_t (*)[2])t,
+                    if (hipMalloc(&t, (size_t)2 * 65536 * sizeof(uint2)) != hipSuccess) return fail(c, NTL_ENOMEM, "hipMalloc failed");
+                    hipLaunchKernelGGL(g8k_build_kernel, dim3(256), dim3(256), 0, c->stream, (const uint64_t (*)[2])c->g8, (uint2 *)t,
                                        B.rev_a, B.rev_b);
                     HIPCHK(c, hipGetLastError());
                     it = c->g8k.emplace(k, t).first;
                 }
-                B.g8k = (const uint64_t (*)[2])it->second;
+                B.g8k = (const uint2 *)it->second;
             }
             B.force_redo = 0;
             B.dbg = 0;

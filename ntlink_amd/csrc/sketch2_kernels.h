@@ -63,7 +63,7 @@ struct Sketch2Args {
     uint32_t *redo_list;   /* strips for the exact pass */
     uint32_t *redo_count;
     uint64_t max_word;     /* last word of `packed` that may be read */
-    const uint64_t (*g8k)[2]; /* k-dependent eight-base tables (g8k_build_kernel): [w] first half of a chunk, [65536 + w] second half */
+    const uint2 *g8k;      /* k-dependent eight-base ring tables (g8k_build_kernel): [w] first half of a chunk, [65536 + w] second half */
     int q16, r16;          /* k = 16 * q16 + r16 */
     uint32_t rev_a, rev_b; /* (k - 1) % 33, (k - 1) % 31: the rotation that turns the Horner form of the reverse strand into rev */
     int force_redo;        /* tests: flag every strip */
@@ -78,34 +78,37 @@ __device__ __forceinline__ uint32_t sk2_bases16(const uint32_t *__restrict__ pac
     return ntl_alignbit(packed[wi + 1], packed[wi], 2u * a);
 }
 
+/* a 31-bit ring held in bits 0..30 (bit 31 clear), rotated by a uniform amount 1..30 */
+__device__ __forceinline__ uint32_t ring_rotl(uint32_t x, uint32_t n) { return ((x << n) & 0x7FFFFFFFu) | (x >> (31u - n)); }
+__device__ __forceinline__ uint32_t ring_rotr(uint32_t x, uint32_t n) { return ring_rotl(x, 31u - n); }
+__device__ __forceinline__ uint32_t ring_of(uint64_t h) { return (uint32_t)(h >> 33); }
+
 /* The eight-base table g8 (k-independent: {XOR_j srol^(7-j)(seed[b_j]), XOR_j sror^(7-j)(seed[3-b_j])}) in the two forms a
- * 16-base chunk needs, so that a chunk's partial hash is two loads and two XORs without any rotation:
+ * 16-base chunk needs, so that a chunk's partial hash is two loads and two XORs without any rotation -- and only the 31-bit
+ * rings (bits 33..63) of each, which is all the window pass's keys are made of (8 B per entry, 1 MB per k):
  *   T0[w] = {srol^8(f), R(sror^8(u))}   the first eight bases of a chunk       (entry w)
  *   T1[w] = {f,         R(u)}           its second eight bases                 (entry 65536 + w)
  * R = srol^(k-1) on the reverse strand: the rotation that turns the Horner form into rev commutes with every other
  * rotation and XOR, so it is applied to the table once per k instead of to every lane's result. */
-__global__ __launch_bounds__(256) void g8k_build_kernel(const uint64_t (*__restrict__ g8)[2], uint64_t (*__restrict__ g8k)[2],
+__global__ __launch_bounds__(256) void g8k_build_kernel(const uint64_t (*__restrict__ g8)[2], uint2 *__restrict__ g8k,
                                                         uint32_t rev_a, uint32_t rev_b)
 {
     const uint32_t w = blockIdx.x * 256 + threadIdx.x;
     if (w >= 65536u) return;
     const uint64_t f = g8[w][0], u = g8[w][1];
-    g8k[w][0] = srot_h(f, 8, 8);
-    g8k[w][1] = srot_u(srot_h(u, 25, 23), rev_a, rev_b);
-    g8k[65536u + w][0] = f;
-    g8k[65536u + w][1] = srot_u(u, rev_a, rev_b);
+    g8k[w] = make_uint2(ring_of(srot_h(f, 8, 8)), ring_of(srot_u(srot_h(u, 25, 23), rev_a, rev_b)));
+    g8k[65536u + w] = make_uint2(ring_of(f), ring_of(srot_u(u, rev_a, rev_b)));
 }
 
-/* partial hashes of one 16-base chunk: Horner forms over its 16 bases {F, R(U)} and over its first r bases {PF, R(PU)} */
-__device__ __forceinline__ void sk2_chunk(uint32_t so, int r, const Sketch2Args &B, uint64_t &F, uint64_t &U, uint64_t &PF, uint64_t &PU)
+/* partial hashes (rings) of one 16-base chunk: Horner forms over its 16 bases FU = {F, R(U)} and over its first r bases P = {PF, R(PU)} */
+__device__ __forceinline__ void sk2_chunk(uint32_t so, int r, const Sketch2Args &B, uint2 &FU, uint2 &P)
 {
     const uint32_t w0 = so & 0xFFFFu, w1 = so >> 16;
-    const uint64_t a0 = B.g8k[w0][0], a1 = B.g8k[w0][1], b0 = B.g8k[65536u + w1][0], b1 = B.g8k[65536u + w1][1];
-    F = a0 ^ b0;
-    U = a1 ^ b1;
-    PF = 0; PU = 0;
-    if (r == 8) { PF = B.g8k[65536u + w0][0]; PU = B.g8k[65536u + w0][1]; }
-    else if (r) { /* k % 16 not in {0, 8}: four-base and single-base steps on the plain tables, then R */
+    const uint2 a = B.g8k[w0], b = B.g8k[65536u + w1];
+    FU = make_uint2(a.x ^ b.x, a.y ^ b.y);
+    P = make_uint2(0u, 0u);
+    if (r == 8) P = B.g8k[65536u + w0];
+    else if (r) { /* k % 16 not in {0, 8}: four-base and single-base steps on the plain 64-bit tables, then R */
         const SketchArgs &A = B.A;
         uint64_t f = 0, u = 0;
         int j = 0;
@@ -121,7 +124,7 @@ __device__ __forceinline__ void sk2_chunk(uint32_t so, int r, const Sketch2Args 
             f = srol1(f) ^ A.seed_tab[c][0];
             u = sror1(u) ^ A.seed_tab[c][1];
         }
-        PF = f; PU = srot_u(u, B.rev_a, B.rev_b);
+        P = make_uint2(ring_of(f), ring_of(srot_u(u, B.rev_a, B.rev_b)));
     }
 }
 
@@ -140,8 +143,8 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
     constexpr int PAD = BIG ? SK2_PAD : 16;     /* INF entries behind the block minima: a + 2 <= PAD (ntl_sketch_run checks) */
     constexpr int JOBCAP = BIG ? SK2_JOBCAP : 128;
     /* s_c doubles as the exchange area of phase 1:
-       {F16, U16} of chunk L at s_xy[L], {PF, PU} (first k%16 bases) at s_xy[NX + L]; a barrier separates the last read of
-       the partial hashes from the first staged element */
+       the rings {F16, U16} of chunk L at s_xy[L], {PF, PU} (first k%16 bases) at s_xy[NX + L]; a barrier separates the last
+       read of the partial hashes from the first staged element */
     __shared__ uint32_t s_c[C * ST];
     __shared__ uint32_t s_bm[NT + PAD];         /* block minima; INF behind NT */
     __shared__ uint32_t s_pre0[NT + 4];         /* minimum of the first R0 elements of each block */
@@ -152,9 +155,9 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
     __shared__ uint32_t s_t1[BIG ? NT + PAD : 1];
     __shared__ uint16_t s_jobs_big[BIG ? SK2_JOBCAP : 1];
     uint16_t *const s_jobs = BIG ? s_jobs_big : (uint16_t *)&s_roll[0]; /* 256 B = 128 jobs: written two barriers after the last roll */
-    uint64_t (*const s_xy)[2] = (uint64_t (*)[2])s_c;
-    uint32_t *const s_so = (uint32_t *)&s_xy[2 * NX][0]; /* [NX + 1] the chunks' base words, behind the partial hashes */
-    static_assert(sizeof(uint32_t) * C * ST >= sizeof(uint64_t) * 4 * NX + sizeof(uint32_t) * (NX + 1), "the exchange area must fit the element array");
+    uint2 *const s_xy = (uint2 *)s_c;
+    uint32_t *const s_so = (uint32_t *)&s_xy[2 * NX]; /* [NX + 1] the chunks' base words, behind the partial hashes */
+    static_assert(sizeof(uint32_t) * C * ST >= sizeof(uint2) * 2 * NX + sizeof(uint32_t) * (NX + 1), "the exchange area must fit the element array");
 
     const SketchArgs &A = B.A;
     const int L = threadIdx.x;
@@ -180,21 +183,21 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
     uint32_t so = 0;
     if (feeds && !SK2_DBG(B, 8)) {
         so = sk2_bases16(A.T.packed, gp, B.max_word);
-        uint64_t F, U, PF, PU;
-        sk2_chunk(so, B.r16, B, F, U, PF, PU);
-        s_xy[L][0] = F; s_xy[L][1] = U;
+        uint2 FU, P;
+        sk2_chunk(so, B.r16, B, FU, P);
+        s_xy[L] = FU;
         s_so[L] = so;
-        if (B.r16) { s_xy[NX + L][0] = PF; s_xy[NX + L][1] = PU; }
+        if (B.r16) s_xy[NX + L] = P;
     }
     if (L <= B.q16 && !SK2_DBG(B, 8)) { /* chunks NT .. NT+q16 feed the last lanes */
         const int64_t ev = (int64_t)I.E0 + (int64_t)(NT + L) * C;
         if (ev - 16 * (int64_t)(B.q16 + 1) < (int64_t)I.M) {
             const uint32_t sv = sk2_bases16(A.T.packed, gp + (uint64_t)NT * C, B.max_word);
-            uint64_t F, U, PF, PU;
-            sk2_chunk(sv, B.r16, B, F, U, PF, PU);
-            s_xy[NT + L][0] = F; s_xy[NT + L][1] = U;
+            uint2 FU, P;
+            sk2_chunk(sv, B.r16, B, FU, P);
+            s_xy[NT + L] = FU;
             s_so[NT + L] = sv;
-            if (B.r16) { s_xy[NX + NT + L][0] = PF; s_xy[NX + NT + L][1] = PU; }
+            if (B.r16) s_xy[NX + NT + L] = P;
         }
     }
     __syncthreads();
@@ -203,33 +206,34 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
     uint32_t c[C];
 #pragma unroll
     for (int t = 0; t < C; t++) c[t] = SK2_INF;
-    uint64_t fwd = 0, rev = 0;
+    uint32_t fx = 0, ry = 0; /* the rings of the first k-mer's fwd and rev (forms: see the rolling loop) */
     uint32_t si = 0; /* the sixteen bases behind the lane's first k-mer: the chunks q16 (and q16 + 1) further on */
     if (live) {
         {
             const uint32_t lo = s_so[L + B.q16];
             si = B.r16 ? ntl_alignbit(s_so[L + B.q16 + 1], lo, 2u * (uint32_t)B.r16) : lo;
         }
-        uint64_t f = 0, u = 0;
+        uint32_t f = 0, u = 0;
         for (int i = 0; i < B.q16; i++) {
-            if (i) { f = srot_h(f, 16, 16); u = srot_h(u, 17, 15); } /* srol^16, sror^16 */
-            f ^= s_xy[L + i][0];
-            u ^= s_xy[L + i][1];
+            if (i) { f = ring_rotl(f, 16); u = ring_rotr(u, 16); } /* srol^16, sror^16 on the rings */
+            const uint2 p = s_xy[L + i];
+            f ^= p.x;
+            u ^= p.y;
         }
         if (B.r16) {
             const uint32_t r = (uint32_t)B.r16;
-            if (B.q16) { f = srot_h(f, r, r); u = srot_h(u, 33u - r, 31u - r); } /* 1 <= r <= 15 */
-            f ^= s_xy[NX + L + B.q16][0];
-            u ^= s_xy[NX + L + B.q16][1];
+            if (B.q16) { f = ring_rotl(f, r); u = ring_rotr(u, r); } /* 1 <= r <= 15 */
+            const uint2 p = s_xy[NX + L + B.q16];
+            f ^= p.x;
+            u ^= p.y;
         }
-        fwd = f;
-        rev = u; /* the tables carry the reverse strand's final rotation */
+        fx = f;
+        ry = u << 1; /* the tables carry the reverse strand's final rotation */
     }
     __syncthreads(); /* the partial hashes have been read: s_c may take the elements */
     if (live) {
         /* Only the 31-bit rings (bits 33..63) are rolled: fx holds fwd's ring in bits 0..30 (bit 31: junk), ry holds rev's in
            bits 1..31 (bit 0: junk), so that a rotation is two instructions and key = 2 * (F + R) + junk is one. */
-        uint32_t fx = (uint32_t)(fwd >> 33), ry = (uint32_t)(rev >> 32);
         c[0] = (fx << 1) + ry;
         /* byte offset into s_roll of step t = b + 1: 8 * (in<<2 | out) for base b of si / so, as byte b/4 of word b%4 */
         uint32_t wz[4];
