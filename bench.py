@@ -323,7 +323,9 @@ def valu_roofline(pm, avg_launch_ms, bases_per_launch):
     ach = n / (avg_launch_ms * 1e-3)
     return {"achieved": round(ach / 1e9, 2), "peak": round(peak / 1e9, 1), "unit": "G wave-instr/s", "frac": round(ach / peak, 3),
             "lane_instr_per_base": round(n * 64.0 / bases_per_launch, 2), "clock_ghz": clock,
-            "cycles_per_wave_instr": VALU_CYCLES_PER_INSTR, "source": pm.get("valu_source")}
+            "cycles_per_wave_instr": VALU_CYCLES_PER_INSTR, "source": pm.get("valu_source"),
+            "note": "peak = SIMDs x clock / cycles per wave-instruction with the clock of the PMC pass (GRBM_GUI_ACTIVE / duration); "
+                    "the unprofiled launches timed here clock a few % higher, so frac can come out slightly above 1: the kernel sits on this roof"}
 
 
 def cpu_baseline(dev, wl, W, params):
