@@ -38,9 +38,9 @@
  *   (4) A flagged strip writes NONE of its bits (a lane that saw a near tie may have taken the wrong side of it for a
  *       drop); the exact pass redoes the whole strip.  v == 2^32-1 (a window of padding) flags.
  *
- * The hash of a lane's first k-mer is assembled from 16-base partial hashes that neighbouring lanes compute
+ * The rings of a lane's first k-mer are assembled from 16-base partial hashes (rings) that neighbouring lanes compute
  * for their own 16 bases (two 8-base table lookups each) and exchange through LDS:
- *   fwd = XOR_i srol^(k-16(i+1))(F16[L+i]) ^ (first k%16 bases of chunk L+k/16),   same for rev with sror.
+ *   F = XOR_i rotl^(k-16(i+1))(F16[L+i]) ^ (first k%16 bases of chunk L+k/16),   same for rev with rotr.
  */
 #pragma once
 #include "sketch_kernels.h"
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
     }
     __syncthreads();
 
-    /* ---- phase 1b: first k-mer from the partials, then 15 rolling steps; c = h0 >> 32 ---- */
+    /* ---- phase 1b: first k-mer's rings from the partials, then 15 rolling steps; key = 2 * ring sum (see `key` above) ---- */
     uint32_t c[C];
 #pragma unroll
     for (int t = 0; t < C; t++) c[t] = SK2_INF;
