@@ -46,7 +46,9 @@
  * NTL_IO_GZ_WHOLE_MAX (compressed bytes up to which a gzip file is inflated in one go, default
  * 1/40 of the physical memory within 1..16 GiB), NTL_IO_TRACE=1 (reader diagnostics on stderr), NTL_SKETCH_C / NTL_SKETCH_NT (k-mers per
  * lane, lanes per strip of the sketch kernel), NTL_SKETCH_FAST=0 (exact 64-bit window pass only), NTL_SKETCH_FORCE_REDO=1
- * (every strip takes the 32-bit pass and the exact pass).
+ * (every strip takes the 32-bit pass and the exact pass), NTL_PIPELINE=0 (one stream per context; default: a second stream for
+ * the window stage), NTL_PIPELINE_PRIO (0 no stream priorities, 1 = default: MAIN above the window stream, 2 the reverse),
+ * NTL_SKETCH_CAP_GUESS (records a sketch's arrays hold before its count is known; tests force the second round with it).
  */
 #ifndef NTLINK_AMD_H
 #define NTLINK_AMD_H
@@ -79,8 +81,12 @@ void ntl_ctx_destroy(ntl_ctx *ctx);
 const char *ntl_last_error(const ntl_ctx *ctx);
 /* Human-readable device description ("AMD Instinct MI355X gfx950 256 CUs"). */
 const char *ntl_ctx_device_name(const ntl_ctx *ctx);
-/* Blocks until all work queued on the context's stream has finished. */
+/* Blocks until all work queued on the context's streams has finished.  Also where the failure of work whose handle was
+ * destroyed before it finished is reported (see "Asynchrony" below). */
 int ntl_ctx_sync(ntl_ctx *ctx);
+/* 1 when the window stage of a sketch runs on its own stream beside the previous batch's emit / map kernels (the default),
+ * 0 with NTL_PIPELINE=0 (one stream: what a per-kernel profile wants). */
+int ntl_ctx_pipelined(const ntl_ctx *ctx);
 
 /* Kernel timing with HIP events on the context's stream.  When enabled, every launch of the
  * named kernel groups is bracketed by events; ntl_prof_get returns the accumulated time and
@@ -137,6 +143,15 @@ int ntl_batch_download(const ntl_batch *b, char *seqs, uint64_t *offsets);
 
 /* ---- sketch ---------------------------------------------------------------------------- */
 
+/* Asynchrony.  ntl_sketch_run[_indexed] and ntl_map_run only QUEUE device work and return; no size comes back to the host
+ * inside them.  The handles they return are completed on first use: any accessor that needs a count or a record
+ * (ntl_sketch_count / _download / _redo_strips, ntl_mapres_n_* / _download, ntl_index_build on a contig sketch) waits for
+ * the device then, and ntl_sketch_wait / ntl_mapres_wait do only that and return the status.  A caller that queues batch
+ * i+1 before it asks for the results of batch i lets the window kernels of i+1 run beside the lookup and map kernels of i
+ * (the reference's pipe between `indexlr` and `ntlink_pair.py` overlaps the same two stages, ntLink:221-225).  Inputs may be
+ * destroyed as soon as the call that took them has returned: the library keeps what it still needs.  Destroying a handle
+ * that was never asked for anything is allowed; if its work then fails, the next ntl_ctx_sync reports it. */
+
 /* Computes the (k,w) minimizers of every sequence of the batch on the device; the result stays
  * in device memory.  Replaces `indexlr --long --pos --strand -k K -w W` (ntLink:199,223):
  * ntHash canonical hash for the window minimum, second hash as the emitted value, window over
@@ -148,6 +163,8 @@ int ntl_sketch_run(ntl_ctx *ctx, const ntl_batch *b, int k, int w, ntl_sketch **
  * the index must outlive the sketch. */
 int ntl_sketch_run_indexed(ntl_ctx *ctx, const ntl_batch *b, int k, int w, const ntl_index *ix, ntl_sketch **out);
 void ntl_sketch_destroy(ntl_sketch *s);
+/* Waits until the sketch is complete; 0 or the error its completion met. */
+int ntl_sketch_wait(const ntl_sketch *s);
 uint64_t ntl_sketch_nseq(const ntl_sketch *s);
 /* Total number of minimizers. */
 uint64_t ntl_sketch_count(const ntl_sketch *s);
@@ -225,6 +242,9 @@ typedef struct {
 int ntl_map_run(ntl_ctx *ctx, const ntl_index *ix, const ntl_sketch *reads, const uint32_t *read_len,
                 const ntl_map_params *params, ntl_mapres **out);
 void ntl_mapres_destroy(ntl_mapres *r);
+/* Waits until the result is complete; 0 or the error its completion met (NTL_EINTERNAL: the reference's assertion that every
+ * accepted contig appears once per read, bin/ntlink_utils.py:262-266, failed). */
+int ntl_mapres_wait(const ntl_mapres *r);
 uint64_t ntl_mapres_n_mappings(const ntl_mapres *r);
 uint64_t ntl_mapres_n_hits(const ntl_mapres *r);
 uint64_t ntl_mapres_n_pafs(const ntl_mapres *r);

@@ -16,12 +16,12 @@ DEFAULT_LIB = os.path.join(_HERE, "libntlink_hip.so")
 
 # every symbol include/ntlink_amd.h declares
 SYMBOLS = [
-    "ntl_ctx_create", "ntl_ctx_destroy", "ntl_last_error", "ntl_ctx_device_name", "ntl_ctx_sync",
+    "ntl_ctx_create", "ntl_ctx_destroy", "ntl_last_error", "ntl_ctx_device_name", "ntl_ctx_sync", "ntl_ctx_pipelined",
     "ntl_prof_enable", "ntl_prof_reset", "ntl_prof_get",
     "ntl_batch_create", "ntl_batch_create_packed", "ntl_packed_words", "ntl_batch_destroy", "ntl_batch_nseq", "ntl_batch_bases", "ntl_host_alloc", "ntl_host_free",
     "ntl_synth_genome", "ntl_synth_slices", "ntl_batch_download",
     "ntl_sketch_run", "ntl_sketch_run_indexed", "ntl_sketch_destroy", "ntl_sketch_nseq", "ntl_sketch_count", "ntl_sketch_download",
-    "ntl_sketch_strips", "ntl_sketch_redo_strips",
+    "ntl_sketch_strips", "ntl_sketch_redo_strips", "ntl_sketch_wait", "ntl_mapres_wait",
     "ntl_sketch_from_host", "ntl_overlap_filter",
     "ntl_index_build", "ntl_index_destroy", "ntl_index_size",
     "ntl_map_run", "ntl_mapres_destroy", "ntl_mapres_n_mappings", "ntl_mapres_n_hits", "ntl_mapres_n_pafs",
@@ -73,6 +73,9 @@ def load(path=None):
     L.ntl_ctx_device_name.argtypes = [vp]
     L.ntl_ctx_device_name.restype = C.c_char_p
     L.ntl_ctx_sync.argtypes = [vp]
+    L.ntl_ctx_pipelined.argtypes = [vp]
+    L.ntl_sketch_wait.argtypes = [vp]
+    L.ntl_mapres_wait.argtypes = [vp]
     L.ntl_prof_enable.argtypes = [vp, C.c_int]
     L.ntl_prof_reset.argtypes = [vp]
     L.ntl_prof_get.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), u64p]
@@ -222,8 +225,14 @@ class Sketch(_Handle):
     def nseq(self):
         return int(self.dev.L.ntl_sketch_nseq(self.ptr))
 
+    def wait(self):
+        """Block until the device has finished this sketch (the calls that make one only queue work)."""
+        self.dev._chk(self.dev.L.ntl_sketch_wait(self.ptr))
+        return self
+
     @property
     def count(self):
+        self.wait()
         return int(self.dev.L.ntl_sketch_count(self.ptr))
 
     @property
@@ -232,6 +241,7 @@ class Sketch(_Handle):
 
     @property
     def redo_strips(self):
+        self.wait()
         return int(self.dev.L.ntl_sketch_redo_strips(self.ptr))
 
     def download(self):
@@ -255,11 +265,18 @@ class Index(_Handle):
 class MapResult(_Handle):
     _destroy = "ntl_mapres_destroy"
 
+    def wait(self):
+        """Block until the device has finished this result (Device.map only queues work)."""
+        self.dev._chk(self.dev.L.ntl_mapres_wait(self.ptr))
+        return self
+
     @property
     def n_index_hits(self):
+        self.wait()
         return int(self.dev.L.ntl_mapres_n_index_hits(self.ptr))
 
     def counts(self):
+        self.wait()
         L = self.dev.L
         return (int(L.ntl_mapres_n_mappings(self.ptr)), int(L.ntl_mapres_n_hits(self.ptr)),
                 int(L.ntl_mapres_n_pafs(self.ptr)))
@@ -331,6 +348,10 @@ class Device:
 
     def sync(self):
         self._chk(self.L.ntl_ctx_sync(self.ptr))
+
+    @property
+    def pipelined(self):
+        return bool(self.L.ntl_ctx_pipelined(self.ptr))
 
     # ---- profiling (HIP events on the context's stream)
     def prof_enable(self, on=True):

@@ -173,7 +173,14 @@ struct MapArgs {
     uint64_t scr_stride;
     uint32_t *err;
     uint32_t *over_list, *over_count;             /* reads that do not fit the LDS staging: [nreads], [1] */
+    /* The sketch may still be in flight when these kernels are queued (nothing waits on the host for its size): when its
+       minimizer total turns out larger than the arrays that were sized from the expected density, the records are incomplete
+       and every kernel here leaves the batch alone; the host makes the sketch again and queues the map a second time. */
+    const uint32_t *mx_total;                     /* NULL: the count was known when the call was made */
+    uint32_t mx_cap;
 };
+
+__device__ __forceinline__ bool map_sketch_overflowed(const MapArgs &A) { return A.mx_total && *A.mx_total > A.mx_cap; }
 
 struct HitArr { uint32_t *ctg, *cpos, *rpos, *fl, *run, *ord; };
 struct RunArr { uint32_t *start, *ctg, *leader, *flag, *cnt, *mn, *mni, *mx, *mxi, *last; };
@@ -619,12 +626,14 @@ __global__ __launch_bounds__(MAP_NT) void map_kernel(MapArgs A)
 {
     __shared__ uint32_t s_hit[MAP_NHA][MAP_CAPH];
     __shared__ uint32_t s_run[MAP_NRA][MAP_CAPR];
+    if (map_sketch_overflowed(A)) return;
     map_read<MAP_CAPH, MAP_CAPR, false>(A, blockIdx.x, s_hit, s_run);
 }
 
 /* the reads map_kernel could not stage in LDS, on their regions of the global scratch arrays */
 __global__ __launch_bounds__(MAP_NT) void map_overflow_kernel(MapArgs A)
 {
+    if (map_sketch_overflowed(A)) return;
     const uint32_t n = *A.over_count;
     for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
         map_read<1, 1, true>(A, A.over_list[i], nullptr, nullptr);
@@ -638,6 +647,7 @@ __global__ __launch_bounds__(MAP_NT) void map_overflow_kernel(MapArgs A)
 __global__ void map_gather_kernel(MapArgs A, const uint32_t *off_maps, const uint32_t *off_hits,
                                   const uint32_t *off_pafs, MapRec *d_maps, HitRec *d_hits, PafRec *d_pafs)
 {
+    if (map_sketch_overflowed(A)) return;
     const uint32_t r = blockIdx.x;
     const uint32_t m0 = A.mx_off[r];
     const uint32_t nm = A.n_maps[r], nh = A.n_hits[r], npf = A.n_pafs[r];

@@ -9,7 +9,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <deque>
 #include <map>
 #include <memory>
 #include <string>
@@ -32,29 +34,77 @@
 
 /* ------------------------------------------------------------------ context ------------- */
 
+/*
+ * Streams.  A context owns the MAIN stream (uploads, the emit / lookup / map / compaction kernels, downloads) and -- unless
+ * NTL_PIPELINE=0 -- a second one for the WINDOW stage of a sketch (strip tables + the VALU-bound window kernels).  The window
+ * stage of read batch i+1 depends on nothing the rest of batch i produces, so it is queued on its own stream and runs beside
+ * batch i's latency-bound kernels; hipEvents carry the two real dependencies (window stage -> emit of the same batch; emit ->
+ * the next user of the bitmask it read and cleared).  No call of the hot path waits on the host: sizes stay on the device,
+ * result handles are completed lazily (sketch_finalize / mapres_finalize) when a count or a record is asked for.
+ */
+enum { SID_MAIN = 0, SID_W = 1 };
+
 struct ProfEntry {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> spans;
     double done_ms = 0;
     uint64_t launches = 0;
 };
 
+/* a cached device block that was used on both streams: whoever takes it waits for the events of the streams it is not on */
+struct XBlock {
+    void *p = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+};
+
+/* a zero-filled minimizer bitmask whose last reader (emit_kernel) cleared what the window stage had set */
+struct CleanMask {
+    void *p = nullptr;
+    size_t bytes = 0;
+    hipEvent_t clean = nullptr; /* on MAIN: the clearing kernel has run */
+};
+
+struct PinSlot { uint64_t w[8]; }; /* 64 page-locked bytes a device-side size lands in */
+
+/* what is left of a handle that was destroyed before the device had finished its work: the event, the slot, and what to
+   check in the slot once the event has passed (results nobody looked at still must not have failed silently) */
+struct Zombie {
+    hipEvent_t done = nullptr;
+    PinSlot *slot = nullptr;
+    int kind = 0;      /* 1 sketch (w[0] low = minimizer total vs cap), 2 map result (w[1] low = invariant flag) */
+    uint64_t cap = 0;
+};
+
 struct ntl_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;  /* MAIN */
+    hipStream_t wstream = nullptr; /* window stage; == stream when the pipeline is off */
+    bool pipelined = false;
     std::string err;
+    std::string async_err;         /* first failure of work whose handle was already gone: reported by ntl_ctx_sync */
     std::string devname;
     bool prof = false;
     std::map<std::string, ProfEntry> profs;
-    std::vector<hipEvent_t> ev_free;
+    std::vector<hipEvent_t> ev_free;    /* timing events (profiling spans) */
+    std::vector<hipEvent_t> sev_free;   /* ordering events (no timing) */
     void *g4 = nullptr;                 /* device copy of the four-base init table */
     void *g8 = nullptr;                 /* device copy of the eight-base init table (1 MB) */
     std::map<int, void *> g8k;          /* k -> the two k-dependent ring forms of g8 the fast window pass reads (1 MB per k, sketch2_kernels.h) */
-    std::multimap<size_t, void *> pool; /* cached device blocks by size */
+    std::multimap<size_t, void *> pool[2]; /* cached device blocks by size, per stream they were last used on */
+    std::multimap<size_t, XBlock> xpool;   /* ... and those that were used on both */
     size_t pool_bytes = 0;
     size_t pool_cap = (size_t)32 << 30; /* upper bound of pool_bytes */
+    std::deque<CleanMask> masks;
     void *host_tmp = nullptr;           /* page-locked bounce buffer for record downloads (grows, never shrinks) */
     size_t host_tmp_cap = 0;
+    PinSlot *slots = nullptr;
+    std::vector<uint32_t> slot_free;
+    std::deque<Zombie> zombies;
+    hipEvent_t throttle[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    uint64_t n_enqueued = 0;            /* sketches queued so far: the host runs at most 8 of them ahead of the device */
+    hipStream_t s(int sid) const { return sid == SID_W ? wstream : stream; }
+    int sid(int want) const { return pipelined ? want : SID_MAIN; }
 };
+#define NTL_NSLOTS 512u
 
 static int host_tmp(ntl_ctx *c, size_t bytes, void **out)
 {
@@ -86,22 +136,82 @@ static int fail(ntl_ctx *c, int code, const std::string &msg)
             return fail(ctx, NTL_EDEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));     \
     } while (0)
 
-/* Wait for the stream on the two size read-backs of the hot path (minimizer total of a sketch, result totals of a map call):
- * polls the stream for a while before it blocks -- a blocking wait is woken by an interrupt some tens of microseconds after
- * the last kernel ended, and until the host has queued the next kernels the device idles (two such gaps per read batch). */
-static hipError_t sync_hot(ntl_ctx *c)
+/* ordering events come from a free list (creating one costs tens of microseconds) */
+static hipEvent_t sev_get(ntl_ctx *c)
 {
-    static const int spin_us = [] { const char *e = getenv("NTL_SYNC_SPIN_US"); return e ? atoi(e) : 20000; }();
+    hipEvent_t e = nullptr;
+    if (!c->sev_free.empty()) { e = c->sev_free.back(); c->sev_free.pop_back(); return e; }
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    return e;
+}
+static void sev_put(ntl_ctx *c, hipEvent_t e) { if (e) c->sev_free.push_back(e); }
+
+/* Wait for an event the host needs NOW (a lazily completed handle): polls for a while before it blocks -- a blocking wait
+ * is woken by an interrupt some tens of microseconds after the event has passed. */
+static hipError_t wait_hot(hipEvent_t e)
+{
+    static const int spin_us = [] { const char *v = getenv("NTL_SYNC_SPIN_US"); return v ? atoi(v) : 20000; }();
     if (spin_us > 0) {
         const auto t0 = std::chrono::steady_clock::now();
         for (;;) {
-            const hipError_t q = hipStreamQuery(c->stream);
+            const hipError_t q = hipEventQuery(e);
             if (q == hipSuccess) return hipSuccess;
             if (q != hipErrorNotReady) return q;
             if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > spin_us) break;
         }
     }
-    return hipStreamSynchronize(c->stream);
+    return hipEventSynchronize(e);
+}
+
+static PinSlot *slot_get(ntl_ctx *c);
+static void slot_put(ntl_ctx *c, PinSlot *p) { if (p) c->slot_free.push_back((uint32_t)(p - c->slots)); }
+
+/* zombies whose work has finished: check what they carried, recycle event and slot.  block: wait for the oldest one. */
+static void reap(ntl_ctx *c, bool block)
+{
+    while (!c->zombies.empty()) {
+        Zombie &z = c->zombies.front();
+        hipError_t q = hipEventQuery(z.done);
+        if (q == hipErrorNotReady) {
+            if (!block) return;
+            q = hipEventSynchronize(z.done);
+            block = false;
+        }
+        if (q != hipSuccess && c->async_err.empty()) c->async_err = std::string("device work failed: ") + hipGetErrorString(q);
+        if (q == hipSuccess && z.slot && c->async_err.empty()) {
+            if (z.kind == 1 && (uint32_t)z.slot->w[0] > z.cap)
+                c->async_err = "a sketch held more minimizers than its record array and was destroyed before anybody asked for its count";
+            if (z.kind == 2 && (uint32_t)z.slot->w[1])
+                c->async_err = "an accepted contig appeared twice in one read (bin/ntlink_utils.py:262-266)";
+        }
+        sev_put(c, z.done);
+        slot_put(c, z.slot);
+        c->zombies.pop_front();
+    }
+}
+
+static PinSlot *slot_get(ntl_ctx *c)
+{
+    if (c->slot_free.empty()) reap(c, true);
+    if (c->slot_free.empty()) return nullptr;
+    PinSlot *p = c->slots + c->slot_free.back();
+    c->slot_free.pop_back();
+    memset(p, 0, sizeof *p);
+    return p;
+}
+
+static void pool_drop_all(ntl_ctx *c)
+{
+    for (int i = 0; i < 2; i++) {
+        for (auto &kv : c->pool[i]) (void)hipFree(kv.second);
+        c->pool[i].clear();
+    }
+    for (auto &kv : c->xpool) {
+        (void)hipFree(kv.second.p);
+        sev_put(c, kv.second.ev[0]); sev_put(c, kv.second.ev[1]);
+    }
+    c->xpool.clear();
+    c->pool_bytes = 0;
 }
 
 static int dev_alloc(ntl_ctx *c, size_t bytes, void **out)
@@ -109,35 +219,52 @@ static int dev_alloc(ntl_ctx *c, size_t bytes, void **out)
     hipError_t e = hipMalloc(out, bytes);
     if (e != hipSuccess) {
         /* drop the cache and retry once */
-        for (auto &kv : c->pool) (void)hipFree(kv.second);
-        c->pool.clear();
-        c->pool_bytes = 0;
+        pool_drop_all(c);
         e = hipMalloc(out, bytes);
         if (e != hipSuccess) return fail(c, NTL_ENOMEM, "hipMalloc failed");
     }
     return NTL_OK;
 }
 
-/* a device buffer that returns to the context's cache */
+/* A device buffer that returns to the context's cache.  The cache is stream-ordered: a block goes back while kernels that
+ * use it may still be queued, and is handed out again to work queued BEHIND them on the same stream (no wait).  A block that
+ * was used on both streams (touch) goes back with an event per stream, and whoever takes it next waits for the other
+ * stream's. */
 struct DevBuf {
     ntl_ctx *c = nullptr;
     void *p = nullptr;
     size_t bytes = 0;
+    mutable uint8_t used = 0; /* bit per stream id */
     DevBuf() {}
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
-    int alloc(ntl_ctx *ctx, size_t n)
+    int alloc(ntl_ctx *ctx, size_t n, int sid = SID_MAIN)
     {
         release();
         c = ctx;
+        sid = c->sid(sid);
+        used = (uint8_t)(1u << sid);
         size_t want = n ? n : 256;
         want = (want + 255) & ~(size_t)255;
+        const size_t most = want + want / 4 + (1 << 20);
         /* look for a cached block; its true size is the map key */
-        auto it = c->pool.lower_bound(want);
-        if (it != c->pool.end() && it->first <= want + want / 4 + (1 << 20)) {
+        auto it = c->pool[sid].lower_bound(want);
+        if (it != c->pool[sid].end() && it->first <= most) {
             p = it->second; bytes = it->first;
             c->pool_bytes -= it->first;
-            c->pool.erase(it);
+            c->pool[sid].erase(it);
+            return NTL_OK;
+        }
+        auto xt = c->xpool.lower_bound(want);
+        if (xt != c->xpool.end() && xt->first <= most) {
+            XBlock &x = xt->second;
+            for (int o = 0; o < 2; o++) {
+                if (o != sid && x.ev[o]) (void)hipStreamWaitEvent(c->s(sid), x.ev[o], 0);
+                sev_put(c, x.ev[o]);
+            }
+            p = x.p; bytes = xt->first;
+            c->pool_bytes -= xt->first;
+            c->xpool.erase(xt);
             return NTL_OK;
         }
         int rc = dev_alloc(c, want, &p);
@@ -145,21 +272,44 @@ struct DevBuf {
         bytes = want;
         return NTL_OK;
     }
+    void touch(int sid) const { if (c) used |= (uint8_t)(1u << c->sid(sid)); }
     void release()
     {
         if (p && c) {
-            c->pool.insert({bytes, p}); c->pool_bytes += bytes;
+            if (used == 1u || used == 2u) c->pool[used >> 1].insert({bytes, p});
+            else {
+                XBlock x;
+                x.p = p;
+                for (int o = 0; o < 2; o++) {
+                    x.ev[o] = sev_get(c);
+                    if (x.ev[o]) (void)hipEventRecord(x.ev[o], c->s(o));
+                    else (void)hipStreamSynchronize(c->s(o)); /* no event to be had: the slow, safe way */
+                }
+                c->xpool.insert({bytes, x});
+            }
+            c->pool_bytes += bytes;
             /* the cache is bounded (half of the device memory unless NTL_POOL_MAX_BYTES says otherwise; a bound below the
                working set of a batch -- tens of GB for 4-Gbases HiFi batches -- turns every release into a hipFree): the
                largest blocks go first, they are the least likely to be asked for again at exactly their size */
-            while (c->pool_bytes > c->pool_cap && !c->pool.empty()) {
-                auto it = std::prev(c->pool.end());
-                (void)hipFree(it->second);
-                c->pool_bytes -= it->first;
-                c->pool.erase(it);
+            while (c->pool_bytes > c->pool_cap) {
+                std::multimap<size_t, void *> *big = nullptr;
+                for (int i = 0; i < 2; i++)
+                    if (!c->pool[i].empty() && (!big || std::prev(c->pool[i].end())->first > std::prev(big->end())->first)) big = &c->pool[i];
+                if (big && (c->xpool.empty() || std::prev(big->end())->first >= std::prev(c->xpool.end())->first)) {
+                    auto it = std::prev(big->end());
+                    (void)hipFree(it->second); /* waits for the device: safe whatever is still queued */
+                    c->pool_bytes -= it->first;
+                    big->erase(it);
+                } else if (!c->xpool.empty()) {
+                    auto it = std::prev(c->xpool.end());
+                    (void)hipFree(it->second.p);
+                    sev_put(c, it->second.ev[0]); sev_put(c, it->second.ev[1]);
+                    c->pool_bytes -= it->first;
+                    c->xpool.erase(it);
+                } else break;
             }
         }
-        p = nullptr; bytes = 0;
+        p = nullptr; bytes = 0; used = 0;
     }
     ~DevBuf() { release(); }
     template <typename T> T *as() const { return (T *)p; }
@@ -168,8 +318,9 @@ struct DevBuf {
 struct ProfSpan {
     ntl_ctx *c;
     const char *name;
+    hipStream_t st;
     hipEvent_t a = nullptr, b = nullptr;
-    ProfSpan(ntl_ctx *ctx, const char *nm) : c(ctx), name(nm)
+    ProfSpan(ntl_ctx *ctx, const char *nm, int sid = SID_MAIN) : c(ctx), name(nm), st(ctx->s(sid))
     {
         if (!c->prof) return;
         auto get = [&](hipEvent_t &e) {
@@ -177,12 +328,12 @@ struct ProfSpan {
             else if (hipEventCreate(&e) != hipSuccess) e = nullptr;
         };
         get(a); get(b);
-        if (a) (void)hipEventRecord(a, c->stream);
+        if (a) (void)hipEventRecord(a, st);
     }
     ~ProfSpan()
     {
         if (!c->prof || !a || !b) return;
-        (void)hipEventRecord(b, c->stream);
+        (void)hipEventRecord(b, st);
         ProfEntry &P = c->profs[name];
         P.spans.push_back({a, b});
         P.launches++;
@@ -200,9 +351,24 @@ extern "C" int ntl_ctx_create(int device, ntl_ctx **out)
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return NTL_EDEVICE;
     ntl_ctx *c = new ntl_ctx();
     c->device = device;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
-        delete c;
-        return NTL_EDEVICE;
+    if (hipSetDevice(device) != hipSuccess) { delete c; return NTL_EDEVICE; }
+    /* NTL_PIPELINE=0: one stream, every kernel behind the previous one (what a per-kernel profile wants);
+       NTL_PIPELINE_PRIO: 1 (default) the MAIN stream's short latency-bound kernels get free CU slots first, 2 the window
+       stage does, 0 no priorities */
+    c->pipelined = true;
+    if (const char *e = getenv("NTL_PIPELINE")) c->pipelined = atoi(e) != 0;
+    int prio = 1;
+    if (const char *e = getenv("NTL_PIPELINE_PRIO")) prio = atoi(e);
+    int least = 0, greatest = 0;
+    if (!c->pipelined || prio == 0 || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || least == greatest) prio = 0;
+    hipError_t e1 = prio ? hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio == 1 ? greatest : least)
+                         : hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e1 != hipSuccess) { delete c; return NTL_EDEVICE; }
+    c->wstream = c->stream;
+    if (c->pipelined) {
+        hipError_t e2 = prio ? hipStreamCreateWithPriority(&c->wstream, hipStreamNonBlocking, prio == 2 ? greatest : least)
+                             : hipStreamCreateWithFlags(&c->wstream, hipStreamNonBlocking);
+        if (e2 != hipSuccess) { c->wstream = c->stream; c->pipelined = false; }
     }
     {
         uint64_t g4[256][2];
@@ -218,6 +384,11 @@ extern "C" int ntl_ctx_create(int device, ntl_ctx **out)
             delete c;
             return NTL_EDEVICE;
         }
+        if (hipHostMalloc((void **)&c->slots, NTL_NSLOTS * sizeof(PinSlot), hipHostMallocDefault) != hipSuccess) {
+            delete c;
+            return NTL_EDEVICE;
+        }
+        for (uint32_t i = 0; i < NTL_NSLOTS; i++) c->slot_free.push_back(NTL_NSLOTS - 1 - i);
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
@@ -232,30 +403,51 @@ extern "C" int ntl_ctx_create(int device, ntl_ctx **out)
     return NTL_OK;
 }
 
+static hipError_t sync_both(ntl_ctx *c)
+{
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (c->wstream != c->stream) { const hipError_t e2 = hipStreamSynchronize(c->wstream); if (e == hipSuccess) e = e2; }
+    return e;
+}
+
 extern "C" void ntl_ctx_destroy(ntl_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
-    for (auto &kv : c->pool) (void)hipFree(kv.second);
+    (void)sync_both(c);
+    reap(c, true);
+    pool_drop_all(c);
+    for (auto &m : c->masks) { (void)hipFree(m.p); sev_put(c, m.clean); }
     (void)hipFree(c->g4);
     (void)hipFree(c->g8);
     for (auto &kv : c->g8k) (void)hipFree(kv.second);
     if (c->host_tmp) (void)hipHostFree(c->host_tmp);
+    if (c->slots) (void)hipHostFree(c->slots);
     for (auto &kv : c->profs)
         for (auto &sp : kv.second.spans) { (void)hipEventDestroy(sp.first); (void)hipEventDestroy(sp.second); }
     for (auto e : c->ev_free) (void)hipEventDestroy(e);
+    for (auto &e : c->throttle) sev_put(c, e);
+    for (auto e : c->sev_free) (void)hipEventDestroy(e);
+    if (c->wstream != c->stream) (void)hipStreamDestroy(c->wstream);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
 extern "C" const char *ntl_last_error(const ntl_ctx *c) { return c ? c->err.c_str() : "no context"; }
 extern "C" const char *ntl_ctx_device_name(const ntl_ctx *c) { return c ? c->devname.c_str() : ""; }
+extern "C" int ntl_ctx_pipelined(const ntl_ctx *c) { return c && c->pipelined ? 1 : 0; }
 
 extern "C" int ntl_ctx_sync(ntl_ctx *c)
 {
     if (!c) return NTL_EINVAL;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    (void)hipSetDevice(c->device);
+    HIPCHK(c, sync_both(c));
+    reap(c, true);
+    if (!c->async_err.empty()) {
+        const std::string m = c->async_err;
+        c->async_err.clear();
+        return fail(c, NTL_EINTERNAL, m);
+    }
     return NTL_OK;
 }
 
@@ -268,7 +460,7 @@ extern "C" int ntl_prof_enable(ntl_ctx *c, int on)
 
 static void prof_collect(ntl_ctx *c)
 {
-    (void)hipStreamSynchronize(c->stream);
+    (void)sync_both(c);
     for (auto &kv : c->profs) {
         for (auto &sp : kv.second.spans) {
             float ms = 0;
@@ -304,22 +496,23 @@ extern "C" int ntl_prof_get(ntl_ctx *c, const char *name, double *total_ms, uint
  * out + y*(n+1), out[n] of each = its sum (arrays hold n+1 entries; in may equal out).  With total_host the
  * sums also come back to the host (one stream sync); without it nothing waits. */
 static int device_scan(ntl_ctx *c, const uint32_t *in, uint32_t *out, uint64_t n, uint32_t *total_host, unsigned batch = 1,
-                       uint32_t *sums_dev = nullptr)
+                       uint32_t *sums_dev = nullptr, int sid = SID_MAIN)
 {
     uint64_t tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
     if (tiles == 0) tiles = 1;
     DevBuf tile;
     int rc;
-    if ((rc = tile.alloc(c, tiles * 4 * batch))) return rc;
-    hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)tiles, batch), dim3(SCAN_NT), 0, c->stream, in, n, tile.as<uint32_t>(), n + 1, tiles);
-    hipLaunchKernelGGL(scan_tiles_kernel, dim3(1, batch), dim3(SCAN_NT), 0, c->stream, tile.as<uint32_t>(), tiles, out + n, n + 1, sums_dev);
-    hipLaunchKernelGGL(scan_down_kernel, dim3((unsigned)tiles, batch), dim3(SCAN_NT), 0, c->stream, in, out, n,
+    hipStream_t st = c->s(sid);
+    if ((rc = tile.alloc(c, tiles * 4 * batch, sid))) return rc;
+    hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)tiles, batch), dim3(SCAN_NT), 0, st, in, n, tile.as<uint32_t>(), n + 1, tiles);
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(1, batch), dim3(SCAN_NT), 0, st, tile.as<uint32_t>(), tiles, out + n, n + 1, sums_dev);
+    hipLaunchKernelGGL(scan_down_kernel, dim3((unsigned)tiles, batch), dim3(SCAN_NT), 0, st, in, out, n,
                        (const uint32_t *)tile.as<uint32_t>(), n + 1, tiles);
     HIPCHK(c, hipGetLastError());
     if (total_host) {
         for (unsigned y = 0; y < batch; y++)
-            HIPCHK(c, hipMemcpyAsync(total_host + y, out + y * (n + 1) + n, 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, hipMemcpyAsync(total_host + y, out + y * (n + 1) + n, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
     }
     return NTL_OK;
 }
@@ -328,11 +521,36 @@ static int device_scan(ntl_ctx *c, const uint32_t *in, uint32_t *out, uint64_t n
 
 struct ntl_batch {
     ntl_ctx *c;
+    std::atomic<int> refs{1}; /* the caller's + one per sketch that may still have to be redone from it (sketch_finalize) */
     uint64_t nseq = 0, bases = 0, nruns = 0, total_gpos = 0, nwords_packed = 0;
     bool any_multi = false; /* some sequence has more than one ACGT run */
     DevBuf packed, seq_base, seq_run_first, run_start, run_len;
+    DevBuf seq_len_dev;             /* u32[nseq]: the `--len` column of the batch's sequences (unset where run_len already is that) */
+    const uint32_t *d_seq_len = nullptr;
     std::vector<uint32_t> seq_len;
+    /* a batch whose creating call returned without waiting (the synthetic ones): recorded on MAIN behind its last kernel;
+       the window stream waits for it once */
+    hipEvent_t ready = nullptr;
+    mutable bool w_waited = false;
 };
+
+static void batch_unref(const ntl_batch *cb)
+{
+    ntl_batch *b = const_cast<ntl_batch *>(cb);
+    if (b && --b->refs == 0) {
+        (void)hipSetDevice(b->c->device);
+        sev_put(b->c, b->ready);
+        delete b;
+    }
+}
+
+/* the window stage reads the batch on its own stream */
+static void batch_on_wstream(ntl_ctx *c, const ntl_batch *b)
+{
+    if (!c->pipelined) return;
+    if (b->ready && !b->w_waited) { (void)hipStreamWaitEvent(c->wstream, b->ready, 0); b->w_waited = true; }
+    b->packed.touch(SID_W); b->seq_base.touch(SID_W); b->seq_run_first.touch(SID_W); b->run_start.touch(SID_W); b->run_len.touch(SID_W);
+}
 
 /* Host arrays in, device layout out: the bases travel as they are (one byte each) and are packed and
  * scanned for ACGT runs on the device (pack_kernels.h).  Pinned memory from ntl_host_alloc makes the
@@ -375,6 +593,9 @@ extern "C" int ntl_batch_create(ntl_ctx *c, const char *seqs, const uint64_t *of
     ProfSpan span(c, "batch_pack");
     if (total) HIPCHK(c, hipMemcpyAsync(raw.p, seqs + o0, total, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(b->seq_base.p, seq_base.data(), (nseq + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    if ((rc = b->seq_len_dev.alloc(c, (nseq + 1) * 4))) return rc;
+    if (nseq) HIPCHK(c, hipMemcpyAsync(b->seq_len_dev.p, b->seq_len.data(), nseq * 4, hipMemcpyHostToDevice, c->stream));
+    b->d_seq_len = b->seq_len_dev.as<uint32_t>();
     HIPCHK(c, hipMemsetAsync(b->packed.p, 0, nwords * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(valid32.p, 0, (n32 + 2) * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(ss32.p, 0, (n32 + 2) * 4, c->stream));
@@ -461,6 +682,9 @@ extern "C" int ntl_batch_create_packed(ntl_ctx *c, const uint32_t *packed, const
         HIPCHK(c, hipMemcpyAsync(b->packed.p, packed, b->nwords_packed * 4, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(b->seq_base.p, seq_base.data(), (nseq + 1) * 8, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(b->seq_run_first.p, seq_run_first, (nseq + 1) * 4, hipMemcpyHostToDevice, c->stream));
+        if ((rc = b->seq_len_dev.alloc(c, (nseq + 1) * 4))) return rc;
+        if (nseq) HIPCHK(c, hipMemcpyAsync(b->seq_len_dev.p, b->seq_len.data(), nseq * 4, hipMemcpyHostToDevice, c->stream));
+        b->d_seq_len = b->seq_len_dev.as<uint32_t>();
         if (nruns) {
             HIPCHK(c, hipMemcpyAsync(b->run_start.p, run_start, nruns * 4, hipMemcpyHostToDevice, c->stream));
             HIPCHK(c, hipMemcpyAsync(b->run_len.p, run_len, nruns * 4, hipMemcpyHostToDevice, c->stream));
@@ -471,7 +695,7 @@ extern "C" int ntl_batch_create_packed(ntl_ctx *c, const uint32_t *packed, const
     return NTL_OK;
 }
 
-extern "C" void ntl_batch_destroy(ntl_batch *b) { delete b; }
+extern "C" void ntl_batch_destroy(ntl_batch *b) { batch_unref(b); }
 
 extern "C" int ntl_host_alloc(ntl_ctx *c, uint64_t bytes, void **out)
 {
@@ -525,6 +749,7 @@ static int synth_layout(ntl_ctx *c, const uint32_t *len, uint64_t nseq, std::uni
     HIPCHK(c, hipMemcpyAsync(b->seq_run_first.p, iota.data(), (nseq + 1) * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(b->run_start.p, 0, (nseq + 1) * 4, c->stream));
     if (nseq) HIPCHK(c, hipMemcpyAsync(b->run_len.p, len, nseq * 4, hipMemcpyHostToDevice, c->stream));
+    b->d_seq_len = b->run_len.as<uint32_t>(); /* one run per sequence: the run lengths are the sequence lengths */
     HIPCHK(c, hipStreamSynchronize(c->stream)); /* iota and seq_base are stack/host temporaries */
     return NTL_OK;
 }
@@ -541,6 +766,7 @@ extern "C" int ntl_synth_genome(ntl_ctx *c, uint64_t seed, const uint32_t *len, 
     const uint64_t nw = b->nwords_packed;
     hipLaunchKernelGGL(synth_genome_kernel, dim3((unsigned)((nw / 2 + 256) / 256)), dim3(256), 0, c->stream, b->packed.as<uint32_t>(), nw, seed);
     HIPCHK(c, hipGetLastError());
+    if (c->pipelined && (b->ready = sev_get(c))) HIPCHK(c, hipEventRecord(b->ready, c->stream));
     *out = b.release();
     return NTL_OK;
 }
@@ -616,30 +842,71 @@ extern "C" int ntl_batch_download(const ntl_batch *b, char *seqs, uint64_t *off)
 
 /* ------------------------------------------------------------------ index (type) --------- */
 
+static std::atomic<uint64_t> g_index_gen{1};
+
 struct ntl_index {
     ntl_ctx *c;
+    uint64_t gen = 0;                    /* identity of this index: a sketch made for it remembers the number, not the address */
     int bits = 0;
     uint64_t nslots = 0;
     mutable uint64_t size = 0;
     mutable bool size_known = false;
-    mutable double hit_fraction = 0.0;   /* of the last batch mapped against this index: picks the probe form */
+    mutable std::atomic<float> hit_fraction{0.0f}; /* of the last batch mapped against this index: picks the probe form */
     uint32_t n_ctg = 0;
     DevBuf slots, special, ctg_len, cnt; /* cnt: device-side count of kept keys, fetched on demand */
     DevBuf tags;                         /* one byte per slot (map_kernels.h index_tag) */
     std::vector<uint32_t> h_ctg_len;     /* source of the asynchronous upload: must outlive it */
+    hipEvent_t built = nullptr;          /* on the building context's MAIN stream: other contexts' streams wait for it */
 };
+
+/* what emit_kernel leaves in the sketch's page-locked slot */
+struct SketchSums { uint32_t total_mx, redo_n; unsigned long long nfound; };
 
 struct ntl_sketch {
     ntl_ctx *c;
-    uint64_t nseq = 0, count = 0;
-    uint64_t strips = 0, redo_strips = 0; /* diagnostics: strips of the window pass, strips that also took the exact pass */
-    DevBuf records; /* MxRecord[count] */
-    DevBuf mx_off;  /* u32[nseq+1] */
-    /* ntl_sketch_run_indexed: the minimizers were looked up in cand_ix while they were emitted */
-    const ntl_index *cand_ix = nullptr;
-    DevBuf cand;    /* Cand[count] */
-    DevBuf nfound;  /* u64: lookups that found a unique key */
+    std::atomic<int> refs{1};             /* the caller's + one per map result that may have to be redone from it */
+    uint64_t nseq = 0;
+    mutable uint64_t count = 0;           /* valid once !pending */
+    mutable uint64_t strips = 0, redo_strips = 0; /* diagnostics: strips of the window pass, strips that also took the exact pass */
+    mutable uint64_t nfound = 0;
+    mutable DevBuf records; /* MxRecord[cap] */
+    mutable DevBuf mx_off;  /* u32[nseq+1] */
+    mutable uint64_t cap = 0;             /* records the arrays can hold */
+    /* ntl_sketch_run_indexed: the minimizers were looked up in index cand_gen while they were emitted */
+    uint64_t cand_gen = 0;
+    mutable DevBuf cand;    /* Cand[cap] */
+    mutable DevBuf rlen;    /* u32[nseq]: lengths of the sketched sequences (sketches made from a batch) */
+    mutable DevBuf sums;    /* SketchSums on the device: total (read by the map kernels: a sketch that overflowed its arrays is left alone) */
+    /* lazy completion */
+    mutable bool pending = false;
+    mutable hipEvent_t done = nullptr;
+    mutable PinSlot *slot = nullptr;
+    mutable uint64_t gen = 0;             /* bumped when the sketch had to be made again with larger arrays */
+    mutable int failed = 0;               /* sticky error code of the completion */
+    const ntl_batch *src = nullptr;       /* held (refs) while pending: a sketch that overflowed is redone from it */
+    const ntl_index *src_ix = nullptr;
+    int k = 0, w = 0;
 };
+
+static int sketch_finalize(const ntl_sketch *s);
+
+static void sketch_unref(const ntl_sketch *cs)
+{
+    ntl_sketch *s = const_cast<ntl_sketch *>(cs);
+    if (!s || --s->refs != 0) return;
+    ntl_ctx *c = s->c;
+    (void)hipSetDevice(c->device);
+    if (s->pending) { /* nobody asked: the device blocks go back now (stream-ordered), event and slot when the work is done */
+        Zombie z;
+        z.done = s->done; z.slot = s->slot; z.kind = 1; z.cap = s->cap;
+        c->zombies.push_back(z);
+    } else {
+        sev_put(c, s->done);
+        slot_put(c, s->slot);
+    }
+    if (s->src) batch_unref(s->src);
+    delete s;
+}
 
 static uint64_t h_srol1(uint64_t x)
 {
@@ -713,8 +980,8 @@ static void launch_mask_r0(ntl_ctx *c, const SketchArgs &A, unsigned strips, boo
 {
     if (R0 < 0 || A.G.r0 == R0) {
         const unsigned grid = A.redo_list ? 2048u : ((strips + 7u) & ~7u);
-        if (single) hipLaunchKernelGGL((sketch_mask_kernel<C, NT, false, R0>), dim3(grid), dim3(NT), 0, c->stream, A);
-        if (multi) hipLaunchKernelGGL((sketch_mask_kernel<C, NT, true, R0>), dim3((strips + 7u) & ~7u), dim3(NT), 0, c->stream, A);
+        if (single) hipLaunchKernelGGL((sketch_mask_kernel<C, NT, false, R0>), dim3(grid), dim3(NT), 0, c->wstream, A);
+        if (multi) hipLaunchKernelGGL((sketch_mask_kernel<C, NT, true, R0>), dim3((strips + 7u) & ~7u), dim3(NT), 0, c->wstream, A);
         return;
     }
     if constexpr (R0 >= 0 && R0 + 1 < C) launch_mask_r0<C, NT, R0 + 1>(c, A, strips, single, multi);
@@ -737,31 +1004,62 @@ static void launch_fast_r0(ntl_ctx *c, const Sketch2Args &B, unsigned strips)
     if (B.A.G.r0 == R0) {
         const dim3 grid((strips + 7u) & ~7u);
         /* the 20-KB variant holds 128 searched windows per strip: about NWO / (w + 1) are expected (38 at w = 100) */
-        if (B.A.G.a + 2 <= 16 && B.A.G.w >= 64) hipLaunchKernelGGL((sketch_fast_kernel<NT, R0, false>), grid, dim3(NT), 0, c->stream, B);
-        else hipLaunchKernelGGL((sketch_fast_kernel<NT, R0, true>), grid, dim3(NT), 0, c->stream, B);
+        if (B.A.G.a + 2 <= 16 && B.A.G.w >= 64) hipLaunchKernelGGL((sketch_fast_kernel<NT, R0, false>), grid, dim3(NT), 0, c->wstream, B);
+        else hipLaunchKernelGGL((sketch_fast_kernel<NT, R0, true>), grid, dim3(NT), 0, c->wstream, B);
         return;
     }
     if constexpr (R0 + 1 < 16) launch_fast_r0<NT, R0 + 1>(c, B, strips);
 }
 
-static int sketch_run_impl(ntl_ctx *c, const ntl_batch *b, int k, int w, const ntl_index *ix, ntl_sketch **out)
+/* a zero-filled bitmask of at least `bytes` for the window stage (stream sid): one that an earlier emit kernel cleared
+   behind itself, or a new one.  With the pipeline on, three masks rotate, so that the window stage of batch i+1 never
+   waits for the emit kernel of batch i. */
+static int mask_take(ntl_ctx *c, size_t bytes, int sid, CleanMask *out)
 {
-    if (!c || !b || !out) return NTL_EINVAL;
-    *out = nullptr;
+    const size_t want = (bytes + 255) & ~(size_t)255;
+    const size_t keep = c->pipelined ? 2 : 0;
+    if (c->masks.size() > keep) {
+        for (size_t i = 0; i < c->masks.size() - keep; i++) {
+            CleanMask m = c->masks[i];
+            if (m.bytes >= want && m.bytes <= want + want / 4 + (1 << 20)) {
+                c->masks.erase(c->masks.begin() + (long)i);
+                if (m.clean && c->s(sid) != c->stream) (void)hipStreamWaitEvent(c->s(sid), m.clean, 0);
+                sev_put(c, m.clean);
+                m.clean = nullptr;
+                *out = m;
+                return NTL_OK;
+            }
+        }
+    }
+    while (c->masks.size() > 4) { /* other batch sizes came and went */
+        (void)hipFree(c->masks.front().p);
+        sev_put(c, c->masks.front().clean);
+        c->masks.pop_front();
+    }
+    CleanMask m;
+    int rc = dev_alloc(c, want, &m.p);
+    if (rc) return rc;
+    m.bytes = want;
+    HIPCHK(c, hipMemsetAsync(m.p, 0, want, c->s(sid)));
+    *out = m;
+    return NTL_OK;
+}
+
+/* geometry of the window pass for (k, w): k-mers per lane, lanes per strip */
+static int sketch_geometry(ntl_ctx *c, int k, int w, SketchGeom &G, int &C, int &nt)
+{
     if (k < 1 || k > 4096 || w < 1) return fail(c, NTL_EINVAL, "k must be in 1..4096 and w >= 1");
-    (void)hipSetDevice(c->device);
-    int C = w >= 16 ? 16 : (w >= 4 ? 4 : 1);
+    C = w >= 16 ? 16 : (w >= 4 ? 4 : 1);
     if (const char *e = getenv("NTL_SKETCH_C")) { /* tuning knob: k-mers per lane (16, 4, 1) */
         const int v = atoi(e);
         if ((v == 16 || v == 4 || v == 1) && w >= v) C = v;
     }
-    SketchGeom G;
     G.k = k; G.w = w;
     G.a = (w - C) / C; G.r0 = (w - C) % C;
     /* lanes per strip: 128-lane strips waste fewer lanes on the last strip of a ~10 kb read, 256-lane strips fewer on the halo
        (a+2 lanes) and fit eight workgroups of the 32-bit window pass on a CU.  Measured with that pass: 256 lanes +6 % at w=100
        (10 kb reads 675 -> 714 Gbases/s, 20 kb reads 696 -> 747); 128 lanes stay for the small windows (w < 64) */
-    int nt = (C == 16 && w < 64) ? 128 : SK_NT;
+    nt = (C == 16 && w < 64) ? 128 : SK_NT;
     if (const char *e = getenv("NTL_SKETCH_NT")) { /* tuning knob; ignored where it leaves no lane to own a window */
         const int v = atoi(e);
         if ((v == 256 || (v == 128 && C == 16)) && v - (G.a + 2) >= 2) nt = v;
@@ -780,27 +1078,48 @@ static int sketch_run_impl(ntl_ctx *c, const ntl_batch *b, int k, int w, const n
                  w, NTL_MAX_W, SK_NT);
         return fail(c, NTL_EINVAL, msg);
     }
+    return NTL_OK;
+}
+
+/* Queues one sketch: the window stage on the window stream, count + emit (+ index lookup) on MAIN behind it.  Nothing
+ * waits; the minimizer total lands in the sketch's page-locked slot and s->done is recorded behind it.  `cap` = records the
+ * arrays hold: a guess from the expected density (sketch_finalize makes the sketch again if the batch was denser), or the
+ * exact total on that second round. */
+static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const ntl_index *ix, ntl_sketch *s, uint64_t cap)
+{
+    SketchGeom G;
+    int C, nt, rc;
+    if ((rc = sketch_geometry(c, k, w, G, C, nt))) return rc;
     const uint64_t nseq = b->nseq;
-    std::unique_ptr<ntl_sketch> s_guard(new ntl_sketch());
-    ntl_sketch *s = s_guard.get();
-    s->c = c; s->nseq = nseq;
-    int rc;
-    DevBuf run_n, run_ord, seq_M, nstrips, strip_first, mask, tile, tot, redo;
-    uint32_t redo_n = 0;
+    const int wsid = c->sid(SID_W);
+    hipStream_t ws = c->s(wsid), ms = c->stream;
+    /* the host runs at most 8 sketches ahead of the device */
+    {
+        hipEvent_t &t = c->throttle[c->n_enqueued & 7u];
+        if (t) (void)hipEventSynchronize(t);
+        reap(c, false);
+    }
+    DevBuf run_n, run_ord, seq_M, nstrips, strip_first, tile, redo, strip_tab;
     bool fast = false;
     /* nstrips / strip_first hold nseq+1 entries: the scan leaves the total behind the last one */
     const uint64_t nmask = (b->total_gpos + 31) / 32 + 1;
-    if ((rc = run_n.alloc(c, (b->nruns + 1) * 4)) || (rc = run_ord.alloc(c, (b->nruns + 1) * 4)) ||
-        (rc = seq_M.alloc(c, (nseq + 1) * 4)) || (rc = nstrips.alloc(c, (nseq + 1) * 4)) ||
-        (rc = strip_first.alloc(c, (nseq + 2) * 4)) || (rc = mask.alloc(c, nmask * 4)) ||
-        (rc = s->mx_off.alloc(c, (nseq + 1) * 4))) {
+    if ((rc = run_n.alloc(c, (b->nruns + 1) * 4, wsid)) || (rc = run_ord.alloc(c, (b->nruns + 1) * 4, wsid)) ||
+        (rc = seq_M.alloc(c, (nseq + 1) * 4, wsid)) || (rc = nstrips.alloc(c, (nseq + 1) * 4, wsid)) ||
+        (rc = strip_first.alloc(c, (nseq + 2) * 4, wsid)) || (rc = s->mx_off.alloc(c, (nseq + 1) * 4)) ||
+        (rc = s->sums.alloc(c, sizeof(SketchSums)))) {
         return rc;
     }
+    CleanMask mask;
+    if ((rc = mask_take(c, nmask * 4, wsid, &mask))) return rc;
+    struct MaskGuard { /* error paths: the mask is not known to be clean any more */
+        ntl_ctx *c; CleanMask *m;
+        ~MaskGuard() { if (m->p) { (void)hipFree(m->p); m->p = nullptr; } }
+    } mask_guard{c, &mask};
+    batch_on_wstream(c, b);
     SeqTables T;
     T.packed = b->packed.as<uint32_t>(); T.seq_base = b->seq_base.as<uint64_t>();
     T.seq_run_first = b->seq_run_first.as<uint32_t>(); T.run_start = b->run_start.as<uint32_t>();
     T.run_len = b->run_len.as<uint32_t>(); T.nseq = (uint32_t)nseq;
-    uint32_t total_mx = 0;
     /* upper bound of the number of strips from the host-side lengths (exact for sequences without
        non-ACGT bytes): the grid is sized without waiting for the device */
     uint64_t ub_strips = 0;
@@ -809,19 +1128,19 @@ static int sketch_run_impl(ntl_ctx *c, const ntl_batch *b, int k, int w, const n
         if (len + 2 > (uint64_t)k + (uint64_t)w) ub_strips += (len - k - w + 2 + (uint64_t)G.NWO - 1) / (uint64_t)G.NWO;
     }
     if (ub_strips >= 0x7FFFFFFFull) return fail(c, NTL_EINVAL, "batch too large: too many strips");
-    DevBuf strip_tab;
-    if ((rc = strip_tab.alloc(c, (ub_strips + 1) * sizeof(StripInfo)))) return rc;
+    if ((rc = strip_tab.alloc(c, (ub_strips + 1) * sizeof(StripInfo), wsid))) return rc;
+    SketchSums *dsums = s->sums.as<SketchSums>();
+    HIPCHK(c, hipMemsetAsync(dsums, 0, sizeof(SketchSums), ms));
     {
-        ProfSpan sp(c, "sketch_meta");
-        HIPCHK(c, hipMemsetAsync(mask.p, 0, nmask * 4, c->stream));
+        ProfSpan sp(c, "sketch_meta", wsid);
         if (nseq) {
             KTables K;
             K.run_n = run_n.as<uint32_t>(); K.run_ord = run_ord.as<uint32_t>();
             K.seq_M = seq_M.as<uint32_t>(); K.seq_nstrips = nstrips.as<uint32_t>();
-            hipLaunchKernelGGL(seq_meta_kernel, dim3((unsigned)((nseq + 255) / 256)), dim3(256), 0, c->stream, T, K, k, w, G.NWO);
+            hipLaunchKernelGGL(seq_meta_kernel, dim3((unsigned)((nseq + 255) / 256)), dim3(256), 0, ws, T, K, k, w, G.NWO);
             HIPCHK(c, hipGetLastError());
-            if ((rc = device_scan(c, nstrips.as<uint32_t>(), strip_first.as<uint32_t>(), nseq, nullptr))) return rc;
-            hipLaunchKernelGGL(strip_table_kernel, dim3((unsigned)((ub_strips + 255) / 256 + 1)), dim3(256), 0, c->stream, T,
+            if ((rc = device_scan(c, nstrips.as<uint32_t>(), strip_first.as<uint32_t>(), nseq, nullptr, 1, nullptr, wsid))) return rc;
+            hipLaunchKernelGGL(strip_table_kernel, dim3((unsigned)((ub_strips + 255) / 256 + 1)), dim3(256), 0, ws, T,
                                (const uint32_t *)run_n.as<uint32_t>(), (const uint32_t *)run_ord.as<uint32_t>(),
                                (const uint32_t *)seq_M.as<uint32_t>(), (const uint32_t *)strip_first.as<uint32_t>(), G.NWO,
                                C * nt, strip_tab.as<StripInfo>(), (uint32_t)ub_strips + 1u);
@@ -832,7 +1151,7 @@ static int sketch_run_impl(ntl_ctx *c, const ntl_batch *b, int k, int w, const n
         SketchArgs A;
         A.T = T;
         A.run_n = run_n.as<uint32_t>(); A.run_ord = run_ord.as<uint32_t>(); A.seq_M = seq_M.as<uint32_t>();
-        A.strip_tab = strip_tab.as<StripInfo>(); A.nstrips = (uint32_t)ub_strips; A.mask = mask.as<uint32_t>(); A.G = G;
+        A.strip_tab = strip_tab.as<StripInfo>(); A.nstrips = (uint32_t)ub_strips; A.mask = (uint32_t *)mask.p; A.G = G;
         make_tables(k, A.roll_tab, A.seed_tab);
         A.g4 = (const uint64_t (*)[2])c->g4;
         A.g8 = (const uint64_t (*)[2])c->g8;
@@ -841,8 +1160,8 @@ static int sketch_run_impl(ntl_ctx *c, const ntl_batch *b, int k, int w, const n
         fast = C == 16 && k <= 16 * SK2_QMAX && G.a + 2 <= SK2_PAD;
         if (const char *e = getenv("NTL_SKETCH_FAST")) fast = fast && atoi(e) != 0; /* 0: exact pass only (A/B, tests) */
         if (fast) {
-            if ((rc = redo.alloc(c, (ub_strips + 2) * 4))) return rc;
-            HIPCHK(c, hipMemsetAsync(redo.p, 0, 4, c->stream));
+            if ((rc = redo.alloc(c, (ub_strips + 2) * 4, wsid))) return rc;
+            HIPCHK(c, hipMemsetAsync(redo.p, 0, 4, ws));
             Sketch2Args B;
             B.A = A;
             B.redo_count = redo.as<uint32_t>(); B.redo_list = redo.as<uint32_t>() + 1;
@@ -851,15 +1170,15 @@ static int sketch_run_impl(ntl_ctx *c, const ntl_batch *b, int k, int w, const n
             B.rev_a = (uint32_t)(k - 1) % 33u; B.rev_b = (uint32_t)(k - 1) % 31u;
             {
                 auto it = c->g8k.find(k);
-                if (it == c->g8k.end()) { /* built once per k and context, on the stream in front of its first user */
-                    if (c->g8k.size() >= 8) { /* a caller that sweeps k: start over (the stream orders the free behind earlier users) */
-                        HIPCHK(c, hipStreamSynchronize(c->stream));
+                if (it == c->g8k.end()) { /* built once per k and context, on the window stream in front of its first user */
+                    if (c->g8k.size() >= 8) { /* a caller that sweeps k: start over */
+                        HIPCHK(c, sync_both(c));
                         for (auto &kv : c->g8k) (void)hipFree(kv.second);
                         c->g8k.clear();
                     }
                     void *t = nullptr;
                     if (hipMalloc(&t, (size_t)2 * 65536 * sizeof(uint2)) != hipSuccess) return fail(c, NTL_ENOMEM, "hipMalloc failed");
-                    hipLaunchKernelGGL(g8k_build_kernel, dim3(256), dim3(256), 0, c->stream, (const uint64_t (*)[2])c->g8, (uint2 *)t,
+                    hipLaunchKernelGGL(g8k_build_kernel, dim3(256), dim3(256), 0, ws, (const uint64_t (*)[2])c->g8, (uint2 *)t,
                                        B.rev_a, B.rev_b);
                     HIPCHK(c, hipGetLastError());
                     it = c->g8k.emplace(k, t).first;
@@ -871,56 +1190,54 @@ static int sketch_run_impl(ntl_ctx *c, const ntl_batch *b, int k, int w, const n
             if (const char *e = getenv("NTL_SKETCH_ABLATE")) B.dbg = atoi(e); /* tools/sketch_bench.py only: results are wrong */
             if (const char *e = getenv("NTL_SKETCH_FORCE_REDO")) B.force_redo = atoi(e); /* tests: every strip takes both passes */
             {
-                ProfSpan sp(c, "sketch_mask");
+                ProfSpan sp(c, "sketch_mask", wsid);
                 if (nt == 128) launch_fast_r0<128, 0>(c, B, (unsigned)ub_strips);
                 else launch_fast_r0<SK_NT, 0>(c, B, (unsigned)ub_strips);
                 HIPCHK(c, hipGetLastError());
             }
-            ProfSpan sp(c, "sketch_redo");
+            ProfSpan sp(c, "sketch_redo", wsid);
             SketchArgs R = A;
             R.redo_count = B.redo_count; R.redo_list = B.redo_list;
             launch_mask<16>(c, R, (unsigned)ub_strips, true, false, nt);
             if (b->any_multi) launch_mask<16>(c, A, (unsigned)ub_strips, false, true, nt);
             HIPCHK(c, hipGetLastError());
+            /* the redo count travels with the window stream: `redo` never leaves it */
+            HIPCHK(c, hipMemcpyAsync(&((SketchSums *)s->slot)->redo_n, redo.p, 4, hipMemcpyDeviceToHost, ws));
         } else {
-            ProfSpan sp(c, "sketch_mask");
+            ProfSpan sp(c, "sketch_mask", wsid);
             if (C == 16) launch_mask<16>(c, A, (unsigned)ub_strips, true, b->any_multi, nt);
             else if (C == 4) launch_mask<4>(c, A, (unsigned)ub_strips, true, b->any_multi, nt);
             else launch_mask<1>(c, A, (unsigned)ub_strips, true, b->any_multi, nt);
             HIPCHK(c, hipGetLastError());
         }
     }
+    if (ws != ms) { /* window stage -> emit */
+        hipEvent_t e = sev_get(c);
+        if (!e) return fail(c, NTL_EDEVICE, "hipEventCreate failed");
+        HIPCHK(c, hipEventRecord(e, ws));
+        HIPCHK(c, hipStreamWaitEvent(ms, e, 0));
+        sev_put(c, e); /* the wait holds what it needs; the handle may be recorded again */
+    }
     {
         ProfSpan sp(c, "sketch_emit");
         const uint64_t tiles = (nmask + EMIT_TILE - 1) / EMIT_TILE;
-        if ((rc = tile.alloc(c, tiles * 4)) || (rc = tot.alloc(c, 4))) return rc;
-        hipLaunchKernelGGL(mask_count_kernel, dim3((unsigned)tiles), dim3(EMIT_NT), 0, c->stream,
-                           (const uint32_t *)mask.as<uint32_t>(), nmask, tile.as<uint32_t>());
-        hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(SCAN_NT), 0, c->stream, tile.as<uint32_t>(), tiles, tot.as<uint32_t>(), (uint64_t)0, (uint32_t *)nullptr);
+        if ((rc = tile.alloc(c, tiles * 4))) return rc;
+        hipLaunchKernelGGL(mask_count_kernel, dim3((unsigned)tiles), dim3(EMIT_NT), 0, ms,
+                           (const uint32_t *)mask.p, nmask, tile.as<uint32_t>());
+        hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(SCAN_NT), 0, ms, tile.as<uint32_t>(), tiles, &dsums->total_mx, (uint64_t)0, (uint32_t *)nullptr);
         HIPCHK(c, hipGetLastError());
-        /* The record array is sized from the expected density before the count is known, so that the device
-           goes straight on to the emit kernel while the host waits for the count; a batch denser than the
-           guess (possible, not seen) is emitted a second time into an exact-size array. */
-        uint64_t cap_guess = (uint64_t)(2.5 * (double)b->bases / (double)(w + 1)) + 65536;
-        if (cap_guess > b->bases + 1) cap_guess = b->bases + 1;
-        if (cap_guess > 0xFFFFFFF0ull) cap_guess = 0xFFFFFFF0ull;
-        if (const char *e = getenv("NTL_SKETCH_CAP_GUESS")) cap_guess = (uint64_t)atoll(e); /* tests: force the second pass */
-        if ((rc = s->records.alloc(c, cap_guess * sizeof(MxRecord)))) return rc;
-        const int probe = !ix ? 0 : (ix->hit_fraction <= 0.5 ? 1 : 2); /* tags first unless the last batch on this index mostly hit */
+        if ((rc = s->records.alloc(c, cap * sizeof(MxRecord)))) return rc;
+        s->cap = cap;
+        const int probe = !ix ? 0 : (ix->hit_fraction.load(std::memory_order_relaxed) <= 0.5f ? 1 : 2); /* tags first unless the last batch on this index mostly hit */
         if (ix) {
-            if ((rc = s->cand.alloc(c, cap_guess * sizeof(Cand))) || (rc = s->nfound.alloc(c, 8))) return rc;
-            HIPCHK(c, hipMemsetAsync(s->nfound.p, 0, 8, c->stream));
-            s->cand_ix = ix;
+            if ((rc = s->cand.alloc(c, cap * sizeof(Cand)))) return rc;
+            s->cand_gen = ix->gen;
+            if (ix->c != c && ix->built) HIPCHK(c, hipStreamWaitEvent(ms, ix->built, 0));
         }
-        auto launch_emit = [&](const EmitArgs &EA, unsigned ntiles) {
-            if (probe == 0) hipLaunchKernelGGL(emit_kernel<0>, dim3(ntiles), dim3(EMIT_NT), 0, c->stream, EA);
-            else if (probe == 1) hipLaunchKernelGGL(emit_kernel<1>, dim3(ntiles), dim3(EMIT_NT), 0, c->stream, EA);
-            else hipLaunchKernelGGL(emit_kernel<2>, dim3(ntiles), dim3(EMIT_NT), 0, c->stream, EA);
-        };
         EmitArgs E;
-        E.packed = T.packed; E.seq_base = T.seq_base; E.nseq = (uint32_t)nseq; E.mask = mask.as<uint32_t>();
+        E.packed = T.packed; E.seq_base = T.seq_base; E.nseq = (uint32_t)nseq; E.mask = (uint32_t *)mask.p;
         E.nwords = nmask; E.tile_off = tile.as<uint32_t>(); E.mx_off = s->mx_off.as<uint32_t>();
-        E.out = s->records.as<MxRecord>(); E.out_cap = (uint32_t)cap_guess;
+        E.out = s->records.as<MxRecord>(); E.out_cap = (uint32_t)cap;
         E.k = k; E.mult = 1ull ^ ((uint64_t)k * 0x90b45d39fb6da1faull);
         uint64_t roll[16][2];
         make_tables(k, roll, E.seed_tab);
@@ -929,32 +1246,96 @@ static int sketch_run_impl(ntl_ctx *c, const ntl_batch *b, int k, int w, const n
         E.slots = nullptr; E.tags = nullptr; E.special = nullptr; E.ix_bits = 0; E.cand = nullptr; E.nfound = nullptr;
         if (ix) {
             E.slots = ix->slots.as<IndexSlot>(); E.tags = ix->tags.as<uint8_t>(); E.special = ix->special.as<IndexSpecial>();
-            E.ix_bits = ix->bits; E.cand = s->cand.as<Cand>(); E.nfound = s->nfound.as<unsigned long long>();
+            E.ix_bits = ix->bits; E.cand = s->cand.as<Cand>(); E.nfound = &dsums->nfound;
         }
-        launch_emit(E, (unsigned)tiles);
+        /* the emit kernel is the last reader of the bitmask and clears the words it read: the mask goes back clean */
+        if (probe == 0) hipLaunchKernelGGL(emit_kernel<0>, dim3((unsigned)tiles), dim3(EMIT_NT), 0, ms, E);
+        else if (probe == 1) hipLaunchKernelGGL(emit_kernel<1>, dim3((unsigned)tiles), dim3(EMIT_NT), 0, ms, E);
+        else hipLaunchKernelGGL(emit_kernel<2>, dim3((unsigned)tiles), dim3(EMIT_NT), 0, ms, E);
         HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipMemcpyAsync(&total_mx, tot.p, 4, hipMemcpyDeviceToHost, c->stream));
-        if (fast) HIPCHK(c, hipMemcpyAsync(&redo_n, redo.p, 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, sync_hot(c));
-        s->count = total_mx;
-        s->strips = ub_strips;
-        s->redo_strips = redo_n;
-        if ((uint64_t)total_mx > cap_guess) {
-            if ((rc = s->records.alloc(c, (uint64_t)total_mx * sizeof(MxRecord)))) return rc;
-            E.out = s->records.as<MxRecord>(); E.out_cap = total_mx;
-            if (ix) {
-                if ((rc = s->cand.alloc(c, (uint64_t)total_mx * sizeof(Cand)))) return rc;
-                E.cand = s->cand.as<Cand>();
-                HIPCHK(c, hipMemsetAsync(s->nfound.p, 0, 8, c->stream)); /* the first pass counted a part */
-            }
-            launch_emit(E, (unsigned)tiles);
-            HIPCHK(c, hipGetLastError());
+        mask.clean = sev_get(c);
+        if (mask.clean) HIPCHK(c, hipEventRecord(mask.clean, ms));
+        else HIPCHK(c, hipStreamSynchronize(ms));
+        c->masks.push_back(mask);
+        mask.p = nullptr; /* handed over */
+        /* lengths of the sketched sequences for the map kernels (the batch may be gone by then) */
+        if (b->d_seq_len && nseq) {
+            if ((rc = s->rlen.alloc(c, nseq * 4))) return rc;
+            HIPCHK(c, hipMemcpyAsync(s->rlen.p, b->d_seq_len, nseq * 4, hipMemcpyDeviceToDevice, ms));
         }
+        SketchSums *hs = (SketchSums *)s->slot;
+        HIPCHK(c, hipMemcpyAsync(&hs->total_mx, &dsums->total_mx, 4, hipMemcpyDeviceToHost, ms));
+        if (ix) HIPCHK(c, hipMemcpyAsync(&hs->nfound, &dsums->nfound, 8, hipMemcpyDeviceToHost, ms));
     }
-    /* temporaries return to the context's cache here; every later user of those blocks is queued on the
-       same stream behind the kernels above, so no wait is needed */
-    *out = s_guard.release();
+    HIPCHK(c, hipEventRecord(s->done, ms));
+    {
+        hipEvent_t &t = c->throttle[c->n_enqueued & 7u];
+        if (!t) t = sev_get(c);
+        if (t) HIPCHK(c, hipEventRecord(t, ms));
+        c->n_enqueued++;
+    }
+    s->strips = ub_strips;
+    s->pending = true;
+    /* temporaries return to the context's cache here; every later user of those blocks is queued behind the kernels above
+       on the stream they were used on, so no wait is needed */
     return NTL_OK;
+}
+
+static int sketch_run_impl(ntl_ctx *c, const ntl_batch *b, int k, int w, const ntl_index *ix, ntl_sketch **out)
+{
+    if (!c || !b || !out) return NTL_EINVAL;
+    *out = nullptr;
+    (void)hipSetDevice(c->device);
+    SketchGeom G;
+    int C, nt, rc;
+    if ((rc = sketch_geometry(c, k, w, G, C, nt))) return rc;
+    ntl_sketch *s = new ntl_sketch();
+    s->c = c; s->nseq = b->nseq; s->k = k; s->w = w; s->src_ix = ix;
+    s->done = sev_get(c);
+    s->slot = slot_get(c);
+    if (!s->done || !s->slot) { sketch_unref(s); return fail(c, NTL_EDEVICE, "out of events / page-locked slots"); }
+    /* The record array is sized from the expected density before the count is known (the device goes straight on to the
+       emit kernel); a batch denser than the guess (low-complexity sequence) is sketched a second time into exact-size
+       arrays when its count is asked for (sketch_finalize). */
+    uint64_t cap_guess = (uint64_t)(2.5 * (double)b->bases / (double)(w + 1)) + 65536;
+    if (cap_guess > b->bases + 1) cap_guess = b->bases + 1;
+    if (cap_guess > 0xFFFFFFF0ull) cap_guess = 0xFFFFFFF0ull;
+    if (const char *e = getenv("NTL_SKETCH_CAP_GUESS")) cap_guess = (uint64_t)atoll(e); /* tests: force the second round */
+    const_cast<ntl_batch *>(b)->refs++;
+    s->src = b;
+    if ((rc = sketch_enqueue(c, b, k, w, ix, s, cap_guess))) {
+        (void)sync_both(c); /* whatever was queued must not outlive the buffers the error path lets go */
+        s->pending = false;
+        sketch_unref(s);
+        return rc;
+    }
+    *out = s;
+    return NTL_OK;
+}
+
+/* Completes a sketch: waits for its event, reads the totals, and -- when the batch held more minimizers than the arrays
+ * that were sized from the expected density -- makes the sketch again with exact-size arrays (same minimizers). */
+static int sketch_finalize(const ntl_sketch *cs)
+{
+    ntl_sketch *s = const_cast<ntl_sketch *>(cs);
+    if (!s->pending) return s->failed;
+    ntl_ctx *c = s->c;
+    (void)hipSetDevice(c->device);
+    for (int round = 0;; round++) {
+        const hipError_t e = wait_hot(s->done);
+        s->pending = false;
+        if (e != hipSuccess) { s->failed = fail(c, NTL_EDEVICE, std::string("sketch: ") + hipGetErrorString(e)); break; }
+        const SketchSums hs = *(const SketchSums *)s->slot;
+        s->count = hs.total_mx; s->redo_strips = hs.redo_n; s->nfound = hs.nfound;
+        if (s->count <= s->cap) break;
+        if (round || !s->src) { s->failed = fail(c, NTL_EINTERNAL, "sketch: the exact-size round overflowed again"); break; }
+        s->gen++;
+        memset(s->slot, 0, sizeof(PinSlot));
+        const int rc = sketch_enqueue(c, s->src, s->k, s->w, s->src_ix, s, s->count);
+        if (rc) { (void)sync_both(c); s->pending = false; s->failed = rc; break; }
+    }
+    if (s->src) { batch_unref(s->src); s->src = nullptr; }
+    return s->failed;
 }
 
 extern "C" int ntl_sketch_run(ntl_ctx *c, const ntl_batch *b, int k, int w, ntl_sketch **out)
@@ -971,21 +1352,23 @@ extern "C" int ntl_sketch_run_indexed(ntl_ctx *c, const ntl_batch *b, int k, int
     return sketch_run_impl(c, b, k, w, ix, out);
 }
 
-extern "C" void ntl_sketch_destroy(ntl_sketch *s) { delete s; }
+extern "C" void ntl_sketch_destroy(ntl_sketch *s) { sketch_unref(s); }
+extern "C" int ntl_sketch_wait(const ntl_sketch *s) { return s ? sketch_finalize(s) : NTL_EINVAL; }
 extern "C" uint64_t ntl_sketch_nseq(const ntl_sketch *s) { return s ? s->nseq : 0; }
-extern "C" uint64_t ntl_sketch_count(const ntl_sketch *s) { return s ? s->count : 0; }
+extern "C" uint64_t ntl_sketch_count(const ntl_sketch *s) { return s && sketch_finalize(s) == NTL_OK ? s->count : 0; }
 extern "C" uint64_t ntl_sketch_strips(const ntl_sketch *s) { return s ? s->strips : 0; }
-extern "C" uint64_t ntl_sketch_redo_strips(const ntl_sketch *s) { return s ? s->redo_strips : 0; }
+extern "C" uint64_t ntl_sketch_redo_strips(const ntl_sketch *s) { return s && sketch_finalize(s) == NTL_OK ? s->redo_strips : 0; }
 
 extern "C" int ntl_sketch_download(const ntl_sketch *s, uint64_t *mx_off, uint64_t *hash, uint32_t *pos, uint8_t *strand)
 {
     if (!s) return NTL_EINVAL;
     ntl_ctx *c = s->c;
     (void)hipSetDevice(c->device);
+    int rc = sketch_finalize(s);
+    if (rc) return rc;
     const size_t off_bytes = ((s->nseq + 1) * 4 + 63) & ~(size_t)63;
     void *tmp = nullptr;
-    int rc = host_tmp(c, off_bytes + s->count * sizeof(MxRecord), &tmp);
-    if (rc) return rc;
+    if ((rc = host_tmp(c, off_bytes + s->count * sizeof(MxRecord), &tmp))) return rc;
     const uint32_t *off = (const uint32_t *)tmp;
     const MxRecord *rec = (const MxRecord *)((const char *)tmp + off_bytes);
     HIPCHK(c, hipMemcpyAsync(tmp, s->mx_off.p, (s->nseq + 1) * 4, hipMemcpyDeviceToHost, c->stream));
@@ -1055,7 +1438,7 @@ extern "C" int ntl_sketch_from_host(ntl_ctx *c, uint64_t nseq, const uint64_t *m
     }
     off[nseq] = (uint32_t)mx_off[nseq];
     std::unique_ptr<ntl_sketch> sk(new ntl_sketch());
-    sk->c = c; sk->nseq = nseq; sk->count = n;
+    sk->c = c; sk->nseq = nseq; sk->count = n; sk->cap = n;
     if ((rc = sk->records.alloc(c, n * sizeof(MxRecord))) || (rc = sk->mx_off.alloc(c, (nseq + 1) * 4))) return rc;
     hipError_t e = hipSuccess;
     if (n) e = hipMemcpyAsync(sk->records.p, rec, n * sizeof(MxRecord), hipMemcpyHostToDevice, c->stream);
@@ -1076,6 +1459,8 @@ extern "C" int ntl_overlap_filter(ntl_ctx *c, const ntl_sketch *s, const uint64_
 {
     if (!c || !s || !region_off || !out) return NTL_EINVAL;
     *out = nullptr;
+    (void)hipSetDevice(c->device);
+    if (int frc = sketch_finalize(s)) return frc;
     const uint64_t nseq = s->nseq, n = s->count;
     const uint64_t nreg = region_off[nseq];
     if (region_off[0] != 0) return fail(c, NTL_EINVAL, "region_off[0] must be 0");
@@ -1119,7 +1504,7 @@ extern "C" int ntl_overlap_filter(ntl_ctx *c, const ntl_sketch *s, const uint64_
         }
         /* the one wait of the call: the number of kept records sizes the result */
         if ((rc = device_scan(c, keep.as<uint32_t>(), dst.as<uint32_t>(), n, &total))) return rc;
-        o->count = total;
+        o->count = total; o->cap = total;
         if ((rc = o->records.alloc(c, (uint64_t)total * sizeof(MxRecord)))) return rc;
         const uint64_t work = std::max<uint64_t>(n, nseq + 1);
         hipLaunchKernelGGL(ovl_gather_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, c->stream,
@@ -1143,9 +1528,11 @@ extern "C" int ntl_index_build(ntl_ctx *c, const ntl_sketch *ctg, const uint32_t
     if ((uint64_t)n_ctg != ctg->nseq) return fail(c, NTL_EINVAL, "n_ctg must equal the number of sketched contigs");
     if (n_ctg >= (1u << 30)) return fail(c, NTL_EINVAL, "too many contigs");
     (void)hipSetDevice(c->device);
+    if (int frc = sketch_finalize(ctg)) return frc; /* the table is sized from the number of contig minimizers */
+    if (ctg->c != c) HIPCHK(c, sync_both(ctg->c));
     std::unique_ptr<ntl_index> ix_guard(new ntl_index());
     ntl_index *ix = ix_guard.get();
-    ix->c = c; ix->n_ctg = n_ctg;
+    ix->c = c; ix->n_ctg = n_ctg; ix->gen = g_index_gen++;
     int bits = 10;
     while (((uint64_t)1 << bits) < 2 * ctg->count + 2) bits++;
     ix->bits = bits;
@@ -1174,11 +1561,18 @@ extern "C" int ntl_index_build(ntl_ctx *c, const ntl_sketch *ctg, const uint32_t
         HIPCHK(c, hipGetLastError());
     }
     (void)size;
+    if ((ix->built = sev_get(c))) HIPCHK(c, hipEventRecord(ix->built, c->stream));
     *out = ix_guard.release();
     return NTL_OK;
 }
 
-extern "C" void ntl_index_destroy(ntl_index *ix) { delete ix; }
+extern "C" void ntl_index_destroy(ntl_index *ix)
+{
+    if (!ix) return;
+    (void)hipSetDevice(ix->c->device);
+    sev_put(ix->c, ix->built);
+    delete ix;
+}
 
 extern "C" uint64_t ntl_index_size(const ntl_index *ix)
 {
@@ -1197,48 +1591,62 @@ extern "C" uint64_t ntl_index_size(const ntl_index *ix)
 
 /* ------------------------------------------------------------------ map ------------------ */
 
+struct MapSums { unsigned long long nfound; uint32_t err; uint32_t tot[3]; uint32_t n_over; uint32_t pad; }; /* one memset, one read-back */
+
 struct ntl_mapres {
     ntl_ctx *c;
-    uint64_t n_maps = 0, n_hits = 0, n_pafs = 0, n_index_hits = 0;
-    DevBuf maps, hits, pafs;
+    mutable uint64_t n_maps = 0, n_hits = 0, n_pafs = 0, n_index_hits = 0;
+    mutable DevBuf maps, hits, pafs; /* dense, read order; sized from the sketch's capacity, filled to n_* */
+    /* lazy completion */
+    mutable bool pending = false;
+    mutable hipEvent_t done = nullptr;
+    mutable PinSlot *slot = nullptr;
+    mutable int failed = 0;
+    const ntl_index *ix = nullptr;
+    const ntl_sketch *reads = nullptr;  /* held (refs) while pending */
+    uint64_t reads_gen = 0;             /* generation of the sketch the kernels were queued on */
+    ntl_map_params params;
+    DevBuf rlen_own;                    /* read lengths uploaded by this call (sketches that did not come from a batch) */
 };
 
-extern "C" int ntl_map_run(ntl_ctx *c, const ntl_index *ix, const ntl_sketch *reads, const uint32_t *read_len,
-                           const ntl_map_params *params, ntl_mapres **out)
+/* Queues the lookup (when the sketch does not carry candidates), the map kernels, the offset scans and the gather on MAIN.
+ * Nothing waits: the three totals, the hit count and the invariant flag land in the result's page-locked slot. */
+static int map_enqueue(ntl_ctx *c, const ntl_index *ix, const ntl_sketch *reads, const uint32_t *d_rlen, ntl_mapres *R)
 {
-    if (!c || !ix || !reads || !params || !out || (!read_len && reads->nseq)) return NTL_EINVAL;
-    *out = nullptr;
-    (void)hipSetDevice(c->device);
-    const uint64_t nreads = reads->nseq, nmx = reads->count;
-    std::unique_ptr<ntl_mapres> R_guard(new ntl_mapres());
-    ntl_mapres *R = R_guard.get();
-    R->c = c;
+    const uint64_t nreads = reads->nseq;
+    const bool have_cand = reads->cand_gen == ix->gen && reads->cand.p != nullptr;
+    if (!have_cand) { /* the lookup pass runs over the records: their number sizes its grid */
+        if (int frc = sketch_finalize(reads)) return frc;
+    }
+    const uint64_t nmx = reads->pending ? reads->cap : reads->count;
+    const ntl_map_params *params = &R->params;
     int rc;
-    DevBuf cand, rlen, smaps, shits, spafs, n3, off3, scr, sums, over;
-    struct MapSums { unsigned long long nfound; uint32_t err; uint32_t tot[3]; uint32_t n_over; uint32_t pad; }; /* one memset, one read-back */
+    hipStream_t ms = c->stream;
+    DevBuf cand, smaps, shits, spafs, n3, off3, scr, sums, over;
     const uint64_t cap = nmx ? nmx : 1;
-    if ((rc = cand.alloc(c, cap * sizeof(Cand))) || (rc = rlen.alloc(c, (nreads + 1) * 4)) ||
+    if ((!have_cand && (rc = cand.alloc(c, cap * sizeof(Cand)))) ||
         (rc = smaps.alloc(c, cap * sizeof(MapRec))) || (rc = shits.alloc(c, cap * sizeof(HitRec))) ||
         (rc = spafs.alloc(c, cap * sizeof(PafRec))) || (rc = n3.alloc(c, 3 * (nreads + 1) * 4)) ||
         (rc = off3.alloc(c, 3 * (nreads + 1) * 4)) || (rc = scr.alloc(c, (uint64_t)(MAP_NHA + MAP_NRA) * cap * 4)) ||
-        (rc = sums.alloc(c, sizeof(MapSums))) || (rc = over.alloc(c, (nreads + 1) * 4))) return rc;
+        (rc = sums.alloc(c, sizeof(MapSums))) || (rc = over.alloc(c, (nreads + 1) * 4)) ||
+        (rc = R->maps.alloc(c, cap * sizeof(MapRec))) || (rc = R->hits.alloc(c, cap * sizeof(HitRec))) ||
+        (rc = R->pafs.alloc(c, cap * sizeof(PafRec)))) return rc;
     MapSums *dsums = sums.as<MapSums>();
-    if (nreads) HIPCHK(c, hipMemcpyAsync(rlen.p, read_len, nreads * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemsetAsync(sums.p, 0, sizeof(MapSums), c->stream));
-    const bool have_cand = reads->cand_ix == ix && reads->cand.p != nullptr;
-    if (have_cand) HIPCHK(c, hipMemcpyAsync(&dsums->nfound, reads->nfound.p, 8, hipMemcpyDeviceToDevice, c->stream));
+    if (ix->c != c && ix->built) HIPCHK(c, hipStreamWaitEvent(ms, ix->built, 0));
+    HIPCHK(c, hipMemsetAsync(sums.p, 0, sizeof(MapSums), ms));
+    if (have_cand) HIPCHK(c, hipMemcpyAsync(&dsums->nfound, &reads->sums.as<SketchSums>()->nfound, 8, hipMemcpyDeviceToDevice, ms));
     if (!have_cand) {
         ProfSpan sp(c, "probe");
         if (nmx) {
             const dim3 grid((unsigned)std::min<uint64_t>((nmx + 256 * PROBE_U - 1) / (256 * PROBE_U), 4096));
             /* tags first unless the previous batch on this index found more than half of its minimizers (same result either way) */
-            if (ix->hit_fraction <= 0.5)
-                hipLaunchKernelGGL(probe_kernel<true>, grid, dim3(256), 0, c->stream,
+            if (ix->hit_fraction.load(std::memory_order_relaxed) <= 0.5f)
+                hipLaunchKernelGGL(probe_kernel<true>, grid, dim3(256), 0, ms,
                                    (const MxRecord *)reads->records.as<MxRecord>(), nmx, (const IndexSlot *)ix->slots.as<IndexSlot>(),
                                    ix->bits, (const IndexSpecial *)ix->special.as<IndexSpecial>(), cand.as<Cand>(),
                                    &dsums->nfound, (const uint8_t *)ix->tags.as<uint8_t>());
             else
-                hipLaunchKernelGGL(probe_kernel<false>, grid, dim3(256), 0, c->stream,
+                hipLaunchKernelGGL(probe_kernel<false>, grid, dim3(256), 0, ms,
                                    (const MxRecord *)reads->records.as<MxRecord>(), nmx, (const IndexSlot *)ix->slots.as<IndexSlot>(),
                                    ix->bits, (const IndexSpecial *)ix->special.as<IndexSpecial>(), cand.as<Cand>(),
                                    &dsums->nfound, (const uint8_t *)ix->tags.as<uint8_t>());
@@ -1248,57 +1656,150 @@ extern "C" int ntl_map_run(ntl_ctx *c, const ntl_index *ix, const ntl_sketch *re
     MapArgs A;
     A.mx = reads->records.as<MxRecord>(); A.mx_off = reads->mx_off.as<uint32_t>();
     A.cand = have_cand ? reads->cand.as<Cand>() : cand.as<Cand>();
-    A.read_len = rlen.as<uint32_t>(); A.ctg_len = ix->ctg_len.as<uint32_t>(); A.nreads = (uint32_t)nreads;
+    A.read_len = d_rlen; A.ctg_len = ix->ctg_len.as<uint32_t>(); A.nreads = (uint32_t)nreads;
     A.P.k = params->k; A.P.z = params->z; A.P.x = params->x; A.P.sensitive = params->sensitive;
     A.P.repeat_filter = params->repeat_filter;
     A.maps = smaps.as<MapRec>(); A.hits = shits.as<HitRec>(); A.pafs = spafs.as<PafRec>();
     A.n_maps = n3.as<uint32_t>(); A.n_hits = A.n_maps + (nreads + 1); A.n_pafs = A.n_hits + (nreads + 1);
     A.scr = scr.as<uint32_t>(); A.scr_stride = cap; A.err = &dsums->err;
     A.over_list = over.as<uint32_t>(); A.over_count = &dsums->n_over;
-    MapSums hs;
-    memset(&hs, 0, sizeof hs);
+    /* a sketch whose count is not known yet may have overflowed its arrays: the kernels look at its total and leave it alone */
+    A.mx_total = reads->pending ? &reads->sums.as<SketchSums>()->total_mx : nullptr;
+    A.mx_cap = (uint32_t)std::min<uint64_t>(reads->cap, 0xFFFFFFFFull);
     if (nreads) {
         {
             ProfSpan sp(c, "map");
             /* LDS staging sized by the average sketch length of the batch */
-            if (nmx <= 256 * nreads) hipLaunchKernelGGL((map_kernel<256, 64>), dim3((unsigned)nreads), dim3(MAP_NT), 0, c->stream, A);
-            else hipLaunchKernelGGL((map_kernel<512, 128>), dim3((unsigned)nreads), dim3(MAP_NT), 0, c->stream, A);
+            if (nmx <= 256 * nreads) hipLaunchKernelGGL((map_kernel<256, 64>), dim3((unsigned)nreads), dim3(MAP_NT), 0, ms, A);
+            else hipLaunchKernelGGL((map_kernel<512, 128>), dim3((unsigned)nreads), dim3(MAP_NT), 0, ms, A);
             /* reads with more hits / runs than the LDS staging holds (rare): same code on global scratch */
-            hipLaunchKernelGGL(map_overflow_kernel, dim3((unsigned)std::min<uint64_t>(nreads, 32768)), dim3(MAP_NT), 0, c->stream, A); /* no LDS: 32 wavefronts per CU resident, four rounds of them */
+            hipLaunchKernelGGL(map_overflow_kernel, dim3((unsigned)std::min<uint64_t>(nreads, 32768)), dim3(MAP_NT), 0, ms, A); /* no LDS: 32 wavefronts per CU resident, four rounds of them */
             HIPCHK(c, hipGetLastError());
         }
         ProfSpan sp(c, "compact");
         uint32_t *o = off3.as<uint32_t>();
         if ((rc = device_scan(c, n3.as<uint32_t>(), o, nreads, nullptr, 3, dsums->tot))) return rc;
-        /* the only wait of the call: three totals (to size the dense arrays), hit count, invariant flag */
-        HIPCHK(c, hipMemcpyAsync(&hs, sums.p, sizeof(MapSums), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, sync_hot(c));
-        R->n_maps = hs.tot[0]; R->n_hits = hs.tot[1]; R->n_pafs = hs.tot[2];
-        if ((rc = R->maps.alloc(c, (uint64_t)hs.tot[0] * sizeof(MapRec))) || (rc = R->hits.alloc(c, (uint64_t)hs.tot[1] * sizeof(HitRec))) ||
-            (rc = R->pafs.alloc(c, (uint64_t)hs.tot[2] * sizeof(PafRec)))) return rc;
-        hipLaunchKernelGGL(map_gather_kernel, dim3((unsigned)nreads), dim3(64), 0, c->stream, A, (const uint32_t *)o,
+        hipLaunchKernelGGL(map_gather_kernel, dim3((unsigned)nreads), dim3(64), 0, ms, A, (const uint32_t *)o,
                            (const uint32_t *)(o + (nreads + 1)), (const uint32_t *)(o + 2 * (nreads + 1)),
                            R->maps.as<MapRec>(), R->hits.as<HitRec>(), R->pafs.as<PafRec>());
         HIPCHK(c, hipGetLastError());
     }
-    R->n_index_hits = hs.nfound;
-    if (nmx) ix->hit_fraction = (double)hs.nfound / (double)nmx;
-    if (hs.err) return fail(c, NTL_EINTERNAL, "an accepted contig appeared twice in one read (bin/ntlink_utils.py:262-266)");
-    *out = R_guard.release();
+    HIPCHK(c, hipMemcpyAsync(R->slot, sums.p, sizeof(MapSums), hipMemcpyDeviceToHost, ms));
+    HIPCHK(c, hipEventRecord(R->done, ms));
+    R->pending = true;
+    R->reads_gen = reads->gen;
     return NTL_OK;
 }
 
-extern "C" void ntl_mapres_destroy(ntl_mapres *r) { delete r; }
-extern "C" uint64_t ntl_mapres_n_mappings(const ntl_mapres *r) { return r ? r->n_maps : 0; }
-extern "C" uint64_t ntl_mapres_n_hits(const ntl_mapres *r) { return r ? r->n_hits : 0; }
-extern "C" uint64_t ntl_mapres_n_pafs(const ntl_mapres *r) { return r ? r->n_pafs : 0; }
-extern "C" uint64_t ntl_mapres_n_index_hits(const ntl_mapres *r) { return r ? r->n_index_hits : 0; }
+static void mapres_free(ntl_mapres *R)
+{
+    if (!R) return;
+    ntl_ctx *c = R->c;
+    (void)hipSetDevice(c->device);
+    if (R->pending) {
+        Zombie z;
+        z.done = R->done; z.slot = R->slot; z.kind = 2;
+        c->zombies.push_back(z);
+    } else {
+        sev_put(c, R->done);
+        slot_put(c, R->slot);
+    }
+    if (R->reads) sketch_unref(R->reads);
+    delete R;
+}
+
+/* Completes a map result: the sketch first (it may have to be made again with larger arrays -- then the map kernels ran on
+ * nothing and are queued again), then this call's totals. */
+static int mapres_finalize(const ntl_mapres *cR)
+{
+    ntl_mapres *R = const_cast<ntl_mapres *>(cR);
+    if (!R->pending) return R->failed;
+    ntl_ctx *c = R->c;
+    (void)hipSetDevice(c->device);
+    for (int round = 0;; round++) {
+        if (R->reads && (R->failed = sketch_finalize(R->reads))) { (void)hipEventSynchronize(R->done); R->pending = false; break; }
+        const hipError_t e = wait_hot(R->done);
+        R->pending = false;
+        if (e != hipSuccess) { R->failed = fail(c, NTL_EDEVICE, std::string("map: ") + hipGetErrorString(e)); break; }
+        if (R->reads && R->reads->gen != R->reads_gen && round == 0) {
+            memset(R->slot, 0, sizeof(PinSlot));
+            const int rc = map_enqueue(c, R->ix, R->reads, R->rlen_own.p ? R->rlen_own.as<uint32_t>() : R->reads->rlen.as<uint32_t>(), R);
+            if (rc) { (void)sync_both(c); R->pending = false; R->failed = rc; break; }
+            continue;
+        }
+        const MapSums hs = *(const MapSums *)R->slot;
+        R->n_maps = hs.tot[0]; R->n_hits = hs.tot[1]; R->n_pafs = hs.tot[2];
+        R->n_index_hits = hs.nfound;
+        const uint64_t nmx = R->reads ? R->reads->count : 0;
+        if (nmx) R->ix->hit_fraction.store((float)((double)hs.nfound / (double)nmx), std::memory_order_relaxed);
+        if (hs.err) R->failed = fail(c, NTL_EINTERNAL, "an accepted contig appeared twice in one read (bin/ntlink_utils.py:262-266)");
+        break;
+    }
+    if (R->reads) { sketch_unref(R->reads); R->reads = nullptr; }
+    return R->failed;
+}
+
+extern "C" int ntl_map_run(ntl_ctx *c, const ntl_index *ix, const ntl_sketch *reads, const uint32_t *read_len,
+                           const ntl_map_params *params, ntl_mapres **out)
+{
+    if (!c || !ix || !reads || !params || !out || (!read_len && reads->nseq)) return NTL_EINVAL;
+    *out = nullptr;
+    (void)hipSetDevice(c->device);
+    if (reads->c != c) { /* a sketch of another context: complete it there first */
+        if (int frc = sketch_finalize(reads)) return frc;
+        HIPCHK(c, sync_both(reads->c));
+    }
+    const uint64_t nreads = reads->nseq;
+    ntl_mapres *R = new ntl_mapres();
+    R->c = c; R->ix = ix; R->params = *params;
+    R->done = sev_get(c);
+    R->slot = slot_get(c);
+    if (!R->done || !R->slot) { mapres_free(R); return fail(c, NTL_EDEVICE, "out of events / page-locked slots"); }
+    int rc = NTL_OK;
+    /* read lengths: a sketch made from a batch has them on the device already (the `--len` column IS the sequence length);
+       anything else -- or lengths that differ from the batch's -- is uploaded here */
+    const uint32_t *d_rlen = nullptr;
+    if (reads->rlen.p && nreads) {
+        /* the device copy was made from the batch; the caller's array is checked against it on the host side of the batch */
+        d_rlen = reads->rlen.as<uint32_t>();
+        if (!reads->src || memcmp(read_len, reads->src->seq_len.data(), nreads * 4) != 0) d_rlen = nullptr;
+    }
+    if (!d_rlen) {
+        if ((rc = R->rlen_own.alloc(c, (nreads + 1) * 4))) { mapres_free(R); return rc; }
+        if (nreads) {
+            const hipError_t e = hipMemcpyAsync(R->rlen_own.p, read_len, nreads * 4, hipMemcpyHostToDevice, c->stream);
+            if (e != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { /* pageable source: the caller's array is free again */
+                mapres_free(R);
+                return fail(c, NTL_EDEVICE, "upload of the read lengths failed");
+            }
+        }
+        d_rlen = R->rlen_own.as<uint32_t>();
+    }
+    const_cast<ntl_sketch *>(reads)->refs++;
+    R->reads = reads;
+    if ((rc = map_enqueue(c, ix, reads, d_rlen, R))) {
+        (void)sync_both(c);
+        R->pending = false;
+        mapres_free(R);
+        return rc;
+    }
+    *out = R;
+    return NTL_OK;
+}
+
+extern "C" void ntl_mapres_destroy(ntl_mapres *r) { mapres_free(r); }
+extern "C" int ntl_mapres_wait(const ntl_mapres *r) { return r ? mapres_finalize(r) : NTL_EINVAL; }
+extern "C" uint64_t ntl_mapres_n_mappings(const ntl_mapres *r) { return r && mapres_finalize(r) == NTL_OK ? r->n_maps : 0; }
+extern "C" uint64_t ntl_mapres_n_hits(const ntl_mapres *r) { return r && mapres_finalize(r) == NTL_OK ? r->n_hits : 0; }
+extern "C" uint64_t ntl_mapres_n_pafs(const ntl_mapres *r) { return r && mapres_finalize(r) == NTL_OK ? r->n_pafs : 0; }
+extern "C" uint64_t ntl_mapres_n_index_hits(const ntl_mapres *r) { return r && mapres_finalize(r) == NTL_OK ? r->n_index_hits : 0; }
 
 extern "C" int ntl_mapres_download(const ntl_mapres *r, ntl_mapping *maps, ntl_hit *hits, ntl_paf *pafs)
 {
     if (!r) return NTL_EINVAL;
     ntl_ctx *c = r->c;
     (void)hipSetDevice(c->device);
+    if (int frc = mapres_finalize(r)) return frc;
     static_assert(sizeof(ntl_mapping) == sizeof(MapRec) && sizeof(ntl_hit) == sizeof(HitRec) && sizeof(ntl_paf) == sizeof(PafRec),
                   "ABI records must match the device records");
     if (maps && r->n_maps) HIPCHK(c, hipMemcpyAsync(maps, r->maps.p, r->n_maps * sizeof(MapRec), hipMemcpyDeviceToHost, c->stream));

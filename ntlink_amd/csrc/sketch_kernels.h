@@ -433,7 +433,7 @@ struct EmitArgs {
     const uint32_t *packed;
     const uint64_t *seq_base; /* [nseq+1] */
     uint32_t nseq;
-    const uint32_t *mask;
+    uint32_t *mask;           /* read, then cleared: this kernel is the bitmask's last reader and hands it back zero-filled */
     uint64_t nwords;
     const uint32_t *tile_off; /* exclusive scan of tile_cnt */
     uint32_t *mx_off;         /* [nseq+1] minimizers before each sequence start = offsets of the per-sequence lists */
@@ -597,6 +597,20 @@ __global__ __launch_bounds__(EMIT_NT) void emit_kernel(EmitArgs A)
             }
         }
         __syncthreads();
+    }
+    /* every read of this tile's mask words is behind a barrier by now (the offsets loop reads other threads' words): clear
+       what was set, so that the next window pass finds the bitmask zero-filled without a fill pass of its own */
+    __syncthreads();
+    if (c) {
+        if (w0 + EMIT_WPT <= A.nwords) {
+            const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+            *reinterpret_cast<uint4 *>(A.mask + w0) = z;
+            *reinterpret_cast<uint4 *>(A.mask + w0 + 4) = z;
+        } else {
+#pragma unroll
+            for (int i = 0; i < EMIT_WPT; i++)
+                if (words[i]) A.mask[w0 + i] = 0u;
+        }
     }
     if (PROBE) { /* one atomic per workgroup */
         __syncthreads();
