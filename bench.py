@@ -9,8 +9,14 @@ bounded by 32-bit base indices), 23 GB of the 288.
 
   contig stage (once, reported as contig_stage_ms): sketch the contigs, build the index.
   one STEP = one pass of the hot path over the rank's whole read set: for each of its sub-batches
-             sketch -> probe -> map (accepted contigs + PAF blocks) -> compacted records in HBM.
+             sketch -> index lookup -> map (accepted contigs + PAF blocks) -> compacted records in HBM.
+             The calls only queue device work (include/ntlink_amd.h "Asynchrony"): the window stage of
+             sub-batch i+1 runs on its own stream beside the lookup / map kernels of sub-batch i.
   value    = read bases of all ranks x steps / max-over-ranks wall time of the K timed steps.
+
+Behind the timed region the same context runs a few steps with the second stream off: those per-kernel
+durations are of kernels running alone (what `roofline` quotes and what the rocprofv3 summaries in
+profiles/ hold); the durations measured inside the pipelined steps are reported beside them.
 
 N > 1: one process per GPU (the driver launches `python -m torch.distributed.run ... bench.py --gpus N`;
 a bare `python bench.py --gpus N` starts those N ranks itself as a child process).  Reads shard, the contig
@@ -29,10 +35,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
-# integer VALU issue roof, measured per instruction class (tools/valu_calib2.hip, profiles/r02a_valu_calib2.txt):
-# 4.06 SIMD cycles per wave64 instruction for the sketch kernel's mix at 8 waves/SIMD, 1024 SIMDs.
-VALU_CYCLES_PER_INSTR = 4.06
 N_SIMD = 1024
+STAGES = ("sketch_meta", "sketch_mask", "sketch_redo", "sketch_emit", "probe", "map", "compact")
 
 
 def parse_args(argv=None):
@@ -44,8 +48,10 @@ def parse_args(argv=None):
     ap.add_argument("--strong", action="store_true", help="strong scaling: the workload's read set is split over the ranks")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debugging only; reported)")
     ap.add_argument("--batch-bases", type=float, default=3.95e9, help="read bases per device batch")
+    ap.add_argument("--serial-steps", type=int, default=2, help="steps of the kernels-alone pass behind the timed region (0 = none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--no-others", action="store_true", help="skip the other single-GPU configs (other_workloads)")
     ap.add_argument("--e2e-bases", type=float, default=32e9, help="read bases of the end-to-end (file to file) leg")
     ap.add_argument("--lib", default=None, help="C-ABI library to load (tests point this at the SIMT-mock build)")
     ap.add_argument("--spawn-check", action="store_true", help="ranks only report the world size (CPU test of the launcher)")
@@ -75,39 +81,37 @@ def kernel_signature():
     """Identifies the kernel sources a PMC pass was taken on (profiles/traffic.json is stale after an edit)."""
     h = hashlib.sha1()
     d = os.path.join(ROOT, "ntlink_amd", "csrc")
-    for f in ("sketch_kernels.h", "sketch2_kernels.h", "dev_common.h", "ntl_hip.hip"):
+    for f in ("sketch_kernels.h", "sketch2_kernels.h", "dev_common.h", "map_kernels.h", "index_common.h"):
         p = os.path.join(d, f)
         if os.path.exists(p):
             h.update(open(p, "rb").read())
     return h.hexdigest()[:12]
 
 
-def main():
-    args = parse_args()
-    if args.gpus > 1 and "RANK" not in os.environ:
-        sys.exit(spawn_ranks(args))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.spawn_check:  # CPU-only: proves that --gpus N yields N communicating ranks
+def pin_rank(local_rank, local_world):
+    """Several ranks on one host: each keeps to its own slice of the cores (its parser / emitter threads are sized to it by
+    NTL_IO_THREADS), so that eight ranks do not start eight full-size thread pools on top of each other."""
+    if local_world <= 1 or os.environ.get("NTL_PIN", "1") == "0" or not hasattr(os, "sched_getaffinity"):
+        return None
+    cpus = sorted(os.sched_getaffinity(0))
+    per = max(1, len(cpus) // local_world)
+    mine = cpus[local_rank * per:(local_rank + 1) * per] or cpus
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return None
+    os.environ.setdefault("NTL_IO_THREADS", str(max(2, min(32, len(mine)))))
+    return len(mine)
+
+
+class Comm:
+    """barrier / max / sum / gather over the ranks (RCCL on GPUs, gloo under the SIMT mock); a single process needs none"""
+
+    def __init__(self, use_cuda, local_rank):
+        self.dist, self.use_cuda, self.local_rank = None, use_cuda, local_rank
+        if "RANK" not in os.environ:
+            return
         import torch
-        import torch.distributed as dist
-        dist.init_process_group("gloo")
-        t = torch.ones(1)
-        dist.all_reduce(t)
-        if dist.get_rank() == 0:
-            print(json.dumps({"spawn_check": True, "n_gpus": int(t.item()), "world": dist.get_world_size()}), flush=True)
-        dist.destroy_process_group()
-        return
-    import numpy as np
-    import torch
-    sys.path.insert(0, ROOT)
-    from ntlink_amd import capi, synth
-    dist = None
-    use_cuda = args.lib is None
-    if use_cuda:
-        torch.cuda.set_device(local_rank)
-    if "RANK" in os.environ:  # one rank per GPU, RCCL for barrier/max only
         import torch.distributed as dist
         sys.stdout.flush()
         saved = os.dup(1)
@@ -124,21 +128,66 @@ def main():
             sys.stdout.flush()
             os.dup2(saved, 1)
             os.close(saved)
+        self.dist = dist
 
-    dev = capi.Device(local_rank if use_cuda else 0, lib_path=args.lib)
-    W = synth.workload(args.workload, args.scale)
+    def barrier(self, devs):
+        if self.dist is not None:
+            if self.use_cuda:
+                self.dist.barrier(device_ids=[self.local_rank])
+            else:
+                self.dist.barrier()
+        if self.use_cuda:
+            import torch
+            torch.cuda.synchronize()
+        for d in devs:
+            d.sync()
+
+    def _t(self, v):
+        import torch
+        return torch.tensor([float(v)], dtype=torch.float64, device="cuda" if self.use_cuda else "cpu")
+
+    def max(self, v):
+        if self.dist is None:
+            return float(v)
+        t = self._t(v)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum(self, v):
+        if self.dist is None:
+            return float(v)
+        t = self._t(v)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return float(t.item())
+
+    def gather(self, v):
+        if self.dist is None:
+            return [float(v)]
+        import torch
+        t = self._t(v)
+        out = [torch.zeros_like(t) for _ in range(self.dist.get_world_size())]
+        self.dist.all_gather(out, t)
+        return [float(x.item()) for x in out]
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+
+
+def run_workload(dev, comm, name, args, steps, warmup, rank, world, serial_steps):
+    """Generates workload `name` on the device, runs the contig stage once, `warmup` + `steps` timed pipelined steps and
+    `serial_steps` steps with the second stream off.  Returns the measurements; the workload stays open in R["wl"]."""
+    import numpy as np
+    from ntlink_amd import synth
+    W = synth.workload(name, args.scale)
     k, w = W["k"], W["w"]
     total_read_bases = W["read_bases"]
     my_bases = total_read_bases // world if args.strong else total_read_bases
     t0 = time.perf_counter()
-    wl = synth.DeviceWorkload(dev, args.workload, args.scale, read_bases=my_bases, batch_bases=int(args.batch_bases),
+    wl = synth.DeviceWorkload(dev, name, args.scale, read_bases=my_bases, batch_bases=int(args.batch_bases),
                               read_seed=(2 + rank) if not args.strong else (2, rank))
     dev.sync()
     gen_s = time.perf_counter() - t0
-    ctg_len = wl.ctg_len
-    contig_bases = int(ctg_len.sum())
-    read_bases = wl.read_bases
-    n_reads = int(sum(len(x) for x in wl.read_lens))
     params = dict(k=k, z=1000, x=0.0, sensitive=W["sensitive"], repeat_filter=False)
     stats = dict(read_mx=0, index_hits=0, counts=[0, 0, 0])
 
@@ -148,28 +197,33 @@ def main():
     dev.sync()
     t0 = time.perf_counter()
     csk = dev.sketch(wl.contigs, k, w)
-    ix = dev.index(csk, ctg_len)
+    ix = dev.index(csk, wl.ctg_len)
     index_size = len(ix)
     dev.sync()
     contig_stage_ms = (time.perf_counter() - t0) * 1e3
     contig_prof = {nm: dev.prof_get(nm) for nm in ("sketch_meta", "sketch_mask", "sketch_redo", "sketch_emit", "index")}
     contig_mx = csk.count
 
-    # NTL_BENCH_STREAMS worker threads, each with its own context (stream) on the GPU, take the sub-batches in turn: while one
-    # waits on the host for a size (two waits per sub-batch), the other's kernels keep the device busy.  Same work per step.
+    # NTL_BENCH_STREAMS > 1 (experiments only): that many worker threads, each with its own context, take the sub-batches in turn
     n_streams = max(1, int(os.environ.get("NTL_BENCH_STREAMS", "1")))
     devs = [dev] + [dev.clone() for _ in range(n_streams - 1)]
     for d in devs[1:]:
         d.prof_enable(True)
 
     def run_batches(d, items, collect, acc):
+        held = []
         for rb, rl in items:
             rsk = d.sketch(rb, k, w, index=ix)  # looked up in the index while emitted: no separate probe pass
-            res = d.map(ix, rsk, rl, **params)
+            res = d.map(ix, rsk, rl, **params)  # queued behind it; nothing waits
             if collect:
-                acc["read_mx"] += rsk.count
-                acc["index_hits"] += res.n_index_hits
-                acc["counts"] = [a + b for a, b in zip(acc["counts"], res.counts())]
+                held.append((rsk, res))         # asked for their counts only after everything is queued
+            else:
+                res.close()
+                rsk.close()
+        for rsk, res in held:
+            acc["read_mx"] += rsk.count
+            acc["index_hits"] += res.n_index_hits
+            acc["counts"] = [a + b for a, b in zip(acc["counts"], res.counts())]
             res.close()
             rsk.close()
 
@@ -192,110 +246,202 @@ def main():
                 stats["read_mx"] += a["read_mx"]; stats["index_hits"] += a["index_hits"]
                 stats["counts"] = [x + y for x, y in zip(stats["counts"], a["counts"])]
 
-    def barrier():
-        if dist is not None:
-            if use_cuda:
-                dist.barrier(device_ids=[local_rank])
-            else:
-                dist.barrier()
-        if use_cuda:
-            torch.cuda.synchronize()
-        for d in devs:
-            d.sync()
-
-    for i in range(args.warmup):
+    for i in range(warmup):
         step(collect=(i == 0))
-    if args.warmup == 0:
+    if warmup == 0:
         stats["read_mx"] = None
     for d in devs:
         d.prof_reset()
-    barrier()
+    comm.barrier(devs)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
-    barrier()
+    comm.barrier(devs)  # ntl_ctx_sync: also where a failure of queued work nobody looked at is raised
     elapsed = time.perf_counter() - t0
-    names = ("sketch_meta", "sketch_mask", "sketch_redo", "sketch_emit", "probe", "map", "compact")
-    prof = {nm: tuple(sum(x) for x in zip(*[d.prof_get(nm) for d in devs])) for nm in names}
-    for d in devs:
-        d.prof_enable(False)
+    prof = {nm: tuple(sum(x) for x in zip(*[d.prof_get(nm) for d in devs])) for nm in STAGES}
     if stats["read_mx"] is None:
         step(collect=True)
-    if dist is not None:
-        dev_t = "cuda" if use_cuda else "cpu"
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev_t)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        tb = torch.tensor([float(read_bases)], dtype=torch.float64, device=dev_t)
-        dist.all_reduce(tb, op=dist.ReduceOp.SUM)
-        total_bases = float(tb.item())
-    else:
-        total_bases = float(read_bases)
+        comm.barrier(devs)
+    # ---- kernels alone: the same steps with the window stage back on the one stream
+    serial = None
+    pipelined = dev.pipelined
+    if serial_steps > 0:
+        for d in devs:
+            if d.pipelined:
+                d.set_pipeline(False)
+            d.prof_reset()
+        comm.barrier(devs)
+        t0 = time.perf_counter()
+        for _ in range(serial_steps):
+            step()
+        comm.barrier(devs)
+        s_elapsed = time.perf_counter() - t0
+        serial = {"steps": serial_steps, "ms_per_step": s_elapsed / serial_steps * 1e3,
+                  "prof": {nm: tuple(sum(x) for x in zip(*[d.prof_get(nm) for d in devs])) for nm in STAGES}}
+        if pipelined:
+            for d in devs:
+                d.set_pipeline(True)
+    for d in devs:
+        d.prof_enable(False)
+    for d in devs[1:]:
+        d.close()
+    per_rank_ms = [x / steps * 1e3 for x in comm.gather(elapsed)]
+    per_rank_bases = comm.gather(wl.read_bases)
+    elapsed_max = comm.max(elapsed)
+    total_bases = comm.sum(wl.read_bases)
+    return dict(name=name, W=W, wl=wl, ix=ix, csk=csk, params=params, stats=stats, gen_s=gen_s, contig_stage_ms=contig_stage_ms,
+                contig_prof=contig_prof, contig_mx=contig_mx, index_size=index_size, elapsed=elapsed_max, total_bases=total_bases,
+                prof=prof, serial=serial, pipelined=pipelined, per_rank_ms=per_rank_ms, per_rank_bases=per_rank_bases, steps=steps,
+                n_streams=n_streams)
 
+
+def summarize(R, args, world, dev_name):
+    """The JSON fields of one workload run (value, stage times, the two rooflines)."""
+    W, wl, steps = R["W"], R["wl"], R["steps"]
+    k, w = W["k"], W["w"]
+    d = 2.0 / (w + 1)
+    ms_per_step = R["elapsed"] / steps * 1e3
+    value = R["total_bases"] * steps / R["elapsed"] / 1e9
+    read_bases = wl.read_bases
+    stats = R["stats"]
+    hfrac = stats["index_hits"] / max(stats["read_mx"] or 1, 1)
+    nb = len(wl.read_batches)
+
+    def window(prof, nsteps):
+        ms, n = prof["sketch_mask"]
+        per_step = n / max(nsteps, 1)
+        avg = ms / max(n, 1)
+        bpl = read_bases / max(per_step, 1)
+        return avg, bpl, n
+
+    avg_pipe, bases_per_launch, n_pipe = window(R["prof"], steps)
+    if R["serial"]:
+        avg_alone, _, n_alone = window(R["serial"]["prof"], R["serial"]["steps"])
+    else:
+        avg_alone, n_alone = avg_pipe, n_pipe
+    bytes_per_launch = (0.25 + 16.0 * d) * bases_per_launch
+    ach = lambda ms: bytes_per_launch / (ms * 1e-3) / 1e9 if ms > 0 else 0.0  # noqa: E731
+    pm = pmc_summary(R["name"], args.scale, bases_per_launch)
+    whole_b = 0.25 + d * (48.0 + 32.0 * hfrac)  # SURVEY 8(d): B = B_s + B_p + B_c with the measured hit fraction
+    whole_gbs = whole_b * read_bases / (ms_per_step * 1e-3) / 1e9 if world == 1 else whole_b * R["total_bases"] / world / (ms_per_step * 1e-3) / 1e9
+    mode = "two streams: window stage of sub-batch i+1 beside lookup/map of sub-batch i" if R["pipelined"] else "one stream (NTL_PIPELINE=0)"
+    cfg = {"workload": f"{R['name']}: {len(wl.ctg_len)} contigs / {int(wl.ctg_len.sum())} bp assembly (sketched + indexed once: "
+                       f"contig_stage_ms) + {read_bases} read bases per GPU per step ({int(sum(len(x) for x in wl.read_lens))} reads, mean {W['read_len']} bp, "
+                       f"lognormal; generated on the device, {nb} distinct HBM-resident sub-batches), "
+                       f"k={k} w={w} z=1000 x=0 sensitive={W['sensitive']} paf=True verbose=True",
+           "scale": args.scale, "hit_fraction": round(hfrac, 4),
+           "read_minimizers_per_step": stats["read_mx"], "contig_minimizers": R["contig_mx"],
+           "index_size": R["index_size"], "mappings_hits_pafs_per_step": list(stats["counts"]),
+           "device": dev_name, "gen_s": round(R["gen_s"], 2),
+           "contig_stage_ms": round(R["contig_stage_ms"], 2),
+           "contig_stage_kernels_ms": {nm: round(v[0], 3) for nm, v in R["contig_prof"].items() if v[1]},
+           "value_incl_contig_stage_once": round(R["total_bases"] * steps / (R["elapsed"] + R["contig_stage_ms"] * 1e-3) / 1e9, 4),
+           "timed_region_s": round(R["elapsed"], 3),
+           "pipeline": {"value_measured_with": mode, "host_waits_per_step": 0,
+                        "bench_streams": R["n_streams"]},
+           "stage_ms_per_step": {nm: round(v[0] / steps, 3) for nm, v in R["prof"].items()},
+           "stage_ms_note": "kernel spans inside the timed (pipelined) steps: they overlap each other, so they add up to more than ms_per_step; "
+                            "kernels alone: serial_pass"}
+    if R["serial"]:
+        cfg["serial_pass"] = {"what": "the same steps on the same context with the second stream off, behind the timed region: one kernel at a time",
+                              "steps": R["serial"]["steps"], "ms_per_step": round(R["serial"]["ms_per_step"], 3),
+                              "Gbases_per_s": round(read_bases / (R["serial"]["ms_per_step"] * 1e-3) / 1e9, 2),
+                              "stage_ms_per_step": {nm: round(v[0] / R["serial"]["steps"], 3) for nm, v in R["serial"]["prof"].items()}}
+    roof = {"bound": "hbm", "kernel": pm.get("kernel", "sketch window kernel (read batches)"),
+            "achieved": round(ach(avg_alone), 2), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(ach(avg_alone) / HBM_PEAK_GBS, 5), "traffic": pm.get("traffic"),
+            "traffic_source": pm.get("traffic_source"),
+            "bytes_per_base": round(0.25 + 16.0 * d, 4), "bases_per_launch": int(bases_per_launch),
+            "avg_launch_ms": round(avg_alone, 4), "launches": n_alone,
+            "measured_in": ("serial pass behind the timed region (kernels alone; the rocprofv3 summaries under profiles/ are of NTL_PIPELINE=0 runs and agree with this)"
+                            if R["serial"] else "timed region"),
+            "kernel_Gbases_per_s": round(bases_per_launch / (avg_alone * 1e-3) / 1e9, 1) if avg_alone > 0 else None,
+            "in_timed_region": {"avg_launch_ms": round(avg_pipe, 4), "launches": n_pipe, "achieved": round(ach(avg_pipe), 2),
+                                "frac": round(ach(avg_pipe) / HBM_PEAK_GBS, 5),
+                                "note": "HIP events on the window stream inside the pipelined steps: the kernel shares the CUs with the previous sub-batch's lookup / map kernels"},
+            "whole_path": {"bytes_per_base": round(whole_b, 4), "formula": "0.25 + d (48 + 32 h), SURVEY 8(d), h = measured hit fraction",
+                           "achieved": round(whole_gbs, 1), "unit": "GB/s per GPU", "frac": round(whole_gbs / HBM_PEAK_GBS, 5)},
+            "note": "integer/VALU-bound kernel (SURVEY 7): the 60 % HBM target of north_star is out of reach for a rolling hash (about 100 integer "
+                    "operations per algorithmic byte); the roof that binds is VALU issue, in `valu`",
+            "valu": valu_roofline(pm, avg_alone, bases_per_launch)}
+    return value, ms_per_step, cfg, roof
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if args.spawn_check:  # CPU-only: proves that --gpus N yields N communicating ranks
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        if dist.get_rank() == 0:
+            print(json.dumps({"spawn_check": True, "n_gpus": int(t.item()), "world": dist.get_world_size()}), flush=True)
+        dist.destroy_process_group()
+        return
+    cores_mine = pin_rank(local_rank, local_world)
+    import torch
+    sys.path.insert(0, ROOT)
+    from ntlink_amd import capi
+    use_cuda = args.lib is None
+    if use_cuda:
+        torch.cuda.set_device(local_rank)
+    comm = Comm(use_cuda, local_rank)
+    dev = capi.Device(local_rank if use_cuda else 0, lib_path=args.lib)
+
+    R = run_workload(dev, comm, args.workload, args, args.steps, args.warmup, rank, world, args.serial_steps)
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        value = total_bases * args.steps / elapsed / 1e9
-        d = 2.0 / (w + 1)
-        # dominant kernel: the read-sketch window kernel.  Algorithmic bytes: 0.25 + 16 d per base.
-        mask_ms, mask_n = prof["sketch_mask"]
-        launches_per_step = mask_n / max(args.steps, 1)
-        avg_launch_ms = mask_ms / max(mask_n, 1)
-        bases_per_launch = read_bases / max(launches_per_step, 1)
-        bytes_per_launch = (0.25 + 16.0 * d) * bases_per_launch
-        achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
-        hfrac = stats["index_hits"] / max(stats["read_mx"], 1)
-        pm = pmc_summary(args.workload, args.scale, bases_per_launch)
-        nb = len(wl.read_batches)
+        value, ms_per_step, cfg, roof = summarize(R, args, world, dev.name)
         out = {
             "metric": "read Gbases/s mapped (ntLink pair, paf=True)",
             "value": round(value, 4), "unit": "Gbases/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {len(ctg_len)} contigs / {contig_bases} bp assembly (sketched + indexed once: "
-                                   f"contig_stage_ms) + {read_bases} read bases per GPU per step ({n_reads} reads, mean {W['read_len']} bp, "
-                                   f"lognormal; generated on the device, {nb} distinct HBM-resident sub-batches), "
-                                   f"k={k} w={w} z=1000 x=0 sensitive={W['sensitive']} paf=True verbose=True",
-                       "scale": args.scale, "hit_fraction": round(hfrac, 4),
-                       "read_minimizers_per_step": stats["read_mx"], "contig_minimizers": contig_mx,
-                       "index_size": index_size, "mappings_hits_pafs_per_step": list(stats["counts"]),
-                       "device": dev.name, "gen_s": round(gen_s, 2),
-                       "contig_stage_ms": round(contig_stage_ms, 2),
-                       "contig_stage_kernels_ms": {nm: round(v[0], 3) for nm, v in contig_prof.items() if v[1]},
-                       "value_incl_contig_stage_once": round(total_bases * args.steps / (elapsed + contig_stage_ms * 1e-3) / 1e9, 4),
-                       "timed_region_s": round(elapsed, 3),
-                       "stage_ms_per_step": {nm: round(v[0] / args.steps, 3) for nm, v in prof.items()}},
-            "roofline": {"bound": "hbm", "kernel": pm.get("kernel", "sketch window kernel (read batches)"),
-                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pm.get("traffic"),
-                         "traffic_source": pm.get("traffic_source"),
-                         "bytes_per_base": round(0.25 + 16.0 * d, 4), "bases_per_launch": int(bases_per_launch),
-                         "avg_launch_ms": round(avg_launch_ms, 4), "launches": mask_n,
-                         "kernel_Gbases_per_s": round(bases_per_launch / (avg_launch_ms * 1e-3) / 1e9, 1) if avg_launch_ms > 0 else None,
-                         "note": "integer/VALU-bound kernel (SURVEY 7): the VALU-issue roof, per instruction class, is in `valu`",
-                         "valu": valu_roofline(pm, avg_launch_ms, bases_per_launch)},
+            "config": cfg, "roofline": roof,
+            "per_rank_ms_per_step": [round(x, 3) for x in R["per_rank_ms"]],
+            "per_rank_bases_per_step": [int(x) for x in R["per_rank_bases"]],
         }
+        if cores_mine:
+            out["cores_per_rank"] = cores_mine
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(dev, wl, W, params)
+            out["cpu_baseline"] = cpu_baseline(dev, R["wl"], R["W"], R["params"])
         if world == 1 and not args.no_e2e and use_cuda:
-            for h in wl.read_batches:
+            for h in R["wl"].read_batches:
                 h.close()
-            wl.read_batches = []
-            out["end_to_end"] = end_to_end(dev, wl, W, args)
+            R["wl"].read_batches = []
+            out["end_to_end"] = end_to_end(dev, R["wl"], R["W"], args)
+    R["ix"].close(); R["csk"].close(); R["wl"].close()
+    if world == 1 and rank == 0 and not args.no_others and args.scale == 1.0:
+        # the other single-GPU configurations of BASELINE.json under the same clock (fewer steps; same definitions)
+        others = {}
+        for name, st in (("C2", 40), ("C5", 3)):
+            if name == args.workload:
+                continue
+            Ro = run_workload(dev, comm, name, args, st, 1, 0, 1, 1)
+            v, ms, cfg_o, roof_o = summarize(Ro, args, 1, dev.name)
+            others[name] = {"value": round(v, 3), "unit": "Gbases/s", "ms_per_step": round(ms, 3), "steps": st,
+                            "workload": cfg_o["workload"], "hit_fraction": cfg_o["hit_fraction"],
+                            "stage_ms_per_step": cfg_o["stage_ms_per_step"], "serial_pass": cfg_o.get("serial_pass"),
+                            "window_kernel": {key: roof_o[key] for key in ("kernel", "avg_launch_ms", "bases_per_launch", "kernel_Gbases_per_s", "achieved", "frac", "traffic", "traffic_source")},
+                            "whole_path": roof_o["whole_path"], "valu": roof_o["valu"]}
+            Ro["ix"].close(); Ro["csk"].close(); Ro["wl"].close()
+        out["other_workloads"] = others
+    if rank == 0:
         print(json.dumps(out), flush=True)
-    ix.close()
-    csk.close()
-    wl.close()
-    for d in devs[1:]:
-        d.close()
     dev.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    comm.close()
 
 
 def pmc_summary(workload, scale, bases_per_launch):
     """HBM bytes and VALU instructions per launch of the dominant kernel from the rocprofv3 PMC passes of this
-    same command (tools/gpu_round.sh: FETCH_SIZE, WRITE_SIZE and the SQ counters in separate --pmc runs; PMC
+    same command (tools/gpu_round3.sh: FETCH_SIZE, WRITE_SIZE and the SQ counters in separate --pmc runs; PMC
     counters cannot be read from inside the process).  profiles/traffic.json records the kernel sources and the
     bases per launch it was taken on: anything else is reported as stale, not quoted."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
@@ -308,24 +454,28 @@ def pmc_summary(workload, scale, bases_per_launch):
         return {"traffic": None, "traffic_source": "stale: profiles/traffic.json was taken on other kernel sources or launch sizes"}
     return {"traffic": t["bytes_per_launch"], "traffic_source": t["source"], "kernel": t.get("kernel"),
             "valu_wave_instr_per_launch": t.get("valu_wave_instr_per_launch"), "valu_source": t.get("valu_source"),
-            "clock_ghz": t.get("clock_ghz")}
+            "valu_busy_frac": t.get("valu_busy_frac"), "valu_cycles_per_wave_instr": t.get("valu_cycles_per_wave_instr"),
+            "clock_ghz": t.get("clock_ghz"), "isa_histogram": t.get("isa_histogram")}
 
 
 def valu_roofline(pm, avg_launch_ms, bases_per_launch):
-    """The roof that binds the kernel: VALU issue.  Peak from the per-instruction-class calibration
-    (tools/valu_calib2.hip): the kernel's integer mix issues one wave64 instruction per 4.06 SIMD cycles at
-    8 waves/SIMD (v_xor/v_add/v_mov 2.5, everything else 4.1-4.4); clock from GRBM_GUI_ACTIVE of the PMC pass."""
+    """The roof that binds the window kernel: VALU issue.  `frac` = the fraction of SIMD cycles in which the kernel's wavefronts
+    had a VALU instruction executing, from the counters of the PMC pass (SQ_ACTIVE_INST_VALU x 4 / (SIMDs x GRBM_GUI_ACTIVE / XCDs)):
+    a measured utilisation, never above 1.  `peak` = the instruction rate at which that fraction would be 1 with this kernel's
+    own mix (achieved / frac); the per-class issue costs behind the mix are in profiles/valu_cycles.json and the kernel's class
+    histogram in the file named by isa_histogram."""
     n = pm.get("valu_wave_instr_per_launch")
+    busy = pm.get("valu_busy_frac")
     if not n or avg_launch_ms <= 0:
         return None
-    clock = pm.get("clock_ghz") or 2.35
-    peak = N_SIMD * clock * 1e9 / VALU_CYCLES_PER_INSTR
     ach = n / (avg_launch_ms * 1e-3)
-    return {"achieved": round(ach / 1e9, 2), "peak": round(peak / 1e9, 1), "unit": "G wave-instr/s", "frac": round(ach / peak, 3),
-            "lane_instr_per_base": round(n * 64.0 / bases_per_launch, 2), "clock_ghz": clock,
-            "cycles_per_wave_instr": VALU_CYCLES_PER_INSTR, "source": pm.get("valu_source"),
-            "note": "peak = SIMDs x clock / cycles per wave-instruction with the clock of the PMC pass (GRBM_GUI_ACTIVE / duration); "
-                    "the unprofiled launches timed here clock a few % higher, so frac can come out slightly above 1: the kernel sits on this roof"}
+    out = {"achieved": round(ach / 1e9, 2), "unit": "G wave-instr/s", "lane_instr_per_base": round(n * 64.0 / bases_per_launch, 2),
+           "source": pm.get("valu_source"), "isa_histogram": pm.get("isa_histogram")}
+    if busy:
+        out.update({"frac": round(min(busy, 1.0), 3), "peak": round(ach / 1e9 / min(busy, 1.0), 1),
+                    "cycles_per_wave_instr": pm.get("valu_cycles_per_wave_instr"), "clock_ghz": pm.get("clock_ghz"),
+                    "note": "frac = VALU-busy SIMD cycles / SIMD cycles of the profiled launches (counters, not a model); peak = achieved / frac"})
+    return out
 
 
 def cpu_baseline(dev, wl, W, params):
@@ -336,7 +486,7 @@ def cpu_baseline(dev, wl, W, params):
     ntlink_pair.py maps on one thread (bin/ntlink_pair.py:336-414)."""
     import numpy as np
     import oracle
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     k, w = W["k"], W["w"]
     T = {}
 
@@ -364,6 +514,10 @@ def cpu_baseline(dev, wl, W, params):
     oracle.sketch_batch(rbuf[:int(roff[small])], roff[:small + 1], k, w, threads=4)
     lap("read_sketch_t4", t0)
     t4_bases = int(roff[small])
+    # the all-cores leg, twice: the first call also pays for creating the thread team and first-touching the output arrays
+    t0 = time.perf_counter()
+    ro, rh, rp, rs = oracle.sketch_batch(rbuf, roff, k, w, threads=cores)
+    lap("read_sketch_all_cores_first_call", t0)
     t0 = time.perf_counter()
     ro, rh, rp, rs = oracle.sketch_batch(rbuf, roff, k, w, threads=cores)
     lap("read_sketch_all_cores", t0)
@@ -378,16 +532,21 @@ def cpu_baseline(dev, wl, W, params):
     # whole-sample rates; the contig work is amortised over a 30x read set, so the read stages are what scales
     best = bases / (T["read_sketch_all_cores"] + T["map_read_parallel"]) / 1e9
     faithful = 1.0 / (T["read_sketch_t4"] / t4_bases + T["map_1_thread"] / t4_bases) / 1e9
+    per_thread_t4 = t4_bases / T["read_sketch_t4"] / 4.0
     return {"value": round(best, 4), "unit": "Gbases/s", "cores": cores, "kind": "port",
             "sample": f"all {len(wl.ctg_len)} contigs + {nreads} reads ({bases} bases, one coverage of the assembly) of the same generator; "
-                      f"value = read sketch + read-parallel map on {cores} threads; reference-faithful settings "
+                      f"value = read sketch + read-parallel map on {cores} threads (second call: thread team and output pages warm); reference-faithful settings "
                       f"(indexlr t=4, map on 1 thread) timed on the first {small} reads ({t4_bases} bases)",
             "reference_faithful": {"value": round(faithful, 4), "unit": "Gbases/s", "cores": 4,
                                    "what": "indexlr -t 4 (ntLink:27) piped into a single-threaded map loop; the pipe overlaps them, "
                                            "so the true rate lies between this serial figure and the slower of the two stages"},
+            "if_it_scaled": {"value": round(1.0 / (1.0 / (per_thread_t4 * cores) + T["map_read_parallel"] / bases) / 1e9, 3), "unit": "Gbases/s",
+                             "what": f"per-thread sketch rate at t=4 ({per_thread_t4 / 1e6:.1f} Mbases/s/thread) x {cores} threads + the measured read-parallel map: "
+                                     "the ceiling of the same code if it scaled perfectly over the host's cores"},
             "stages_s": T,
             "stage_rates": {"read_sketch_t4_Mbases_per_s": round(t4_bases / T["read_sketch_t4"] / 1e6, 1),
                             "read_sketch_all_cores_Mbases_per_s": round(bases / T["read_sketch_all_cores"] / 1e6, 1),
+                            "read_sketch_all_cores_first_call_Mbases_per_s": round(bases / T["read_sketch_all_cores_first_call"] / 1e6, 1),
                             "map_1_thread_Mbases_per_s": round(t4_bases / T["map_1_thread"] / 1e6, 1),
                             "map_read_parallel_Mbases_per_s": round(bases / T["map_read_parallel"] / 1e6, 1),
                             "contig_sketch_all_cores_Mbases_per_s": round(int(coff[-1]) / T["contig_sketch_all_cores"] / 1e6, 1)},

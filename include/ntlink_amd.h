@@ -87,6 +87,9 @@ int ntl_ctx_sync(ntl_ctx *ctx);
 /* 1 when the window stage of a sketch runs on its own stream beside the previous batch's emit / map kernels (the default),
  * 0 with NTL_PIPELINE=0 (one stream: what a per-kernel profile wants). */
 int ntl_ctx_pipelined(const ntl_ctx *ctx);
+/* Turns the second stream off / on again at a quiet point (waits for everything queued first).  NTL_EINVAL when the
+ * context was created under NTL_PIPELINE=0. */
+int ntl_ctx_set_pipeline(ntl_ctx *ctx, int on);
 
 /* Kernel timing with HIP events on the context's stream.  When enabled, every launch of the
  * named kernel groups is bracketed by events; ntl_prof_get returns the accumulated time and

@@ -16,7 +16,7 @@ DEFAULT_LIB = os.path.join(_HERE, "libntlink_hip.so")
 
 # every symbol include/ntlink_amd.h declares
 SYMBOLS = [
-    "ntl_ctx_create", "ntl_ctx_destroy", "ntl_last_error", "ntl_ctx_device_name", "ntl_ctx_sync", "ntl_ctx_pipelined",
+    "ntl_ctx_create", "ntl_ctx_destroy", "ntl_last_error", "ntl_ctx_device_name", "ntl_ctx_sync", "ntl_ctx_pipelined", "ntl_ctx_set_pipeline",
     "ntl_prof_enable", "ntl_prof_reset", "ntl_prof_get",
     "ntl_batch_create", "ntl_batch_create_packed", "ntl_packed_words", "ntl_batch_destroy", "ntl_batch_nseq", "ntl_batch_bases", "ntl_host_alloc", "ntl_host_free",
     "ntl_synth_genome", "ntl_synth_slices", "ntl_batch_download",
@@ -74,6 +74,7 @@ def load(path=None):
     L.ntl_ctx_device_name.restype = C.c_char_p
     L.ntl_ctx_sync.argtypes = [vp]
     L.ntl_ctx_pipelined.argtypes = [vp]
+    L.ntl_ctx_set_pipeline.argtypes = [vp, C.c_int]
     L.ntl_sketch_wait.argtypes = [vp]
     L.ntl_mapres_wait.argtypes = [vp]
     L.ntl_prof_enable.argtypes = [vp, C.c_int]
@@ -352,6 +353,10 @@ class Device:
     @property
     def pipelined(self):
         return bool(self.L.ntl_ctx_pipelined(self.ptr))
+
+    def set_pipeline(self, on):
+        """Window stage on its own stream (on) or behind everything else on the one stream (off); drains the device first."""
+        self._chk(self.L.ntl_ctx_set_pipeline(self.ptr, int(bool(on))))
 
     # ---- profiling (HIP events on the context's stream)
     def prof_enable(self, on=True):

@@ -78,6 +78,7 @@ struct ntl_ctx {
     int device = 0;
     hipStream_t stream = nullptr;  /* MAIN */
     hipStream_t wstream = nullptr; /* window stage; == stream when the pipeline is off */
+    hipStream_t wstream_own = nullptr; /* the second stream itself (ntl_ctx_set_pipeline switches wstream between it and MAIN) */
     bool pipelined = false;
     std::string err;
     std::string async_err;         /* first failure of work whose handle was already gone: reported by ntl_ctx_sync */
@@ -369,6 +370,7 @@ extern "C" int ntl_ctx_create(int device, ntl_ctx **out)
         hipError_t e2 = prio ? hipStreamCreateWithPriority(&c->wstream, hipStreamNonBlocking, prio == 2 ? greatest : least)
                              : hipStreamCreateWithFlags(&c->wstream, hipStreamNonBlocking);
         if (e2 != hipSuccess) { c->wstream = c->stream; c->pipelined = false; }
+        else c->wstream_own = c->wstream;
     }
     {
         uint64_t g4[256][2];
@@ -428,7 +430,7 @@ extern "C" void ntl_ctx_destroy(ntl_ctx *c)
     for (auto e : c->ev_free) (void)hipEventDestroy(e);
     for (auto &e : c->throttle) sev_put(c, e);
     for (auto e : c->sev_free) (void)hipEventDestroy(e);
-    if (c->wstream != c->stream) (void)hipStreamDestroy(c->wstream);
+    if (c->wstream_own) (void)hipStreamDestroy(c->wstream_own);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -436,6 +438,20 @@ extern "C" void ntl_ctx_destroy(ntl_ctx *c)
 extern "C" const char *ntl_last_error(const ntl_ctx *c) { return c ? c->err.c_str() : "no context"; }
 extern "C" const char *ntl_ctx_device_name(const ntl_ctx *c) { return c ? c->devname.c_str() : ""; }
 extern "C" int ntl_ctx_pipelined(const ntl_ctx *c) { return c && c->pipelined ? 1 : 0; }
+
+/* Switches the window stage between its own stream and MAIN at a quiet point (both streams are drained first).  bench.py
+ * times the pipelined steps, then a few serial ones whose per-kernel durations are those of kernels running alone. */
+extern "C" int ntl_ctx_set_pipeline(ntl_ctx *c, int on)
+{
+    if (!c) return NTL_EINVAL;
+    (void)hipSetDevice(c->device);
+    HIPCHK(c, sync_both(c));
+    reap(c, true);
+    if (on && !c->wstream_own) return fail(c, NTL_EINVAL, "this context was created without a window stream (NTL_PIPELINE=0)");
+    c->pipelined = on != 0;
+    c->wstream = on ? c->wstream_own : c->stream;
+    return NTL_OK;
+}
 
 extern "C" int ntl_ctx_sync(ntl_ctx *c)
 {

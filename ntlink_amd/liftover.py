@@ -1,7 +1,7 @@
 """Liftover of the verbose mappings to the coordinates of the scaffolded sequences.
 
-Same names and arguments as the reference's bin/ntlink_liftover_mappings.py (`read_agp` :39-50, `liftover_mappings`
-:125-143, `main` :146-161); the per-line / per-read work (`liftover_ctg_mappings` :61-87, `print_adjusted_mappings`
+Same entry points as the reference's bin/ntlink_liftover_mappings.py (`read_agp` :39-50, `liftover_mappings`
+:125-143, `main` :146-161); `read_agp` returns plain tuples of the columns the native call takes.  The per-line / per-read work (`liftover_ctg_mappings` :61-87, `print_adjusted_mappings`
 :89-121) is native (csrc/ntl_liftover.cpp, `ntl_liftover` of include/ntlink_amd.h), several threads over pieces of the
 file cut where the read id changes.  No GPU is involved."""
 import argparse
@@ -12,40 +12,29 @@ import numpy as np
 from . import capi
 
 
-class AGP:
-    "One sequence line of an AGP file (attributes of the reference's class, bin/ntlink_liftover_mappings.py:16-36)"
-
-    def __init__(self, path_id, scaf_start, scaf_end, contig_id, orientation, ctg_start, ctg_end, component_id):
-        self.path_id = path_id
-        self.scaf_start = int(scaf_start)
-        self.scaf_end = int(scaf_end)
-        self.contig_id = contig_id
-        self.orientation = orientation
-        self.ctg_start = int(ctg_start)
-        self.ctg_end = int(ctg_end)
-        self.component_id = int(component_id)
-
-    def get_ctg_length(self):
-        return self.ctg_end - self.ctg_start + 1
-
-    def get_scaf_length(self):
-        return self.scaf_end - self.scaf_start + 1
-
-    def __str__(self):
-        return f"{self.path_id}, {self.scaf_start}, {self.contig_id}"
+# columns of an AGP sequence line, in file order; ntl_liftover takes five of them
+_AGP_COLUMNS = ("object", "object_beg", "object_end", "part_number", "component_type", "component_id", "component_beg",
+                "component_end", "orientation")
 
 
 def read_agp(agp_filename):
-    "AGP file -> {contig id: AGP}; gap lines (component type N or P) are skipped, nine columns are required"
-    agp_dict = {}
-    with open(agp_filename, "r", encoding="utf-8") as agp_file:
-        for line in agp_file:
-            path_id, scaf_start, scaf_end, component_id, component_type, ctg_id, ctg_start, ctg_end, orientation = \
-                line.strip().split("\t")
-            if component_type in ("N", "P"):
+    """AGP file -> {contig id: (path id, scaf_start, ctg_start, ctg_end, orientation)}: the five columns `ntl_liftover`
+    takes, one tuple per component (the last line of a contig id wins: the reference keeps a dict, read_agp :39-50).
+    Gap lines (component type N or P) carry no contig and are left out; a line that does not have the nine AGP columns, or
+    whose coordinates are not integers, raises ValueError (the reference fails on the same lines)."""
+    table = {}
+    with open(agp_filename, "r", encoding="utf-8") as fh:
+        for lineno, line in enumerate(fh, 1):
+            cols = line.strip().split("\t")
+            if len(cols) != len(_AGP_COLUMNS):
+                raise ValueError(f"{agp_filename}:{lineno}: {len(cols)} columns, an AGP line has {len(_AGP_COLUMNS)}")
+            rec = dict(zip(_AGP_COLUMNS, cols))
+            if rec["component_type"] in ("N", "P"):
                 continue
-            agp_dict[ctg_id] = AGP(path_id, scaf_start, scaf_end, ctg_id, orientation, ctg_start, ctg_end, component_id)
-    return agp_dict
+            int(rec["object_end"]), int(rec["part_number"])  # the reference converts these too: same inputs fail
+            table[rec["component_id"]] = (rec["object"], int(rec["object_beg"]), int(rec["component_beg"]),
+                                          int(rec["component_end"]), rec["orientation"])
+    return table
 
 
 def _blob(strings):
@@ -61,12 +50,12 @@ def liftover_mappings(mappings_filename, agp_dict, output, k):
     lib = capi.load()
     entries = list(agp_dict.items())
     ctg_blob, ctg_off = _blob([c for c, _ in entries])
-    path_blob, path_off = _blob([e.path_id for _, e in entries])
-    scaf_start = np.array([e.scaf_start for _, e in entries], dtype=np.int64)
-    ctg_start = np.array([e.ctg_start for _, e in entries], dtype=np.int64)
-    ctg_end = np.array([e.ctg_end for _, e in entries], dtype=np.int64)
+    path_blob, path_off = _blob([e[0] for _, e in entries])
+    scaf_start = np.array([e[1] for _, e in entries], dtype=np.int64)
+    ctg_start = np.array([e[2] for _, e in entries], dtype=np.int64)
+    ctg_end = np.array([e[3] for _, e in entries], dtype=np.int64)
     # only `+` and `-` move anything; every other orientation string means "leave the positions alone"
-    ori = bytes((e.orientation.encode()[0] if len(e.orientation.encode()) == 1 else ord("?")) for _, e in entries)
+    ori = bytes((e[4].encode()[0] if len(e[4].encode()) == 1 else ord("?")) for _, e in entries)
     nin, nout = C.c_uint64(0), C.c_uint64(0)
     rc = lib.ntl_liftover(str(mappings_filename).encode(), str(output).encode(), int(k), len(entries),
                           ctg_blob, capi._ptr(ctg_off, C.c_uint64), path_blob, capi._ptr(path_off, C.c_uint64),

@@ -31,7 +31,7 @@ class PairOutputs:
     """<prefix>.verbose_mapping.tsv / .paf writers + the pair tally, fed batch by batch in read order."""
 
     def __init__(self, prefix, ctg_names, ctg_len, k, f, verbose, paf, part=""):
-        """part: suffix of this rank's part files in a multi-process run (rank 0 writes the final names)"""
+        """part: suffix of this rank's part files in a multi-process run (the final names appear by a rename at the end)"""
         self.prefix, self.part = prefix, part
         self.ctg_names, self.ctg_len = ctg_names, ctg_len
         self.verbose_fh = open(prefix + ".verbose_mapping.tsv" + part, "w") if verbose else None
@@ -77,9 +77,12 @@ class PairOutputs:
         """Error convention of the reference: partial outputs are deleted (bin/ntlink_pair.py:608-613)."""
         self.close()
         for ext, on in ((".verbose_mapping.tsv", self.verbose_fh), (".paf", self.paf_fh)):
-            for path in {self.prefix + ext + self.part, self.prefix + ext}:
+            for path in {self.prefix + ext + self.part, self.prefix + ext, self.prefix + ext + ".assembling"}:
                 if on and os.path.exists(path):
-                    os.remove(path)
+                    try:
+                        os.remove(path)
+                    except FileNotFoundError:  # another rank was faster
+                        pass
 
 
 def finish_pairs(tally, prefix, n, a, write_pairs_tsv):
@@ -410,12 +413,9 @@ def _map_batches(dev, ix, batches, drain, stats, t_mark, w, **map_kw):
     work(devs[0])
     for t in threads:
         t.join()
-    for d in devs[1:]:
-        if state["error"] is None:
-            # results of this context may still sit in the writer's queue: their page-locked buffers go back to it later
-            stats.setdefault("_extra_devices", []).append(d)
-        else:
-            d.close()
+    # Results of the cloned contexts may still sit in the writer's queue (or be in its hands), as views into their page-locked
+    # buffers: the contexts are closed by run_pair only after the writer thread has been joined -- on the error path too.
+    stats.setdefault("_extra_devices", []).extend(devs[1:])
     if state["error"] is not None:
         raise state["error"]
 
@@ -443,6 +443,12 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
                                                     repeat_filter=repeats, verbose=verbose))
         comm.barrier()
         return None
+    if comm.world > 1 and root:
+        # leftovers of a run that died: part files and half-assembled outputs must not be taken for this run's
+        import glob
+        for ext in (".verbose_mapping.tsv", ".paf"):
+            for stale in glob.glob(glob.escape(prefix + ext) + ".part*") + glob.glob(glob.escape(prefix + ext) + ".assembling"):
+                os.remove(stale)
     comm.barrier()  # nobody creates the verbose file before everyone has looked for it
     t_start = time.perf_counter()
     read_paths = reads.split() if isinstance(reads, str) else list(reads)
@@ -454,7 +460,10 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
     ctg = seqio.load_all([target], packed=packed)  # used once: page-locking a buffer for it would cost more than the staged copy
     ctg_len = ctg.lengths
     t_ctg_parsed = time.perf_counter()
-    part = "" if root else f".part{comm.rank}"
+    # Several ranks: EVERY rank (0 too) writes part files; the final names appear only by a rename after all parts are in
+    # place -- a run that dies half way leaves no well-formed <prefix>.verbose_mapping.tsv with a fraction of the reads,
+    # which the next run (this driver and the reference alike, bin/ntlink_pair.py:565-567) would take for a checkpoint.
+    part = "" if comm.world == 1 else f".part{comm.rank}"
     out = PairOutputs(prefix, ctg.names, ctg_len, k, f, verbose, paf, part=part)
 
     def consume(pres, names, lens):
@@ -499,8 +508,11 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
             exts = [e for e, on in ((".verbose_mapping.tsv", verbose), (".paf", paf)) if on]
             sizes = comm.allgather([os.path.getsize(prefix + e + part) for e in exts])
             for j, e in enumerate(exts):
-                if not root:
-                    _append_part(prefix + e, prefix + e + part, sum(sz[j] for sz in sizes[:comm.rank]))
+                _append_part(prefix + e + ".assembling", prefix + e + part, sum(sz[j] for sz in sizes[:comm.rank]))
+            comm.barrier()  # every part is in place
+            if root:
+                for e in exts:
+                    os.replace(prefix + e + ".assembling", prefix + e)
             mine = (out.tally.export(), {key: stats[key] for key in ("read_bases", "reads", "read_minimizers", "index_hits", "parsed_bytes")})
             parts = comm.gather(mine)  # pair-tally deltas and five counters per rank
             if root:

@@ -173,22 +173,28 @@ def shard_plan(paths, rank, world):
         paths = [paths]
     if world == 1:
         return list(paths)
-    sizes = []
+    import stat as _stat
+    sizes, regular = [], []
     for p in paths:
-        try:
-            sizes.append(os.path.getsize(p) if p != "-" else 0)
-        except OSError:
-            sizes.append(0)
+        if p == "-":
+            raise ValueError("reads from stdin cannot be shared out between ranks: give the files by name")
+        st = os.stat(p)  # a missing input is an error here, as it is for the single-process reader
+        regular.append(_stat.S_ISREG(st.st_mode))
+        sizes.append(st.st_size if regular[-1] else 0)
     total = sum(sizes)
     lo_r, hi_r = total * rank // world, total * (rank + 1) // world
     plan, at = [], 0
-    for p, sz in zip(paths, sizes):
+    for p, sz, reg in zip(paths, sizes, regular):
         f0, f1 = at, at + sz
         at = f1
-        if p == "-":
-            raise ValueError("reads from stdin cannot be shared out between ranks: give the files by name")
+        if not reg:
+            # a FIFO / /dev/fd/N (process substitution): its size is unknown and it can be read once -- the whole input goes
+            # to the rank whose share begins where it stands in the concatenation (the last rank when nothing follows it)
+            if lo_r <= f0 < hi_r or (f0 >= total and rank == world - 1):
+                plan.append(p)
+            continue
         if sz == 0:
-            continue  # no records
+            continue  # an empty regular file: no records
         if not _splittable(p):
             if lo_r <= f0 < hi_r:  # whole file to the owner of its first byte
                 plan.append(p)

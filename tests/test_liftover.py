@@ -40,6 +40,22 @@ def test_liftover_equals_reference(case, threads, tmp_path, monkeypatch):
     assert nout == case["lines"] == exp.count(b"\n") and nin >= nout
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES, ids=lambda c: c["name"])
+def test_liftover_on_the_gpu_box(case, tmp_path, monkeypatch):
+    """The same 22 imported-reference cases through the hipcc-built library as it is on the GPU box (row f5 is host code, but
+    the library the driver's GPU tier loads is the one that must pass), default thread count of that host."""
+    from ntlink_amd import capi
+    assert capi.load()._name == capi.DEFAULT_LIB
+    monkeypatch.setenv("NTL_IO_MIN_CHUNK", "2000")
+    out = tmp_path / "lifted.tsv"
+    agp = liftover.read_agp(os.path.join(GOLD, case["agp"]))
+    nin, nout = liftover.liftover_mappings(_mappings_file(case, tmp_path), agp, str(out), case["k"])
+    exp = gzip.open(os.path.join(GOLD, "gen", "liftover", case["name"] + ".liftover.tsv.gz"), "rb").read()
+    assert out.read_bytes() == exp
+    assert nout == case["lines"] and nin >= nout
+
+
 def test_liftover_cli_and_errors(tmp_path):
     case = CASES[0]
     out = tmp_path / "o.tsv"
