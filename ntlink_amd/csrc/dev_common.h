@@ -204,17 +204,21 @@ __device__ __forceinline__ void hash_init_g4(const uint32_t *__restrict__ packed
 template <int NT>
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *s_tmp, uint32_t &total)
 {
+    /* a DPP scan inside every wavefront, the wavefront totals through LDS: two barriers (the log-step scan over LDS this
+       replaces took eighteen for 256 threads, in kernels whose time is the latency of exactly such steps) */
+    static_assert(NT % 64 == 0 && NT <= 1024, "whole wavefronts");
     const int t = threadIdx.x;
-    s_tmp[t] = v;
+    const uint32_t incl = ntl_wave_incl_scan(v);
+    if ((t & 63) == 63) s_tmp[t >> 6] = incl;
     __syncthreads();
-    for (int d = 1; d < NT; d <<= 1) {
-        uint32_t add = t >= d ? s_tmp[t - d] : 0u;
-        __syncthreads();
-        s_tmp[t] += add;
-        __syncthreads();
+    uint32_t before = 0, all = 0;
+#pragma unroll
+    for (int wv = 0; wv < NT / 64; wv++) {
+        const uint32_t x = s_tmp[wv];
+        before += wv < (t >> 6) ? x : 0u;
+        all += x;
     }
-    uint32_t incl = s_tmp[t];
-    total = s_tmp[NT - 1];
-    __syncthreads();
-    return incl - v;
+    total = all;
+    __syncthreads(); /* s_tmp may be written again */
+    return before + incl - v;
 }

@@ -110,3 +110,16 @@ __device__ __forceinline__ double ntl_mul_add_rn(double x, double d, double k)
 /* streaming (non-temporal) 64-bit global accesses: data touched once should not evict reused lines from L2 */
 __device__ __forceinline__ uint64_t ntl_stream_load(const uint64_t *p) { return __builtin_nontemporal_load(p); }
 __device__ __forceinline__ void ntl_stream_store(uint64_t *p, uint64_t v) { __builtin_nontemporal_store(v, p); }
+
+/* inclusive prefix sum over the 64 lanes of a wavefront: four DPP row shifts inside the rows of 16, then the row totals
+   broadcast forward (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3) -- six v_add_u32 with DPP operands */
+__device__ __forceinline__ uint32_t ntl_wave_incl_scan(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false); /* row_shr:1 */
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false); /* row_shr:2 */
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false); /* row_shr:4 */
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false); /* row_shr:8 */
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false); /* row_bcast:15 -> rows 1, 3 */
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false); /* row_bcast:31 -> rows 2, 3 */
+    return v;
+}

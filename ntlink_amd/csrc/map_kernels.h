@@ -154,11 +154,15 @@ struct HitRec { uint32_t ctg_pos, read_pos; uint8_t ctg_strand, read_strand, pad
 struct PafRec { uint32_t read, ctg, q_start, q_end, t_start, t_end, n_hits, strand; };
 
 #define MAP_NT 64
-/* hits / runs per read staged in LDS: template parameters of map_kernel (512/128 for dense sketches,
-   256/64 -- twice the resident wavefronts -- when reads carry few minimizers; 1024/128 measured slower); larger reads
-   use global scratch */
-#define MAP_NHA 6    /* per-hit u32 arrays */
-#define MAP_NRA 10   /* per-run u32 arrays */
+/* Hits / runs per read staged in LDS are template parameters of map_kernel; reads are sorted into three size classes by
+   their number of minimizers (map_classify_kernel) and each class runs with the staging that fits it: 256/64, 512/128,
+   1024/128.  Per hit 16 bytes of LDS (three 32-bit words and two 16-bit indices), per run 26: 5.6 KB, 11.3 KB and 19.3 KB per
+   wavefront -- 28, 14 and 8 wavefronts per CU.  (Round 2: six + ten 32-bit arrays, 17 KB for 512 hits, 9 wavefronts per CU,
+   and every read above 512 hits -- a fifth of 20-kb HiFi reads -- on the global scratch arrays.)  Reads beyond the largest
+   class use global scratch (map_overflow_kernel), where every array is 32 bits wide. */
+#define MAP_NHA 5    /* per-hit u32 arrays of the global scratch form */
+#define MAP_NRA 10   /* per-run u32 arrays of the global scratch form */
+#define MAP_NCLASS 3
 
 struct MapArgs {
     const MxRecord *mx;
@@ -173,6 +177,8 @@ struct MapArgs {
     uint64_t scr_stride;
     uint32_t *err;
     uint32_t *over_list, *over_count;             /* reads that do not fit the LDS staging: [nreads], [1] */
+    uint32_t *class_list;                         /* [MAP_NCLASS][nreads] reads of each size class (map_classify_kernel) */
+    uint32_t *class_count;                        /* [MAP_NCLASS] */
     /* The sketch may still be in flight when these kernels are queued (nothing waits on the host for its size): when its
        minimizer total turns out larger than the arrays that were sized from the expected density, the records are incomplete
        and every kernel here leaves the batch alone; the host makes the sketch again and queues the map a second time. */
@@ -182,33 +188,44 @@ struct MapArgs {
 
 __device__ __forceinline__ bool map_sketch_overflowed(const MapArgs &A) { return A.mx_total && *A.mx_total > A.mx_cap; }
 
-struct HitArr { uint32_t *ctg, *cpos, *rpos, *fl, *run, *ord; };
-struct RunArr { uint32_t *start, *ctg, *leader, *flag, *cnt, *mn, *mni, *mx, *mxi, *last; };
+/* Per-hit state.  cf = contig << 3 | HF_KEEP | read strand << 1 | contig strand (contig ids stay below 2^29, ntl_index_build);
+   IT = uint16_t in LDS (indices below the class's capacity), uint32_t on the global scratch. */
+template <typename IT> struct HitArr { uint32_t *cf, *cpos, *rpos; IT *run, *ord; };
+template <typename IT> struct RunArr { uint32_t *ctg, *mn, *mx; IT *start, *leader, *flag, *cnt, *mni, *mxi, *last; };
 
 #define HF_CS 1u   /* contig strand */
 #define HF_RS 2u   /* read strand */
 #define HF_KEEP 4u
+#define HF_CTG_SHIFT 3
 #define RF_NOISY 1u
 #define RF_SUB 2u
 #define AX_DUP 1u
 #define AX_FILT 2u
 #define AX_BRK 4u
 
+/* flags of the PAF stage, set by several lanes on neighbouring entries: a 32-bit atomic on the word that holds the entry */
+__device__ __forceinline__ void map_ax_or(uint32_t *aux, uint32_t i, uint32_t bits) { atomicOr(&aux[i], bits); }
+__device__ __forceinline__ void map_ax_or(uint16_t *aux, uint32_t i, uint32_t bits)
+{
+    atomicOr(reinterpret_cast<uint32_t *>(aux) + (i >> 1), bits << (16u * (i & 1u))); /* the arrays start on a word boundary */
+}
+
 /* stable in-place compaction of the hits whose HF_KEEP bit is set; returns the new count */
-__device__ __forceinline__ uint32_t map_compact(HitArr H, uint32_t n)
+template <typename IT>
+__device__ __forceinline__ uint32_t map_compact(HitArr<IT> H, uint32_t n)
 {
     const uint32_t lane = threadIdx.x;
     uint32_t m = 0;
     for (uint32_t c = 0; c < n; c += MAP_NT) {
         const uint32_t i = c + lane;
-        uint32_t a = 0, b = 0, d = 0, f = 0;
-        if (i < n) { a = H.ctg[i]; b = H.cpos[i]; d = H.rpos[i]; f = H.fl[i]; }
-        const bool keep = i < n && (f & HF_KEEP);
+        uint32_t a = 0, b = 0, d = 0;
+        if (i < n) { a = H.cf[i]; b = H.cpos[i]; d = H.rpos[i]; }
+        const bool keep = i < n && (a & HF_KEEP);
         const unsigned long long bal = __ballot(keep);
         __syncthreads(); /* every lane holds its element before anything is overwritten */
         if (keep) {
             const uint32_t o = m + ntl_mbcnt(bal);
-            H.ctg[o] = a; H.cpos[o] = b; H.rpos[o] = d; H.fl[o] = f & ~HF_KEEP;
+            H.cf[o] = a & ~HF_KEEP; H.cpos[o] = b; H.rpos[o] = d;
         }
         m += (uint32_t)__popcll(bal);
     }
@@ -217,26 +234,30 @@ __device__ __forceinline__ uint32_t map_compact(HitArr H, uint32_t n)
 }
 
 /* run id of every hit (consecutive hits on one contig, itertools.groupby); returns #runs */
-__device__ __forceinline__ uint32_t map_number_runs(HitArr H, uint32_t n)
+template <typename IT>
+__device__ __forceinline__ uint32_t map_number_runs(HitArr<IT> H, uint32_t n)
 {
     const uint32_t lane = threadIdx.x;
     uint32_t R = 0;
     for (uint32_t c = 0; c < n; c += MAP_NT) {
         const uint32_t i = c + lane;
-        const bool isb = i < n && (i == 0 || H.ctg[i] != H.ctg[i - 1]);
+        const bool isb = i < n && (i == 0 || (H.cf[i] >> HF_CTG_SHIFT) != (H.cf[i - 1] >> HF_CTG_SHIFT));
         const unsigned long long bal = __ballot(isb);
-        if (i < n) H.run[i] = R + ntl_mbcnt(bal) + (isb ? 1u : 0u) - 1u;
+        if (i < n) H.run[i] = (IT)(R + ntl_mbcnt(bal) + (isb ? 1u : 0u) - 1u);
         R += (uint32_t)__popcll(bal);
     }
     __syncthreads();
     return R;
 }
 
-__device__ __forceinline__ void map_fill_runs(HitArr H, uint32_t n, RunArr RU, uint32_t R)
+template <typename IT>
+__device__ __forceinline__ void map_fill_runs(HitArr<IT> H, uint32_t n, RunArr<IT> RU, uint32_t R)
 {
     const uint32_t lane = threadIdx.x;
-    for (uint32_t i = lane; i < n; i += MAP_NT)
-        if (i == 0 || H.ctg[i] != H.ctg[i - 1]) { RU.start[H.run[i]] = i; RU.ctg[H.run[i]] = H.ctg[i]; }
+    for (uint32_t i = lane; i < n; i += MAP_NT) {
+        const uint32_t cg = H.cf[i] >> HF_CTG_SHIFT;
+        if (i == 0 || cg != (H.cf[i - 1] >> HF_CTG_SHIFT)) { RU.start[H.run[i]] = (IT)i; RU.ctg[H.run[i]] = cg; }
+    }
     __syncthreads();
     /* leader = first run on the same contig */
     for (uint32_t r = lane; r < R; r += MAP_NT) {
@@ -244,18 +265,37 @@ __device__ __forceinline__ void map_fill_runs(HitArr H, uint32_t n, RunArr RU, u
         const uint32_t c = RU.ctg[r];
         for (uint32_t j = 0; j < r; j++)
             if (RU.ctg[j] == c) { ld = j; break; }
-        RU.leader[r] = ld;
+        RU.leader[r] = (IT)ld;
         RU.flag[r] = 0;
     }
     __syncthreads();
+}
+
+/* (value, index) of the first minimum / first maximum over the lanes of the wavefront: butterfly with ties to the smaller
+   index; lanes without a candidate pass idx = 0xFFFFFFFF */
+__device__ __forceinline__ void map_wave_argmin(uint32_t &v, uint32_t &idx)
+{
+    const int lane = (int)threadIdx.x;
+    for (int d = 1; d < MAP_NT; d <<= 1) {
+        const uint32_t ov = __shfl(v, lane ^ d), oi = __shfl(idx, lane ^ d);
+        if (oi != NTL_NONE && (idx == NTL_NONE || ov < v || (ov == v && oi < idx))) { v = ov; idx = oi; }
+    }
+}
+__device__ __forceinline__ void map_wave_argmax(uint32_t &v, uint32_t &idx)
+{
+    const int lane = (int)threadIdx.x;
+    for (int d = 1; d < MAP_NT; d <<= 1) {
+        const uint32_t ov = __shfl(v, lane ^ d), oi = __shfl(idx, lane ^ d);
+        if (oi != NTL_NONE && (idx == NTL_NONE || ov > v || (ov == v && oi < idx))) { v = ov; idx = oi; }
+    }
 }
 
 /* One read on one wavefront.  GLOBAL = false: hits and runs live in the workgroup's LDS arrays -- the pointers are set from
  * them unconditionally, so every access is a DS instruction; a read that does not fit (more than MAP_CAPH hits or MAP_CAPR
  * runs) is put on the overflow list and left alone.  GLOBAL = true (map_overflow_kernel): the same code on the read's region
  * of the global scratch arrays. */
-template <int MAP_CAPH, int MAP_CAPR, bool GLOBAL>
-__device__ __forceinline__ void map_read(const MapArgs &A, const uint32_t r, uint32_t (*s_hit)[MAP_CAPH], uint32_t (*s_run)[MAP_CAPR])
+template <int MAP_CAPH, int MAP_CAPR, bool GLOBAL, typename IT>
+__device__ __forceinline__ void map_read(const MapArgs &A, const uint32_t r, HitArr<IT> HL, RunArr<IT> RL)
 {
     const uint32_t lane = threadIdx.x;
     const uint32_t m0 = A.mx_off[r], m1 = A.mx_off[r + 1], nmx = m1 - m0;
@@ -273,20 +313,23 @@ __device__ __forceinline__ void map_read(const MapArgs &A, const uint32_t r, uin
             nc += (uint32_t)__popcll(__ballot(v));
         }
     }
-    HitArr H;
+    HitArr<IT> H = HL;
+    RunArr<IT> RU = RL;
     if (!GLOBAL) {
         if (nc > MAP_CAPH) { /* wave-uniform */
             if (lane == 0) A.over_list[atomicAdd(A.over_count, 1u)] = r;
             return;
         }
-        H.ctg = s_hit[0]; H.cpos = s_hit[1]; H.rpos = s_hit[2]; H.fl = s_hit[3]; H.run = s_hit[4]; H.ord = s_hit[5];
     } else {
         uint32_t *g = A.scr + m0;
-        H.ctg = g; H.cpos = g + A.scr_stride; H.rpos = g + 2 * A.scr_stride; H.fl = g + 3 * A.scr_stride;
-        H.run = g + 4 * A.scr_stride; H.ord = g + 5 * A.scr_stride;
+        H.cf = g; H.cpos = g + A.scr_stride; H.rpos = g + 2 * A.scr_stride;
+        H.run = (IT *)(g + 3 * A.scr_stride); H.ord = (IT *)(g + 4 * A.scr_stride);
+        uint32_t *q = A.scr + MAP_NHA * A.scr_stride + m0;
+        RU.ctg = q; RU.mn = q + A.scr_stride; RU.mx = q + 2 * A.scr_stride;
+        RU.start = (IT *)(q + 3 * A.scr_stride); RU.leader = (IT *)(q + 4 * A.scr_stride); RU.flag = (IT *)(q + 5 * A.scr_stride);
+        RU.cnt = (IT *)(q + 6 * A.scr_stride); RU.mni = (IT *)(q + 7 * A.scr_stride); RU.mxi = (IT *)(q + 8 * A.scr_stride);
+        RU.last = (IT *)(q + 9 * A.scr_stride);
     }
-    RunArr RU;
-    RU.start = nullptr;
 
     if (nc == 0) goto done;
 
@@ -303,8 +346,8 @@ __device__ __forceinline__ void map_read(const MapArgs &A, const uint32_t r, uin
         const unsigned long long bal = __ballot(v);
         if (v) {
             const uint32_t o = n + ntl_mbcnt(bal);
-            H.ctg[o] = cd.meta >> 2; H.cpos[o] = cd.cpos; H.rpos[o] = mr.pos;
-            H.fl[o] = ((cd.meta >> 1) & 1u) | ((mr.meta & 1u) << 1);
+            H.cf[o] = ((cd.meta >> 2) << HF_CTG_SHIFT) | ((cd.meta >> 1) & 1u) | ((mr.meta & 1u) << 1);
+            H.cpos[o] = cd.cpos; H.rpos[o] = mr.pos;
         }
         n += (uint32_t)__popcll(bal);
     }
@@ -313,12 +356,12 @@ __device__ __forceinline__ void map_read(const MapArgs &A, const uint32_t r, uin
     if (P.repeat_filter) {
         /* :368-374 drop minimizers that occur more than once among the read's hits, then z */
         for (uint32_t i = lane; i < n; i += MAP_NT) {
-            const uint32_t c = H.ctg[i], p = H.cpos[i];
+            const uint32_t c = H.cf[i] >> HF_CTG_SHIFT, p = H.cpos[i];
             bool dup = false;
             for (uint32_t j = 0; j < n; j++)
-                if (j != i && H.ctg[j] == c && H.cpos[j] == p) { dup = true; break; }
+                if (j != i && (H.cf[j] >> HF_CTG_SHIFT) == c && H.cpos[j] == p) { dup = true; break; }
             const bool keep = !dup && (int64_t)A.ctg_len[c] >= (int64_t)P.z;
-            H.fl[i] = (H.fl[i] & ~HF_KEEP) | (keep ? HF_KEEP : 0u);
+            H.cf[i] = (H.cf[i] & ~HF_KEEP) | (keep ? HF_KEEP : 0u);
         }
         __syncthreads();
         n = map_compact(H, n);
@@ -331,61 +374,43 @@ __device__ __forceinline__ void map_read(const MapArgs &A, const uint32_t r, uin
             if (lane == 0) A.over_list[atomicAdd(A.over_count, 1u)] = r;
             return;
         }
-        RU.start = s_run[0]; RU.ctg = s_run[1]; RU.leader = s_run[2]; RU.flag = s_run[3]; RU.cnt = s_run[4];
-        RU.mn = s_run[5]; RU.mni = s_run[6]; RU.mx = s_run[7]; RU.mxi = s_run[8]; RU.last = s_run[9];
-    } else {
-        uint32_t *g = A.scr + MAP_NHA * A.scr_stride + m0;
-        RU.start = g; RU.ctg = g + A.scr_stride; RU.leader = g + 2 * A.scr_stride; RU.flag = g + 3 * A.scr_stride;
-        RU.cnt = g + 4 * A.scr_stride; RU.mn = g + 5 * A.scr_stride; RU.mni = g + 6 * A.scr_stride;
-        RU.mx = g + 7 * A.scr_stride; RU.mxi = g + 8 * A.scr_stride; RU.last = g + 9 * A.scr_stride;
     }
     map_fill_runs(H, n, RU, R);
 
     /* bin/ntlink_utils.py:217-234 noisy contigs: span on the contig longer than the read allows */
     {
         if (R <= 8 && n >= 128) {
-            /* few, long runs (HiFi: hundreds of hits on one contig): the lanes share each run and
-               lane 0 merges the 64 partial results; H.ord is free until the PAF stage and holds >= 256 entries (MAP_CAPH in LDS;
-               a read is on the global scratch only with more than MAP_CAPH candidates or more than MAP_CAPR > 8 runs) */
-            uint32_t *tmp = H.ord;
+            /* few, long runs (HiFi: hundreds of hits on one contig): the lanes share each run, a butterfly over the wavefront
+               merges their partial results (first argmin / first argmax: ties go to the smaller index) */
             for (uint32_t q = 0; q < R; q++) {
-                const uint32_t s = RU.start[q], e = q + 1 < R ? RU.start[q + 1] : n;
+                const uint32_t s = RU.start[q], e = q + 1 < R ? (uint32_t)RU.start[q + 1] : n;
                 uint32_t mn = 0, mni = NTL_NONE, mx = 0, mxi = NTL_NONE;
                 for (uint32_t i = s + lane; i < e; i += MAP_NT) { /* i ascends: strict compares keep the first */
                     const uint32_t p = H.cpos[i];
                     if (mni == NTL_NONE || p < mn) { mn = p; mni = i; }
                     if (mxi == NTL_NONE || p > mx) { mx = p; mxi = i; }
                 }
-                __syncthreads(); /* tmp of the previous run has been consumed */
-                tmp[lane] = mn; tmp[MAP_NT + lane] = mni; tmp[2 * MAP_NT + lane] = mx; tmp[3 * MAP_NT + lane] = mxi;
-                __syncthreads();
-                if (lane == 0) {
-                    uint32_t bmn = 0, bmni = NTL_NONE, bmx = 0, bmxi = NTL_NONE;
-                    for (uint32_t l = 0; l < MAP_NT; l++) {
-                        const uint32_t a = tmp[l], ai = tmp[MAP_NT + l], b = tmp[2 * MAP_NT + l], bi = tmp[3 * MAP_NT + l];
-                        if (ai != NTL_NONE && (bmni == NTL_NONE || a < bmn || (a == bmn && ai < bmni))) { bmn = a; bmni = ai; }
-                        if (bi != NTL_NONE && (bmxi == NTL_NONE || b > bmx || (b == bmx && bi < bmxi))) { bmx = b; bmxi = bi; }
-                    }
-                    RU.cnt[q] = e - s; RU.mn[q] = bmn; RU.mni[q] = bmni; RU.mx[q] = bmx; RU.mxi[q] = bmxi;
-                }
+                map_wave_argmin(mn, mni);
+                map_wave_argmax(mx, mxi);
+                if (lane == 0) { RU.cnt[q] = (IT)(e - s); RU.mn[q] = mn; RU.mni[q] = (IT)mni; RU.mx[q] = mx; RU.mxi[q] = (IT)mxi; }
             }
         } else
         for (uint32_t q = lane; q < R; q += MAP_NT) {
-            const uint32_t s = RU.start[q], e = q + 1 < R ? RU.start[q + 1] : n;
+            const uint32_t s = RU.start[q], e = q + 1 < R ? (uint32_t)RU.start[q + 1] : n;
             uint32_t mn = H.cpos[s], mni = s, mx = mn, mxi = s;
             for (uint32_t i = s + 1; i < e; i++) {
                 const uint32_t p = H.cpos[i];
                 if (p < mn) { mn = p; mni = i; }  /* first argmin */
                 if (p > mx) { mx = p; mxi = i; }  /* first argmax */
             }
-            RU.cnt[q] = e - s; RU.mn[q] = mn; RU.mni[q] = mni; RU.mx[q] = mx; RU.mxi[q] = mxi;
+            RU.cnt[q] = (IT)(e - s); RU.mn[q] = mn; RU.mni[q] = (IT)mni; RU.mx[q] = mx; RU.mxi[q] = (IT)mxi;
         }
         __syncthreads();
         if (lane == 0) {
             for (uint32_t q = 0; q < R; q++) {
                 const uint32_t ld = RU.leader[q];
                 if (ld == q) continue;
-                RU.cnt[ld] += RU.cnt[q];
+                RU.cnt[ld] = (IT)(RU.cnt[ld] + RU.cnt[q]);
                 if (RU.mn[q] < RU.mn[ld]) { RU.mn[ld] = RU.mn[q]; RU.mni[ld] = RU.mni[q]; }
                 if (RU.mx[q] > RU.mx[ld]) { RU.mx[ld] = RU.mx[q]; RU.mxi[ld] = RU.mxi[q]; }
             }
@@ -407,14 +432,14 @@ __device__ __forceinline__ void map_read(const MapArgs &A, const uint32_t r, uin
                 const double thr = b < a ? b : a;
                 noisy = (double)span > thr;
             }
-            if (noisy) { RU.flag[q] |= RF_NOISY; my_noisy = true; }
+            if (noisy) { RU.flag[q] = (IT)(RU.flag[q] | RF_NOISY); my_noisy = true; }
         }
         const bool any_noisy = __ballot(my_noisy) != 0ull;
         __syncthreads();
         if (any_noisy) {
             for (uint32_t i = lane; i < n; i += MAP_NT) {
                 const bool keep = !(RU.flag[RU.leader[H.run[i]]] & RF_NOISY);
-                H.fl[i] = (H.fl[i] & ~HF_KEEP) | (keep ? HF_KEEP : 0u);
+                H.cf[i] = (H.cf[i] & ~HF_KEEP) | (keep ? HF_KEEP : 0u);
             }
             __syncthreads();
             n = map_compact(H, n);
@@ -427,19 +452,19 @@ __device__ __forceinline__ void map_read(const MapArgs &A, const uint32_t r, uin
     /* bin/ntlink_utils.py:246-258 subsumed runs */
     {
         if (lane == 0) {
-            for (uint32_t q = 0; q < R; q++) RU.last[RU.leader[q]] = q;
+            for (uint32_t q = 0; q < R; q++) RU.last[RU.leader[q]] = (IT)q;
             bool any = false;
             if (!P.sensitive) {
                 /* mark_subsumed_specific :280-294: a run strictly inside (first, last) of any contig
                    marks its whole contig */
                 uint32_t pm = 0;
                 for (uint32_t q = 0; q < R; q++) {
-                    if (pm > q) { RU.flag[RU.leader[q]] |= RF_SUB; any = true; }
+                    if (pm > q) { RU.flag[RU.leader[q]] = (IT)(RU.flag[RU.leader[q]] | RF_SUB); any = true; }
                     if (RU.leader[q] == q && RU.last[q] > pm) pm = RU.last[q];
                 }
                 if (any)
                     for (uint32_t q = 0; q < R; q++)
-                        if (RU.flag[RU.leader[q]] & RF_SUB) RU.flag[q] |= RF_SUB;
+                        if (RU.flag[RU.leader[q]] & RF_SUB) RU.flag[q] = (IT)(RU.flag[q] | RF_SUB);
             } else {
                 /* mark_subsumed_sensitive :271-278: runs strictly between two occurrences of
                    ANOTHER contig */
@@ -447,7 +472,7 @@ __device__ __forceinline__ void map_read(const MapArgs &A, const uint32_t r, uin
                 for (uint32_t q = 0; q < R; q++) {
                     const uint32_t ld = RU.leader[q];
                     const uint32_t cover = l1 != ld ? m1 : m2;
-                    if (cover > q) { RU.flag[q] |= RF_SUB; any = true; }
+                    if (cover > q) { RU.flag[q] = (IT)(RU.flag[q] | RF_SUB); any = true; }
                     if (ld == q) {
                         const uint32_t v = RU.last[q];
                         if (v > m1) { m2 = m1; m1 = v; l1 = q; }
@@ -463,7 +488,7 @@ __device__ __forceinline__ void map_read(const MapArgs &A, const uint32_t r, uin
         if (any_sub) {
             for (uint32_t i = lane; i < n; i += MAP_NT) {
                 const bool keep = !(RU.flag[H.run[i]] & RF_SUB);
-                H.fl[i] = (H.fl[i] & ~HF_KEEP) | (keep ? HF_KEEP : 0u);
+                H.cf[i] = (H.cf[i] & ~HF_KEEP) | (keep ? HF_KEEP : 0u);
             }
             __syncthreads();
             n = map_compact(H, n);
@@ -479,14 +504,14 @@ __device__ __forceinline__ void map_read(const MapArgs &A, const uint32_t r, uin
 
     /* bin/ntlink_pair.py:382-388 one record per accepted contig, hits in read order */
     for (uint32_t q = lane; q < R; q += MAP_NT) {
-        const uint32_t s = RU.start[q], e = q + 1 < R ? RU.start[q + 1] : n;
+        const uint32_t s = RU.start[q], e = q + 1 < R ? (uint32_t)RU.start[q + 1] : n;
         MapRec M;
         M.read = r; M.ctg = RU.ctg[q]; M.n_hits = e - s; M.pad = 0; M.hit_off = s;
         A.maps[m0 + q] = M;
     }
     for (uint32_t i = lane; i < n; i += MAP_NT) {
         HitRec h;
-        const uint32_t f = H.fl[i];
+        const uint32_t f = H.cf[i];
         h.ctg_pos = H.cpos[i]; h.read_pos = H.rpos[i];
         h.ctg_strand = (uint8_t)(f & 1u); h.read_strand = (uint8_t)((f >> 1) & 1u);
         h.pad[0] = h.pad[1] = 0;
@@ -495,7 +520,7 @@ __device__ __forceinline__ void map_read(const MapArgs &A, const uint32_t r, uin
 
     /* bin/ntlink_paf_output.py:103-135 */
     for (uint32_t q = 0; q < R; q++) {
-        const uint32_t s = RU.start[q], e = q + 1 < R ? RU.start[q + 1] : n;
+        const uint32_t s = RU.start[q], e = q + 1 < R ? (uint32_t)RU.start[q + 1] : n;
         const uint32_t m = e - s;
         const uint32_t ctg = RU.ctg[q];
         /* :95-101 read order == (ctg_pos, read_pos) order, or its exact reverse */
@@ -505,7 +530,7 @@ __device__ __forceinline__ void map_read(const MapArgs &A, const uint32_t r, uin
             const uint32_t i = c + lane;
             bool x1 = true, x2 = true, sm = false;
             if (i < e) {
-                const uint32_t f = H.fl[i];
+                const uint32_t f = H.cf[i];
                 sm = (f & 1u) == ((f >> 1) & 1u);
                 if (i + 1 < e) { x1 = H.cpos[i] <= H.cpos[i + 1]; x2 = H.cpos[i] > H.cpos[i + 1]; }
             }
@@ -527,7 +552,7 @@ __device__ __forceinline__ void map_read(const MapArgs &A, const uint32_t r, uin
             continue;
         }
         /* general case: order by (ctg_pos, read_pos) by rank counting */
-        uint32_t *aux = H.run; /* run ids are no longer needed: reuse as per-sorted-index flags */
+        IT *aux = H.run; /* run ids are no longer needed: reuse as per-sorted-index flags */
         __syncthreads();
         for (uint32_t i = s + lane; i < e; i += MAP_NT) {
             const uint32_t cp = H.cpos[i], rp = H.rpos[i];
@@ -536,7 +561,7 @@ __device__ __forceinline__ void map_read(const MapArgs &A, const uint32_t r, uin
                 const uint32_t cj = H.cpos[j];
                 rk += (cj < cp || (cj == cp && H.rpos[j] < rp)) ? 1u : 0u;
             }
-            H.ord[s + rk] = i;
+            H.ord[s + rk] = (IT)i;
         }
         __syncthreads();
         /* :60-93 transitions between sorted neighbours, duplicate contig positions */
@@ -573,16 +598,16 @@ __device__ __forceinline__ void map_read(const MapArgs &A, const uint32_t r, uin
                 if (tr) continue;
                 const bool d0 = aux[s + t] & AX_DUP, d1 = aux[s + t + 1] & AX_DUP;
                 if (d0 || d1) continue;
-                if (t + 2 >= nt) { atomicOr(&aux[s + t + 1], AX_BRK); continue; }
+                if (t + 2 >= nt) { map_ax_or(aux, s + t + 1, AX_BRK); continue; }
                 const uint32_t c2 = H.rpos[H.ord[s + t + 2]];
                 const bool d2 = (aux[s + t + 2] & AX_DUP) != 0;
-                if (d2 || (incr ? a <= c2 : a >= c2)) { atomicOr(&aux[s + t + 1], AX_FILT); continue; }
+                if (d2 || (incr ? a <= c2 : a >= c2)) { map_ax_or(aux, s + t + 1, AX_FILT); continue; }
                 if (t > 0) {
                     const uint32_t cm = H.rpos[H.ord[s + t - 1]];
                     const bool dm = (aux[s + t - 1] & AX_DUP) != 0;
-                    if (dm || (incr ? cm <= b : cm >= b)) { atomicOr(&aux[s + t], AX_FILT); continue; }
+                    if (dm || (incr ? cm <= b : cm >= b)) { map_ax_or(aux, s + t, AX_FILT); continue; }
                 }
-                atomicOr(&aux[s + t + 1], AX_BRK);
+                map_ax_or(aux, s + t + 1, AX_BRK);
             }
             __syncthreads();
         }
@@ -590,7 +615,7 @@ __device__ __forceinline__ void map_read(const MapArgs &A, const uint32_t r, uin
         if (lane == 0) {
             uint32_t first = 0, last = 0, cnt = 0, sm = 0, k_np = np;
             for (uint32_t t = 0; t <= m; t++) {
-                const uint32_t ax = t < m ? aux[s + t] : AX_BRK;
+                const uint32_t ax = t < m ? (uint32_t)aux[s + t] : AX_BRK;
                 if (t < m && (ax & AX_FILT)) continue;
                 if (t == m || (ax & AX_BRK)) {
                     if (cnt) {
@@ -607,10 +632,10 @@ __device__ __forceinline__ void map_read(const MapArgs &A, const uint32_t r, uin
                 }
                 if (!cnt) first = t;
                 last = t; cnt++;
-                const uint32_t f = H.fl[H.ord[s + t]];
+                const uint32_t f = H.cf[H.ord[s + t]];
                 sm += (f & 1u) == ((f >> 1) & 1u) ? 1u : 0u;
             }
-            aux[s] = k_np - np; /* publish the number of blocks */
+            aux[s] = (IT)(k_np - np); /* publish the number of blocks */
         }
         __syncthreads();
         np += aux[s];
@@ -621,13 +646,51 @@ done:
     if (lane == 0) { A.n_maps[r] = R; A.n_hits[r] = n; A.n_pafs[r] = np; }
 }
 
-template <int MAP_CAPH, int MAP_CAPR>
+/* size class of every read by its number of minimizers (an upper bound of its hits): one thread per read, one atomic per
+   wavefront and class; the order inside a class list is irrelevant (every read writes its own output regions) */
+__global__ void map_classify_kernel(MapArgs A)
+{
+    if (map_sketch_overflowed(A)) return;
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    int cls = -1;
+    if (r < A.nreads) {
+        const uint32_t nmx = A.mx_off[r + 1] - A.mx_off[r];
+        cls = nmx <= 256u ? 0 : (nmx <= 512u ? 1 : 2);
+    }
+#pragma unroll
+    for (int k = 0; k < MAP_NCLASS; k++) {
+        const unsigned long long bal = __ballot(cls == k);
+        if (bal == 0ull) continue;
+        uint32_t base = 0;
+        const uint32_t lane = threadIdx.x & 63u;
+        if (lane == (uint32_t)(__ffsll((long long)bal) - 1)) base = atomicAdd(&A.class_count[k], (uint32_t)__popcll(bal));
+        base = __shfl(base, __ffsll((long long)bal) - 1);
+        if (cls == k) A.class_list[(uint64_t)k * A.nreads + base + ntl_mbcnt(bal)] = r;
+    }
+}
+
+template <int MAP_CAPH, int MAP_CAPR, int CLASS>
 __global__ __launch_bounds__(MAP_NT) void map_kernel(MapArgs A)
 {
-    __shared__ uint32_t s_hit[MAP_NHA][MAP_CAPH];
-    __shared__ uint32_t s_run[MAP_NRA][MAP_CAPR];
+    __shared__ uint32_t s_h32[3][MAP_CAPH];
+    __shared__ uint32_t s_h16[MAP_CAPH];      /* two uint16 arrays (run, ord), on a word boundary for the flag atomics */
+    __shared__ uint32_t s_r32[3][MAP_CAPR];
+    __shared__ uint32_t s_r16[(7 * MAP_CAPR + 1) / 2];
     if (map_sketch_overflowed(A)) return;
-    map_read<MAP_CAPH, MAP_CAPR, false>(A, blockIdx.x, s_hit, s_run);
+    HitArr<uint16_t> H;
+    H.cf = s_h32[0]; H.cpos = s_h32[1]; H.rpos = s_h32[2];
+    H.run = reinterpret_cast<uint16_t *>(s_h16); H.ord = H.run + MAP_CAPH;
+    RunArr<uint16_t> RU;
+    RU.ctg = s_r32[0]; RU.mn = s_r32[1]; RU.mx = s_r32[2];
+    uint16_t *q = reinterpret_cast<uint16_t *>(s_r16);
+    RU.start = q; RU.leader = q + MAP_CAPR; RU.flag = q + 2 * MAP_CAPR; RU.cnt = q + 3 * MAP_CAPR; RU.mni = q + 4 * MAP_CAPR;
+    RU.mxi = q + 5 * MAP_CAPR; RU.last = q + 6 * MAP_CAPR;
+    const uint32_t n = A.class_count[CLASS];
+    const uint32_t *list = A.class_list + (uint64_t)CLASS * A.nreads;
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+        map_read<MAP_CAPH, MAP_CAPR, false, uint16_t>(A, list[i], H, RU);
+        __syncthreads(); /* the staging arrays are reused by the next read */
+    }
 }
 
 /* the reads map_kernel could not stage in LDS, on their regions of the global scratch arrays */
@@ -636,7 +699,7 @@ __global__ __launch_bounds__(MAP_NT) void map_overflow_kernel(MapArgs A)
     if (map_sketch_overflowed(A)) return;
     const uint32_t n = *A.over_count;
     for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
-        map_read<1, 1, true>(A, A.over_list[i], nullptr, nullptr);
+        map_read<1, 1, true, uint32_t>(A, A.over_list[i], HitArr<uint32_t>(), RunArr<uint32_t>());
         __syncthreads();
     }
 }

@@ -1237,7 +1237,11 @@ static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const nt
     {
         ProfSpan sp(c, "sketch_emit");
         const uint64_t tiles = (nmask + EMIT_TILE - 1) / EMIT_TILE;
-        if ((rc = tile.alloc(c, tiles * 4))) return rc;
+        DevBuf tile_seq;
+        if ((rc = tile.alloc(c, tiles * 4)) || (rc = tile_seq.alloc(c, (tiles + 2) * 4))) return rc;
+        if (nseq)
+            hipLaunchKernelGGL(tile_seq_kernel, dim3((unsigned)((nseq + 255) / 256)), dim3(256), 0, ms, (const uint64_t *)T.seq_base, (uint32_t)nseq,
+                               tiles, tile_seq.as<uint32_t>());
         hipLaunchKernelGGL(mask_count_kernel, dim3((unsigned)tiles), dim3(EMIT_NT), 0, ms,
                            (const uint32_t *)mask.p, nmask, tile.as<uint32_t>());
         hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(SCAN_NT), 0, ms, tile.as<uint32_t>(), tiles, &dsums->total_mx, (uint64_t)0, (uint32_t *)nullptr);
@@ -1252,7 +1256,7 @@ static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const nt
         }
         EmitArgs E;
         E.packed = T.packed; E.seq_base = T.seq_base; E.nseq = (uint32_t)nseq; E.mask = (uint32_t *)mask.p;
-        E.nwords = nmask; E.tile_off = tile.as<uint32_t>(); E.mx_off = s->mx_off.as<uint32_t>();
+        E.nwords = nmask; E.tile_off = tile.as<uint32_t>(); E.tile_seq = tile_seq.as<uint32_t>(); E.mx_off = s->mx_off.as<uint32_t>();
         E.out = s->records.as<MxRecord>(); E.out_cap = (uint32_t)cap;
         E.k = k; E.mult = 1ull ^ ((uint64_t)k * 0x90b45d39fb6da1faull);
         uint64_t roll[16][2];
@@ -1542,7 +1546,7 @@ extern "C" int ntl_index_build(ntl_ctx *c, const ntl_sketch *ctg, const uint32_t
     if (!c || !ctg || !out || (!ctg_len && n_ctg)) return NTL_EINVAL;
     *out = nullptr;
     if ((uint64_t)n_ctg != ctg->nseq) return fail(c, NTL_EINVAL, "n_ctg must equal the number of sketched contigs");
-    if (n_ctg >= (1u << 30)) return fail(c, NTL_EINVAL, "too many contigs");
+    if (n_ctg >= (1u << 29)) return fail(c, NTL_EINVAL, "too many contigs"); /* contig id << 3 | flags in one word (map_kernels.h) */
     (void)hipSetDevice(c->device);
     if (int frc = sketch_finalize(ctg)) return frc; /* the table is sized from the number of contig minimizers */
     if (ctg->c != c) HIPCHK(c, sync_both(ctg->c));
@@ -1607,7 +1611,8 @@ extern "C" uint64_t ntl_index_size(const ntl_index *ix)
 
 /* ------------------------------------------------------------------ map ------------------ */
 
-struct MapSums { unsigned long long nfound; uint32_t err; uint32_t tot[3]; uint32_t n_over; uint32_t pad; }; /* one memset, one read-back */
+struct MapSums { unsigned long long nfound; uint32_t err; uint32_t tot[3]; uint32_t n_over; uint32_t n_class[MAP_NCLASS]; }; /* one memset, one read-back */
+static_assert(sizeof(MapSums) <= sizeof(PinSlot), "the sums must fit a page-locked slot");
 
 struct ntl_mapres {
     ntl_ctx *c;
@@ -1638,13 +1643,14 @@ static int map_enqueue(ntl_ctx *c, const ntl_index *ix, const ntl_sketch *reads,
     const ntl_map_params *params = &R->params;
     int rc;
     hipStream_t ms = c->stream;
-    DevBuf cand, smaps, shits, spafs, n3, off3, scr, sums, over;
+    DevBuf cand, smaps, shits, spafs, n3, off3, scr, sums, over, classes;
     const uint64_t cap = nmx ? nmx : 1;
     if ((!have_cand && (rc = cand.alloc(c, cap * sizeof(Cand)))) ||
         (rc = smaps.alloc(c, cap * sizeof(MapRec))) || (rc = shits.alloc(c, cap * sizeof(HitRec))) ||
         (rc = spafs.alloc(c, cap * sizeof(PafRec))) || (rc = n3.alloc(c, 3 * (nreads + 1) * 4)) ||
         (rc = off3.alloc(c, 3 * (nreads + 1) * 4)) || (rc = scr.alloc(c, (uint64_t)(MAP_NHA + MAP_NRA) * cap * 4)) ||
         (rc = sums.alloc(c, sizeof(MapSums))) || (rc = over.alloc(c, (nreads + 1) * 4)) ||
+        (rc = classes.alloc(c, (uint64_t)MAP_NCLASS * (nreads + 1) * 4)) ||
         (rc = R->maps.alloc(c, cap * sizeof(MapRec))) || (rc = R->hits.alloc(c, cap * sizeof(HitRec))) ||
         (rc = R->pafs.alloc(c, cap * sizeof(PafRec)))) return rc;
     MapSums *dsums = sums.as<MapSums>();
@@ -1679,17 +1685,21 @@ static int map_enqueue(ntl_ctx *c, const ntl_index *ix, const ntl_sketch *reads,
     A.n_maps = n3.as<uint32_t>(); A.n_hits = A.n_maps + (nreads + 1); A.n_pafs = A.n_hits + (nreads + 1);
     A.scr = scr.as<uint32_t>(); A.scr_stride = cap; A.err = &dsums->err;
     A.over_list = over.as<uint32_t>(); A.over_count = &dsums->n_over;
+    A.class_list = classes.as<uint32_t>(); A.class_count = dsums->n_class;
     /* a sketch whose count is not known yet may have overflowed its arrays: the kernels look at its total and leave it alone */
     A.mx_total = reads->pending ? &reads->sums.as<SketchSums>()->total_mx : nullptr;
     A.mx_cap = (uint32_t)std::min<uint64_t>(reads->cap, 0xFFFFFFFFull);
     if (nreads) {
         {
             ProfSpan sp(c, "map");
-            /* LDS staging sized by the average sketch length of the batch */
-            if (nmx <= 256 * nreads) hipLaunchKernelGGL((map_kernel<256, 64>), dim3((unsigned)nreads), dim3(MAP_NT), 0, ms, A);
-            else hipLaunchKernelGGL((map_kernel<512, 128>), dim3((unsigned)nreads), dim3(MAP_NT), 0, ms, A);
-            /* reads with more hits / runs than the LDS staging holds (rare): same code on global scratch */
-            hipLaunchKernelGGL(map_overflow_kernel, dim3((unsigned)std::min<uint64_t>(nreads, 32768)), dim3(MAP_NT), 0, ms, A); /* no LDS: 32 wavefronts per CU resident, four rounds of them */
+            /* reads by size class, each class with the LDS staging that fits it (resident-size grids looping over their lists) */
+            const dim3 grid((unsigned)std::min<uint64_t>(nreads, 32768));
+            hipLaunchKernelGGL(map_classify_kernel, dim3((unsigned)((nreads + 255) / 256)), dim3(256), 0, ms, A);
+            hipLaunchKernelGGL((map_kernel<256, 64, 0>), grid, dim3(MAP_NT), 0, ms, A);
+            hipLaunchKernelGGL((map_kernel<512, 128, 1>), grid, dim3(MAP_NT), 0, ms, A);
+            hipLaunchKernelGGL((map_kernel<1024, 128, 2>), grid, dim3(MAP_NT), 0, ms, A);
+            /* reads with more hits / runs than the largest staging holds (rare): same code on global scratch */
+            hipLaunchKernelGGL(map_overflow_kernel, grid, dim3(MAP_NT), 0, ms, A); /* no LDS: 32 wavefronts per CU resident, four rounds of them */
             HIPCHK(c, hipGetLastError());
         }
         ProfSpan sp(c, "compact");

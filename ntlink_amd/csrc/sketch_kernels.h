@@ -429,6 +429,20 @@ __global__ __launch_bounds__(EMIT_NT) void mask_count_kernel(const uint32_t *mas
     if (threadIdx.x == 0) tile_cnt[blockIdx.x] = total;
 }
 
+/* tile_seq[b] = the sequence the first position of emit tile b lies in (largest s with seq_base[s] <= b * 32 * EMIT_TILE; 0
+ * in front of the first sequence), for b = 0 .. ntiles: one thread per SEQUENCE writes the few tiles that start inside it, so that
+ * no emit workgroup has to search the sequence table (three rounds of dependent loads and barriers per workgroup before). */
+__global__ void tile_seq_kernel(const uint64_t *__restrict__ seq_base, uint32_t nseq, uint64_t ntiles, uint32_t *__restrict__ tile_seq)
+{
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nseq) return;
+    const uint64_t span = (uint64_t)EMIT_TILE * 32;
+    const uint64_t lo = s == 0 ? 0 : seq_base[s];
+    uint64_t b = (lo + span - 1) / span;
+    const uint64_t end = s + 1 < nseq ? (seq_base[s + 1] + span - 1) / span : ntiles + 1; /* first tile that starts at or behind the next sequence */
+    for (; b < end && b <= ntiles; b++) tile_seq[b] = (uint32_t)s;
+}
+
 struct EmitArgs {
     const uint32_t *packed;
     const uint64_t *seq_base; /* [nseq+1] */
@@ -436,6 +450,7 @@ struct EmitArgs {
     uint32_t *mask;           /* read, then cleared: this kernel is the bitmask's last reader and hands it back zero-filled */
     uint64_t nwords;
     const uint32_t *tile_off; /* exclusive scan of tile_cnt */
+    const uint32_t *tile_seq; /* [ntiles + 1] sequence at the first position of each tile (tile_seq_kernel) */
     uint32_t *mx_off;         /* [nseq+1] minimizers before each sequence start = offsets of the per-sequence lists */
     MxRecord *out;
     uint32_t out_cap;         /* records `out` can hold (it is sized before the count is known) */
@@ -483,30 +498,16 @@ __global__ __launch_bounds__(EMIT_NT) void emit_kernel(EmitArgs A)
     s_g4[t][0] = A.g4[t][0];
     s_g4[t][1] = A.g4[t][1];
     const uint64_t tile_w0 = (uint64_t)blockIdx.x * EMIT_TILE;
-    /* Sequences that overlap this tile of 65536 base positions.  First sequence: largest s with
-       seq_base[s] <= first position, found by the whole workgroup -- every round the threads test 256
-       evenly spaced candidates of the remaining range and count the hits (two dependent loads for 65 k
-       sequences instead of the sixteen of a one-thread binary search). */
-    {
-        const uint64_t gp0 = tile_w0 * 32;
-        uint32_t lo = 0, len = A.nseq; /* answer lies in [lo, lo + len); candidate 0 of a round always counts */
-        while (len > 1) {
-            const uint32_t step = (len + EMIT_NT - 1) / EMIT_NT;
-            const uint32_t cand = lo + (uint32_t)t * step;
-            if (t == 0) s_range[0] = 0;
-            __syncthreads();
-            if ((uint32_t)t * step < len && (t == 0 || A.seq_base[cand] <= gp0)) atomicAdd(&s_range[0], 1u);
-            __syncthreads();
-            const uint32_t hit = s_range[0]; /* >= 1 */
-            __syncthreads();
-            const uint32_t nlo = lo + (hit - 1) * step;
-            const uint32_t rest = lo + len - nlo;
-            lo = nlo;
-            len = rest < step ? rest : step;
-        }
-        if (t == 0) s_range[0] = lo;
-        __syncthreads();
-    }
+    /* Sequences that overlap this tile of 65536 base positions: from the one its first position lies in to the one the next
+       tile's first position lies in (tile_seq_kernel); their starts are cached in LDS.  More than EMIT_SEQ_CAP of them (tiny
+       sequences) falls back to binary searches in global memory. */
+    const uint32_t s_lo = A.nseq ? A.tile_seq[blockIdx.x] : 0u;
+    const uint32_t s_hi = A.nseq ? A.tile_seq[blockIdx.x + 1] + 1u : 0u; /* candidates [s_lo, s_hi) */
+    const uint64_t gp_last = tile_w0 * 32 + (uint64_t)EMIT_TILE * 32 - 1;
+    const bool cached = s_hi - s_lo <= EMIT_SEQ_CAP;
+    const uint32_t ncache = cached ? s_hi - s_lo : EMIT_SEQ_CAP;
+    for (uint32_t i = t; i < ncache; i += EMIT_NT) s_base[i] = A.seq_base[s_lo + i];
+    /* (the barriers of the scan below stand between these stores and their readers) */
     const uint64_t w0 = tile_w0 + (uint64_t)t * EMIT_WPT;
     uint32_t words[EMIT_WPT];
     uint32_t c = 0;
@@ -521,21 +522,6 @@ __global__ __launch_bounds__(EMIT_NT) void emit_kernel(EmitArgs A)
     for (int i = 0; i < EMIT_WPT; i++) c += (uint32_t)__popc(words[i]);
     uint32_t total;
     const uint32_t excl = block_excl_scan<EMIT_NT>(c, s_tmp, total);
-    /* last sequence: count the cached starts that lie inside the tile; more than EMIT_SEQ_CAP of them
-       (tiny sequences) falls back to binary searches in global memory */
-    const uint32_t s_lo = s_range[0];
-    const uint64_t gp_last = tile_w0 * 32 + (uint64_t)EMIT_TILE * 32 - 1;
-    const uint32_t ncache = A.nseq - s_lo < EMIT_SEQ_CAP ? A.nseq - s_lo : EMIT_SEQ_CAP;
-    if (t == 0) s_range[1] = 0;
-    __syncthreads();
-    for (uint32_t i = t; i < ncache; i += EMIT_NT) {
-        const uint64_t v = A.seq_base[s_lo + i];
-        s_base[i] = v;
-        if (v <= gp_last) atomicAdd(&s_range[1], 1u);
-    }
-    __syncthreads();
-    const bool cached = s_range[1] < ncache || s_lo + ncache == A.nseq;
-    const uint32_t s_hi = cached ? s_lo + s_range[1] : A.nseq; /* candidates [s_lo, s_hi) */
     const uint32_t tile_base = A.tile_off[blockIdx.x];
     {
         uint32_t r = excl;

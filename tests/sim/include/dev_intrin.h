@@ -82,3 +82,13 @@ inline double ntl_mul_add_rn(double x, double d, double k)
 
 inline uint64_t ntl_stream_load(const uint64_t *p) { return *p; }
 inline void ntl_stream_store(uint64_t *p, uint64_t v) { *p = v; }
+
+inline uint32_t ntl_wave_incl_scan(uint32_t v)
+{
+    const int l = (int)(sim::tid & 63u);
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl(v, l >= d ? l - d : l);
+        if (l >= d) v += t;
+    }
+    return v;
+}

@@ -108,16 +108,18 @@ def test_synthetic_workloads_vs_oracle(dev, cfg):
 
 
 def test_long_read_uses_global_scratch(dev):
-    """A read with far more than 512 hits and 128 runs (LDS capacities of the map kernel)."""
+    """A read with far more than 1024 hits and 128 runs (the largest LDS staging of the map kernels), one with few hits on more
+    than 128 contigs, and reads of the two larger LDS size classes."""
     rng = np.random.default_rng(3)
     contigs = [bytes(synth.random_bases(rng, 3000)) for _ in range(400)]
     order = rng.permutation(400)
     read = b"".join(contigs[i] for i in order[:300])
     # few hits on many contigs: the hits fit the LDS staging, the runs (> 128) do not -> map_overflow_kernel as well
     patchy = b"".join(contigs[i][1000:1048] for i in order[:200])
-    reads = [read, contigs[5] + contigs[5], b"ACGT", patchy, contigs[7][:500]]
+    reads = [read, contigs[5] + contigs[5], b"ACGT", patchy, contigs[7][:500], contigs[9] + contigs[11] + contigs[13][:2000], contigs[21] + contigs[22][:1500]]
     got = pc.check_full_pipeline(dev, contigs, reads, 24, 20, z=1000)
-    assert 128 < int((got["maps"]["read"] == 3).sum()) and int(got["maps"]["n_hits"][got["maps"]["read"] == 3].sum()) <= 512
+    assert 128 < int((got["maps"]["read"] == 3).sum()) and int(got["maps"]["n_hits"][got["maps"]["read"] == 3].sum()) <= 1024
+    assert 512 < int(got["maps"]["n_hits"][got["maps"]["read"] == 5].sum()) <= 1024 and 256 < int(got["maps"]["n_hits"][got["maps"]["read"] == 6].sum()) <= 512
     pc.check_full_pipeline(dev, contigs, reads, 24, 20, z=1000, sensitive=True)
 
 

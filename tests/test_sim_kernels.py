@@ -262,14 +262,16 @@ def test_sim_map_overflow_reads_take_the_global_scratch_kernel(dev):
     """More hits than the LDS staging holds, and few hits on more contigs than it has runs: map_overflow_kernel."""
     from ntlink_amd import synth
     rng = np.random.default_rng(3)
-    contigs = [bytes(synth.random_bases(rng, 1500)) for _ in range(120)]
-    order = rng.permutation(120)
-    dense = b"".join(contigs[i] for i in order[:40])                  # > 256 hits
-    patchy = b"".join(contigs[i][700:748] for i in order[:110])       # < 256 hits, > 64 runs
-    got = pc.check_full_pipeline(dev, contigs, [dense, patchy, contigs[3][:400]], 24, 20, z=1000)
+    contigs = [bytes(synth.random_bases(rng, 1500)) for _ in range(150)]
+    order = rng.permutation(150)
+    dense = b"".join(contigs[i] for i in order[:40])                  # > 1024 hits (the largest size class)
+    patchy = b"".join(contigs[i][700:748] for i in order[:140])       # < 1024 hits, > 128 runs
+    mid = b"".join(contigs[i][:1200] for i in order[40:46])          # 256 < minimizers <= 1024: the two larger LDS classes
+    got = pc.check_full_pipeline(dev, contigs, [dense, patchy, contigs[3][:400], mid, mid[:4000]], 24, 20, z=1000)
     maps = got["maps"]
-    assert int(maps["n_hits"][maps["read"] == 0].sum()) > 256
-    assert int((maps["read"] == 1).sum()) > 64 and int(maps["n_hits"][maps["read"] == 1].sum()) <= 256
+    assert int(maps["n_hits"][maps["read"] == 0].sum()) > 1024
+    assert int((maps["read"] == 1).sum()) > 128 and int(maps["n_hits"][maps["read"] == 1].sum()) <= 1024
+    assert 512 < int(maps["n_hits"][maps["read"] == 3].sum()) <= 1024 and 256 < int(maps["n_hits"][maps["read"] == 4].sum()) <= 512
 
 
 def test_sim_packed_batches_sketch_like_ascii_batches(dev, tmp_path):
