@@ -155,7 +155,7 @@ struct PafRec { uint32_t read, ctg, q_start, q_end, t_start, t_end, n_hits, stra
 
 #define MAP_NT 64
 /* Hits / runs per read staged in LDS are template parameters of map_kernel; reads are sorted into three size classes by
-   their number of minimizers (map_classify_kernel) and each class runs with the staging that fits it: 256/64, 512/128,
+   their number of minimizers (map_class_of) and each class runs with the staging that fits it: 256/64, 512/128,
    1024/128.  Per hit 16 bytes of LDS (three 32-bit words and two 16-bit indices), per run 26: 5.6 KB, 11.3 KB and 19.3 KB per
    wavefront -- 28, 14 and 8 wavefronts per CU.  (Round 2: six + ten 32-bit arrays, 17 KB for 512 hits, 9 wavefronts per CU,
    and every read above 512 hits -- a fifth of 20-kb HiFi reads -- on the global scratch arrays.)  Reads beyond the largest
@@ -177,8 +177,7 @@ struct MapArgs {
     uint64_t scr_stride;
     uint32_t *err;
     uint32_t *over_list, *over_count;             /* reads that do not fit the LDS staging: [nreads], [1] */
-    uint32_t *class_list;                         /* [MAP_NCLASS][nreads] reads of each size class (map_classify_kernel) */
-    uint32_t *class_count;                        /* [MAP_NCLASS] */
+    uint32_t *nmx_out;                            /* [1] the batch's number of read minimizers, for the host's hit fraction */
     /* The sketch may still be in flight when these kernels are queued (nothing waits on the host for its size): when its
        minimizer total turns out larger than the arrays that were sized from the expected density, the records are incomplete
        and every kernel here leaves the batch alone; the host makes the sketch again and queues the map a second time. */
@@ -646,29 +645,12 @@ done:
     if (lane == 0) { A.n_maps[r] = R; A.n_hits[r] = n; A.n_pafs[r] = np; }
 }
 
-/* size class of every read by its number of minimizers (an upper bound of its hits): one thread per read, one atomic per
-   wavefront and class; the order inside a class list is irrelevant (every read writes its own output regions) */
-__global__ void map_classify_kernel(MapArgs A)
-{
-    if (map_sketch_overflowed(A)) return;
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    int cls = -1;
-    if (r < A.nreads) {
-        const uint32_t nmx = A.mx_off[r + 1] - A.mx_off[r];
-        cls = nmx <= 256u ? 0 : (nmx <= 512u ? 1 : 2);
-    }
-#pragma unroll
-    for (int k = 0; k < MAP_NCLASS; k++) {
-        const unsigned long long bal = __ballot(cls == k);
-        if (bal == 0ull) continue;
-        uint32_t base = 0;
-        const uint32_t lane = threadIdx.x & 63u;
-        if (lane == (uint32_t)(__ffsll((long long)bal) - 1)) base = atomicAdd(&A.class_count[k], (uint32_t)__popcll(bal));
-        base = __shfl(base, __ffsll((long long)bal) - 1);
-        if (cls == k) A.class_list[(uint64_t)k * A.nreads + base + ntl_mbcnt(bal)] = r;
-    }
-}
+/* size class of a read by its number of minimizers (an upper bound of its hits) */
+__device__ __forceinline__ int map_class_of(uint32_t nmx) { return nmx <= 256u ? 0 : (nmx <= 512u ? 1 : 2); }
 
+/* One launch per size class, each over ALL reads with a resident-size grid: a wavefront looks at 64 consecutive reads at a
+   time (one coalesced load of their offsets), votes which of them belong to its class and maps those one after the other.
+   No list, no atomic; a class without reads costs one pass over the offsets. */
 template <int MAP_CAPH, int MAP_CAPR, int CLASS>
 __global__ __launch_bounds__(MAP_NT) void map_kernel(MapArgs A)
 {
@@ -685,11 +667,18 @@ __global__ __launch_bounds__(MAP_NT) void map_kernel(MapArgs A)
     uint16_t *q = reinterpret_cast<uint16_t *>(s_r16);
     RU.start = q; RU.leader = q + MAP_CAPR; RU.flag = q + 2 * MAP_CAPR; RU.cnt = q + 3 * MAP_CAPR; RU.mni = q + 4 * MAP_CAPR;
     RU.mxi = q + 5 * MAP_CAPR; RU.last = q + 6 * MAP_CAPR;
-    const uint32_t n = A.class_count[CLASS];
-    const uint32_t *list = A.class_list + (uint64_t)CLASS * A.nreads;
-    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
-        map_read<MAP_CAPH, MAP_CAPR, false, uint16_t>(A, list[i], H, RU);
-        __syncthreads(); /* the staging arrays are reused by the next read */
+    const uint32_t lane = threadIdx.x;
+    for (uint64_t base = (uint64_t)blockIdx.x * MAP_NT; base < A.nreads; base += (uint64_t)gridDim.x * MAP_NT) {
+        const uint64_t r = base + lane;
+        bool mine = false;
+        if (r < A.nreads) mine = map_class_of(A.mx_off[r + 1] - A.mx_off[r]) == CLASS;
+        unsigned long long bal = __ballot(mine);
+        while (bal) {
+            const uint32_t j = (uint32_t)__ffsll((long long)bal) - 1u;
+            bal &= bal - 1ull;
+            map_read<MAP_CAPH, MAP_CAPR, false, uint16_t>(A, (uint32_t)(base + j), H, RU);
+            __syncthreads(); /* the staging arrays are reused by the next read */
+        }
     }
 }
 
@@ -713,6 +702,7 @@ __global__ void map_gather_kernel(MapArgs A, const uint32_t *off_maps, const uin
     if (map_sketch_overflowed(A)) return;
     const uint32_t r = blockIdx.x;
     const uint32_t m0 = A.mx_off[r];
+    if (r == 0 && threadIdx.x == 0) *A.nmx_out = A.mx_off[A.nreads];
     const uint32_t nm = A.n_maps[r], nh = A.n_hits[r], npf = A.n_pafs[r];
     const uint32_t om = off_maps[r], oh = off_hits[r], op = off_pafs[r];
     for (uint32_t i = threadIdx.x; i < nm; i += blockDim.x) {

@@ -72,6 +72,7 @@ struct Zombie {
     PinSlot *slot = nullptr;
     int kind = 0;      /* 1 sketch (w[0] low = minimizer total vs cap), 2 map result (w[1] low = invariant flag) */
     uint64_t cap = 0;
+    std::shared_ptr<std::atomic<float>> hitf; /* 2: where the batch's hit fraction goes (MapSums: nfound / nmx) */
 };
 
 struct ntl_ctx {
@@ -184,6 +185,10 @@ static void reap(ntl_ctx *c, bool block)
                 c->async_err = "a sketch held more minimizers than its record array and was destroyed before anybody asked for its count";
             if (z.kind == 2 && (uint32_t)z.slot->w[1])
                 c->async_err = "an accepted contig appeared twice in one read (bin/ntlink_utils.py:262-266)";
+            if (z.kind == 2 && z.hitf) { /* MapSums: w[0] = nfound, high half of w[3] = nmx */
+                const uint32_t nmx = (uint32_t)(z.slot->w[3] >> 32);
+                if (nmx) z.hitf->store((float)((double)z.slot->w[0] / (double)nmx), std::memory_order_relaxed);
+            }
         }
         sev_put(c, z.done);
         slot_put(c, z.slot);
@@ -867,7 +872,9 @@ struct ntl_index {
     uint64_t nslots = 0;
     mutable uint64_t size = 0;
     mutable bool size_known = false;
-    mutable std::atomic<float> hit_fraction{0.0f}; /* of the last batch mapped against this index: picks the probe form */
+    /* hit fraction of the last COMPLETED batch mapped against this index: picks the probe form of the next one.  Shared with
+       results that are destroyed before they complete (their zombies report when their work is done). */
+    std::shared_ptr<std::atomic<float>> hit_fraction = std::make_shared<std::atomic<float>>(0.0f);
     uint32_t n_ctg = 0;
     DevBuf slots, special, ctg_len, cnt; /* cnt: device-side count of kept keys, fetched on demand */
     DevBuf tags;                         /* one byte per slot (map_kernels.h index_tag) */
@@ -1019,8 +1026,10 @@ static void launch_fast_r0(ntl_ctx *c, const Sketch2Args &B, unsigned strips)
 {
     if (B.A.G.r0 == R0) {
         const dim3 grid((strips + 7u) & ~7u);
-        /* the 20-KB variant holds 128 searched windows per strip: about NWO / (w + 1) are expected (38 at w = 100) */
-        if (B.A.G.a + 2 <= 16 && B.A.G.w >= 64) hipLaunchKernelGGL((sketch_fast_kernel<NT, R0, false>), grid, dim3(NT), 0, c->wstream, B);
+        /* the 20-KB variants hold 128 searched windows per strip: about NWO / (w + 1) are expected (38 at w = 100) */
+        static const int lanes = [] { const char *e = getenv("NTL_SKETCH_LANES"); return e ? atoi(e) : 1; }(); /* 0: every lane walks its windows (A/B) */
+        if (B.A.G.a + 2 <= 16 && B.A.G.w >= 64 && B.A.G.a >= 2 && lanes && B.dbg == 0) hipLaunchKernelGGL((sketch_lanes_kernel<NT, R0>), grid, dim3(NT), 0, c->wstream, B);
+        else if (B.A.G.a + 2 <= 16 && B.A.G.w >= 64) hipLaunchKernelGGL((sketch_fast_kernel<NT, R0, false>), grid, dim3(NT), 0, c->wstream, B);
         else hipLaunchKernelGGL((sketch_fast_kernel<NT, R0, true>), grid, dim3(NT), 0, c->wstream, B);
         return;
     }
@@ -1248,7 +1257,7 @@ static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const nt
         HIPCHK(c, hipGetLastError());
         if ((rc = s->records.alloc(c, cap * sizeof(MxRecord)))) return rc;
         s->cap = cap;
-        const int probe = !ix ? 0 : (ix->hit_fraction.load(std::memory_order_relaxed) <= 0.5f ? 1 : 2); /* tags first unless the last batch on this index mostly hit */
+        const int probe = !ix ? 0 : (ix->hit_fraction->load(std::memory_order_relaxed) <= 0.5f ? 1 : 2); /* tags first unless the last batch on this index mostly hit */
         if (ix) {
             if ((rc = s->cand.alloc(c, cap * sizeof(Cand)))) return rc;
             s->cand_gen = ix->gen;
@@ -1611,7 +1620,7 @@ extern "C" uint64_t ntl_index_size(const ntl_index *ix)
 
 /* ------------------------------------------------------------------ map ------------------ */
 
-struct MapSums { unsigned long long nfound; uint32_t err; uint32_t tot[3]; uint32_t n_over; uint32_t n_class[MAP_NCLASS]; }; /* one memset, one read-back */
+struct MapSums { unsigned long long nfound; uint32_t err; uint32_t tot[3]; uint32_t n_over; uint32_t nmx; }; /* one memset, one read-back */
 static_assert(sizeof(MapSums) <= sizeof(PinSlot), "the sums must fit a page-locked slot");
 
 struct ntl_mapres {
@@ -1627,6 +1636,7 @@ struct ntl_mapres {
     const ntl_sketch *reads = nullptr;  /* held (refs) while pending */
     uint64_t reads_gen = 0;             /* generation of the sketch the kernels were queued on */
     ntl_map_params params;
+    std::shared_ptr<std::atomic<float>> hitf; /* the index's hit fraction (the index itself may be gone when this completes) */
     DevBuf rlen_own;                    /* read lengths uploaded by this call (sketches that did not come from a batch) */
 };
 
@@ -1643,14 +1653,13 @@ static int map_enqueue(ntl_ctx *c, const ntl_index *ix, const ntl_sketch *reads,
     const ntl_map_params *params = &R->params;
     int rc;
     hipStream_t ms = c->stream;
-    DevBuf cand, smaps, shits, spafs, n3, off3, scr, sums, over, classes;
+    DevBuf cand, smaps, shits, spafs, n3, off3, scr, sums, over;
     const uint64_t cap = nmx ? nmx : 1;
     if ((!have_cand && (rc = cand.alloc(c, cap * sizeof(Cand)))) ||
         (rc = smaps.alloc(c, cap * sizeof(MapRec))) || (rc = shits.alloc(c, cap * sizeof(HitRec))) ||
         (rc = spafs.alloc(c, cap * sizeof(PafRec))) || (rc = n3.alloc(c, 3 * (nreads + 1) * 4)) ||
         (rc = off3.alloc(c, 3 * (nreads + 1) * 4)) || (rc = scr.alloc(c, (uint64_t)(MAP_NHA + MAP_NRA) * cap * 4)) ||
         (rc = sums.alloc(c, sizeof(MapSums))) || (rc = over.alloc(c, (nreads + 1) * 4)) ||
-        (rc = classes.alloc(c, (uint64_t)MAP_NCLASS * (nreads + 1) * 4)) ||
         (rc = R->maps.alloc(c, cap * sizeof(MapRec))) || (rc = R->hits.alloc(c, cap * sizeof(HitRec))) ||
         (rc = R->pafs.alloc(c, cap * sizeof(PafRec)))) return rc;
     MapSums *dsums = sums.as<MapSums>();
@@ -1662,7 +1671,7 @@ static int map_enqueue(ntl_ctx *c, const ntl_index *ix, const ntl_sketch *reads,
         if (nmx) {
             const dim3 grid((unsigned)std::min<uint64_t>((nmx + 256 * PROBE_U - 1) / (256 * PROBE_U), 4096));
             /* tags first unless the previous batch on this index found more than half of its minimizers (same result either way) */
-            if (ix->hit_fraction.load(std::memory_order_relaxed) <= 0.5f)
+            if (ix->hit_fraction->load(std::memory_order_relaxed) <= 0.5f)
                 hipLaunchKernelGGL(probe_kernel<true>, grid, dim3(256), 0, ms,
                                    (const MxRecord *)reads->records.as<MxRecord>(), nmx, (const IndexSlot *)ix->slots.as<IndexSlot>(),
                                    ix->bits, (const IndexSpecial *)ix->special.as<IndexSpecial>(), cand.as<Cand>(),
@@ -1685,21 +1694,21 @@ static int map_enqueue(ntl_ctx *c, const ntl_index *ix, const ntl_sketch *reads,
     A.n_maps = n3.as<uint32_t>(); A.n_hits = A.n_maps + (nreads + 1); A.n_pafs = A.n_hits + (nreads + 1);
     A.scr = scr.as<uint32_t>(); A.scr_stride = cap; A.err = &dsums->err;
     A.over_list = over.as<uint32_t>(); A.over_count = &dsums->n_over;
-    A.class_list = classes.as<uint32_t>(); A.class_count = dsums->n_class;
+    A.nmx_out = &dsums->nmx;
     /* a sketch whose count is not known yet may have overflowed its arrays: the kernels look at its total and leave it alone */
     A.mx_total = reads->pending ? &reads->sums.as<SketchSums>()->total_mx : nullptr;
     A.mx_cap = (uint32_t)std::min<uint64_t>(reads->cap, 0xFFFFFFFFull);
     if (nreads) {
         {
             ProfSpan sp(c, "map");
-            /* reads by size class, each class with the LDS staging that fits it (resident-size grids looping over their lists) */
-            const dim3 grid((unsigned)std::min<uint64_t>(nreads, 32768));
-            hipLaunchKernelGGL(map_classify_kernel, dim3((unsigned)((nreads + 255) / 256)), dim3(256), 0, ms, A);
-            hipLaunchKernelGGL((map_kernel<256, 64, 0>), grid, dim3(MAP_NT), 0, ms, A);
-            hipLaunchKernelGGL((map_kernel<512, 128, 1>), grid, dim3(MAP_NT), 0, ms, A);
-            hipLaunchKernelGGL((map_kernel<1024, 128, 2>), grid, dim3(MAP_NT), 0, ms, A);
+            /* reads by size class, each class with the LDS staging that fits it; resident-size grids (28 / 14 / 8 wavefronts
+               per CU fit) looping over all reads, 64 at a time */
+            const uint64_t groups = (nreads + MAP_NT - 1) / MAP_NT;
+            hipLaunchKernelGGL((map_kernel<256, 64, 0>), dim3((unsigned)std::min<uint64_t>(groups, 8192)), dim3(MAP_NT), 0, ms, A);
+            hipLaunchKernelGGL((map_kernel<512, 128, 1>), dim3((unsigned)std::min<uint64_t>(groups, 4096)), dim3(MAP_NT), 0, ms, A);
+            hipLaunchKernelGGL((map_kernel<1024, 128, 2>), dim3((unsigned)std::min<uint64_t>(groups, 2048)), dim3(MAP_NT), 0, ms, A);
             /* reads with more hits / runs than the largest staging holds (rare): same code on global scratch */
-            hipLaunchKernelGGL(map_overflow_kernel, grid, dim3(MAP_NT), 0, ms, A); /* no LDS: 32 wavefronts per CU resident, four rounds of them */
+            hipLaunchKernelGGL(map_overflow_kernel, dim3((unsigned)std::min<uint64_t>(nreads, 8192)), dim3(MAP_NT), 0, ms, A); /* no LDS: 32 wavefronts per CU resident */
             HIPCHK(c, hipGetLastError());
         }
         ProfSpan sp(c, "compact");
@@ -1724,7 +1733,7 @@ static void mapres_free(ntl_mapres *R)
     (void)hipSetDevice(c->device);
     if (R->pending) {
         Zombie z;
-        z.done = R->done; z.slot = R->slot; z.kind = 2;
+        z.done = R->done; z.slot = R->slot; z.kind = 2; z.hitf = R->hitf;
         c->zombies.push_back(z);
     } else {
         sev_put(c, R->done);
@@ -1756,8 +1765,7 @@ static int mapres_finalize(const ntl_mapres *cR)
         const MapSums hs = *(const MapSums *)R->slot;
         R->n_maps = hs.tot[0]; R->n_hits = hs.tot[1]; R->n_pafs = hs.tot[2];
         R->n_index_hits = hs.nfound;
-        const uint64_t nmx = R->reads ? R->reads->count : 0;
-        if (nmx) R->ix->hit_fraction.store((float)((double)hs.nfound / (double)nmx), std::memory_order_relaxed);
+        if (hs.nmx) R->hitf->store((float)((double)hs.nfound / (double)hs.nmx), std::memory_order_relaxed);
         if (hs.err) R->failed = fail(c, NTL_EINTERNAL, "an accepted contig appeared twice in one read (bin/ntlink_utils.py:262-266)");
         break;
     }
@@ -1777,7 +1785,7 @@ extern "C" int ntl_map_run(ntl_ctx *c, const ntl_index *ix, const ntl_sketch *re
     }
     const uint64_t nreads = reads->nseq;
     ntl_mapres *R = new ntl_mapres();
-    R->c = c; R->ix = ix; R->params = *params;
+    R->c = c; R->ix = ix; R->params = *params; R->hitf = ix->hit_fraction;
     R->done = sev_get(c);
     R->slot = slot_get(c);
     if (!R->done || !R->slot) { mapres_free(R); return fail(c, NTL_EDEVICE, "out of events / page-locked slots"); }

@@ -474,3 +474,374 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
     }
     if (L == 0 && flagged) B.redo_list[atomicAdd(B.redo_count, 1u)] = strip;
 }
+
+
+/*
+ * sketch_lanes_kernel: the same window pass for 64 <= w <= 255, run only where a minimum can change.
+ *
+ * Same strip, same keys, same bits and the same flagged strips as sketch_fast_kernel<NT, R0, false>.  What differs: of the
+ * 17 windows that start in a lane's block, the minimum changes in about 16 * 2 / (w + 1) of the lanes (one in eight at
+ * w = 250).  Every lane still hashes, rolls and stages its sixteen keys, but then only decides -- from the block minima --
+ * whether anything can happen in its windows:
+ *     x0  = minimum of window 0   = min(own block, whole blocks L+1..L+a, first R0 elements of block L+a+1)
+ *     x16 = minimum of window 16  = min(whole blocks L+1..L+a+1, first R0 elements of block L+a+2)
+ *     ent >= a lower bound of the sixteen elements that enter at windows 1..16 = min(block L+a+1, first R0 of block L+a+2)
+ * If x0 == x16 and ent > x0 + SK2_NEAR, the element m that attains x0 is still the lone minimum of window 16: everything else
+ * in window 16 was in window 0 (so it is above x0 + SK2_NEAR by the invariant) or entered (above it by the test), hence the
+ * value x0 in window 16 is m itself, m lies in all seventeen windows, and none of them changes its minimizer: the lane has
+ * nothing to do and nothing to flag ("exact" (2) holds for each of its windows).  Every other lane -- and every lane at a
+ * strip or sequence edge -- is put on a list, and the lanes of ONE wavefront walk the listed blocks' windows exactly as
+ * sketch_fast_kernel's phases 4-5 do (keys read back from LDS).  Which wavefront: the strip index picks it, so that over
+ * consecutive strips the four SIMDs of a CU get the same share of this single-wavefront phase (and of the search phase,
+ * which another wavefront takes).  About 30 % fewer VALU instructions per strip than walking all 256 lanes' windows.
+ */
+template <int NT, int R0>
+__global__ __launch_bounds__(NT) void sketch_lanes_kernel(Sketch2Args B)
+{
+    constexpr int C = 16;
+    constexpr int NBW = (C * NT + 31) / 32;
+    constexpr int ST = NT;
+    constexpr int NX = NT + SK2_QMAX + 1;
+    constexpr int PAD = 16;
+    constexpr int JOBCAP = 128;
+    constexpr uint32_t NW = NT / 64;
+    __shared__ uint32_t s_c[C * ST];
+    __shared__ uint32_t s_bm[NT + PAD];         /* block minima; INF behind NT */
+    __shared__ uint32_t s_pre0[NT + 4];         /* minimum of the first R0 elements of each block */
+    __shared__ uint32_t s_bits[NBW];
+    __shared__ uint32_t s_njobs, s_flag, s_nalive;
+    __shared__ uint32_t s_roll[64];             /* the rolling table; after phase 1b the list of lanes with work (uint8[NT]) */
+    __shared__ uint32_t s_t0[NT + PAD];         /* range-minimum level; after the lanes' decision the job list (uint16[JOBCAP]) */
+    static_assert(NT <= 256 && JOBCAP * 2 <= (NT + PAD) * 4, "the lists alias the rolling table and the range-minimum level");
+    uint8_t *const s_list = (uint8_t *)&s_roll[0];
+    uint16_t *const s_jobs = (uint16_t *)&s_t0[0];
+    uint2 *const s_xy = (uint2 *)s_c;
+    uint32_t *const s_so = (uint32_t *)&s_xy[2 * NX];
+    static_assert(sizeof(uint32_t) * C * ST >= sizeof(uint2) * 2 * NX + sizeof(uint32_t) * (NX + 1), "the exchange area must fit the element array");
+
+    const SketchArgs &A = B.A;
+    const int L = threadIdx.x;
+    const SketchGeom G = A.G;
+    const uint32_t per_xcd = gridDim.x >> 3; /* consecutive strips on one XCD (see sketch_mask_kernel) */
+    const uint32_t strip = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (strip >= A.nstrips) return;
+    const StripInfo I = A.strip_tab[strip];
+    if (I.seq == NTL_NONE || I.multi != 0) return; /* strips that cross non-ACGT runs: sketch_mask_kernel<.., MULTI = true> */
+    if (L < 16) { s_roll[2 * L] = (uint32_t)(A.roll_tab[L][0] >> 33); s_roll[2 * L + 1] = (uint32_t)(A.roll_tab[L][1] >> 32); }
+    if (L < NBW) s_bits[L] = 0;
+    if (L < PAD) s_bm[NT + L] = SK2_INF;
+    if (L < 4) s_pre0[NT + L] = SK2_INF;
+    if (L == 0) { s_njobs = 0; s_nalive = 0; s_flag = B.force_redo ? 1u : 0u; }
+
+    const int64_t e_lane = (int64_t)I.E0 + (int64_t)L * C; /* ordinal of this lane's element t = 0 */
+    const uint64_t gp = (uint64_t)((int64_t)I.base + I.P0 + (int64_t)L * C);
+
+    /* ---- phase 1a: 16-base partial hashes of the lane's own chunk (and of the chunks behind the strip) ---- */
+    const bool live = e_lane < (int64_t)I.M;
+    const bool feeds = e_lane - 16 * (int64_t)(B.q16 + 1) < (int64_t)I.M;
+    uint32_t so = 0;
+    if (feeds) {
+        so = sk2_bases16(A.T.packed, gp, B.max_word);
+        uint2 FU, P;
+        sk2_chunk(so, B.r16, B, FU, P);
+        s_xy[L] = FU;
+        s_so[L] = so;
+        if (B.r16) s_xy[NX + L] = P;
+    }
+    if (L <= B.q16) {
+        const int64_t ev = (int64_t)I.E0 + (int64_t)(NT + L) * C;
+        if (ev - 16 * (int64_t)(B.q16 + 1) < (int64_t)I.M) {
+            const uint32_t sv = sk2_bases16(A.T.packed, gp + (uint64_t)NT * C, B.max_word);
+            uint2 FU, P;
+            sk2_chunk(sv, B.r16, B, FU, P);
+            s_xy[NT + L] = FU;
+            s_so[NT + L] = sv;
+            if (B.r16) s_xy[NX + NT + L] = P;
+        }
+    }
+    __syncthreads();
+
+    /* ---- phase 1b: first k-mer's rings from the partials, then 15 rolling steps (as in sketch_fast_kernel) ---- */
+    uint32_t c[C];
+#pragma unroll
+    for (int t = 0; t < C; t++) c[t] = SK2_INF;
+    uint32_t fx = 0, ry = 0, si = 0;
+    if (live) {
+        {
+            const uint32_t lo = s_so[L + B.q16];
+            si = B.r16 ? ntl_alignbit(s_so[L + B.q16 + 1], lo, 2u * (uint32_t)B.r16) : lo;
+        }
+        uint32_t f = 0, u = 0;
+        for (int i = 0; i < B.q16; i++) {
+            if (i) { f = ring_rotl(f, 16); u = ring_rotr(u, 16); }
+            const uint2 p = s_xy[L + i];
+            f ^= p.x;
+            u ^= p.y;
+        }
+        if (B.r16) {
+            const uint32_t r = (uint32_t)B.r16;
+            if (B.q16) { f = ring_rotl(f, r); u = ring_rotr(u, r); }
+            const uint2 p = s_xy[NX + L + B.q16];
+            f ^= p.x;
+            u ^= p.y;
+        }
+        fx = f;
+        ry = u << 1;
+    }
+    __syncthreads(); /* the partial hashes have been read: s_c may take the elements */
+    if (live) {
+        c[0] = (fx << 1) + ry;
+        uint32_t wz[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const uint32_t o2 = r < 2 ? so << (3 - 2 * r) : so >> (2 * r - 3);
+            const uint32_t i2 = r < 3 ? si << (5 - 2 * r) : si >> (2 * r - 5);
+            wz[r] = (o2 & 0x18181818u) | (i2 & 0x60606060u);
+        }
+#pragma unroll
+        for (int t = 1; t < C; t++) {
+            const int b = t - 1;
+            const uint32_t off = ntl_bfe(wz[b & 3], 8u * (uint32_t)(b >> 2), 8u);
+            const uint2 sd = *(const uint2 *)((const char *)s_roll + off);
+            fx = ((fx << 1) | ((fx >> 30) & 1u)) ^ sd.x;
+            const uint32_t a = ry ^ sd.y;
+            ry = ntl_alignbit(a >> 1, a, 1);
+            c[t] = (fx << 1) + ry;
+        }
+        if (e_lane < 0 || e_lane + C > (int64_t)I.M) { /* strip edges only */
+#pragma unroll
+            for (int t = 0; t < C; t++) {
+                const int64_t e = e_lane + t;
+                if (e < 0 || e >= (int64_t)I.M) c[t] = SK2_INF;
+            }
+        }
+    }
+
+    /* ---- phase 2: stage; minimum of the first R0 elements and of the whole block ---- */
+    uint32_t pre0 = SK2_INF, bmv = SK2_INF;
+#pragma unroll
+    for (int t = 0; t < C; t++) {
+        s_c[t * ST + L] = c[t];
+        if (t < R0) pre0 = c[t] < pre0 ? c[t] : pre0;
+        else bmv = c[t] < bmv ? c[t] : bmv;
+    }
+    bmv = pre0 < bmv ? pre0 : bmv;
+    s_bm[L] = bmv;
+    s_pre0[L] = pre0;
+    __syncthreads(); /* also: the last read of the rolling table lies behind -- s_roll may take the lane list */
+
+    /* ---- phase 3: minimum over the whole blocks L+1 .. L+a (one radix-4 level: a + 2 <= 16) ---- */
+    uint32_t fa = SK2_INF;
+    if (G.a >= 1) {
+        const uint32_t *cur = s_bm;
+        int span = 1;
+        if (4 <= G.a) {
+            uint32_t m = cur[L];
+#pragma unroll
+            for (int q = 1; q < 4; q++) { const uint32_t v = cur[L + q]; m = v < m ? v : m; }
+            s_t0[L] = m;
+            if (L < PAD) s_t0[NT + L] = SK2_INF;
+            __syncthreads();
+            cur = s_t0;
+            span = 4;
+        }
+        for (int o = 0; o < G.a; o += span) {
+            const int at = o + span <= G.a ? o : G.a - span;
+            const uint32_t v = cur[L + 1 + at];
+            fa = v < fa ? v : fa;
+        }
+    }
+
+    /* ---- phase 4a: can the minimum change in this lane's windows?  (see the header of this kernel) ---- */
+    const bool own = L < G.LW && e_lane + G.w <= (int64_t)I.M;
+    {
+        bool work = false;
+        if (own) {
+            const int Lr = L + G.a + 1;
+            const uint32_t p1 = s_pre0[Lr], b1 = s_bm[Lr], p2 = s_pre0[Lr + 1];
+            uint32_t x0 = bmv < fa ? bmv : fa;
+            x0 = p1 < x0 ? p1 : x0;
+            uint32_t x16 = fa < b1 ? fa : b1;
+            x16 = p2 < x16 ? p2 : x16;
+            const uint32_t ent = b1 < p2 ? b1 : p2;
+            const bool inside = e_lane >= 0 && e_lane + C + G.w <= (int64_t)I.M; /* all 17 windows lie in the sequence */
+            work = !inside || x0 != x16 || ent - x0 <= SK2_NEAR || L == 0 || L == G.LW - 1;
+        }
+        const unsigned long long bal = __ballot(work);
+        __syncthreads(); /* every lane has read the range-minimum level: s_t0 may take the job list (and s_roll is long dead) */
+        if (bal != 0ull) {
+            uint32_t base = 0;
+            const int first = __ffsll((long long)bal) - 1;
+            if ((L & 63) == first) base = atomicAdd(&s_nalive, (uint32_t)__popcll(bal));
+            base = __shfl(base, first);
+            if (work) s_list[base + ntl_mbcnt(bal)] = (uint8_t)L;
+        }
+    }
+    __syncthreads();
+
+    /* ---- phases 4-5 for the listed lanes: wavefront (strip + round) mod NW takes round `round` of 64 list entries ---- */
+    {
+        const uint32_t nalive = s_nalive;
+        const uint32_t round = (((uint32_t)L >> 6) + NW - (strip % NW)) % NW;
+        const uint32_t li = round * 64u + ((uint32_t)L & 63u);
+        const bool act = li < nalive;
+        if (__ballot(act) != 0ull) {
+            const int Lx = act ? (int)s_list[li] : 0;
+            const int64_t ex = (int64_t)I.E0 + (int64_t)Lx * C;
+            /* the block's keys back from LDS, suffix minima in place (c[j] = min of elements j..15) */
+#pragma unroll
+            for (int t = 0; t < C; t++) c[t] = s_c[t * ST + Lx];
+#pragma unroll
+            for (int j = C - 2; j >= 0; j--) c[j] = c[j] < c[j + 1] ? c[j] : c[j + 1];
+            uint32_t fx2 = SK2_INF; /* whole blocks Lx+1 .. Lx+a */
+            for (int o = 1; o <= G.a; o++) { const uint32_t v = s_bm[Lx + o]; fx2 = v < fx2 ? v : fx2; }
+            uint32_t chg = 0, le = 0;
+            const bool inside = ex >= 0 && ex + C + G.w <= (int64_t)I.M;
+            const bool all_inside = __ballot(act && !inside) == 0ull;
+            auto window_pass = [&](auto chk) {
+                constexpr bool CHECK = decltype(chk)::value;
+                const int Lr = Lx + G.a + 1;
+                uint32_t P = fx2;
+                {
+                    const uint32_t hh = s_pre0[Lr];
+                    P = hh < P ? hh : P;
+                }
+                uint32_t xp = 0, acc = 0, lacc = 0;
+                uint32_t dlo = SK2_INF, dhi = 0;
+#pragma unroll
+                for (int j = 0; j <= C; j++) {
+                    const int rt = R0 + j;
+                    uint32_t hh = 0;
+                    if (j > 0) {
+                        const int tp = rt - 1 < C ? rt - 1 : rt - 1 - C;
+                        const int Lb = rt - 1 < C ? Lr : Lr + 1;
+                        hh = s_c[tp * ST + Lb];
+                        P = hh < P ? hh : P;
+                    }
+                    uint32_t x = P;
+                    if (j < C) x = P < c[j] ? P : c[j];
+                    if (j > 0) {
+                        uint32_t d = hh - xp;
+                        if (!CHECK) { acc = ntl_shl1_or_ne(acc, x, xp); lacc = ntl_shl1_or_lt_diff(lacc, hh, xp, d); }
+                        else if (ex + j + G.w <= (int64_t)I.M && ex + j >= 0) {
+                            chg |= (x != xp ? 1u : 0u) << j;
+                            le |= (hh < xp ? 1u : 0u) << j;
+                        } else d = 0x80000000u;
+                        dlo = d < dlo ? d : dlo;
+                        dhi = d > dhi ? d : dhi;
+                    }
+                    xp = x;
+                }
+                if (!CHECK) { chg = ntl_brev(acc) >> 15; le = ntl_brev(lacc) >> 15; }
+                return dlo <= SK2_NEAR || dhi >= 0u - SK2_NEAR;
+            };
+            if (act) {
+                const bool near = all_inside ? window_pass(NtlFalse()) : window_pass(NtlTrue());
+                if (near) {
+                    s_flag = 2u;
+#ifdef NTL_SIM
+                    if (getenv("NTL_SK2_DEBUG")) fprintf(stderr, "strip %u lane %d near tie M=%u E0=%d\n", strip, Lx, I.M, I.E0);
+#endif
+                }
+                if (Lx == 0) { if (ex + 1 + G.w <= (int64_t)I.M) chg |= 2u; le &= ~2u; }
+                if (Lx == G.LW - 1) { chg &= 0xFFFFu; le &= 0xFFFFu; }
+                const uint32_t drop = chg & le, rise = chg & ~le;
+                if (drop) {
+                    const uint32_t p0 = (uint32_t)(Lx * C + G.w - 1);
+                    const uint64_t v = (uint64_t)drop << (p0 & 31u);
+                    atomicOr(&s_bits[p0 >> 5], (uint32_t)v);
+                    if (v >> 32) atomicOr(&s_bits[(p0 >> 5) + 1], (uint32_t)(v >> 32));
+                }
+                if (rise) {
+                    uint32_t at = atomicAdd(&s_njobs, (uint32_t)__popc(rise));
+                    uint32_t m = rise;
+                    while (m) {
+                        const int j = __ffs(m) - 1;
+                        m &= m - 1;
+                        if (at < (uint32_t)JOBCAP) s_jobs[at] = (uint16_t)(Lx * C + j);
+                        at++;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    /* ---- phase 6: position of the minimum of every window whose minimum rose (as in sketch_fast_kernel); the jobs start at
+       another wavefront than the one that walked the windows ---- */
+    {
+        uint32_t njobs = s_njobs;
+        if (njobs > (uint32_t)JOBCAP) { njobs = JOBCAP; if (L == 0) s_flag = 4u; }
+        const uint32_t Lq = ((uint32_t)L + 64u * ((strip + NW / 2u) % NW)) % (uint32_t)NT; /* rotated lane number: same quads */
+        const uint32_t q = Lq & 3u, grp = Lq >> 2;
+        const uint32_t rounds = (njobs + NT / 4 - 1) / (NT / 4);
+        for (uint32_t it = 0; it < rounds; it++) {
+            const uint32_t i = it * (NT / 4) + grp;
+            const bool act = i < njobs;
+            if (__ballot(act) == 0ull) break;
+            const uint32_t g = s_jobs[act ? i : 0u], ge = g + (uint32_t)G.w;
+            const uint32_t b0 = g >> 4, b1 = (ge - 1) >> 4, t0 = g & 15u, t1 = (ge - 1) & 15u;
+            uint32_t val[12];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const uint32_t t = q + 4u * r, b = b0 + 1 + q + 4u * r;
+                val[r] = s_c[t * ST + b0];
+                val[4 + r] = s_c[t * ST + b1];
+                val[8 + r] = s_bm[b < (uint32_t)(NT + PAD - 1) ? b : (uint32_t)(NT + PAD - 1)];
+            }
+            uint32_t v = SK2_INF;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const uint32_t t = q + 4u * r, b = b0 + 1 + q + 4u * r;
+                val[r] = (t >= t0 && (b1 > b0 || t <= t1)) ? val[r] : SK2_INF;
+                val[4 + r] = (b1 > b0 && t <= t1) ? val[4 + r] : SK2_INF;
+                val[8 + r] = b < b1 ? val[8 + r] : SK2_INF;
+                v = val[r] < v ? val[r] : v;
+                v = val[4 + r] < v ? val[4 + r] : v;
+                v = val[8 + r] < v ? val[8 + r] : v;
+            }
+            v = ntl_quad_min(v);
+            const uint32_t vn = v + SK2_NEAR;
+            uint32_t mk = 0;
+#pragma unroll
+            for (int r = 0; r < 12; r++) mk = ntl_shl1_or_le(mk, val[r], vn);
+            uint32_t n = (uint32_t)__popc(mk);
+            const uint32_t r1 = 11u - (uint32_t)(__ffs(mk | 0x1000u) - 1);
+            uint32_t code = r1 < 4 ? b0 * 16 + q + 4u * r1 : (r1 < 8 ? b1 * 16 + q + 4u * (r1 - 4) : (0x10000u | (b0 + 1 + q + 4u * (r1 - 8))));
+            n = ntl_quad_sum(v != SK2_INF ? n : 2u);
+            code = ntl_quad_min(n && mk ? code : SK2_INF);
+            const bool blk = code >= 0x10000u && code != SK2_INF;
+            const uint32_t bb = blk ? (code & 0xFFFFu) : 0u;
+            uint32_t mk2 = 0;
+#pragma unroll
+            for (int r = 0; r < 4; r++) mk2 = ntl_shl1_or_le(mk2, s_c[(q + 4u * r) * ST + bb], vn);
+            const uint32_t n2 = ntl_quad_sum((uint32_t)__popc(mk2));
+            const uint32_t p2 = ntl_quad_min(mk2 ? bb * 16 + q + 4u * (3u - (uint32_t)(__ffs(mk2) - 1)) : SK2_INF);
+            const bool ok = n == 1 && (!blk || n2 == 1);
+            const uint32_t pos = blk ? p2 : code;
+            if (act && q == 0) {
+                if (ok) atomicOr(&s_bits[pos >> 5], 1u << (pos & 31u));
+                else {
+                    s_flag = 8u;
+#ifdef NTL_SIM
+                    if (getenv("NTL_SK2_DEBUG")) fprintf(stderr, "strip %u job g=%u: minimum %x occurs %u/%u times (M=%u E0=%d)\n", strip, g, v, n, n2, I.M, I.E0);
+#endif
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    /* ---- phase 7: proven minimizers to the global bitmask; flagged strips to the exact pass ---- */
+    const uint32_t flagged = s_flag;
+    if (L < NBW && !flagged) {
+        const uint32_t word = s_bits[L];
+        if (word) {
+            const uint64_t g0 = (uint64_t)((int64_t)I.base + I.P0 + 32 * (int64_t)L);
+            const uint32_t sh = (uint32_t)g0 & 31u;
+            atomicOr(&A.mask[g0 >> 5], word << sh);
+            if (sh && (word >> (32u - sh))) atomicOr(&A.mask[(g0 >> 5) + 1], word >> (32u - sh));
+        }
+    }
+    if (L == 0 && flagged) B.redo_list[atomicAdd(B.redo_count, 1u)] = strip;
+}

@@ -503,6 +503,8 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
         out.close()
         stats["t_drain_tail"] = time.perf_counter() - t_fin  # writers still busy after the last device batch
         stats["parsed_bytes"] = io_stats.get("parsed_bytes", 0)
+        stats["reader"] = {key: round(io_stats.get(key, 0.0), 4) for key in ("t_reader_count", "t_reader_alloc", "t_reader_parse")}
+        stats["reader"]["batches"] = io_stats.get("reader_batches", 0)
         if comm.world > 1:
             t_fin = time.perf_counter()
             exts = [e for e, on in ((".verbose_mapping.tsv", verbose), (".paf", paf)) if on]

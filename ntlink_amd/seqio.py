@@ -282,6 +282,11 @@ def load(paths, max_bases=None, alloc=None, ahead=None, stats=None, packed=False
                         t_2 = time.perf_counter()
                         if L.ntl_fastx_copy(h, buf.ctypes.data, off.ctypes.data, names.ctypes.data, noff.ctypes.data) != 0:
                             raise OSError(f"{path}: gather failed")
+                    if stats is not None:  # busy time of the reader thread, by phase (the rest of its wall time it waits for a free queue slot)
+                        t_3 = time.perf_counter()
+                        for key, dt in (("t_reader_count", t_1 - t_0), ("t_reader_alloc", t_2 - t_1), ("t_reader_parse", t_3 - t_2)):
+                            stats[key] = stats.get(key, 0.0) + dt
+                        stats["reader_batches"] = stats.get("reader_batches", 0) + 1
                     if trace:
                         print(f"ntl_fastx batch: read+count {t_1 - t_0:.4f}s alloc {t_2 - t_1:.4f}s parse {time.perf_counter() - t_2:.4f}s "
                               f"bases {nb.value} t={time.perf_counter():.4f}", file=sys.stderr)
