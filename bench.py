@@ -88,22 +88,6 @@ def kernel_signature():
     return h.hexdigest()[:12]
 
 
-def pin_rank(local_rank, local_world):
-    """Several ranks on one host: each keeps to its own slice of the cores (its parser / emitter threads are sized to it by
-    NTL_IO_THREADS), so that eight ranks do not start eight full-size thread pools on top of each other."""
-    if local_world <= 1 or os.environ.get("NTL_PIN", "1") == "0" or not hasattr(os, "sched_getaffinity"):
-        return None
-    cpus = sorted(os.sched_getaffinity(0))
-    per = max(1, len(cpus) // local_world)
-    mine = cpus[local_rank * per:(local_rank + 1) * per] or cpus
-    try:
-        os.sched_setaffinity(0, mine)
-    except OSError:
-        return None
-    os.environ.setdefault("NTL_IO_THREADS", str(max(2, min(32, len(mine)))))
-    return len(mine)
-
-
 class Comm:
     """barrier / max / sum / gather over the ranks (RCCL on GPUs, gloo under the SIMT mock); a single process needs none"""
 
@@ -391,9 +375,10 @@ def main():
             print(json.dumps({"spawn_check": True, "n_gpus": int(t.item()), "world": dist.get_world_size()}), flush=True)
         dist.destroy_process_group()
         return
+    sys.path.insert(0, ROOT)
+    from ntlink_amd.dist_pair import pin_rank
     cores_mine = pin_rank(local_rank, local_world)
     import torch
-    sys.path.insert(0, ROOT)
     from ntlink_amd import capi
     use_cuda = args.lib is None
     if use_cuda:

@@ -76,6 +76,16 @@ struct ntl_fastx {
     char *stage = nullptr;     /* from the buffer cache: pages already faulted in by an earlier file */
     size_t stage_cap = 0;
     size_t stage_off = 0, stage_have = 0; /* stage[0 .. stage_have) = input bytes from stage_off on */
+    /* bgzf: a BGZF (bgzip) file, or a range of its members: inflated group by group, the members of a group in parallel, from a
+       mapping of the compressed file into `stage` (the serial source's buffer and bookkeeping).  Text offsets (cur, stage_off)
+       count from the first byte of member z_lo. */
+    bool bgzf = false;
+    const unsigned char *zmm = nullptr;
+    size_t zmm_len = 0;
+    size_t z_lo = 0, z_stop = (size_t)-1; /* compressed offsets of the first member and of the first member behind the range */
+    size_t z_pos = 0;                     /* next member to inflate */
+    size_t stop_text = (size_t)-1;        /* text offset at which member z_stop begins (known once z_pos has reached it) */
+    size_t text_end = (size_t)-1;         /* first record start at or behind stop_text: where this reader's records end */
     bool fastq = false;
     std::vector<Range> ranges;
     /* contiguous copies of the current batch for the pointer accessors */
@@ -503,6 +513,88 @@ static bool bgzf_table(const unsigned char *in, size_t n, std::vector<size_t> &m
     return moff.size() > 2;
 }
 
+/* header of the BGZF member at `pos`: its size in the file and the size of its text; false when there is no valid member */
+static bool bgzf_member(const unsigned char *in, size_t n, size_t pos, size_t *bsize_out, size_t *isize_out)
+{
+    if (pos + 18 + 8 > n || in[pos] != 0x1f || in[pos + 1] != 0x8b || in[pos + 2] != 8 || !(in[pos + 3] & 4)) return false;
+    const size_t xlen = (size_t)in[pos + 10] | ((size_t)in[pos + 11] << 8);
+    if (pos + 12 + xlen > n) return false;
+    size_t bsize = 0;
+    for (size_t q = pos + 12; q + 4 <= pos + 12 + xlen;) {
+        const size_t slen = (size_t)in[q + 2] | ((size_t)in[q + 3] << 8);
+        if (in[q] == 'B' && in[q + 1] == 'C' && slen == 2 && q + 6 <= pos + 12 + xlen) bsize = ((size_t)in[q + 4] | ((size_t)in[q + 5] << 8)) + 1;
+        q += 4 + slen;
+    }
+    if (bsize < 12 + xlen + 8 || pos + bsize > n) return false;
+    uint32_t isize;
+    memcpy(&isize, in + pos + bsize - 4, 4);
+    if (isize > (1u << 16)) return false; /* BGZF members hold at most 64 KiB of text */
+    *bsize_out = bsize; *isize_out = isize;
+    return true;
+}
+
+/* First member start at or behind `pos` (n when there is none): the four magic bytes, a well-formed header, and two more
+ * well-formed members (or the end of the file) behind it -- compressed data that happens to look like one header does not
+ * look like three in a row. */
+static size_t bgzf_member_at_or_after(const unsigned char *in, size_t n, size_t pos)
+{
+    if (pos == 0) return 0;
+    for (size_t q = pos; q + 26 <= n; q++) {
+        if (in[q] != 0x1f) {
+            const unsigned char *f = (const unsigned char *)memchr(in + q, 0x1f, n - q);
+            if (!f) return n;
+            q = (size_t)(f - in);
+            if (q + 26 > n) return n;
+        }
+        size_t at = q, ok = 0;
+        for (; ok < 3 && at < n; ok++) {
+            size_t bs, is;
+            if (!bgzf_member(in, n, at, &bs, &is)) break;
+            at += bs;
+        }
+        if (ok == 3 || (ok > 0 && at == n)) return q;
+    }
+    return n;
+}
+
+struct BgzfMember { size_t pos, bsize, isize, out; };
+
+/* inflates the listed members (each an independent gzip member) to dst + out, several at a time */
+static bool bgzf_inflate(const unsigned char *in, const std::vector<BgzfMember> &ms, char *dst)
+{
+    const size_t nm = ms.size();
+    if (!nm) return true;
+    const LibDeflate &L = libdeflate();
+    const size_t T = std::min<size_t>(io_threads(), std::max<size_t>(1, nm / 4));
+    std::vector<int> bad(T, 0);
+    run_threads(T, [&](size_t t) {
+        void *d = L.ok ? L.alloc() : nullptr;
+        z_stream zs;
+        bool z_on = false;
+        for (size_t i = nm * t / T; i < nm * (t + 1) / T; i++) {
+            const BgzfMember &m = ms[i];
+            if (d) {
+                size_t ain = 0, aout = 0;
+                if (L.gzip_ex(d, in + m.pos, m.bsize, dst + m.out, m.isize, &ain, &aout) != 0 || aout != m.isize) { bad[t] = 1; break; }
+                continue;
+            }
+            if (!z_on) { /* no libdeflate in this image: zlib, one stream object per thread */
+                memset(&zs, 0, sizeof zs);
+                if (inflateInit2(&zs, 16 + MAX_WBITS) != Z_OK) { bad[t] = 1; break; }
+                z_on = true;
+            } else inflateReset(&zs);
+            zs.next_in = (Bytef *)(in + m.pos); zs.avail_in = (uInt)m.bsize;
+            zs.next_out = (Bytef *)(dst + m.out); zs.avail_out = (uInt)m.isize;
+            const int rc = inflate(&zs, Z_FINISH);
+            if ((rc != Z_STREAM_END && !(rc == Z_OK && m.isize == 0)) || zs.avail_out != 0) { bad[t] = 1; break; }
+        }
+        if (d) L.release(d);
+        if (z_on) inflateEnd(&zs);
+    });
+    for (int x : bad) if (x) return false;
+    return true;
+}
+
 /* Inflates every gzip member of [in, in + n) into one malloc'd buffer (`gzip -cd` of a whole file held in
  * memory); BGZF members in parallel.  False on corrupt data or when libdeflate is missing; the caller then
  * streams through zlib. */
@@ -567,6 +659,8 @@ static bool inflate_whole(const unsigned char *in, size_t n, char **out, size_t 
     return true;
 }
 
+static void bgzf_fill(ntl_fastx *r, size_t need);
+
 static void set_format(ntl_fastx *r, const char *p, const char *e)
 {
     while (p < e && (*p == '\n' || *p == '\r')) p++; /* format = first header character */
@@ -604,6 +698,23 @@ extern "C" int ntl_fastx_open(const char *path, ntl_fastx **out)
             set_format(r, (const char *)head, (const char *)head + hn);
             *out = r;
             return NTL_OK;
+        }
+        {   /* BGZF: members inflate independently -- any size, bounded memory, several threads, and ranges of members can be
+               read on their own (ntl_fastx_open_range) */
+            size_t bs = 0, is = 0;
+            void *m = (hn >= 28 && (head[3] & 4)) ? mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0) : MAP_FAILED;
+            if (m != MAP_FAILED && bgzf_member((const unsigned char *)m, (size_t)st.st_size, 0, &bs, &is) && !getenv("NTL_IO_NO_BGZF")) {
+                r->bgzf = true;
+                r->zmm = (const unsigned char *)m; r->zmm_len = (size_t)st.st_size;
+                /* the format is that of the file's first record, wherever a range of it starts */
+                std::vector<char> first(is + 64);
+                std::vector<BgzfMember> one{{0, bs, is, 0}};
+                if (!bgzf_inflate(r->zmm, one, first.data())) { ntl_fastx_close(r); return NTL_EINVAL; }
+                set_format(r, first.data(), first.data() + std::min<size_t>(is, 64));
+                *out = r;
+                return NTL_OK;
+            }
+            if (m != MAP_FAILED) munmap(m, (size_t)st.st_size);
         }
         if ((size_t)st.st_size <= whole_max) {
             void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
@@ -666,6 +777,29 @@ extern "C" int ntl_fastx_open_range(const char *path, uint64_t lo, uint64_t hi, 
     ntl_fastx *r = nullptr;
     int rc = ntl_fastx_open(path, &r);
     if (rc != NTL_OK) return rc;
+    if (r->bgzf) { /* lo / hi are offsets in the COMPRESSED file: the members that start in [lo, hi) */
+        const size_t n = r->zmm_len;
+        if (hi == 0 || hi > n) hi = n;
+        if (lo > hi) lo = hi;
+        r->z_lo = bgzf_member_at_or_after(r->zmm, n, (size_t)lo);
+        r->z_stop = hi >= n ? n : bgzf_member_at_or_after(r->zmm, n, (size_t)hi);
+        if (r->z_stop < r->z_lo) r->z_stop = r->z_lo;
+        r->z_pos = r->z_lo;
+        if (r->z_lo > 0) { /* the first record of the range: the first record start behind the first line end of its text */
+            size_t need = (size_t)1 << 20;
+            for (;;) {
+                bgzf_fill(r, need);
+                if (!r->err.empty()) { ntl_fastx_close(r); return NTL_EINVAL; }
+                const char *b = r->stage, *e = r->stage + r->stage_have;
+                const char *q = b < e ? find_boundary(b, e, r->fastq) : e;
+                if (q < e || r->src_eof) { r->cur = (size_t)(q - b); break; }
+                need *= 4;
+            }
+            if (r->text_end != (size_t)-1 && r->cur > r->text_end) r->cur = r->text_end;
+        }
+        *out = r;
+        return NTL_OK;
+    }
     if (!r->seekable) { ntl_fastx_close(r); return NTL_EINVAL; }
     const size_t size = r->file_size;
     if (hi == 0 || hi > size) hi = size;
@@ -685,6 +819,11 @@ extern "C" int ntl_fastx_open_range(const char *path, uint64_t lo, uint64_t hi, 
 /* The byte range [*lo, *hi) of the file this reader covers (0, 0 for sources that are not plain files). */
 extern "C" void ntl_fastx_range(const ntl_fastx *r, uint64_t *lo, uint64_t *hi)
 {
+    if (r && r->bgzf) { /* compressed bytes of the members this reader owns */
+        if (lo) *lo = r->z_lo;
+        if (hi) *hi = r->z_stop == (size_t)-1 ? r->zmm_len : r->z_stop;
+        return;
+    }
     if (lo) *lo = r && r->seekable ? r->range_lo : 0;
     if (hi) *hi = r && r->seekable ? r->file_size : 0;
 }
@@ -695,6 +834,7 @@ extern "C" void ntl_fastx_close(ntl_fastx *r)
     if (r->z_init) inflateEnd(&r->zs);
     if (r->map) buf_cache().give((char *)r->map, r->map_cap);
     if (r->mm) munmap((void *)r->mm, r->mm_len);
+    if (r->zmm) munmap((void *)r->zmm, r->zmm_len);
     if (r->fd >= 0) close(r->fd);
     if (r->stage) buf_cache().give(r->stage, r->stage_cap);
     delete r;
@@ -773,6 +913,84 @@ static bool stage_reserve(ntl_fastx *r, size_t want)
     return true;
 }
 
+/* BGZF source: inflates members behind z_pos into the stage buffer until it holds `need` bytes of text (or the source ends).
+ * A ranged reader (z_stop set) ends at the first record start at or behind the text of member z_stop -- `find_boundary` from
+ * there, the same function of the same bytes that gives the NEXT range its first record, so that neighbouring ranges see every
+ * record once; the members needed to find it are inflated as far as it takes. */
+static void bgzf_fill(ntl_fastx *r, size_t need)
+{
+    const size_t NONE = (size_t)-1;
+    for (;;) {
+        if (r->src_eof) return;
+        if (r->text_end != NONE) { /* the closing record start is known: nothing behind it belongs to this reader */
+            if (r->cur > r->text_end) r->cur = r->text_end; /* the range's first record starts behind its end: it owns nothing */
+            const size_t keep = r->text_end > r->stage_off ? r->text_end - r->stage_off : 0;
+            if (r->stage_have > keep) r->stage_have = keep;
+            r->src_eof = true;
+            return;
+        }
+        const bool tail = r->stop_text != NONE; /* behind the range: small steps, only to find the closing record start */
+        if (!tail && r->stage_have >= need) return;
+        if (!tail && r->z_stop != NONE && r->z_pos >= r->z_stop) { r->stop_text = r->stage_off + r->stage_have; continue; }
+        if (r->z_pos >= r->zmm_len) { /* end of the file */
+            if (r->z_stop != NONE) { r->text_end = r->stage_off + r->stage_have; continue; }
+            r->src_eof = true;
+            return;
+        }
+        std::vector<BgzfMember> ms;
+        size_t total = 0, pos = r->z_pos;
+        const size_t limit = !tail && r->z_stop != NONE ? std::min(r->z_stop, r->zmm_len) : r->zmm_len;
+        const size_t want = tail ? (size_t)1 << 20 : std::max<size_t>(need - r->stage_have, (size_t)4 << 20);
+        bool foreign = false;
+        while (pos < limit && total < want) {
+            size_t bs, is;
+            if (!bgzf_member(r->zmm, r->zmm_len, pos, &bs, &is)) { foreign = true; break; }
+            ms.push_back({pos, bs, is, total});
+            total += is; pos += bs;
+        }
+        if (foreign && ms.empty()) {
+            /* not a BGZF member: zero padding, or an ordinary gzip member somebody concatenated (`cat a.bgz b.gz`; gzip -cd reads
+               that too) -- inflated as a stream, on this thread, to wherever it ends */
+            if (r->zmm[pos] == 0) { r->z_pos = pos + 1; continue; }
+            z_stream zs;
+            memset(&zs, 0, sizeof zs);
+            if (r->zmm[pos] != 0x1f || inflateInit2(&zs, 16 + MAX_WBITS) != Z_OK) { r->err = "corrupt gzip data"; r->src_eof = true; return; }
+            zs.next_in = (Bytef *)(r->zmm + pos);
+            size_t in_left = r->zmm_len - pos;
+            int rc = Z_OK;
+            while (rc != Z_STREAM_END) {
+                if (r->stage_cap - r->stage_have < (1u << 16) && !stage_reserve(r, std::max<size_t>(r->stage_cap * 2, (size_t)8 << 20))) { inflateEnd(&zs); r->src_eof = true; return; }
+                zs.avail_in = (uInt)std::min<size_t>(in_left, (size_t)1 << 30);
+                const uInt in0 = zs.avail_in;
+                zs.next_out = (Bytef *)(r->stage + r->stage_have);
+                zs.avail_out = (uInt)std::min<size_t>(r->stage_cap - r->stage_have, (size_t)1 << 30);
+                const uInt out0 = zs.avail_out;
+                rc = inflate(&zs, Z_NO_FLUSH);
+                in_left -= in0 - zs.avail_in;
+                r->stage_have += out0 - zs.avail_out;
+                if (rc != Z_OK && rc != Z_STREAM_END && !(rc == Z_BUF_ERROR && zs.avail_out == 0)) {
+                    inflateEnd(&zs);
+                    r->err = zs.msg ? zs.msg : "corrupt gzip data"; r->src_eof = true;
+                    return;
+                }
+                if (rc != Z_STREAM_END && in_left == 0 && zs.avail_in == 0) { inflateEnd(&zs); r->err = "unexpected end of gzip data"; r->src_eof = true; return; }
+            }
+            inflateEnd(&zs);
+            r->z_pos = r->zmm_len - in_left;
+            continue;
+        }
+        if (!stage_reserve(r, r->stage_have + total + 64)) { r->src_eof = true; return; }
+        if (!bgzf_inflate(r->zmm, ms, r->stage + r->stage_have)) { r->err = "corrupt BGZF data"; r->src_eof = true; return; }
+        r->stage_have += total;
+        r->z_pos = pos;
+        if (tail) {
+            const char *b0 = r->stage + (r->stop_text - r->stage_off), *e = r->stage + r->stage_have;
+            const char *q = b0 < e ? find_boundary(b0, e, r->fastq) : e;
+            if (q < e) r->text_end = r->stage_off + (size_t)(q - r->stage);
+        }
+    }
+}
+
 /* Makes the input bytes [cur, cur + need) (clipped to the end) addressable; returns their start, *avail = how
  * many there are, *at_eof = they reach the end of the input. */
 static const char *view(ntl_fastx *r, size_t need, size_t *avail, bool *at_eof)
@@ -831,6 +1049,13 @@ static const char *view(ntl_fastx *r, size_t need, size_t *avail, bool *at_eof)
         }
         *avail = target;
         *at_eof = target == remain;
+        return r->stage;
+    }
+    if (r->bgzf) {
+        bgzf_fill(r, need);
+        if (r->cur < r->stage_off) { r->stage_off = r->cur; r->stage_have = 0; } /* the range ends in front of its first record start: it owns nothing */
+        *avail = std::min(r->stage_have, need);
+        *at_eof = r->src_eof && *avail == r->stage_have;
         return r->stage;
     }
     /* serial: read on until `need` bytes are there or the source ends */

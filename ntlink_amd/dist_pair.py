@@ -13,6 +13,23 @@ import os
 import sys
 
 
+def pin_rank(local_rank, local_world):
+    """Several ranks on one host: each keeps to its own contiguous slice of the cores, and its parser / emitter thread pools
+    (NTL_IO_THREADS, unless the caller set it) are sized to that slice -- eight ranks must not start eight full-size pools
+    and two device workers each on top of one another.  NTL_PIN=0 leaves the affinity alone.  -> cores of this rank, or None."""
+    if local_world <= 1 or os.environ.get("NTL_PIN", "1") == "0" or not hasattr(os, "sched_getaffinity"):
+        return None
+    cpus = sorted(os.sched_getaffinity(0))
+    per = max(1, len(cpus) // local_world)
+    mine = cpus[local_rank * per:(local_rank + 1) * per] or cpus
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return None
+    os.environ.setdefault("NTL_IO_THREADS", str(max(2, min(64, len(mine)))))
+    return len(mine)
+
+
 class DistComm:
     def __init__(self, backend="gloo"):
         import torch.distributed as dist
@@ -53,6 +70,7 @@ def main(argv=None):
         print("usage: ... -m ntlink_amd.dist_pair pair target=<fa> reads='<files>' [k= w= ...]", file=sys.stderr)
         return 2
     cli.apply_threads(kv, given)
+    pin_rank(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))
     import time
     t0 = time.perf_counter()
     comm = DistComm("gloo")  # a few host objects only; the device work needs no collective

@@ -153,12 +153,17 @@ def _open_native(L, item):
 
 
 def _splittable(path):
-    """plain regular file (not gzip): byte ranges of it can be read independently"""
+    """A plain regular file (not gzip), or a BGZF file (bgzip: gzip members that carry their own size in a `BC` extra field):
+    byte ranges of it can be read independently (ntl_fastx_open_range; for BGZF the ranges are in the compressed file and
+    cut at member starts)."""
     try:
         if path == "-" or not os.path.isfile(path) or os.path.getsize(path) == 0:
             return False
         with open(path, "rb") as f:
-            return f.read(2) != b"\x1f\x8b"
+            head = f.read(18)
+        if head[:2] != b"\x1f\x8b":
+            return True
+        return len(head) >= 18 and head[2] == 8 and bool(head[3] & 4) and head[12:14] == b"BC" and not os.environ.get("NTL_IO_NO_BGZF")
     except OSError:
         return False
 

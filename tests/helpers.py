@@ -76,3 +76,18 @@ def load_scenario(name):
     exp = {ext: read_text(os.path.join(d, name + ext + ".gz"))
            for ext in (".verbose_mapping.tsv", ".paf", ".pairs.tsv")}
     return meta, ctext, rtext, exp
+
+
+def write_bgzf(path, data, block=0xFF00, level=6):
+    """`bgzip` without htslib: gzip members of at most `block` bytes of text, each with the BC extra field that holds its
+    compressed size, and the empty EOF member bgzip appends."""
+    import struct
+    import zlib
+    with open(path, "wb") as fh:
+        chunks = [data[i:i + block] for i in range(0, len(data), block)] + [b""]
+        for ch in chunks:
+            co = zlib.compressobj(level, zlib.DEFLATED, -15)
+            body = co.compress(ch) + co.flush()
+            bsize = 12 + 6 + len(body) + 8
+            fh.write(b"\x1f\x8b\x08\x04" + b"\x00" * 4 + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize - 1))
+            fh.write(body + struct.pack("<II", zlib.crc32(ch) & 0xFFFFFFFF, len(ch)))

@@ -55,3 +55,28 @@ def test_two_ranks_strong_scaling_line_on_the_simt_mock():
     per_rank = int(two["config"]["workload"].split(" read bases per GPU")[0].split("+ ")[-1])
     assert abs(2 * per_rank - 200_000) < 40_000  # C2 at scale 0.0004 is 200 kbases of reads: split two ways (a few 10-kb reads each)
     assert two["ms_per_step"] > 0 and two["config"]["index_size"] > 0 and two["config"]["mappings_hits_pafs_per_step"][0] > 0
+
+
+def test_eight_ranks_strong_scaling_line_on_the_simt_mock():
+    """configs[3]'s shape: `bench.py --gpus 8 --strong` -- eight gloo ranks, each with an eighth of the read set; the line
+    carries every rank's time and bases so that an imbalance would show."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from sim import simlib
+    lib = simlib.build()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--lib", lib, "--workload", "C2", "--scale", "0.0008", "--steps", "1",
+                        "--warmup", "1", "--no-e2e", "--no-cpu-baseline", "--batch-bases", "100000", "--serial-steps", "0", "--gpus", "8", "--strong"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["scaling"] == "strong"
+    assert len(out["per_rank_ms_per_step"]) == 8 and len(out["per_rank_bases_per_step"]) == 8
+    assert abs(sum(out["per_rank_bases_per_step"]) - 400_000) < 100_000  # C2 at scale 0.0008: 400 kbases of reads over all ranks
+    assert max(out["per_rank_ms_per_step"]) == pytest_approx(out["ms_per_step"])
+
+
+def pytest_approx(v):
+    import pytest
+    return pytest.approx(v, rel=1e-3, abs=1e-3)

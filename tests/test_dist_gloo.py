@@ -10,7 +10,7 @@ import sys
 import numpy as np
 import pytest
 
-from helpers import GEN, REF, TEST7_PAF, read_text
+from helpers import GEN, REF, TEST7_PAF, read_text, write_bgzf
 from ntlink_amd import seqio
 from ntlink_amd.pipeline import shard_range
 from sim import simlib
@@ -91,9 +91,10 @@ def _run_ranks(tmp_path, world, port, args):
     assert subprocess.call(cmd, cwd=tmp_path, env=env, timeout=900) == 0
 
 
-@pytest.mark.parametrize("world,port", [(2, 29571), (3, 29572)])
+@pytest.mark.parametrize("world,port", [(2, 29571), (3, 29572), (8, 29574)])
 def test_ranks_equal_single_process(tmp_path, world, port):
-    """top-5 reads of test 7 in one plain FASTA: five reads over 2 / 3 ranks, every cut falls inside a read."""
+    """top-5 reads of test 7 in one plain FASTA: five reads over 2 / 3 / 8 ranks, every cut falls inside a read (with eight
+    ranks -- the node size of BASELINE.json configs[3] -- some ranks own no read start at all)."""
     for n in ("scaffolds_4.fa", "long_reads_4_top5.fa"):
         shutil.copy(os.path.join(REF, n), tmp_path / n)
     _run_ranks(tmp_path, world, port, ["target=scaffolds_4.fa", "reads=long_reads_4_top5.fa", "k=40", "w=100", "paf=True",
@@ -135,3 +136,85 @@ def test_three_ranks_many_reads_and_files(tmp_path):
     for ext in (".verbose_mapping.tsv", ".paf", ".pairs.tsv"):
         assert read_text(pre + ext) == read_text(d + ext), ext
     assert read_text(pre + ".pairs.tsv") == read_text(os.path.join(REF, "expected_outputs", "scaffolds_1.fa.k32.w250.z1000.pairs.tsv"))
+
+
+def test_eight_ranks_many_reads_and_files(tmp_path):
+    """BASELINE.json configs[3] in miniature: eight ranks (one node's worth) share test 1's reads, given as three plain files;
+    every rank parses about an eighth of the bytes, the outputs are those of one process, no part file is left behind."""
+    shutil.copy(os.path.join(REF, "scaffolds_1.fa"), tmp_path / "scaffolds_1.fa")
+    recs = list(__import__("oracle").read_fastx(os.path.join(REF, "long_reads_1.fa")))
+    cuts = [0, len(recs) // 3, len(recs) * 2 // 3, len(recs)]
+    names = ["a.fa", "b.fa", "c.fa"]
+    for (a, b), n in zip(zip(cuts, cuts[1:]), names):
+        with open(tmp_path / n, "wt") as fh:
+            for name, seq in recs[a:b]:
+                fh.write(f">{name}\n{seq.decode() if isinstance(seq, bytes) else seq}\n")
+    _run_ranks(tmp_path, 8, 29575, ["target=scaffolds_1.fa", "reads=" + " ".join(names), "k=32", "w=250", "paf=True", "ntlink_pairs_tsv=True", "v=1"])
+    pre = str(tmp_path / "scaffolds_1.fa.k32.w250.z1000")
+    d = os.path.join(GEN, "fixtures", "t1_k32_w250")
+    for ext in (".verbose_mapping.tsv", ".paf", ".pairs.tsv"):
+        assert read_text(pre + ext) == read_text(d + ext), ext
+    assert not [f for f in os.listdir(tmp_path) if ".part" in f or f.endswith(".assembling")]
+    rep = dict(line.strip().split(": ", 1) for line in open(pre + ".n1.scaffold.dot.time") if ": " in line)
+    per = json.loads(rep["ntlink_amd parsed_bytes_per_rank"])
+    total = sum(os.path.getsize(tmp_path / n) for n in names)
+    assert len(per) == 8 and sum(per) == total
+    longest = max(len(s) for _, s in recs) + 200
+    assert all(abs(b - total / 8) <= longest for b in per)
+
+
+def test_a_dead_run_leaves_no_checkpoint(tmp_path):
+    """Stale part files and a half-assembled output of a run that died must neither survive nor be taken for a checkpoint."""
+    for n in ("scaffolds_4.fa", "long_reads_4_top5.fa"):
+        shutil.copy(os.path.join(REF, n), tmp_path / n)
+    pre = str(tmp_path / "scaffolds_4.fa.k40.w100.z1000")
+    for stale in (".verbose_mapping.tsv.part1", ".paf.part5", ".verbose_mapping.tsv.assembling"):
+        with open(pre + stale, "w") as fh:
+            fh.write("junk\tfrom\ta\tdead:+_run:+\n")
+    _run_ranks(tmp_path, 2, 29576, ["target=scaffolds_4.fa", "reads=long_reads_4_top5.fa", "k=40", "w=100", "paf=True", "ntlink_pairs_tsv=True"])
+    d = os.path.join(GEN, "fixtures", "t7_top5_k40_w100")
+    assert read_text(pre + ".verbose_mapping.tsv") == read_text(d + ".verbose_mapping.tsv")
+    assert read_text(pre + ".paf") == read_text(d + ".paf")
+    assert not [f for f in os.listdir(tmp_path) if ".part" in f or f.endswith(".assembling")]
+
+
+@pytest.mark.parametrize("fastq,block", [(False, 0xFF00), (True, 0xFF00), (False, 700), (True, 333)])
+def test_bgzf_member_ranges_see_every_record_once(tmp_path, fastq, block):
+    """A BGZF file is cut below file granularity: ranks own ranges of its members (ranges in the compressed file, cut at member
+    starts, records cut where the plain-file ranges cut them: the first record start behind the first line end).  The ranks'
+    record lists in rank order are the serial reader's, with tiny members too (records spanning dozens of members), and every
+    rank's share of the compressed bytes is about total / world."""
+    import gzip
+    rng = np.random.default_rng(11)
+    lines = []
+    for i in range(300):
+        n = int(rng.integers(1, 9000))
+        s = "".join(rng.choice(list("ACGTN"), n))
+        if fastq:
+            q = "".join(rng.choice(list("@+>I5"), n))
+            lines.append(f"@q{i} c\n{s}\n+\n{q}\n")
+        else:
+            lines.append(f">q{i} comment\n{s}\n")
+    data = "".join(lines).encode()
+    p = tmp_path / ("r.fq.gz" if fastq else "r.fa.gz")
+    write_bgzf(str(p), data, block=block)
+    assert gzip.open(p, "rb").read() == data  # a valid multi-member gzip file
+    plain = tmp_path / "plain.fa"
+    plain.write_bytes(b">x\nACGT\n")
+    paths = [str(plain), str(p)]
+    want = _records(paths)
+    assert len(want) == 301
+    total = sum(os.path.getsize(x) for x in paths)
+    for world in (1, 2, 3, 8, 50):
+        got, parsed = [], []
+        for r in range(world):
+            plan = seqio.shard_plan(paths, r, world)
+            st = {}
+            for ss in seqio.load(plan, max_bases=40_000, stats=st):
+                for i, n in enumerate(ss.names.tolist()):
+                    got.append((n, bytes(ss.buf[int(ss.offsets[i]):int(ss.offsets[i + 1])])))
+            parsed.append(st.get("parsed_bytes", 0))
+        assert got == want, (world, len(got))
+        assert sum(parsed) == total
+        if 1 < world <= 8:
+            assert max(parsed) < total / world + 0x10000 + 64  # a rank's share + at most one member
