@@ -206,9 +206,14 @@ def run_workload(dev, comm, name, args, steps, warmup, rank, world, serial_steps
                 res.close()
                 rsk.close()
 
+        trace = os.environ.get("NTL_BENCH_TRACE")
         for rb, rl in items:
+            t_a = time.perf_counter()
             rsk = d.sketch(rb, k, w, index=ix)  # looked up in the index while emitted: no separate probe pass
+            t_b = time.perf_counter()
             res = d.map(ix, rsk, rl, **params)  # queued behind it; nothing waits
+            if trace:
+                print(f"bench trace: sketch call {1e3 * (t_b - t_a):.3f} ms, map call {1e3 * (time.perf_counter() - t_b):.3f} ms", file=sys.stderr)
             if collect:
                 held.append((rsk, res))
                 take(2)

@@ -163,6 +163,7 @@ struct PafRec { uint32_t read, ctg, q_start, q_end, t_start, t_end, n_hits, stra
 #define MAP_NHA 5    /* per-hit u32 arrays of the global scratch form */
 #define MAP_NRA 10   /* per-run u32 arrays of the global scratch form */
 #define MAP_NCLASS 3
+#define MAP_GROUP 8  /* consecutive reads a wavefront looks at per step (small: a batch of 50 k reads must still fill the device) */
 
 struct MapArgs {
     const MxRecord *mx;
@@ -648,8 +649,8 @@ done:
 /* size class of a read by its number of minimizers (an upper bound of its hits) */
 __device__ __forceinline__ int map_class_of(uint32_t nmx) { return nmx <= 256u ? 0 : (nmx <= 512u ? 1 : 2); }
 
-/* One launch per size class, each over ALL reads with a resident-size grid: a wavefront looks at 64 consecutive reads at a
-   time (one coalesced load of their offsets), votes which of them belong to its class and maps those one after the other.
+/* One launch per size class, each over ALL reads with a resident-size grid: a wavefront looks at MAP_GROUP consecutive reads
+   at a time, votes which of them belong to its class and maps those one after the other.
    No list, no atomic; a class without reads costs one pass over the offsets. */
 template <int MAP_CAPH, int MAP_CAPR, int CLASS>
 __global__ __launch_bounds__(MAP_NT) void map_kernel(MapArgs A)
@@ -668,10 +669,10 @@ __global__ __launch_bounds__(MAP_NT) void map_kernel(MapArgs A)
     RU.start = q; RU.leader = q + MAP_CAPR; RU.flag = q + 2 * MAP_CAPR; RU.cnt = q + 3 * MAP_CAPR; RU.mni = q + 4 * MAP_CAPR;
     RU.mxi = q + 5 * MAP_CAPR; RU.last = q + 6 * MAP_CAPR;
     const uint32_t lane = threadIdx.x;
-    for (uint64_t base = (uint64_t)blockIdx.x * MAP_NT; base < A.nreads; base += (uint64_t)gridDim.x * MAP_NT) {
+    for (uint64_t base = (uint64_t)blockIdx.x * MAP_GROUP; base < A.nreads; base += (uint64_t)gridDim.x * MAP_GROUP) {
         const uint64_t r = base + lane;
         bool mine = false;
-        if (r < A.nreads) mine = map_class_of(A.mx_off[r + 1] - A.mx_off[r]) == CLASS;
+        if (lane < MAP_GROUP && r < A.nreads) mine = map_class_of(A.mx_off[r + 1] - A.mx_off[r]) == CLASS;
         unsigned long long bal = __ballot(mine);
         while (bal) {
             const uint32_t j = (uint32_t)__ffsll((long long)bal) - 1u;

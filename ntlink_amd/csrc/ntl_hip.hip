@@ -220,9 +220,15 @@ static void pool_drop_all(ntl_ctx *c)
     c->pool_bytes = 0;
 }
 
+static const bool g_pool_trace = getenv("NTL_POOL_TRACE") != nullptr; /* diagnostics: every hipMalloc / hipFree of the block cache on stderr */
+
 static int dev_alloc(ntl_ctx *c, size_t bytes, void **out)
 {
+    const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(out, bytes);
+    if (g_pool_trace)
+        fprintf(stderr, "ntl pool: hipMalloc %.1f MB -> %s in %.3f ms (cached %.1f MB of %.1f)\n", bytes / 1e6, e == hipSuccess ? "ok" : "FAILED",
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), c->pool_bytes / 1e6, c->pool_cap / 1e6);
     if (e != hipSuccess) {
         /* drop the cache and retry once */
         pool_drop_all(c);
@@ -252,6 +258,15 @@ struct DevBuf {
         used = (uint8_t)(1u << sid);
         size_t want = n ? n : 256;
         want = (want + 255) & ~(size_t)255;
+        /* Size classes (32 per power of two, at most 3 % over the request): consecutive read batches ask for arrays whose
+           sizes differ in the fourth digit, and a cached block a hair smaller than the request is useless -- without classes
+           every batch allocated its largest arrays anew while the cache filled with near-misses up to its bound and then
+           evicted (hipFree: a device-wide wait) exactly the blocks the next batch wanted (C5: 2.6 s per step instead of 0.45). */
+        if (want >= ((size_t)1 << 20)) {
+            size_t step = (size_t)1 << 15;
+            while ((step << 6) <= want) step <<= 1; /* step = 2^(floor(log2 want) - 5) */
+            want = (want + step - 1) & ~(step - 1);
+        }
         const size_t most = want + want / 4 + (1 << 20);
         /* look for a cached block; its true size is the map key */
         auto it = c->pool[sid].lower_bound(want);
@@ -303,6 +318,7 @@ struct DevBuf {
                     if (!c->pool[i].empty() && (!big || std::prev(c->pool[i].end())->first > std::prev(big->end())->first)) big = &c->pool[i];
                 if (big && (c->xpool.empty() || std::prev(big->end())->first >= std::prev(c->xpool.end())->first)) {
                     auto it = std::prev(big->end());
+                    if (g_pool_trace) fprintf(stderr, "ntl pool: over the bound, hipFree %.1f MB\n", it->first / 1e6);
                     (void)hipFree(it->second); /* waits for the device: safe whatever is still queued */
                     c->pool_bytes -= it->first;
                     big->erase(it);
@@ -1027,7 +1043,10 @@ static void launch_fast_r0(ntl_ctx *c, const Sketch2Args &B, unsigned strips)
     if (B.A.G.r0 == R0) {
         const dim3 grid((strips + 7u) & ~7u);
         /* the 20-KB variants hold 128 searched windows per strip: about NWO / (w + 1) are expected (38 at w = 100) */
-        static const int lanes = [] { const char *e = getenv("NTL_SKETCH_LANES"); return e ? atoi(e) : 1; }(); /* 0: every lane walks its windows (A/B) */
+        /* NTL_SKETCH_LANES=1: sketch_lanes_kernel, the variant that walks only the lanes whose minimum can change -- 30 % fewer
+           VALU instructions, but its single-wavefront phases halve the number of runnable wavefronts per SIMD and the launch
+           takes 5-6 % LONGER (profiles/r03*_lanes*): an experiment that is kept for the record, not the default */
+        static const int lanes = [] { const char *e = getenv("NTL_SKETCH_LANES"); return e ? atoi(e) : 0; }();
         if (B.A.G.a + 2 <= 16 && B.A.G.w >= 64 && B.A.G.a >= 2 && lanes && B.dbg == 0) hipLaunchKernelGGL((sketch_lanes_kernel<NT, R0>), grid, dim3(NT), 0, c->wstream, B);
         else if (B.A.G.a + 2 <= 16 && B.A.G.w >= 64) hipLaunchKernelGGL((sketch_fast_kernel<NT, R0, false>), grid, dim3(NT), 0, c->wstream, B);
         else hipLaunchKernelGGL((sketch_fast_kernel<NT, R0, true>), grid, dim3(NT), 0, c->wstream, B);
@@ -1703,10 +1722,10 @@ static int map_enqueue(ntl_ctx *c, const ntl_index *ix, const ntl_sketch *reads,
             ProfSpan sp(c, "map");
             /* reads by size class, each class with the LDS staging that fits it; resident-size grids (28 / 14 / 8 wavefronts
                per CU fit) looping over all reads, 64 at a time */
-            const uint64_t groups = (nreads + MAP_NT - 1) / MAP_NT;
-            hipLaunchKernelGGL((map_kernel<256, 64, 0>), dim3((unsigned)std::min<uint64_t>(groups, 8192)), dim3(MAP_NT), 0, ms, A);
-            hipLaunchKernelGGL((map_kernel<512, 128, 1>), dim3((unsigned)std::min<uint64_t>(groups, 4096)), dim3(MAP_NT), 0, ms, A);
-            hipLaunchKernelGGL((map_kernel<1024, 128, 2>), dim3((unsigned)std::min<uint64_t>(groups, 2048)), dim3(MAP_NT), 0, ms, A);
+            const uint64_t groups = (nreads + MAP_GROUP - 1) / MAP_GROUP;
+            hipLaunchKernelGGL((map_kernel<256, 64, 0>), dim3((unsigned)std::min<uint64_t>(groups, 4 * 7168)), dim3(MAP_NT), 0, ms, A);
+            hipLaunchKernelGGL((map_kernel<512, 128, 1>), dim3((unsigned)std::min<uint64_t>(groups, 4 * 3584)), dim3(MAP_NT), 0, ms, A);
+            hipLaunchKernelGGL((map_kernel<1024, 128, 2>), dim3((unsigned)std::min<uint64_t>(groups, 4 * 2048)), dim3(MAP_NT), 0, ms, A);
             /* reads with more hits / runs than the largest staging holds (rare): same code on global scratch */
             hipLaunchKernelGGL(map_overflow_kernel, dim3((unsigned)std::min<uint64_t>(nreads, 8192)), dim3(MAP_NT), 0, ms, A); /* no LDS: 32 wavefronts per CU resident */
             HIPCHK(c, hipGetLastError());

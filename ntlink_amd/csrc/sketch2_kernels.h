@@ -682,7 +682,10 @@ __global__ __launch_bounds__(NT) void sketch_lanes_kernel(Sketch2Args B)
     /* ---- phases 4-5 for the listed lanes: wavefront (strip + round) mod NW takes round `round` of 64 list entries ---- */
     {
         const uint32_t nalive = s_nalive;
-        const uint32_t round = (((uint32_t)L >> 6) + NW - (strip % NW)) % NW;
+        /* which wavefront: a hash of the strip index (workgroups reach a CU in an order that correlates with their index:
+           the plain index modulo NW would give every workgroup of a CU the same wavefront) */
+        const uint32_t rot = (strip * 2654435761u) >> 30;
+        const uint32_t round = (((uint32_t)L >> 6) + NW - (rot % NW)) % NW;
         const uint32_t li = round * 64u + ((uint32_t)L & 63u);
         const bool act = li < nalive;
         if (__ballot(act) != 0ull) {
@@ -772,7 +775,7 @@ __global__ __launch_bounds__(NT) void sketch_lanes_kernel(Sketch2Args B)
     {
         uint32_t njobs = s_njobs;
         if (njobs > (uint32_t)JOBCAP) { njobs = JOBCAP; if (L == 0) s_flag = 4u; }
-        const uint32_t Lq = ((uint32_t)L + 64u * ((strip + NW / 2u) % NW)) % (uint32_t)NT; /* rotated lane number: same quads */
+        const uint32_t Lq = ((uint32_t)L + 64u * ((((strip * 2654435761u) >> 28) & 3u) % NW)) % (uint32_t)NT; /* rotated lane number: same quads */
         const uint32_t q = Lq & 3u, grp = Lq >> 2;
         const uint32_t rounds = (njobs + NT / 4 - 1) / (NT / 4);
         for (uint32_t it = 0; it < rounds; it++) {

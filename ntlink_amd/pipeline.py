@@ -456,7 +456,7 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
     io_stats = {}
     # this rank's share of the read files is opened, inflated and parsed from now on, behind the contig stage
     packed = os.environ.get("NTL_HOST_PACK", "1") != "0"  # the parser threads pack to 2 bits per base: a quarter of the PCIe bytes
-    batches = Prefetch(seqio.load(plan, max_bases=batch_bases, alloc=dev.pinned_empty, stats=io_stats, packed=packed))
+    batches = Prefetch(seqio.load_parallel(plan, max_bases=batch_bases, alloc=dev.pinned_empty, stats=io_stats, packed=packed))
     ctg = seqio.load_all([target], packed=packed)  # used once: page-locking a buffer for it would cost more than the staged copy
     ctg_len = ctg.lengths
     t_ctg_parsed = time.perf_counter()
@@ -505,6 +505,7 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
         stats["parsed_bytes"] = io_stats.get("parsed_bytes", 0)
         stats["reader"] = {key: round(io_stats.get(key, 0.0), 4) for key in ("t_reader_count", "t_reader_alloc", "t_reader_parse")}
         stats["reader"]["batches"] = io_stats.get("reader_batches", 0)
+        stats["reader"]["readers"] = io_stats.get("readers", 1)
         if comm.world > 1:
             t_fin = time.perf_counter()
             exts = [e for e, on in ((".verbose_mapping.tsv", verbose), (".paf", paf)) if on]

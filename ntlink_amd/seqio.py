@@ -314,6 +314,98 @@ def load(paths, max_bases=None, alloc=None, ahead=None, stats=None, packed=False
         yield concat(whole)
 
 
+def load_parallel(paths, readers=None, chunk_bytes=None, max_bases=None, stats=None, **kw):
+    """`load` with several readers at once.  The input is cut into chunks -- a file that cannot be cut (gzip stream, FIFO) is
+    one chunk, plain and BGZF files are cut into byte ranges of about chunk_bytes (default: four batches' worth of text) --
+    and `readers` threads each run `load` on one chunk at a time, the next unclaimed one; the batches come out in input
+    order (a chunk's batches wait in its own queue until the chunks before it have been consumed, so at most `readers` chunks
+    are held).  One reader spends its time in two passes per batch (count, then parse into place) that are bound by the kernel's
+    per-page work on the page cache, not by the parser threads; two or three readers on different chunks overlap them.
+    max_bases is required (whole-input loads have nothing to overlap)."""
+    import itertools
+    import queue
+    import threading
+    if isinstance(paths, str):
+        paths = [paths]
+    if readers is None:
+        readers = int(os.environ.get("NTL_IO_READERS", "0")) or (3 if (os.cpu_count() or 1) >= 32 else 1)
+    if max_bases is None or readers <= 1:
+        yield from load(paths, max_bases=max_bases, stats=stats, **kw)
+        return
+    if chunk_bytes is None:
+        chunk_bytes = int(os.environ.get("NTL_IO_CHUNK_BYTES", "0")) or max(4 * int(max_bases), 64 << 20)
+    chunks = []
+    for p in paths:
+        path, lo, hi = p if isinstance(p, tuple) else (p, 0, None)
+        if not _splittable(path):
+            chunks.append(p)
+            continue
+        hi = os.path.getsize(path) if hi is None else int(hi)
+        n = max(1, -(-(hi - int(lo)) // chunk_bytes))
+        if n == 1 and not isinstance(p, tuple):
+            chunks.append(p)
+            continue
+        for i in range(n):
+            a, b = int(lo) + (hi - int(lo)) * i // n, int(lo) + (hi - int(lo)) * (i + 1) // n
+            if a < b:
+                chunks.append((path, a, b))
+    if len(chunks) <= 1:
+        yield from load(paths, max_bases=max_bases, stats=stats, **kw)
+        return
+    END = object()
+    qs = [queue.Queue() for _ in chunks]
+    claim = itertools.count()
+    lock, stop = threading.Lock(), threading.Event()
+    go = threading.Semaphore(readers)  # a reader starts a new chunk only when fewer than `readers` chunks are unconsumed
+    part_stats = []
+
+    def work():
+        while not stop.is_set():
+            go.acquire()
+            if stop.is_set():
+                return
+            with lock:
+                i = next(claim)
+            if i >= len(chunks):
+                return
+            st = {}
+            try:
+                for ss in load([chunks[i]], max_bases=max_bases, stats=st, **kw):
+                    qs[i].put(ss)
+                    if stop.is_set():
+                        break
+                qs[i].put(END)
+            except BaseException as exc:  # re-raised by the consumer at this chunk's place
+                qs[i].put(exc)
+            with lock:
+                part_stats.append(st)
+
+    threads = [threading.Thread(target=work, daemon=True) for _ in range(min(readers, len(chunks)))]
+    for t in threads:
+        t.start()
+    try:
+        for i in range(len(chunks)):
+            while True:
+                item = qs[i].get()
+                if item is END:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                yield item
+            go.release()
+    finally:
+        stop.set()
+        for _ in threads:
+            go.release()
+        for t in threads:
+            t.join()
+        if stats is not None:
+            for st in part_stats:
+                for key, v in st.items():
+                    stats[key] = stats.get(key, 0) + v
+            stats["readers"] = len(threads)
+
+
 def concat(sets):
     if len(sets) == 1:
         return sets[0]

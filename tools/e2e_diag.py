@@ -77,13 +77,14 @@ def main():
         t0 = time.perf_counter()
         files = prepare(d, a.bases, a.workload)
         print(json.dumps({"prepared": len(files), "seconds": round(time.perf_counter() - t0, 1)}), flush=True)
-        configs = [({}, 256_000_000), ({}, 256_000_000),  # twice: page-cache and pool warm-up
-                   ({"NTL_IO_THREADS": "64"}, 256_000_000), ({"NTL_IO_THREADS": "128"}, 256_000_000),
-                   ({"NTL_IO_THREADS": "64"}, 1_000_000_000), ({"NTL_IO_THREADS": "128"}, 1_000_000_000),
-                   ({"NTL_IO_THREADS": "64", "NTL_DEVICE_STREAMS": "1"}, 512_000_000),
-                   ({"NTL_IO_THREADS": "64", "NTL_DEVICE_STREAMS": "3"}, 512_000_000),
-                   ({"NTL_IO_THREADS": "64", "NTL_IO_PREAD": "1"}, 512_000_000),
-                   ({"NTL_IO_THREADS": "64", "NTL_PIPELINE": "0"}, 512_000_000)]
+        configs = [({"NTL_IO_READERS": "1"}, 256_000_000), ({"NTL_IO_READERS": "1"}, 256_000_000),  # twice: page-cache and pool warm-up
+                   ({"NTL_IO_READERS": "2"}, 256_000_000), ({"NTL_IO_READERS": "3"}, 256_000_000), ({"NTL_IO_READERS": "4"}, 256_000_000),
+                   ({"NTL_IO_READERS": "3", "NTL_IO_THREADS": "64"}, 256_000_000),
+                   ({"NTL_IO_READERS": "3", "NTL_IO_THREADS": "16"}, 256_000_000),
+                   ({"NTL_IO_READERS": "6", "NTL_IO_THREADS": "16"}, 256_000_000),
+                   ({"NTL_IO_READERS": "3"}, 512_000_000),
+                   ({"NTL_IO_READERS": "3", "NTL_DEVICE_STREAMS": "1"}, 256_000_000),
+                   ({"NTL_IO_READERS": "3", "NTL_DEVICE_STREAMS": "3"}, 256_000_000)]
         for env, batch in configs:
             subprocess.run([sys.executable, os.path.abspath(__file__), "--run", d, "--batch", str(batch)], env=dict(os.environ, **env), check=False)
         if a.forms:
