@@ -600,7 +600,13 @@ def end_to_end(dev, wl, W, args):
         finally:
             os.chdir(cwd)
         out_bytes = sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d) if f.startswith("asm.fa."))
-        return {"value": round(st["read_bases"] / dt / 1e9, 3), "unit": "Gbases/s", "seconds": round(dt, 3),
+        gz = {}
+        try:  # the forms reads really arrive in (ntLink:113-117,222: `gzip -cd -f FILES`): several .fq.gz files, one bgzip'd file
+            gz = gz_forms(dev, d, files[0], W, cwd)
+        except Exception as exc:
+            gz = {"error": f"{type(exc).__name__}: {exc}"}
+        return {"value": round(st["read_bases"] / dt / 1e9, 3), "unit": "Gbases/s", "seconds": round(dt, 3), "compressed_inputs": gz,
+                "reader": st.get("reader"),
                 "read_bases": st["read_bases"], "reads": st["reads"], "input": f"plain FASTA, {len(files)} read file(s), page cache ({d})",
                 "output_bytes": out_bytes, "prepare_inputs_s": round(prep_s, 1),
                 "t_contig_stage": round(st["t_contigs"], 3), "t_contig_stage_parts": st.get("t_contigs_parts"), "t_wait_for_ingest": round(st["t_ingest"], 3),
@@ -610,6 +616,77 @@ def end_to_end(dev, wl, W, args):
                 "device_streams": int(os.environ.get("NTL_DEVICE_STREAMS", "2"))}
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+def gz_forms(dev, d, fasta, W, cwd, max_bases=2_000_000_000):
+    """The first reads file of the end-to-end leg again as (a) 16 gzip'd FASTQ files and (b) one BGZF (bgzip) FASTQ file, each mapped
+    file to file against the same assembly.  The files are made here with zlib level 1 on a thread per file / per 16 blocks."""
+    import struct
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+    from ntlink_amd import pipeline
+    import numpy as np
+    raw = np.fromfile(os.path.join(d, fasta), np.uint8, count=int(max_bases * 1.01))
+    data = raw.tobytes()
+    del raw
+    recs = data.split(b">")[1:]
+    if not data.endswith(b"\n"):
+        recs = recs[:-1]
+    nfiles = 16
+    per = -(-len(recs) // nfiles)
+
+    def fastq(rs):
+        out = []
+        for r in rs:
+            nl = r.index(b"\n")
+            seq = r[nl + 1:].rstrip(b"\n")
+            out.append(b"@" + r[:nl] + b"\n" + seq + b"\n+\n" + b"I" * len(seq) + b"\n")
+        return b"".join(out)
+
+    def one_gz(i):
+        txt = fastq(recs[i * per:(i + 1) * per])
+        co = zlib.compressobj(1, zlib.DEFLATED, 31)
+        with open(os.path.join(d, f"fq_{i:02d}.fq.gz"), "wb") as fh:
+            fh.write(co.compress(txt) + co.flush())
+        return txt
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(nfiles) as ex:
+        texts = list(ex.map(one_gz, range(nfiles)))
+    whole = b"".join(texts)
+    del texts
+    blocks = [whole[i:i + 0xFF00] for i in range(0, len(whole), 0xFF00)] + [b""]
+
+    def bgzf_blocks(lo):
+        out = []
+        for ch in blocks[lo:lo + 64]:
+            co = zlib.compressobj(1, zlib.DEFLATED, -15)
+            body = co.compress(ch) + co.flush()
+            out.append(b"\x1f\x8b\x08\x04" + b"\x00" * 4 + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(body) + 8 - 1)
+                       + body + struct.pack("<II", zlib.crc32(ch) & 0xFFFFFFFF, len(ch)))
+        return b"".join(out)
+
+    with ThreadPoolExecutor(32) as ex, open(os.path.join(d, "all.fq.bgz.gz"), "wb") as fh:
+        for piece in ex.map(bgzf_blocks, range(0, len(blocks), 64)):
+            fh.write(piece)
+    del whole, blocks, recs, data
+    prep_s = time.perf_counter() - t0
+    out = {"prepare_s": round(prep_s, 1)}
+    os.chdir(d)
+    try:
+        for name, reads in (("16_fq_gz_files", " ".join(f"fq_{i:02d}.fq.gz" for i in range(nfiles))), ("one_bgzf_fq_gz", "all.fq.bgz.gz")):
+            for f in os.listdir(d):
+                if f.startswith("gzrun."):
+                    os.remove(os.path.join(d, f))
+            t0 = time.perf_counter()
+            st = pipeline.run_pair(dev, "asm.fa", reads, prefix="gzrun", k=W["k"], w=W["w"], paf=True, pairs_tsv=True, sensitive=W["sensitive"],
+                                   write_contig_tsv=False)
+            dt = time.perf_counter() - t0
+            out[name] = {"value": round(st["read_bases"] / dt / 1e9, 3), "unit": "Gbases/s", "seconds": round(dt, 3), "read_bases": st["read_bases"],
+                         "compressed_bytes": sum(os.path.getsize(os.path.join(d, x)) for x in reads.split())}
+    finally:
+        os.chdir(cwd)
+    return out
 
 
 if __name__ == "__main__":

@@ -215,7 +215,7 @@ def load(paths, max_bases=None, alloc=None, ahead=None, stats=None, packed=False
     SeqSets of about that many bases; several files are concatenated in the order given and a batch
     never spans two files.  alloc(nbytes) -> uint8 array supplies the sequence buffers (the pair
     driver passes the device's page-locked pool); default numpy.  Opening a gzip file inflates it, so
-    the next `ahead` files (default min(8, cores/4), at most 2 GiB of compressed input) are opened by
+    the next `ahead` files (default min(32, cores/4), at most 2 GiB of compressed input) are opened by
     background threads while the current one is consumed: many .fq.gz files decode in parallel.  An entry of `paths` may
     be (path, lo, hi): the records of a plain file that start in that byte range (shard_plan).  stats["parsed_bytes"]
     accumulates the input bytes consumed (file bytes of plain files and ranges, compressed bytes of gzip files).
@@ -229,7 +229,7 @@ def load(paths, max_bases=None, alloc=None, ahead=None, stats=None, packed=False
     if isinstance(paths, str):
         paths = [paths]
     trace = bool(os.environ.get("NTL_IO_TRACE"))
-    n_ahead = ahead if ahead is not None else min(8, max(1, (os.cpu_count() or 1) // 4))
+    n_ahead = ahead if ahead is not None else min(32, max(1, (os.cpu_count() or 1) // 4))
     whole = []
     pending = collections.deque()  # (path, future of an open handle, compressed bytes)
     todo = iter(paths)
@@ -328,7 +328,7 @@ def load_parallel(paths, readers=None, chunk_bytes=None, max_bases=None, stats=N
     if isinstance(paths, str):
         paths = [paths]
     if readers is None:
-        readers = int(os.environ.get("NTL_IO_READERS", "0")) or (3 if (os.cpu_count() or 1) >= 32 else 1)
+        readers = int(os.environ.get("NTL_IO_READERS", "0")) or (2 if (os.cpu_count() or 1) >= 32 else 1)  # measured on the 256-core GPU host: 1 -> 2 readers +7 %, more only move the wait to the writers
     if max_bases is None or readers <= 1:
         yield from load(paths, max_bases=max_bases, stats=stats, **kw)
         return

@@ -521,3 +521,38 @@ def test_nthash_ring_sums_cannot_wrap():
             assert bin(f ^ r).count("1") % 2 == 0
             c = int(h0[p]) >> 33
             assert c in ((f + r) & 0x7FFFFFFF, (f + r + 1) & 0x7FFFFFFF) and (f + r) & 0x7FFFFFFF != 0x7FFFFFFF
+
+
+def test_parallel_readers_keep_the_input_order(tmp_path):
+    """seqio.load_parallel: several readers on chunks of the input (byte ranges of plain and BGZF files, whole gzip streams),
+    batches handed out in input order -- the records and the byte accounting of one serial reader, for any reader count and
+    chunk size; a consumer that stops early leaves no thread behind."""
+    import gzip
+    import threading
+    from helpers import write_bgzf
+    rng = np.random.default_rng(5)
+    paths = []
+    for f in range(3):
+        p = tmp_path / f"r{f}.fa"
+        with open(p, "w") as fh:
+            for i in range(300):
+                fh.write(f">f{f}_{i} c\n" + "".join(rng.choice(list("ACGTN"), int(rng.integers(1, 5000)))) + "\n")
+        paths.append(str(p))
+    write_bgzf(str(tmp_path / "z.fa.gz"), open(paths[1], "rb").read())
+    with gzip.open(tmp_path / "plain.fa.gz", "wt") as fh:
+        fh.write(">g1\nACGTACGT\n>g2\nTTTT\n")
+    paths[1:1] = [str(tmp_path / "z.fa.gz"), str(tmp_path / "plain.fa.gz")]
+    want = _records(list(seqio.load(paths, max_bases=30_000)))
+    assert len(want) == 1202
+    total = sum(os.path.getsize(p) for p in paths)
+    before = threading.active_count()
+    for readers in (2, 3, 5):
+        for chunk in (50_000, 300_000, 10_000_000):
+            st = {}
+            got = _records(list(seqio.load_parallel(paths, readers=readers, chunk_bytes=chunk, max_bases=30_000, stats=st)))
+            assert got == want, (readers, chunk)
+            assert st["parsed_bytes"] == total
+    g = seqio.load_parallel(paths, readers=3, chunk_bytes=50_000, max_bases=30_000)
+    next(g)
+    g.close()
+    assert threading.active_count() <= before + 1
