@@ -182,7 +182,8 @@ class _Handle:
 
     def close(self):
         if self.ptr:
-            getattr(self.dev.L, self._destroy)(self.ptr)
+            if self.dev.ptr:  # a handle that outlives its context (interpreter shutdown order) must not touch it any more
+                getattr(self.dev.L, self._destroy)(self.ptr)
             self.ptr = None
 
     def __del__(self):
