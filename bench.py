@@ -513,6 +513,13 @@ def cpu_baseline(dev, wl, W, params):
     oracle.sketch_batch(rbuf[:int(roff[small])], roff[:small + 1], k, w, threads=4)
     lap("read_sketch_t4", t0)
     t4_bases = int(roff[small])
+    # where the record-parallel sketch stops scaling on this host: the same 1/8 sample at 16 and 64 threads
+    scaling = {"4": round(t4_bases / T["read_sketch_t4"] / 1e6, 1)}
+    for nt in (16, 64):
+        if nt < cores:
+            t0 = time.perf_counter()
+            oracle.sketch_batch(rbuf[:int(roff[small])], roff[:small + 1], k, w, threads=nt)
+            scaling[str(nt)] = round(t4_bases / max(time.perf_counter() - t0, 1e-4) / 1e6, 1)
     # the all-cores leg, twice: the first call also pays for creating the thread team and first-touching the output arrays
     t0 = time.perf_counter()
     ro, rh, rp, rs = oracle.sketch_batch(rbuf, roff, k, w, threads=cores)
@@ -543,6 +550,7 @@ def cpu_baseline(dev, wl, W, params):
                              "what": f"per-thread sketch rate at t=4 ({per_thread_t4 / 1e6:.1f} Mbases/s/thread) x {cores} threads + the measured read-parallel map: "
                                      "the ceiling of the same code if it scaled perfectly over the host's cores"},
             "stages_s": T,
+            "read_sketch_scaling_Mbases_per_s": dict(scaling, **{str(cores): round(bases / T["read_sketch_all_cores"] / 1e6, 1)}),
             "stage_rates": {"read_sketch_t4_Mbases_per_s": round(t4_bases / T["read_sketch_t4"] / 1e6, 1),
                             "read_sketch_all_cores_Mbases_per_s": round(bases / T["read_sketch_all_cores"] / 1e6, 1),
                             "read_sketch_all_cores_first_call_Mbases_per_s": round(bases / T["read_sketch_all_cores_first_call"] / 1e6, 1),
