@@ -23,6 +23,15 @@ TSV_BLOCK_BYTES = 256 << 20  # text of the read-minimizer TSV parsed per device 
 DEFAULT_BATCH_BASES = 256_000_000  # read bases per device batch (packed: 64 MB); the next batch is parsed meanwhile
 
 
+_TRACE = [] if os.environ.get("NTL_PIPE_TRACE") else None  # (seconds, thread, what, batch): a timeline of the pair driver, dumped at the end
+
+
+def _mark(what, seq=-1):
+    if _TRACE is not None:
+        import threading
+        _TRACE.append((time.perf_counter(), threading.current_thread().name, what, seq))
+
+
 def _log(*a):
     print(datetime.datetime.today(), ":", *a, file=sys.stdout, flush=True)
 
@@ -203,7 +212,9 @@ class Prefetch:
         def run():
             try:
                 for item in gen:
+                    _mark("reader_out")
                     self._q.put(item)
+                    _mark("reader_put_done")
                     if self._stop:
                         gen.close()  # closes the readers the generator holds
                         return
@@ -368,6 +379,7 @@ def _map_batches(dev, ix, batches, drain, stats, t_mark, w, **map_kw):
                 if got is None:
                     return
                 seq, rs_ = got
+                _mark("dev_start", seq)
                 t_dev = time.perf_counter()
                 rl = rs_.lengths
                 with (wdev.batch_packed(rs_) if rs_.packed is not None else wdev.batch(rs_.buf, rs_.offsets)) as rb:
@@ -381,6 +393,7 @@ def _map_batches(dev, ix, batches, drain, stats, t_mark, w, **map_kw):
                             pres = res.download(pinned=True)
                             n_mx, n_hit = rsk.count, res.n_index_hits
                 t_done = time.perf_counter()
+                _mark("dev_done", seq)
                 parts = (t_up - t_dev, t_sk - t_up, t_mp - t_sk, t_done - t_mp)
                 with commit:
                     while state["commit_seq"] != seq and state["error"] is None:
@@ -388,7 +401,9 @@ def _map_batches(dev, ix, batches, drain, stats, t_mark, w, **map_kw):
                     if state["error"] is not None:
                         return
                     t_put = time.perf_counter()
+                    _mark("commit", seq)
                     drain.put(pres, rs_.names, rl)
+                    _mark("handed_over", seq)
                     now = time.perf_counter()
                     stats["t_device"] += t_done - t_dev      # H2D + pack + kernels + D2H, summed over the worker threads
                     for key, v in zip(("upload_pack", "sketch", "map", "download_free"), parts):
@@ -467,7 +482,9 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
     out = PairOutputs(prefix, ctg.names, ctg_len, k, f, verbose, paf, part=part)
 
     def consume(pres, names, lens):
+        _mark("write_start")
         out.add(pres, names, lens)
+        _mark("write_done")
         pres.get("_owner", dev).pinned_release(pres.get("_pinned"))
 
     def emit_contig_tsv(off, h, p, s):
@@ -525,6 +542,11 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
                     for key in ("read_bases", "reads", "read_minimizers", "index_hits", "parsed_bytes"):
                         stats[key] += st[key]
             stats["t_merge"] = time.perf_counter() - t_fin
+        if _TRACE is not None:
+            with open(os.environ["NTL_PIPE_TRACE"], "w") as fh:
+                fh.write(f"# t_start {t_start:.6f} (perf_counter; NTL_IO_TRACE lines carry the same clock)\n")
+                for t, th, what, seq in _TRACE:
+                    fh.write(f"{t - t_start:.6f}\t{th}\t{what}\t{seq}\n")
         if root:
             t_fin = time.perf_counter()
             finish_pairs(out.tally, prefix, n, a, pairs_tsv)

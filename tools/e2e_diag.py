@@ -77,6 +77,11 @@ def main():
         t0 = time.perf_counter()
         files = prepare(d, a.bases, a.workload)
         print(json.dumps({"prepared": len(files), "seconds": round(time.perf_counter() - t0, 1)}), flush=True)
+        if os.environ.get("NTL_E2E_TRACE_ONLY"):
+            for i in range(2):
+                subprocess.run([sys.executable, os.path.abspath(__file__), "--run", d, "--batch", "256000000"],
+                               env=dict(os.environ, NTL_PIPE_TRACE=os.environ["NTL_E2E_TRACE_ONLY"] + f".{i}", NTL_IO_TRACE="1"), check=False)
+            return
         configs = [({"NTL_IO_READERS": "1"}, 256_000_000), ({"NTL_IO_READERS": "1"}, 256_000_000),  # twice: page-cache and pool warm-up
                    ({"NTL_IO_READERS": "2"}, 256_000_000), ({"NTL_IO_READERS": "3"}, 256_000_000), ({"NTL_IO_READERS": "4"}, 256_000_000),
                    ({"NTL_IO_READERS": "3", "NTL_IO_THREADS": "64"}, 256_000_000),
