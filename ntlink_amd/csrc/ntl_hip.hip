@@ -1297,9 +1297,12 @@ static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const nt
             E.ix_bits = ix->bits; E.cand = s->cand.as<Cand>(); E.nfound = &dsums->nfound;
         }
         /* the emit kernel is the last reader of the bitmask and clears the words it read: the mask goes back clean */
-        if (probe == 0) hipLaunchKernelGGL(emit_kernel<0>, dim3((unsigned)tiles), dim3(EMIT_NT), 0, ms, E);
-        else if (probe == 1) hipLaunchKernelGGL(emit_kernel<1>, dim3((unsigned)tiles), dim3(EMIT_NT), 0, ms, E);
-        else hipLaunchKernelGGL(emit_kernel<2>, dim3((unsigned)tiles), dim3(EMIT_NT), 0, ms, E);
+        static const int emit_u = [] { const char *e = getenv("NTL_EMIT_U"); return e ? atoi(e) : 1; }(); /* minimizers in flight per thread */
+        if (probe == 0) hipLaunchKernelGGL((emit_kernel<0, 1>), dim3((unsigned)tiles), dim3(EMIT_NT), 0, ms, E);
+        else if (probe == 1 && emit_u >= 2) hipLaunchKernelGGL((emit_kernel<1, 2>), dim3((unsigned)tiles), dim3(EMIT_NT), 0, ms, E);
+        else if (probe == 1) hipLaunchKernelGGL((emit_kernel<1, 1>), dim3((unsigned)tiles), dim3(EMIT_NT), 0, ms, E);
+        else if (emit_u >= 2) hipLaunchKernelGGL((emit_kernel<2, 2>), dim3((unsigned)tiles), dim3(EMIT_NT), 0, ms, E);
+        else hipLaunchKernelGGL((emit_kernel<2, 1>), dim3((unsigned)tiles), dim3(EMIT_NT), 0, ms, E);
         HIPCHK(c, hipGetLastError());
         mask.clean = sev_get(c);
         if (mask.clean) HIPCHK(c, hipEventRecord(mask.clean, ms));

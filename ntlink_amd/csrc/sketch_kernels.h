@@ -482,7 +482,7 @@ __device__ __forceinline__ uint32_t seq_of(const uint64_t *base, uint32_t lo, ui
 }
 
 /* PROBE: 0 = records only, 1 = + index lookup through the slot tags, 2 = + index lookup on the slots directly (index_common.h) */
-template <int PROBE>
+template <int PROBE, int U = 1>
 __global__ __launch_bounds__(EMIT_NT) void emit_kernel(EmitArgs A)
 {
     unsigned long long found = 0;
@@ -559,27 +559,46 @@ __global__ __launch_bounds__(EMIT_NT) void emit_kernel(EmitArgs A)
         }
         __syncthreads();
         const uint32_t n = total - r0 < EMIT_CAP ? total - r0 : EMIT_CAP;
-        for (uint32_t i = t; i < n; i += EMIT_NT) {
-            const uint64_t gp = tile_w0 * 32 + s_list[i];
-            const uint32_t sq = cached ? s_lo + seq_of(s_base, 0, s_hi - s_lo, gp) : seq_of(A.seq_base, s_lo, s_hi, gp);
-            const uint64_t sb = cached ? s_base[sq - s_lo] : A.seq_base[sq];
-            uint64_t fwd, rev;
-            hash_init_g4(A.packed, gp, A.k, s_g4, s_seed, fwd, rev);
-            uint64_t tt = (fwd + rev) * A.mult;
-            tt ^= tt >> 27;
-            MxRecord R;
-            R.hash = tt;
-            R.pos = (uint32_t)(gp - sb);
-            R.meta = (sq << 1) | (fwd <= rev ? 1u : 0u);
-            if (tile_base + r0 + i < A.out_cap) {
-                A.out[tile_base + r0 + i] = R;
-                if (PROBE) {
-                    IndexProbe<PROBE == 1> pr;
-                    pr.start(tt, A.slots, A.tags, A.ix_bits);
-                    const Cand cd = pr.finish(tt, A.slots, A.tags, A.special, ((uint64_t)1 << A.ix_bits) - 1);
-                    A.cand[tile_base + r0 + i] = cd;
+        /* U minimizers per thread and step, in straight-line code: their base-word loads, and then their first index loads, are
+           in flight together (the kernel's time is the latency of these dependent random accesses, not its arithmetic) */
+        for (uint32_t i0 = t; i0 < n; i0 += U * EMIT_NT) {
+            uint64_t tt[U];
+            MxRecord R[U];
+            bool ok[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t i = i0 + (uint32_t)u * EMIT_NT;
+                const uint32_t ic = i < n ? i : i0; /* past the end: the first one again, result dropped */
+                const uint64_t gp = tile_w0 * 32 + s_list[ic];
+                const uint32_t sq = cached ? s_lo + seq_of(s_base, 0, s_hi - s_lo, gp) : seq_of(A.seq_base, s_lo, s_hi, gp);
+                const uint64_t sb = cached ? s_base[sq - s_lo] : A.seq_base[sq];
+                uint64_t fwd, rev;
+                hash_init_g4(A.packed, gp, A.k, s_g4, s_seed, fwd, rev);
+                uint64_t h = (fwd + rev) * A.mult;
+                h ^= h >> 27;
+                tt[u] = h;
+                R[u].hash = h;
+                R[u].pos = (uint32_t)(gp - sb);
+                R[u].meta = (sq << 1) | (fwd <= rev ? 1u : 0u);
+                ok[u] = i < n && tile_base + r0 + i < A.out_cap;
+            }
+            if (PROBE) {
+                IndexProbe<PROBE == 1> pr[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) pr[u].start(tt[u], A.slots, A.tags, A.ix_bits);
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    if (!ok[u]) continue;
+                    const uint32_t at = tile_base + r0 + i0 + (uint32_t)u * EMIT_NT;
+                    A.out[at] = R[u];
+                    const Cand cd = pr[u].finish(tt[u], A.slots, A.tags, A.special, ((uint64_t)1 << A.ix_bits) - 1);
+                    A.cand[at] = cd;
                     found += cd.meta & 1u;
                 }
+            } else {
+#pragma unroll
+                for (int u = 0; u < U; u++)
+                    if (ok[u]) A.out[tile_base + r0 + i0 + (uint32_t)u * EMIT_NT] = R[u];
             }
         }
         __syncthreads();

@@ -315,3 +315,41 @@ def check_probe_forms(dev, contigs, reads, k, w, **kw):
             assert_same_records(got, exp)
             assert_same_records(got2, exp)
     return fractions
+
+
+def check_async_order(dev, contigs, reads, k, w, **kw):
+    """The calls of the hot path only queue device work: batches are sketched for the index and mapped back to back, their
+    inputs destroyed at once, the NEXT batch queued before the previous one's records are asked for -- records == oracle, per
+    batch.  Then a batch nobody ever asks about: destroying its handles is allowed, and a clean run leaves ntl_ctx_sync clean."""
+    ctg_len = np.array([len(s) for s in contigs], np.uint32)
+    csk = dev.sketch(dev.batch(contigs), k, w)        # the batch handle is dropped at once: the sketch keeps what it needs
+    ix = dev.index(csk, ctg_len)
+    ooff, oh, op, os_ = oracle.sketch_batch(b"".join(contigs), offsets_of(contigs), k, w)
+    oix = oracle.Index(oh, contig_ids(ooff), op, os_)
+    groups = [reads[i::3] for i in range(3)]
+    held = []
+    n_maps = 0
+    for g in groups + [None]:
+        if g is not None:
+            rl = np.array([len(s) for s in g], np.uint32)
+            rb = dev.batch(g)
+            rsk = dev.sketch(rb, k, w, index=ix)
+            res = dev.map(ix, rsk, rl, k=k, **kw)
+            rb.close()
+            rsk.close()                                # before anybody asked for its count
+            held.append((g, rl, res))
+        if len(held) > 1 or (g is None and held):
+            gg, rl, res = held.pop(0)
+            got = res.download()
+            res.close()
+            qoff, qh, qp, qs = oracle.sketch_batch(b"".join(gg), offsets_of(gg), k, w)
+            exp = oracle.map_reads(oix, ctg_len, qoff, rl, qh, qp, qs, k=k, threads=0, **kw)
+            assert_same_records(got, exp)
+            n_maps += len(got["maps"])
+    rb = dev.batch(reads)
+    rsk = dev.sketch(rb, k, w, index=ix)
+    res = dev.map(ix, rsk, np.array([len(s) for s in reads], np.uint32), k=k, **kw)
+    res.close(); rsk.close(); rb.close()               # never looked at
+    dev.sync()                                         # nothing failed behind our back
+    ix.close(); csk.close()
+    return n_maps

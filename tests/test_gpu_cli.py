@@ -50,6 +50,22 @@ def test_ntlink_pair_driver(tmp_path, tag, target, reads, k, w, gold):
         assert set(read_text(str(tmp_path / (prefix + ".paf"))).splitlines()) == TEST7_PAF
 
 
+def test_bgzf_reads_and_parallel_readers(tmp_path, monkeypatch):
+    """Reads as one BGZF (`bgzip`) FASTQ file: members are inflated in parallel and -- with several readers and tiny chunks -- read
+    as ranges of members; outputs byte for byte those of the fixture (test 2 of the reference ships its reads as .fq.gz)."""
+    import gzip
+    from helpers import write_bgzf
+    tag, target, k, w = "t2_k32_w100", "scaffolds_2.fa", 32, 100
+    _stage(tmp_path, target)
+    text = gzip.open(os.path.join(REF, "long_reads_2.fq.gz"), "rb").read()
+    write_bgzf(str(tmp_path / "reads.bgz.fq.gz"), text)
+    env = dict(os.environ, NTL_IO_READERS="3", NTL_IO_CHUNK_BYTES="200000", NTL_IO_THREADS="5", NTL_IO_MIN_CHUNK="20000")
+    cmd = [sys.executable, os.path.join(BIN, "ntLink"), "pair", "-B", f"target={target}", "reads=reads.bgz.fq.gz", f"k={k}", f"w={w}",
+           "paf=True", "ntlink_pairs_tsv=True"]
+    assert subprocess.call(cmd, cwd=tmp_path, env=env) == 0
+    _check_outputs(tmp_path, f"{target}.k{k}.w{w}.z1000", tag, "scaffolds_2.fa.k32.w100")
+
+
 def test_makefile_pipe_two_operators(tmp_path):
     """The reference's own recipe (ntLink:198-199,221-225) with bin/indexlr and bin/ntlink_pair.py
     in place of btllib's indexlr and the reference's ntlink_pair.py, reads split over two files."""

@@ -366,3 +366,48 @@ def test_probe_with_and_without_tags(dev):
     for sens in (False, True):
         fr = pc.check_probe_forms(dev, contigs, reads, 24, 100, z=1000, sensitive=sens)
         assert min(fr) > 0.5
+
+
+def test_async_order_and_unseen_results(dev, monkeypatch):
+    """The queue-only calls on the real device, two streams: handles destroyed early, results asked for one batch late (so the
+    window kernels of a batch really run beside the previous batch's lookup / map kernels); then with a record array that is
+    too small, and the batch nobody asks about, whose overflow the next sync must report."""
+    chroms, cbuf, coff, names, _ = synth.make_assembly(3, 1, 10, 200_000)
+    rbuf, roff, _ = synth.make_reads(4, chroms, 5_000_000, 12_000, 0.02, 0.015, 0.015, lognormal_sigma=0.4)
+    contigs = [cbuf[int(coff[i]):int(coff[i + 1])].tobytes() for i in range(len(coff) - 1)]
+    reads = [rbuf[int(roff[i]):int(roff[i + 1])].tobytes() for i in range(len(roff) - 1)]
+    assert dev.pipelined
+    assert pc.check_async_order(dev, contigs, reads, 32, 100, z=1000) > 100
+    monkeypatch.setenv("NTL_SKETCH_CAP_GUESS", "1000")
+    with pytest.raises(capi.NtlError, match="destroyed before anybody asked"):
+        pc.check_async_order(dev, contigs, reads, 32, 100, z=1000)
+    dev.sync()
+
+
+def test_one_stream_and_back(dev):
+    contigs = pc.fixture_seqs("scaffolds_1.fa")
+    reads = pc.fixture_seqs("long_reads_4_top5.fa")
+    dev.set_pipeline(False)
+    assert not dev.pipelined
+    pc.check_full_pipeline(dev, contigs, reads, 32, 250, z=1000)
+    dev.set_pipeline(True)
+    assert dev.pipelined
+    pc.check_full_pipeline(dev, contigs, reads, 32, 250, z=1000, sensitive=True)
+
+
+@pytest.mark.parametrize("env", [{"NTL_SKETCH_LANES": "1"}, {"NTL_EMIT_U": "2"}, {"NTL_SKETCH_LANES": "1", "NTL_EMIT_U": "2"}],
+                         ids=lambda e: ",".join(f"{k[4:]}={v}" for k, v in e.items()))
+def test_kernel_variants_full_pipeline(dev, monkeypatch, env):
+    """sketch_lanes_kernel (the experiment of DESIGN 4.12) and the two-wide emit kernel on the GPU: scaled-down C3- and C5-like
+    workloads, full pipeline against the oracle, and the fuzz sequences."""
+    import fuzz_cases
+    for k_, v in env.items():
+        monkeypatch.setenv(k_, v)
+    chroms, cbuf, coff, names, _ = synth.make_assembly(1, 1, 12, 250_000, n_run_every=5)
+    contigs = [cbuf[int(coff[i]):int(coff[i + 1])].tobytes() for i in range(len(coff) - 1)]
+    for k, w, rl, sens, err in ((32, 250, 15000, False, (0.02, 0.015, 0.015)), (24, 100, 20000, True, (0.001, 0.0005, 0.0005))):
+        rbuf, roff, _ = synth.make_reads(2, chroms, 6_000_000, rl, *err, lognormal_sigma=0.4)
+        reads = [rbuf[int(roff[i]):int(roff[i + 1])].tobytes() for i in range(len(roff) - 1)]
+        pc.check_full_pipeline(dev, contigs, reads, k, w, z=1000, sensitive=sens)
+    for seed, k, w in ((1, 32, 100), (2, 32, 250), (3, 24, 64), (5, 40, 255)):
+        pc.check_sketch(dev, fuzz_cases.fuzz_sequences(seed), k, w)

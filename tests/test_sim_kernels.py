@@ -300,3 +300,42 @@ def test_sim_probe_with_and_without_tags(dev):
     reads = [contigs[0][500:4000], contigs[1][100:3900] + contigs[2][:2000], _rand_seq(rng, 3000), contigs[0][3000:8000]]
     fr = pc.check_probe_forms(dev, contigs, reads, 24, 30, z=1000)
     assert min(fr) > 0.5
+
+
+def test_sim_async_order_and_unseen_results(dev, monkeypatch):
+    """Queue-only calls, handles destroyed early, results asked for one batch late; then the same with a record array that is
+    too small (both the sketch and the map are made again when the count is finally asked for), and the case nobody asks:
+    the overflow is reported by the next sync instead of vanishing."""
+    from ntlink_amd import capi
+    contigs = pc.fixture_seqs("scaffolds_4.fa")
+    reads = pc.fixture_seqs("long_reads_4_top5.fa")
+    assert pc.check_async_order(dev, contigs, reads, 40, 100, z=1000) > 0
+    monkeypatch.setenv("NTL_SKETCH_CAP_GUESS", "40")
+    with pytest.raises(capi.NtlError, match="destroyed before anybody asked"):
+        pc.check_async_order(dev, contigs, reads, 40, 100, z=1000)  # the records compare equal (redone), the unseen batch is reported
+    dev.sync()  # reported once
+
+
+def test_sim_one_stream_and_back(dev):
+    """ntl_ctx_set_pipeline: the window stage back on the one stream at a quiet point, and out again: same records."""
+    contigs = pc.fixture_seqs("scaffolds_4.fa")
+    reads = pc.fixture_seqs("long_reads_4_top5.fa")
+    assert dev.pipelined
+    dev.set_pipeline(False)
+    assert not dev.pipelined
+    pc.check_full_pipeline(dev, contigs, reads, 40, 100, z=1000)
+    dev.set_pipeline(True)
+    assert dev.pipelined
+    pc.check_full_pipeline(dev, contigs, reads, 40, 100, z=1000, sensitive=True)
+
+
+@pytest.mark.parametrize("env", [{"NTL_SKETCH_LANES": "1"}, {"NTL_EMIT_U": "2"}])
+def test_sim_kernel_variants_full_pipeline(dev, monkeypatch, env):
+    """The window pass that walks only lanes whose minimum can change, and the emit kernel with two minimizers in flight per
+    thread: same records as the oracle on fixtures, fuzz sequences (ties, N patterns) and windows of both 20-KB ranges."""
+    import fuzz_cases
+    for k_, v in env.items():
+        monkeypatch.setenv(k_, v)
+    pc.check_full_pipeline(dev, pc.fixture_seqs("scaffolds_4.fa"), pc.fixture_seqs("long_reads_4_top5.fa"), 40, 100, z=1000)
+    for seed, k, w in ((1, 32, 100), (2, 32, 250), (3, 24, 64)):
+        pc.check_sketch(dev, fuzz_cases.fuzz_sequences(seed)[:12], k, w)
