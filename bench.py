@@ -601,6 +601,16 @@ def end_to_end(dev, wl, W, args):
         cwd = os.getcwd()
         os.chdir(d)
         try:
+            # a first, cold run on one reads file (page-locked staging buffers, worker contexts and thread pools are created on
+            # the way: reported, not hidden), then the timed run on all of them with the process warm -- a 90-Gbases input
+            # amortises the former to nothing
+            t0 = time.perf_counter()
+            st0 = pipeline.run_pair(dev, "asm.fa", files[0], prefix="cold", k=W["k"], w=W["w"], paf=True, pairs_tsv=True,
+                                    sensitive=W["sensitive"], write_contig_tsv=False)
+            dt0 = time.perf_counter() - t0
+            for f in os.listdir(d):
+                if f.startswith("cold."):
+                    os.remove(os.path.join(d, f))
             t0 = time.perf_counter()
             st = pipeline.run_pair(dev, "asm.fa", " ".join(files), k=W["k"], w=W["w"], paf=True, pairs_tsv=True,
                                    sensitive=W["sensitive"])
@@ -614,6 +624,8 @@ def end_to_end(dev, wl, W, args):
         except Exception as exc:
             gz = {"error": f"{type(exc).__name__}: {exc}"}
         return {"value": round(st["read_bases"] / dt / 1e9, 3), "unit": "Gbases/s", "seconds": round(dt, 3), "compressed_inputs": gz,
+                "first_run_cold": {"value": round(st0["read_bases"] / dt0 / 1e9, 3), "unit": "Gbases/s", "seconds": round(dt0, 3), "read_bases": st0["read_bases"],
+                                   "what": "the same driver on the first reads file only, first call in this process"},
                 "reader": st.get("reader"),
                 "read_bases": st["read_bases"], "reads": st["reads"], "input": f"plain FASTA, {len(files)} read file(s), page cache ({d})",
                 "output_bytes": out_bytes, "prepare_inputs_s": round(prep_s, 1),
