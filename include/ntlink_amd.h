@@ -117,6 +117,13 @@ uint64_t ntl_packed_words(uint64_t bases);
 int ntl_batch_create_packed(ntl_ctx *ctx, const uint32_t *packed, const uint64_t *offsets, uint64_t nseq,
                             const uint32_t *seq_run_first, const uint32_t *run_start, const uint32_t *run_len, uint64_t nruns,
                             ntl_batch **out);
+/* The same from a packed stream whose sequences need not be contiguous -- what the one-pass reader (ntl_fastx_next_span /
+ * _parse_span / _copy_span) produces: sequence i = lengths[i] bases from base position positions[i] of the stream (in order,
+ * non-overlapping; bit position 2 * (16 + positions[i] + j) for its base j), span_positions = positions the stream spans;
+ * packed holds ntl_packed_words(span_positions) words.  The words between sequences are never interpreted. */
+int ntl_batch_create_packed_at(ntl_ctx *ctx, const uint32_t *packed, uint64_t span_positions, const uint64_t *positions,
+                               const uint32_t *lengths, uint64_t nseq, const uint32_t *seq_run_first, const uint32_t *run_start,
+                               const uint32_t *run_len, uint64_t nruns, ntl_batch **out);
 uint64_t ntl_batch_nseq(const ntl_batch *b);
 uint64_t ntl_batch_bases(const ntl_batch *b);
 
@@ -283,6 +290,18 @@ int ntl_fastx_copy(const ntl_fastx *r, char *seqs, uint64_t *offsets, char *name
  * as above, *nruns = number of ACGT runs; ntl_fastx_runs then fills seq_run_first[nseq + 1], run_start[nruns], run_len[nruns]. */
 int ntl_fastx_copy_packed(ntl_fastx *r, uint32_t *packed, uint64_t *offsets, char *names, uint64_t *name_offsets, uint64_t *nruns);
 int ntl_fastx_runs(const ntl_fastx *r, uint32_t *seq_run_first, uint32_t *run_start, uint32_t *run_len);
+/* One pass instead of two (count, then parse into place): ntl_fastx_next_span cuts the next span of about max_bases bases
+ * without reading it (*span_bytes = 0 at the end of the input; *packed_words = words the packed array must hold: every parser
+ * thread's range gets room for as many bases as it has bytes -- half as many for FASTQ -- rounded up to whole words);
+ * ntl_fastx_parse_span packs the bases into place and collects records, ids and ACGT runs per thread; ntl_fastx_copy_span
+ * hands them over (positions[nseq] = first base of every sequence in the packed stream, lengths[nseq], ids, the run table of
+ * ntl_fastx_runs, *span_positions for ntl_batch_create_packed_at).  ntl_fastx_parse_span returns NTL_ERANGE when the span cannot
+ * be read this way (a range that ends inside a wrapped FASTQ quality section, qualities shorter than their bases): nothing was
+ * consumed and ntl_fastx_next reads the same records the two-pass way. */
+int ntl_fastx_next_span(ntl_fastx *r, uint64_t max_bases, uint64_t *span_bytes, uint64_t *packed_words);
+int ntl_fastx_parse_span(ntl_fastx *r, uint32_t *packed, uint64_t *nseq, uint64_t *bases, uint64_t *name_bytes, uint64_t *nruns);
+int ntl_fastx_copy_span(const ntl_fastx *r, uint64_t *positions, uint32_t *lengths, char *names, uint64_t *name_offsets,
+                        uint32_t *seq_run_first, uint32_t *run_start, uint32_t *run_len, uint64_t *span_positions);
 const char *ntl_fastx_seqs(ntl_fastx *r);
 const uint64_t *ntl_fastx_offsets(ntl_fastx *r);
 const char *ntl_fastx_names(ntl_fastx *r);

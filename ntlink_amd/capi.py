@@ -18,7 +18,7 @@ DEFAULT_LIB = os.path.join(_HERE, "libntlink_hip.so")
 SYMBOLS = [
     "ntl_ctx_create", "ntl_ctx_destroy", "ntl_last_error", "ntl_ctx_device_name", "ntl_ctx_sync", "ntl_ctx_pipelined", "ntl_ctx_set_pipeline",
     "ntl_prof_enable", "ntl_prof_reset", "ntl_prof_get",
-    "ntl_batch_create", "ntl_batch_create_packed", "ntl_packed_words", "ntl_batch_destroy", "ntl_batch_nseq", "ntl_batch_bases", "ntl_host_alloc", "ntl_host_free",
+    "ntl_batch_create", "ntl_batch_create_packed", "ntl_batch_create_packed_at", "ntl_packed_words", "ntl_batch_destroy", "ntl_batch_nseq", "ntl_batch_bases", "ntl_host_alloc", "ntl_host_free",
     "ntl_synth_genome", "ntl_synth_slices", "ntl_batch_download",
     "ntl_sketch_run", "ntl_sketch_run_indexed", "ntl_sketch_destroy", "ntl_sketch_nseq", "ntl_sketch_count", "ntl_sketch_download",
     "ntl_sketch_strips", "ntl_sketch_redo_strips", "ntl_sketch_wait", "ntl_mapres_wait",
@@ -26,7 +26,7 @@ SYMBOLS = [
     "ntl_index_build", "ntl_index_destroy", "ntl_index_size",
     "ntl_map_run", "ntl_mapres_destroy", "ntl_mapres_n_mappings", "ntl_mapres_n_hits", "ntl_mapres_n_pafs",
     "ntl_mapres_n_index_hits", "ntl_mapres_download",
-    "ntl_fastx_open", "ntl_fastx_open_range", "ntl_fastx_range", "ntl_fastx_close", "ntl_fastx_error", "ntl_fastx_next", "ntl_fastx_sizes", "ntl_fastx_copy", "ntl_fastx_copy_packed", "ntl_fastx_runs", "ntl_fastx_seqs", "ntl_fastx_offsets",
+    "ntl_fastx_open", "ntl_fastx_open_range", "ntl_fastx_range", "ntl_fastx_close", "ntl_fastx_error", "ntl_fastx_next", "ntl_fastx_sizes", "ntl_fastx_copy", "ntl_fastx_copy_packed", "ntl_fastx_runs", "ntl_fastx_next_span", "ntl_fastx_parse_span", "ntl_fastx_copy_span", "ntl_fastx_seqs", "ntl_fastx_offsets",
     "ntl_fastx_names", "ntl_fastx_name_offsets", "ntl_write_indexlr", "ntl_write_verbose", "ntl_write_paf",
     "ntl_tsv_open", "ntl_tsv_close", "ntl_tsv_error", "ntl_tsv_next", "ntl_tsv_sizes", "ntl_tsv_copy",
     "ntl_tally_create", "ntl_tally_destroy", "ntl_tally_add", "ntl_tally_npairs", "ntl_tally_ngaps", "ntl_tally_export", "ntl_tally_merge",
@@ -82,6 +82,10 @@ def load(path=None):
     L.ntl_prof_get.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), u64p]
     L.ntl_batch_create.argtypes = [vp, vp, u64p, C.c_uint64, C.POINTER(vp)]
     L.ntl_batch_create_packed.argtypes = [vp, vp, u64p, C.c_uint64, vp, vp, vp, C.c_uint64, C.POINTER(vp)]
+    L.ntl_batch_create_packed_at.argtypes = [vp, vp, C.c_uint64, vp, vp, C.c_uint64, vp, vp, vp, C.c_uint64, C.POINTER(vp)]
+    L.ntl_fastx_next_span.argtypes = [vp, C.c_uint64, u64p, u64p]
+    L.ntl_fastx_parse_span.argtypes = [vp, vp, u64p, u64p, u64p, u64p]
+    L.ntl_fastx_copy_span.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, u64p]
     L.ntl_packed_words.argtypes = [C.c_uint64]
     L.ntl_packed_words.restype = C.c_uint64
     L.ntl_batch_destroy.argtypes = [vp]
@@ -423,6 +427,12 @@ class Device:
     def batch_packed(self, ss):
         """A SeqSet read with packed=True (seqio.load): 2-bit bases + ACGT-run table made by the parser threads."""
         p = C.c_void_p()
+        if ss.positions is not None:  # read in one pass: the sequences of a parser thread sit at an upper bound of their place
+            lens = ss.lengths
+            self._chk(self.L.ntl_batch_create_packed_at(self.ptr, ss.packed.ctypes.data, int(ss.span_positions), ss.positions.ctypes.data,
+                                                        lens.ctypes.data, len(lens), ss.seq_run_first.ctypes.data, ss.run_start.ctypes.data,
+                                                        ss.run_len.ctypes.data, len(ss.run_start), C.byref(p)))
+            return Batch(self, p)
         self._chk(self.L.ntl_batch_create_packed(self.ptr, ss.packed.ctypes.data, _ptr(ss.offsets, C.c_uint64), len(ss.offsets) - 1,
                                                  ss.seq_run_first.ctypes.data, ss.run_start.ctypes.data, ss.run_len.ctypes.data,
                                                  len(ss.run_start), C.byref(p)))

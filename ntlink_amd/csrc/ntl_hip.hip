@@ -732,6 +732,64 @@ extern "C" int ntl_batch_create_packed(ntl_ctx *c, const uint32_t *packed, const
     return NTL_OK;
 }
 
+/* The same from a packed stream in which the sequences need not be contiguous (ntl_fastx_parse_span: a one-pass reader puts
+ * every parser thread's sequences at an upper bound of their place): sequence i = lengths[i] bases from base position
+ * positions[i] of the stream (non-decreasing, non-overlapping), which spans span_positions positions in all; the words between
+ * sequences are never interpreted. */
+extern "C" int ntl_batch_create_packed_at(ntl_ctx *c, const uint32_t *packed, uint64_t span_positions, const uint64_t *positions,
+                                          const uint32_t *lengths, uint64_t nseq, const uint32_t *seq_run_first, const uint32_t *run_start,
+                                          const uint32_t *run_len, uint64_t nruns, ntl_batch **out)
+{
+    if (!c || !out || !packed || (nseq && (!positions || !lengths)) || !seq_run_first || (nruns && (!run_start || !run_len))) return NTL_EINVAL;
+    *out = nullptr;
+    if (nseq >= ((uint64_t)1 << 31)) return fail(c, NTL_EINVAL, "too many sequences in one batch");
+    if (nruns >= 0xFFFFFFF0ull) return fail(c, NTL_EINVAL, "too many ACGT runs in one batch");
+    if (span_positions >= 0xFFFFFFF0ull - NTL_END_PAD) return fail(c, NTL_EINVAL, "packed stream longer than 2^32 positions");
+    std::unique_ptr<ntl_batch> b(new ntl_batch());
+    b->c = c;
+    b->nseq = nseq;
+    b->seq_len.assign(lengths, lengths + nseq);
+    std::vector<uint64_t> seq_base(nseq + 1);
+    bool multi = false;
+    uint64_t total = 0, prev_end = 0;
+    for (uint64_t i = 0; i < nseq; i++) {
+        if (positions[i] < prev_end || positions[i] + lengths[i] > span_positions) return fail(c, NTL_EINVAL, "sequence positions must be non-overlapping, in order and inside the stream");
+        if (seq_run_first[i + 1] < seq_run_first[i]) return fail(c, NTL_EINVAL, "seq_run_first must be non-decreasing");
+        multi |= seq_run_first[i + 1] - seq_run_first[i] > 1u;
+        seq_base[i] = NTL_LEAD_PAD + positions[i];
+        prev_end = positions[i] + lengths[i];
+        total += lengths[i];
+    }
+    if (seq_run_first[0] != 0 || seq_run_first[nseq] != nruns) return fail(c, NTL_EINVAL, "seq_run_first does not match the run count");
+    seq_base[nseq] = NTL_LEAD_PAD + span_positions;
+    b->bases = total;
+    b->total_gpos = NTL_LEAD_PAD + span_positions;
+    b->nruns = nruns;
+    b->any_multi = multi;
+    b->nwords_packed = (NTL_LEAD_PAD + span_positions + NTL_END_PAD + 15) / 16 + 2;
+    (void)hipSetDevice(c->device);
+    int rc;
+    if ((rc = b->packed.alloc(c, b->nwords_packed * 4)) || (rc = b->seq_base.alloc(c, (nseq + 1) * 8)) ||
+        (rc = b->seq_run_first.alloc(c, (nseq + 1) * 4)) || (rc = b->run_start.alloc(c, (nruns + 1) * 4)) ||
+        (rc = b->run_len.alloc(c, (nruns + 1) * 4)) || (rc = b->seq_len_dev.alloc(c, (nseq + 1) * 4)))
+        return rc;
+    {
+        ProfSpan span(c, "batch_pack");
+        HIPCHK(c, hipMemcpyAsync(b->packed.p, packed, b->nwords_packed * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(b->seq_base.p, seq_base.data(), (nseq + 1) * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(b->seq_run_first.p, seq_run_first, (nseq + 1) * 4, hipMemcpyHostToDevice, c->stream));
+        if (nseq) HIPCHK(c, hipMemcpyAsync(b->seq_len_dev.p, b->seq_len.data(), nseq * 4, hipMemcpyHostToDevice, c->stream));
+        b->d_seq_len = b->seq_len_dev.as<uint32_t>();
+        if (nruns) {
+            HIPCHK(c, hipMemcpyAsync(b->run_start.p, run_start, nruns * 4, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(b->run_len.p, run_len, nruns * 4, hipMemcpyHostToDevice, c->stream));
+        }
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream)); /* the caller's arrays and seq_base are free again */
+    *out = b.release();
+    return NTL_OK;
+}
+
 extern "C" void ntl_batch_destroy(ntl_batch *b) { batch_unref(b); }
 
 extern "C" int ntl_host_alloc(ntl_ctx *c, uint64_t bytes, void **out)

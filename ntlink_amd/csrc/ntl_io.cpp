@@ -93,6 +93,15 @@ struct ntl_fastx {
     std::vector<uint64_t> m_off, m_name_off;
     bool materialized = false;
     std::vector<std::vector<uint32_t>> pk_seq, pk_start, pk_len; /* ACGT runs of the current batch, per range (ntl_fastx_copy_packed) */
+    /* one-pass form (ntl_fastx_next_span / _parse_span / _copy_span): per range where its bases go in the packed stream, and
+       what the single pass collected */
+    std::vector<uint64_t> sp_pos0, sp_bound;                 /* first base position of a range, bases it has room for */
+    std::vector<std::vector<uint64_t>> sp_rec_pos;           /* per range: position of every record's first base */
+    std::vector<std::vector<uint32_t>> sp_rec_len;
+    std::vector<std::string> sp_names;
+    std::vector<std::vector<uint32_t>> sp_name_end;          /* per range: end of every record's id in sp_names[range] */
+    size_t sp_advance = 0;                                   /* input bytes the span covers (cur moves when the parse succeeded) */
+    uint64_t sp_positions = 0;                               /* base positions the packed stream spans (gaps included) */
     std::string err;
 };
 
@@ -1254,6 +1263,195 @@ extern "C" int ntl_fastx_runs(const ntl_fastx *r, uint32_t *seq_run_first, uint3
     }
     seq_run_first[rec] = (uint32_t)run;
     return NTL_OK;
+}
+
+/* ---- one pass: parse straight into place without counting first -------------------------------------------------------
+ * The two-pass reader counts a batch (records, bases, id bytes per thread range) so that every thread can write at its final
+ * offset.  Both passes walk the input, and on a page-cache input each is bound by the kernel's per-page work, not by the
+ * parser: counting costs as much as parsing.  The device does not need the sequences of a batch to be contiguous: a sequence
+ * is (position of its first base in the packed stream, length, ACGT runs).  So a range writes its bases at a position that is
+ * an UPPER bound of where counting would have put it -- the bytes of the ranges before it (a range holds fewer bases than
+ * bytes; half as many for FASTQ, whose qualities are as long as the bases) rounded up to whole packed words -- and collects
+ * its records in its own vectors; a range that outgrows its bound (malformed FASTQ) or ends inside a quality section makes
+ * the call fail with NTL_ERANGE and the caller reads that batch with the two-pass functions instead. */
+struct SpanSink {
+    uint32_t *packed;
+    uint64_t pos0, bound;                                     /* base position of the range's first base; room */
+    std::vector<uint64_t> *rec_pos; std::vector<uint32_t> *rec_len, *name_end;
+    std::string *names;
+    std::vector<uint32_t> *run_seq, *run_start, *run_len;
+    uint64_t nb = 0, i = 0;
+    uint64_t acc = 0, widx = 0;
+    unsigned fill = 0;
+    bool in_run = false, overflow = false;
+    uint64_t seq_nb0 = 0, run_nb0 = 0;
+    void begin() { widx = (NTL_PACK_LEAD + pos0) >> 4; fill = 0; } /* pos0 is a multiple of 16: whole words are this range's own */
+    inline void push(uint64_t bits, unsigned nbits)
+    {
+        acc |= bits << fill;
+        fill += nbits;
+        while (fill >= 32) { packed[widx++] = (uint32_t)acc; acc >>= 32; fill -= 32; }
+    }
+    void finish() { if (fill) packed[widx] = (uint32_t)acc; }
+    inline void close_run(uint64_t at)
+    {
+        if (!in_run) return;
+        run_seq->push_back((uint32_t)i);
+        run_start->push_back((uint32_t)(run_nb0 - seq_nb0));
+        run_len->push_back((uint32_t)(at - run_nb0));
+        in_run = false;
+    }
+    void id(const char *p, size_t n) { names->append(p, n); name_end->push_back((uint32_t)names->size()); rec_pos->push_back(pos0 + nb); }
+    void seq(const char *p, size_t n)
+    {
+        if (nb + n > bound) { overflow = true; return; }
+        const uint64_t K1 = 0x0101010101010101ull, K7F = 0x7F7F7F7F7F7F7F7Full, K80 = 0x8080808080808080ull;
+        size_t k = 0;
+        while (k < n) {
+            if (n - k >= 8) {
+                uint64_t x;
+                memcpy(&x, p + k, 8);
+                const uint64_t u = x & 0xDFDFDFDFDFDFDFDFull; /* fold the case */
+                auto zero_bytes = [&](uint64_t z) { return ~(((z & K7F) + K7F) | z | K7F); };
+                const uint64_t ok = zero_bytes(u ^ (0x41 * K1)) | zero_bytes(u ^ (0x43 * K1)) | zero_bytes(u ^ (0x47 * K1)) | zero_bytes(u ^ (0x54 * K1));
+                if (ok == K80) {
+                    uint64_t v = (x >> 1) & (3 * K1);
+                    v ^= (v >> 1) & K1;
+                    v = (v | (v >> 6)) & 0x000F000F000F000Full;
+                    v = (v | (v >> 12)) & 0x000000FF000000FFull;
+                    v = (v | (v >> 24)) & 0xFFFFull;
+                    if (!in_run) { in_run = true; run_nb0 = nb + k; }
+                    push(v, 16);
+                    k += 8;
+                    continue;
+                }
+            }
+            const uint32_t c = (uint8_t)p[k], uc = c & 0xDFu;
+            const bool okc = uc == 0x41u || uc == 0x43u || uc == 0x47u || uc == 0x54u;
+            const uint32_t t = (c >> 1) & 3u;
+            push(okc ? ((t ^ (t >> 1)) & 3u) : 0u, 2);
+            if (okc) { if (!in_run) { in_run = true; run_nb0 = nb + k; } }
+            else close_run(nb + k);
+            k++;
+        }
+        nb += n;
+    }
+    void end_record() { close_run(nb); rec_len->push_back((uint32_t)(nb - seq_nb0)); i++; seq_nb0 = nb; }
+    uint64_t bases() const { return nb; }
+};
+
+/* Cuts the next span of about max_bases bases (at record boundaries, into per-thread ranges, as ntl_fastx_next does) without
+ * reading it: *span_bytes = input bytes it covers (0 at the end of the input), *packed_words = words the caller's packed
+ * array must hold.  The span becomes the current batch only when ntl_fastx_parse_span succeeds. */
+extern "C" int ntl_fastx_next_span(ntl_fastx *r, uint64_t max_bases, uint64_t *span_bytes, uint64_t *packed_words)
+{
+    if (!r || !span_bytes || !packed_words || !max_bases) return NTL_EINVAL;
+    *span_bytes = 0; *packed_words = 0;
+    r->materialized = false;
+    r->ranges.clear();
+    r->sp_advance = 0;
+    const uint64_t want0 = max_bases * (r->fastq ? 2u : 1u) + (max_bases >> 6);
+    size_t need = (size_t)want0 + (1u << 20);
+    size_t avail; bool at_eof;
+    const char *p0 = view(r, need, &avail, &at_eof);
+    if (!r->err.empty()) return NTL_EINVAL;
+    if (avail == 0) return NTL_OK;
+    const uint64_t want = max_bases * (r->fastq ? 2u : 1u) + (max_bases >> 6);
+    if (want > want0 && !at_eof) {
+        need = (size_t)want + (1u << 20);
+        p0 = view(r, need, &avail, &at_eof);
+        if (!r->err.empty()) return NTL_EINVAL;
+    }
+    size_t end = avail;
+    if (want < avail) {
+        for (;;) {
+            end = (size_t)(find_boundary(p0 + want, p0 + avail, r->fastq) - p0);
+            if (end < avail || at_eof) break;
+            need = avail * 2;
+            p0 = view(r, need, &avail, &at_eof);
+            if (!r->err.empty()) return NTL_EINVAL;
+        }
+    }
+    const char *pe = p0 + end, *fe = p0 + avail;
+    size_t min_chunk = 2u << 20;
+    if (const char *e = getenv("NTL_IO_MIN_CHUNK")) { long v = atol(e); if (v > 0) min_chunk = (size_t)v; }
+    const unsigned T = (unsigned)std::min<size_t>(io_threads(), std::max<size_t>(1, end / min_chunk));
+    r->ranges.resize(T);
+    r->sp_pos0.assign(T, 0); r->sp_bound.assign(T, 0);
+    const char *prev = p0;
+    uint64_t pos = 0;
+    for (unsigned t = 0; t < T; t++) {
+        const char *nxt = t + 1 == T ? pe : std::max(prev, find_boundary(p0 + end / T * (t + 1), pe, r->fastq));
+        r->ranges[t].b = prev; r->ranges[t].e = nxt; r->ranges[t].at_eof = nxt == fe && at_eof;
+        const uint64_t bytes = (uint64_t)(nxt - prev);
+        const uint64_t bound = r->fastq ? bytes / 2 + 1 : bytes; /* a FASTQ record's qualities are as long as its bases */
+        r->sp_pos0[t] = pos; r->sp_bound[t] = bound;
+        pos += (bound + 15) & ~(uint64_t)15;
+        prev = nxt;
+    }
+    r->sp_positions = pos;
+    r->sp_advance = end;
+    *span_bytes = end;
+    *packed_words = ntl_packed_words(pos);
+    return NTL_OK;
+}
+
+/* The one pass over the span: bases packed into place, records / ids / ACGT runs collected per range.  NTL_ERANGE: this span
+ * cannot be read in one pass (see above): nothing was consumed, call ntl_fastx_next for it. */
+extern "C" int ntl_fastx_parse_span(ntl_fastx *r, uint32_t *packed, uint64_t *nseq, uint64_t *bases, uint64_t *name_bytes, uint64_t *nruns)
+{
+    if (!r || !packed || !nseq || !bases || !name_bytes || !nruns) return NTL_EINVAL;
+    const size_t T = r->ranges.size();
+    if (!T || !r->sp_advance) return NTL_EINVAL;
+    r->sp_rec_pos.assign(T, {}); r->sp_rec_len.assign(T, {}); r->sp_names.assign(T, std::string()); r->sp_name_end.assign(T, {});
+    r->pk_seq.assign(T, {}); r->pk_start.assign(T, {}); r->pk_len.assign(T, {});
+    const uint64_t nwords = ntl_packed_words(r->sp_positions);
+    packed[0] = 0; /* the lead pad */
+    for (uint64_t wd = (NTL_PACK_LEAD + r->sp_positions) >> 4; wd < nwords; wd++) packed[wd] = 0;
+    std::vector<int> bad(T, 0);
+    run_threads(T, [&](size_t t) {
+        Range &g = r->ranges[t];
+        g.bad_end = false;
+        SpanSink ps{packed, r->sp_pos0[t], r->sp_bound[t], &r->sp_rec_pos[t], &r->sp_rec_len[t], &r->sp_name_end[t], &r->sp_names[t],
+                    &r->pk_seq[t], &r->pk_start[t], &r->pk_len[t]};
+        ps.begin();
+        parse_range(g.b, g.e, 0, g.at_eof, ps, &g.bad_end);
+        ps.finish();
+        g.nrec = ps.i; g.bases = ps.nb; g.name_bytes = r->sp_names[t].size();
+        if (ps.overflow || g.bad_end || r->sp_rec_pos[t].size() != r->sp_rec_len[t].size()) bad[t] = 1;
+    });
+    for (int x : bad) if (x) { r->ranges.clear(); return NTL_ERANGE; }
+    uint64_t n = 0, b = 0, nb = 0, nr = 0;
+    for (size_t t = 0; t < T; t++) { n += r->ranges[t].nrec; b += r->ranges[t].bases; nb += r->ranges[t].name_bytes; nr += r->pk_seq[t].size(); }
+    *nseq = n; *bases = b; *name_bytes = nb; *nruns = nr;
+    r->cur += r->sp_advance;
+    r->sp_advance = 0;
+    return NTL_OK;
+}
+
+/* The records of the span: positions[nseq] (first base of every sequence in the packed stream), lengths[nseq], ids, and the
+ * ACGT-run table of ntl_fastx_runs.  *span_positions (may be NULL) = base positions the packed stream spans. */
+extern "C" int ntl_fastx_copy_span(const ntl_fastx *r, uint64_t *positions, uint32_t *lengths, char *names, uint64_t *name_offsets,
+                                   uint32_t *seq_run_first, uint32_t *run_start, uint32_t *run_len, uint64_t *span_positions)
+{
+    if (!r || !positions || !lengths || !name_offsets || !seq_run_first) return NTL_EINVAL;
+    const size_t T = r->ranges.size();
+    if (r->sp_rec_pos.size() != T) return NTL_EINVAL;
+    uint64_t rec = 0, nb = 0;
+    name_offsets[0] = 0;
+    for (size_t t = 0; t < T; t++) {
+        const size_t m = r->sp_rec_pos[t].size();
+        if (m) {
+            memcpy(positions + rec, r->sp_rec_pos[t].data(), m * 8);
+            memcpy(lengths + rec, r->sp_rec_len[t].data(), m * 4);
+        }
+        for (size_t i = 0; i < m; i++) name_offsets[rec + i + 1] = nb + r->sp_name_end[t][i];
+        if (!r->sp_names[t].empty()) { if (!names) return NTL_EINVAL; memcpy(names + nb, r->sp_names[t].data(), r->sp_names[t].size()); }
+        nb += r->sp_names[t].size();
+        rec += m;
+    }
+    if (span_positions) *span_positions = r->sp_positions;
+    return ntl_fastx_runs(r, seq_run_first, run_start, run_len);
 }
 
 static void materialize(ntl_fastx *r)

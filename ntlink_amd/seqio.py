@@ -117,10 +117,12 @@ class SeqSet:
     buf = None and carries the device's layout instead (ntl_batch_create_packed): `packed` (uint32 words, 2 bits per base,
     in the buffer `pinned` that came from alloc) and the ACGT-run table seq_run_first / run_start / run_len."""
 
-    def __init__(self, names, buf, offsets, packed=None, runs=None, pinned=None):
+    def __init__(self, names, buf, offsets, packed=None, runs=None, pinned=None, positions=None, span_positions=0):
         self.names, self.buf, self.offsets = Names.of(names), buf, offsets
         self.packed, self.pinned = packed, pinned
         self.seq_run_first, self.run_start, self.run_len = runs if runs is not None else (None, None, None)
+        # read in one pass (ntl_fastx_parse_span): where every sequence starts in the packed stream, and how far the stream spans
+        self.positions, self.span_positions = positions, span_positions
 
     def __len__(self):
         return len(self.names)
@@ -210,6 +212,46 @@ def shard_plan(paths, rank, world):
     return plan
 
 
+def _span_batch(L, h, path, max_bases, alloc, stats):
+    """One batch through the one-pass reader (ntl_fastx_next_span / _parse_span / _copy_span): SeqSet, None at the end of the
+    input, False when this span has to be read the two-pass way."""
+    import ctypes as C
+    t_0 = time.perf_counter()
+    span, nw = C.c_uint64(), C.c_uint64()
+    if L.ntl_fastx_next_span(h, max_bases, C.byref(span), C.byref(nw)) != 0:
+        raise OSError(f"{path if not isinstance(path, tuple) else path[0]}: {L.ntl_fastx_error(h).decode()}")
+    if span.value == 0:
+        return None
+    pinned = alloc(nw.value * 4)
+    words = pinned.view(np.uint32)
+    t_1 = time.perf_counter()
+    n, nb, nn, nr = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+    rc = L.ntl_fastx_parse_span(h, words.ctypes.data, C.byref(n), C.byref(nb), C.byref(nn), C.byref(nr))
+    if rc != 0:
+        if hasattr(alloc, "__self__") and hasattr(alloc.__self__, "pinned_release"):
+            alloc.__self__.pinned_release(pinned)
+        if rc == -5:  # NTL_ERANGE
+            return False
+        raise OSError(f"{path}: {L.ntl_fastx_error(h).decode()}")
+    n = n.value
+    names = np.empty(nn.value, np.uint8)
+    pos, lens, noff = np.empty(n, np.uint64), np.empty(n, np.uint32), np.empty(n + 1, np.uint64)
+    srf, rst, rln = np.empty(n + 1, np.uint32), np.empty(nr.value, np.uint32), np.empty(nr.value, np.uint32)
+    spanpos = C.c_uint64()
+    if L.ntl_fastx_copy_span(h, pos.ctypes.data, lens.ctypes.data, names.ctypes.data, noff.ctypes.data, srf.ctypes.data, rst.ctypes.data,
+                             rln.ctypes.data, C.byref(spanpos)) != 0:
+        raise OSError(f"{path}: gather failed")
+    off = np.zeros(n + 1, np.uint64)
+    np.cumsum(lens, out=off[1:])
+    if stats is not None:
+        t_2 = time.perf_counter()
+        for key, dt in (("t_reader_count", t_1 - t_0), ("t_reader_parse", t_2 - t_1)):
+            stats[key] = stats.get(key, 0.0) + dt
+        stats["reader_batches"] = stats.get("reader_batches", 0) + 1
+        stats["one_pass_batches"] = stats.get("one_pass_batches", 0) + 1
+    return SeqSet(Names(names, noff), None, off, packed=words, runs=(srf, rst, rln), pinned=pinned, positions=pos, span_positions=spanpos.value)
+
+
 def load(paths, max_bases=None, alloc=None, ahead=None, stats=None, packed=False):
     """Native reader (ntl_fastx_*, csrc/ntl_io.cpp).  Whole input as one SeqSet, or, with max_bases,
     SeqSets of about that many bases; several files are concatenated in the order given and a batch
@@ -229,6 +271,7 @@ def load(paths, max_bases=None, alloc=None, ahead=None, stats=None, packed=False
     if isinstance(paths, str):
         paths = [paths]
     trace = bool(os.environ.get("NTL_IO_TRACE"))
+    one_pass = packed and max_bases is not None and os.environ.get("NTL_IO_ONE_PASS", "1") != "0"
     n_ahead = ahead if ahead is not None else min(32, max(1, (os.cpu_count() or 1) // 4))
     whole = []
     pending = collections.deque()  # (path, future of an open handle, compressed bytes)
@@ -258,6 +301,14 @@ def load(paths, max_bases=None, alloc=None, ahead=None, stats=None, packed=False
                 stats["parsed_bytes"] = stats.get("parsed_bytes", 0) + (hi.value - lo.value if hi.value else _size)
             try:
                 while True:
+                    if one_pass:
+                        ss = _span_batch(L, h, path, int(max_bases), alloc or _np_empty, stats)
+                        if ss is None:
+                            break
+                        if ss is not False:
+                            yield ss
+                            continue
+                        # this span cannot be read in one pass (NTL_ERANGE): the two-pass reader below takes the same records
                     n = C.c_uint64()
                     t_0 = time.perf_counter()
                     if L.ntl_fastx_next(h, int(max_bases or 0), C.byref(n)) != 0:

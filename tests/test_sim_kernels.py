@@ -339,3 +339,57 @@ def test_sim_kernel_variants_full_pipeline(dev, monkeypatch, env):
     pc.check_full_pipeline(dev, pc.fixture_seqs("scaffolds_4.fa"), pc.fixture_seqs("long_reads_4_top5.fa"), 40, 100, z=1000)
     for seed, k, w in ((1, 32, 100), (2, 32, 250), (3, 24, 64)):
         pc.check_sketch(dev, fuzz_cases.fuzz_sequences(seed)[:12], k, w)
+
+
+@pytest.mark.parametrize("form", ["fasta", "fasta_wrapped", "fastq", "fastq_wrapped", "fastq_short_quals"])
+def test_sim_one_pass_reader(dev, tmp_path, monkeypatch, form):
+    """The one-pass reader (ntl_fastx_next_span / _parse_span / _copy_span -> ntl_batch_create_packed_at): every parser thread's
+    sequences sit at an upper bound of their place in the packed stream, with gaps between the threads' segments.  Records,
+    lengths and the sketches of every batch equal the serial reader's / the oracle's -- N runs, lower case, IUPAC, empty and tiny
+    records, ids with comments; wrapped FASTQ and qualities shorter than their bases fall back to the two-pass reader."""
+    import oracle
+    from ntlink_amd import seqio
+    rng = np.random.default_rng(21)
+    acgt = np.frombuffer(b"ACGTacgtNR", np.uint8)
+    recs = []
+    for i in range(160):
+        n = int(rng.integers(0, 5000)) if i % 7 else int(rng.integers(0, 40))
+        recs.append((f"r{i}", bytes(acgt[rng.choice(10, n, p=[0.23, 0.23, 0.23, 0.23, 0.02, 0.02, 0.01, 0.01, 0.015, 0.005])])))
+    p = tmp_path / ("x.fq" if form.startswith("fastq") else "x.fa")
+    with open(p, "wb") as fh:
+        for name, sq in recs:
+            if form == "fasta":
+                fh.write(b">" + name.encode() + b" some comment\n" + sq + b"\n")
+            elif form == "fasta_wrapped":
+                fh.write(b">" + name.encode() + b"\n" + b"\n".join(sq[j:j + 70] for j in range(0, len(sq), 70)) + b"\n")
+            elif form == "fastq":
+                fh.write(b"@" + name.encode() + b" c\n" + sq + b"\n+\n" + bytes(rng.choice(np.frombuffer(b"@+>I5", np.uint8), len(sq))) + b"\n")
+            elif form == "fastq_wrapped":
+                q = bytes(rng.choice(np.frombuffer(b"@+>I5", np.uint8), len(sq)))
+                fh.write(b"@" + name.encode() + b"\n" + b"\n".join(sq[j:j + 60] for j in range(0, len(sq), 60)) + b"\n+\n" +
+                         b"\n".join(q[j:j + 60] for j in range(0, len(q), 60)) + b"\n")
+            else:  # one quality line, shorter than the bases: the reader takes "at least one line", so bases > bytes / 2 here
+                fh.write(b"@" + name.encode() + b"\n" + sq + b"\n+\nII\n")
+    monkeypatch.setenv("NTL_IO_THREADS", "5")
+    monkeypatch.setenv("NTL_IO_MIN_CHUNK", "9000")
+    want = [(n, s) for n, s in seqio.read_fastx(str(p))]
+    if form != "fastq_short_quals":  # (there the reference's reader semantics swallow the following lines as quality: `want` is what counts)
+        assert [n for n, _ in want] == [n for n, _ in recs] and [s for _, s in want] == [s for _, s in recs]
+    st = {}
+    got_names, got_lens, n_one = [], [], 0
+    at = 0
+    for ss in seqio.load([str(p)], max_bases=60_000, packed=True, stats=st):
+        names = ss.names.tolist()
+        got_names += names
+        got_lens += ss.lengths.tolist()
+        n_one += ss.positions is not None
+        seqs = [s for _, s in want[at:at + len(names)]]
+        at += len(names)
+        for k, w in ((24, 20), (12, 64)):
+            with dev.batch_packed(ss) as b, dev.sketch(b, k, w) as sk:
+                off, h, q, sd = sk.download()
+            ooff, oh, op, os_ = oracle.sketch_batch(b"".join(seqs), pc.offsets_of(seqs), k, w)
+            assert np.array_equal(off, ooff) and np.array_equal(h, oh) and np.array_equal(q, op) and np.array_equal(sd, os_), (form, k, w)
+    assert got_names == [n for n, _ in want] and got_lens == [len(s) for _, s in want]
+    if form in ("fasta", "fasta_wrapped", "fastq"):
+        assert n_one >= 3 and st.get("one_pass_batches", 0) == n_one  # several batches, all read in one pass
