@@ -143,7 +143,10 @@ static hipEvent_t sev_get(ntl_ctx *c)
 {
     hipEvent_t e = nullptr;
     if (!c->sev_free.empty()) { e = c->sev_free.back(); c->sev_free.pop_back(); return e; }
-    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    /* hipEventBlockingSync: a host thread that waits on such an event sleeps until the interrupt instead of spinning -- the pair
+       driver's worker threads wait for uploads and results most of the time, and on a host that grants the process 16 cores
+       (the GPU boxes: 256 visible, cpu.max = 16) every spinning thread is a parser thread less */
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) return nullptr;
     return e;
 }
 static void sev_put(ntl_ctx *c, hipEvent_t e) { if (e) c->sev_free.push_back(e); }
@@ -152,7 +155,7 @@ static void sev_put(ntl_ctx *c, hipEvent_t e) { if (e) c->sev_free.push_back(e);
  * is woken by an interrupt some tens of microseconds after the event has passed. */
 static hipError_t wait_hot(hipEvent_t e)
 {
-    static const int spin_us = [] { const char *v = getenv("NTL_SYNC_SPIN_US"); return v ? atoi(v) : 20000; }();
+    static const int spin_us = [] { const char *v = getenv("NTL_SYNC_SPIN_US"); return v ? atoi(v) : 100; }();
     if (spin_us > 0) {
         const auto t0 = std::chrono::steady_clock::now();
         for (;;) {
@@ -163,6 +166,18 @@ static hipError_t wait_hot(hipEvent_t e)
         }
     }
     return hipEventSynchronize(e);
+}
+
+/* waits until everything queued on MAIN so far has finished -- on an event, so that the thread sleeps (hipStreamSynchronize
+   spins for a while first) */
+static hipError_t main_wait(ntl_ctx *c)
+{
+    hipEvent_t e = sev_get(c);
+    if (!e) return hipStreamSynchronize(c->stream);
+    hipError_t rc = hipEventRecord(e, c->stream);
+    if (rc == hipSuccess) rc = hipEventSynchronize(e);
+    sev_put(c, e);
+    return rc;
 }
 
 static PinSlot *slot_get(ntl_ctx *c);
@@ -727,7 +742,7 @@ extern "C" int ntl_batch_create_packed(ntl_ctx *c, const uint32_t *packed, const
             HIPCHK(c, hipMemcpyAsync(b->run_len.p, run_len, nruns * 4, hipMemcpyHostToDevice, c->stream));
         }
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream)); /* the caller's arrays and seq_base are free again */
+    HIPCHK(c, main_wait(c)); /* the caller's arrays and seq_base are free again */
     *out = b.release();
     return NTL_OK;
 }
@@ -785,7 +800,7 @@ extern "C" int ntl_batch_create_packed_at(ntl_ctx *c, const uint32_t *packed, ui
             HIPCHK(c, hipMemcpyAsync(b->run_len.p, run_len, nruns * 4, hipMemcpyHostToDevice, c->stream));
         }
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream)); /* the caller's arrays and seq_base are free again */
+    HIPCHK(c, main_wait(c)); /* the caller's arrays and seq_base are free again */
     *out = b.release();
     return NTL_OK;
 }
@@ -1919,6 +1934,6 @@ extern "C" int ntl_mapres_download(const ntl_mapres *r, ntl_mapping *maps, ntl_h
     if (maps && r->n_maps) HIPCHK(c, hipMemcpyAsync(maps, r->maps.p, r->n_maps * sizeof(MapRec), hipMemcpyDeviceToHost, c->stream));
     if (hits && r->n_hits) HIPCHK(c, hipMemcpyAsync(hits, r->hits.p, r->n_hits * sizeof(HitRec), hipMemcpyDeviceToHost, c->stream));
     if (pafs && r->n_pafs) HIPCHK(c, hipMemcpyAsync(pafs, r->pafs.p, r->n_pafs * sizeof(PafRec), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, main_wait(c));
     return NTL_OK;
 }

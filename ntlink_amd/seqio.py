@@ -222,6 +222,7 @@ def _span_batch(L, h, path, max_bases, alloc, stats):
         raise OSError(f"{path if not isinstance(path, tuple) else path[0]}: {L.ntl_fastx_error(h).decode()}")
     if span.value == 0:
         return None
+    t_a = time.perf_counter()
     pinned = alloc(nw.value * 4)
     words = pinned.view(np.uint32)
     t_1 = time.perf_counter()
@@ -245,7 +246,7 @@ def _span_batch(L, h, path, max_bases, alloc, stats):
     np.cumsum(lens, out=off[1:])
     if stats is not None:
         t_2 = time.perf_counter()
-        for key, dt in (("t_reader_count", t_1 - t_0), ("t_reader_parse", t_2 - t_1)):
+        for key, dt in (("t_reader_count", t_a - t_0), ("t_reader_alloc", t_1 - t_a), ("t_reader_parse", t_2 - t_1)):
             stats[key] = stats.get(key, 0.0) + dt
         stats["reader_batches"] = stats.get("reader_batches", 0) + 1
         stats["one_pass_batches"] = stats.get("one_pass_batches", 0) + 1

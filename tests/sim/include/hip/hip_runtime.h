@@ -141,6 +141,7 @@ inline hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return 
 inline hipError_t hipStreamCreate(hipStream_t *s) { *s = nullptr; return hipSuccess; }
 #define hipStreamNonBlocking 1u
 #define hipEventDisableTiming 2u
+#define hipEventBlockingSync 1u
 /* two distinguishable handles so that the product's two-stream bookkeeping (events, per-stream block caches) is exercised;
    the mock itself runs every launch at once, in program order */
 inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { static char tag[64]; static int n = 0; *s = (hipStream_t)&tag[n++ & 63]; return hipSuccess; }

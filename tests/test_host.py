@@ -479,7 +479,8 @@ def test_parser_packs_bases_and_runs_like_the_device(tmp_path, monkeypatch, thre
     monkeypatch.setenv("NTL_IO_THREADS", threads)
     monkeypatch.setenv("NTL_IO_MIN_CHUNK", chunk)
     plain = seqio.load_all([str(p)])
-    for max_bases in (None, 5000):
+    for max_bases, one_pass in ((None, "0"), (5000, "0"), (5000, "1")):
+        monkeypatch.setenv("NTL_IO_ONE_PASS", one_pass)
         sets = list(seqio.load([str(p)], max_bases=max_bases, packed=True))
         at = 0
         for ss in sets:
@@ -488,8 +489,24 @@ def test_parser_packs_bases_and_runs_like_the_device(tmp_path, monkeypatch, thre
             sub_off = plain.offsets[at:at + n + 1] - np.uint64(o0)
             assert np.array_equal(ss.offsets, sub_off) and ss.names.tolist() == plain.names.tolist()[at:at + n] and ss.buf is None
             words, srf, rst, rln = _expected_pack(plain.buf[o0:int(plain.offsets[at + n])], sub_off)
-            assert np.array_equal(ss.packed, words)
             assert np.array_equal(ss.seq_run_first, srf) and np.array_equal(ss.run_start, rst) and np.array_equal(ss.run_len, rln)
+            if one_pass == "0":
+                assert ss.positions is None and np.array_equal(ss.packed, words)
+            else:
+                # one pass: the sequences of a parser thread sit at an upper bound of their place; every sequence's bases,
+                # read back from its position in the stream, are those of the contiguous layout; positions are in order, word
+                # starts of the threads' segments are multiples of 16, nothing overlaps and everything lies inside the stream
+                assert ss.positions is not None and len(ss.packed) == (16 + ss.span_positions + 4096 + 15) // 16 + 2
+                two = np.frombuffer(ss.packed.tobytes(), np.uint8)
+                codes = np.stack([(two >> s) & 3 for s in (0, 2, 4, 6)], axis=1).reshape(-1)
+                exp = np.frombuffer(words.tobytes(), np.uint8)
+                exp_codes = np.stack([(exp >> s) & 3 for s in (0, 2, 4, 6)], axis=1).reshape(-1)
+                ends = ss.positions + ss.lengths
+                assert (ss.positions[1:] >= ends[:-1]).all() and (not n or int(ends[-1]) <= ss.span_positions)
+                for i in range(n):
+                    a, ln = 16 + int(ss.positions[i]), int(ss.lengths[i])
+                    b = 16 + int(sub_off[i])
+                    assert np.array_equal(codes[a:a + ln], exp_codes[b:b + ln]), (i, ln)
             at += n
         assert at == len(plain) == 400
 

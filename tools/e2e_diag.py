@@ -82,6 +82,11 @@ def main():
                 subprocess.run([sys.executable, os.path.abspath(__file__), "--run", d, "--batch", "256000000"],
                                env=dict(os.environ, NTL_PIPE_TRACE=os.environ["NTL_E2E_TRACE_ONLY"] + f".{i}", NTL_IO_TRACE="1"), check=False)
             return
+        if os.environ.get("NTL_E2E_SWEEP2"):
+            for env in ({}, {}, {"NTL_IO_ONE_PASS": "0"}, {"NTL_IO_THREADS": "8"}, {"NTL_IO_THREADS": "16"}, {"NTL_IO_THREADS": "16", "NTL_IO_READERS": "1"},
+                        {"NTL_IO_THREADS": "16", "NTL_IO_READERS": "3"}, {"NTL_IO_THREADS": "24"}, {"NTL_IO_THREADS": "64"}):
+                subprocess.run([sys.executable, os.path.abspath(__file__), "--run", d, "--batch", "256000000"], env=dict(os.environ, **env), check=False)
+            return
         configs = [({"NTL_IO_READERS": "1"}, 256_000_000), ({"NTL_IO_READERS": "1"}, 256_000_000),  # twice: page-cache and pool warm-up
                    ({"NTL_IO_READERS": "2"}, 256_000_000), ({"NTL_IO_READERS": "3"}, 256_000_000), ({"NTL_IO_READERS": "4"}, 256_000_000),
                    ({"NTL_IO_READERS": "3", "NTL_IO_THREADS": "64"}, 256_000_000),
