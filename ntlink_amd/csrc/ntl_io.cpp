@@ -1529,20 +1529,55 @@ extern "C" const uint64_t *ntl_fastx_name_offsets(ntl_fastx *r) { materialize(r)
 /* ------------------------------------------------------------------ writers -------------- */
 
 /* Append-only text buffer over a std::string: raw pointer writes, two digits per division. */
-struct Out {
-    std::string &s;
-    char *p, *end;
-    explicit Out(std::string &str, size_t cap = 1 << 16) : s(str)
+/* A formatter's output buffer.  Buffers are kept between calls (RawPool): a fresh std::string per chunk and call meant an
+ * allocation, its page faults and a zero fill of the whole capacity for every few hundred kilobytes of text -- more than the
+ * formatting itself. */
+struct RawBuf {
+    char *d = nullptr;
+    size_t n = 0, cap = 0;
+    void reserve(size_t c)
     {
-        s.resize(cap);
-        p = &s[0]; end = p + cap;
+        if (c <= cap) return;
+        char *nd = (char *)realloc(d, c);
+        if (!nd) abort();
+        d = nd; cap = c;
+    }
+};
+struct RawPool {
+    std::mutex mu;
+    std::vector<RawBuf> free_list;
+    void take(std::vector<RawBuf> &out, size_t k)
+    {
+        std::lock_guard<std::mutex> g(mu);
+        out.resize(k);
+        for (size_t i = 0; i < k && !free_list.empty(); i++) { out[i] = free_list.back(); free_list.pop_back(); out[i].n = 0; }
+    }
+    void give(std::vector<RawBuf> &bufs)
+    {
+        std::lock_guard<std::mutex> g(mu);
+        for (auto &b : bufs) {
+            if (free_list.size() < 2048 && b.cap <= ((size_t)8 << 20)) free_list.push_back(b);
+            else free(b.d);
+        }
+        bufs.clear();
+    }
+};
+static RawPool &raw_pool() { static RawPool p; return p; }
+
+struct Out {
+    RawBuf &s;
+    char *p, *end;
+    explicit Out(RawBuf &buf, size_t cap = 1 << 16) : s(buf)
+    {
+        s.reserve(cap);
+        p = s.d; end = p + s.cap;
     }
     inline void need(size_t n)
     {
         if ((size_t)(end - p) >= n) return;
-        const size_t used = (size_t)(p - &s[0]);
-        s.resize(std::max(s.size() * 2, used + n + 4096));
-        p = &s[0] + used; end = &s[0] + s.size();
+        const size_t used = (size_t)(p - s.d);
+        s.reserve(std::max(s.cap * 2, used + n + 4096));
+        p = s.d + used; end = s.d + s.cap;
     }
     inline void ch(char c) { *p++ = c; } /* callers reserve with need() */
     inline void bytes(const char *b, size_t n) { need(n + 96); memcpy(p, b, n); p += n; }
@@ -1569,27 +1604,27 @@ struct Out {
         for (int i = 8; i >= 0; i--) { tmp[i] = (char)('0' + x % 10); x /= 10; }
         memcpy(p, tmp, 9); p += 9;
     }
-    void finish() { s.resize((size_t)(p - &s[0])); }
+    void finish() { s.n = (size_t)(p - s.d); }
 };
 
-static int write_all(int fd, const std::string &s)
+static int write_all(int fd, const RawBuf &s)
 {
     size_t done = 0;
-    while (done < s.size()) {
-        ssize_t n = write(fd, s.data() + done, s.size() - done);
-        if (n <= 0) return NTL_EINVAL;
-        done += (size_t)n;
+    while (done < s.n) {
+        const ssize_t k = write(fd, s.d + done, s.n - done);
+        if (k <= 0) return NTL_EINVAL;
+        done += (size_t)k;
     }
     return NTL_OK;
 }
 
-static int pwrite_all(int fd, const std::string &s, off_t at)
+static int pwrite_all(int fd, const RawBuf &s, off_t at)
 {
     size_t done = 0;
-    while (done < s.size()) {
-        ssize_t n = pwrite(fd, s.data() + done, s.size() - done, at + (off_t)done);
-        if (n <= 0) return NTL_EINVAL;
-        done += (size_t)n;
+    while (done < s.n) {
+        const ssize_t k = pwrite(fd, s.d + done, s.n - done, at + (off_t)done);
+        if (k <= 0) return NTL_EINVAL;
+        done += (size_t)k;
     }
     return NTL_OK;
 }
@@ -1616,24 +1651,26 @@ static int format_parallel(int fd, uint64_t n, uint64_t weight_hint, F fmt)
     uint64_t c0 = 0;
     while (c0 < nchunks) {
         const uint64_t c1 = std::min<uint64_t>(nchunks, c0 + (uint64_t)nthr * 16);
-        std::vector<std::string> bufs(c1 - c0);
+        std::vector<RawBuf> bufs;
+        raw_pool().take(bufs, c1 - c0);
         run_threads(nthr, [&](size_t t) {
             for (uint64_t c = c0 + t; c < c1; c += nthr) fmt(c * chunk, std::min<uint64_t>(n, (c + 1) * chunk), bufs[c - c0]);
         });
         if (base == (off_t)-1) {
-            for (auto &b : bufs) { int rc = write_all(fd, b); if (rc) return rc; }
+            for (auto &b : bufs) { int rc = write_all(fd, b); if (rc) { raw_pool().give(bufs); return rc; } }
         } else {
             std::vector<off_t> at(bufs.size() + 1, base);
-            for (size_t i = 0; i < bufs.size(); i++) at[i + 1] = at[i] + (off_t)bufs[i].size();
+            for (size_t i = 0; i < bufs.size(); i++) at[i + 1] = at[i] + (off_t)bufs[i].n;
             std::vector<int> rcs(nthr, 0);
             run_threads(nthr, [&](size_t t) {
                 for (size_t i = t; i < bufs.size(); i += nthr)
                     if (pwrite_all(fd, bufs[i], at[i])) rcs[t] = NTL_EINVAL;
             });
-            for (int rc : rcs) if (rc) return rc;
+            for (int rc : rcs) if (rc) { raw_pool().give(bufs); return rc; }
             base = at[bufs.size()];
-            if (lseek(fd, base, SEEK_SET) == (off_t)-1) return NTL_EINVAL;
+            if (lseek(fd, base, SEEK_SET) == (off_t)-1) { raw_pool().give(bufs); return NTL_EINVAL; }
         }
+        raw_pool().give(bufs);
         c0 = c1;
     }
     return NTL_OK;
@@ -1643,7 +1680,7 @@ extern "C" int ntl_write_indexlr(int fd, uint64_t nseq, const char *names, const
                                  const uint64_t *mx_off, const uint64_t *hash, const uint32_t *pos, const uint8_t *strand)
 {
     if (nseq && (!names || !name_off || !mx_off)) return NTL_EINVAL;
-    return format_parallel(fd, nseq, nseq ? mx_off[nseq] : 0, [&](uint64_t a, uint64_t b, std::string &s) {
+    return format_parallel(fd, nseq, nseq ? mx_off[nseq] : 0, [&](uint64_t a, uint64_t b, RawBuf &s) {
         Out o(s, (size_t)(mx_off[b] - mx_off[a]) * 30 + (size_t)(b - a) * 48 + 256);
         for (uint64_t i = a; i < b; i++) {
             o.bytes(names + name_off[i], name_off[i + 1] - name_off[i]);
@@ -1669,7 +1706,7 @@ extern "C" int ntl_write_verbose(int fd, const ntl_mapping *maps, uint64_t n_map
     if (n_maps && (!maps || !hits || !read_names || !read_name_off || !ctg_names || !ctg_name_off)) return NTL_EINVAL;
     uint64_t w = 0;
     if (n_maps) w = maps[n_maps - 1].hit_off + maps[n_maps - 1].n_hits;
-    return format_parallel(fd, n_maps, w, [&](uint64_t a, uint64_t b, std::string &s) {
+    return format_parallel(fd, n_maps, w, [&](uint64_t a, uint64_t b, RawBuf &s) {
         const uint64_t nh = b > a ? maps[b - 1].hit_off + maps[b - 1].n_hits - maps[a].hit_off : 0;
         Out o(s, (size_t)nh * 22 + (size_t)(b - a) * 80 + 256);
         for (uint64_t i = a; i < b; i++) {
@@ -1698,7 +1735,7 @@ extern "C" int ntl_write_paf(int fd, const ntl_paf *pafs, uint64_t n, const char
                              const uint32_t *read_len, const char *ctg_names, const uint64_t *ctg_name_off, const uint32_t *ctg_len)
 {
     if (n && (!pafs || !read_names || !read_name_off || !read_len || !ctg_names || !ctg_name_off || !ctg_len)) return NTL_EINVAL;
-    return format_parallel(fd, n, n * 12, [&](uint64_t a, uint64_t b, std::string &s) {
+    return format_parallel(fd, n, n * 12, [&](uint64_t a, uint64_t b, RawBuf &s) {
         Out o(s, (size_t)(b - a) * 160 + 256);
         for (uint64_t i = a; i < b; i++) {
             const ntl_paf &p = pafs[i];
