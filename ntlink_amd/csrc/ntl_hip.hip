@@ -1119,7 +1119,10 @@ static void launch_fast_r0(ntl_ctx *c, const Sketch2Args &B, unsigned strips)
         /* NTL_SKETCH_LANES=1: sketch_lanes_kernel, the variant that walks only the lanes whose minimum can change -- 30 % fewer
            VALU instructions, but its single-wavefront phases halve the number of runnable wavefronts per SIMD and the launch
            takes 5-6 % LONGER (profiles/r03*_lanes*): an experiment that is kept for the record, not the default */
-        static const int lanes = [] { const char *e = getenv("NTL_SKETCH_LANES"); return e ? atoi(e) : 0; }();
+        const char *le = getenv("NTL_SKETCH_LANES"); /* read per call: the tests switch it inside one process */
+        const int lanes = le ? atoi(le) : 0;
+        /* NTL_SKETCH_THRESH: sketch_thresh_kernel, threshold-sparsified windows: the other experiment */
+        if (NT == 256 && B.thresh && B.A.G.a + 2 <= 16 && B.dbg == 0) { hipLaunchKernelGGL((sketch_thresh_kernel<256>), grid, dim3(256), 0, c->wstream, B); return; }
         if (B.A.G.a + 2 <= 16 && B.A.G.w >= 64 && B.A.G.a >= 2 && lanes && B.dbg == 0) hipLaunchKernelGGL((sketch_lanes_kernel<NT, R0>), grid, dim3(NT), 0, c->wstream, B);
         else if (B.A.G.a + 2 <= 16 && B.A.G.w >= 64) hipLaunchKernelGGL((sketch_fast_kernel<NT, R0, false>), grid, dim3(NT), 0, c->wstream, B);
         else hipLaunchKernelGGL((sketch_fast_kernel<NT, R0, true>), grid, dim3(NT), 0, c->wstream, B);
@@ -1304,6 +1307,14 @@ static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const nt
             }
             B.force_redo = 0;
             B.dbg = 0;
+            B.thresh = 0;
+            {   /* NTL_SKETCH_THRESH=1 (or = candidates per window, default 12.5): sketch_thresh_kernel for 160 <= w <= 255 */
+                const char *e = getenv("NTL_SKETCH_THRESH"); /* read per call: the tests switch it inside one process */
+                double cpw = e ? atof(e) : 0.0;
+                if (cpw == 1.0) cpw = 12.5;
+                if (cpw > 0 && nt != 128 && w <= 255 && 4096.0 * cpw / w <= 340.0)
+                    B.thresh = (uint32_t)std::min(4294967295.0, 4294967296.0 * cpw / w);
+            }
             if (const char *e = getenv("NTL_SKETCH_ABLATE")) B.dbg = atoi(e); /* tools/sketch_bench.py only: results are wrong */
             if (const char *e = getenv("NTL_SKETCH_FORCE_REDO")) B.force_redo = atoi(e); /* tests: every strip takes both passes */
             {
@@ -1370,7 +1381,8 @@ static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const nt
             E.ix_bits = ix->bits; E.cand = s->cand.as<Cand>(); E.nfound = &dsums->nfound;
         }
         /* the emit kernel is the last reader of the bitmask and clears the words it read: the mask goes back clean */
-        static const int emit_u = [] { const char *e = getenv("NTL_EMIT_U"); return e ? atoi(e) : 1; }(); /* minimizers in flight per thread */
+        const char *eu = getenv("NTL_EMIT_U"); /* minimizers in flight per thread; read per call: the tests switch it inside one process */
+        const int emit_u = eu ? atoi(eu) : 1;
         if (probe == 0) hipLaunchKernelGGL((emit_kernel<0, 1>), dim3((unsigned)tiles), dim3(EMIT_NT), 0, ms, E);
         else if (probe == 1 && emit_u >= 2) hipLaunchKernelGGL((emit_kernel<1, 2>), dim3((unsigned)tiles), dim3(EMIT_NT), 0, ms, E);
         else if (probe == 1) hipLaunchKernelGGL((emit_kernel<1, 1>), dim3((unsigned)tiles), dim3(EMIT_NT), 0, ms, E);

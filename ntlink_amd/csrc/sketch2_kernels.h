@@ -68,6 +68,7 @@ struct Sketch2Args {
     uint32_t rev_a, rev_b; /* (k - 1) % 33, (k - 1) % 31: the rotation that turns the Horner form of the reverse strand into rev */
     int force_redo;        /* tests: flag every strip */
     int dbg;               /* ablation (tools/sketch_bench.py, results WRONG): 1 no search, 2 no window pass, 4 no rolling, 8 no init */
+    uint32_t thresh;       /* sketch_thresh_kernel: keys below it are candidates */
 };
 
 __device__ __forceinline__ uint32_t sk2_bases16(const uint32_t *__restrict__ packed, uint64_t gp, uint64_t max_word)
@@ -831,6 +832,267 @@ __global__ __launch_bounds__(NT) void sketch_lanes_kernel(Sketch2Args B)
 #endif
                 }
             }
+        }
+    }
+    __syncthreads();
+
+    /* ---- phase 7: proven minimizers to the global bitmask; flagged strips to the exact pass ---- */
+    const uint32_t flagged = s_flag;
+    if (L < NBW && !flagged) {
+        const uint32_t word = s_bits[L];
+        if (word) {
+            const uint64_t g0 = (uint64_t)((int64_t)I.base + I.P0 + 32 * (int64_t)L);
+            const uint32_t sh = (uint32_t)g0 & 31u;
+            atomicOr(&A.mask[g0 >> 5], word << sh);
+            if (sh && (word >> (32u - sh))) atomicOr(&A.mask[(g0 >> 5) + 1], word >> (32u - sh));
+        }
+    }
+    if (L == 0 && flagged) B.redo_list[atomicAdd(B.redo_count, 1u)] = strip;
+}
+
+
+/*
+ * sketch_thresh_kernel: the window pass on threshold-sparsified windows (VERDICT r2 item 2b's structural experiment).
+ *
+ * Same strip, same keys, same contract as sketch_fast_kernel<NT, R0, false>: a bit per k-mer that is the argmin of one of the
+ * windows the strip answers for, or the strip on the redo list and none of its bits.  What differs is everything behind the
+ * rolling: no block minima, no 17-window pass, no search jobs.  Only the k-mers with key < T ("candidates"; T = 2^32 * c / w for
+ * about c = 12.5 candidates per window) are looked at again.  They are compacted, in position order, into a list in LDS, and one
+ * lane per candidate decides whether it is the lone minimum of some window:
+ *
+ *   blocker of candidate i   a candidate with key <= key_i + SK2_NEAR (what could be the 64-bit argmin in i's place).
+ *   Rp   position of the nearest blocker to the right, at most pos_i + w  (the list's right sentinel sits at the end `hi` of the
+ *        strip's elements with key 0: no window reaches beyond it);
+ *   i is the argmin of a window  <=  there is no blocker in [Rp - w, pos_i)  (left sentinel: position 0, key 0 -- the strip's
+ *        windows start at element 1).  Then the window [Rp - w, Rp) holds i, no other candidate within SK2_NEAR of it or below,
+ *        and non-candidates are >= T > key_i + SK2_NEAR (a candidate with key + SK2_NEAR >= T flags the strip): by "exact" in
+ *        the header of this file i is that window's 64-bit argmin.  The window lies in the sequence, so the bit is right whoever
+ *        owns the window.
+ *
+ *   Nothing is missed unless the strip is flagged.  Take a window W of the strip.  (a) No candidate in W: then two consecutive
+ *   list entries (sentinels included) are more than w apart -- every candidate checks the distance to its successor, lane 0 also
+ *   the first one's to element 0 -- flag.  (b) The smallest candidate i of W has another candidate j of W within SK2_NEAR: the LEFT
+ *   one of the two scans to the right until its first blocker b, which lies between them (or is the other one), hence in W,
+ *   hence key_b >= key_i; key_b is also <= (the scanning one's key) + SK2_NEAR, and both keys are within SK2_NEAR of key_i: the
+ *   scan sees a blocker within SK2_NEAR of its own key -- flag.  That is why the right scan is never cut short, while the left one
+ *   only covers what the decision needs.  (c) Otherwise i has no blocker inside W, Rp lies behind W, the start of W is
+ *   <= Rp - w, and a blocker in [Rp - w, pos_i) would lie in W: there is none, the bit is set.
+ *
+ * More candidates than SK2T_CAP in a strip (low T-quantile sequence): flag.
+ */
+#define SK2T_CAP 404
+
+template <int NT>
+__global__ __launch_bounds__(NT) void sketch_thresh_kernel(Sketch2Args B)
+{
+    constexpr int C = 16;
+    constexpr int NBW = (C * NT + 31) / 32;
+    constexpr int ST = NT;
+    constexpr int NX = NT + SK2_QMAX + 1;
+    constexpr uint32_t NW = NT / 64;
+    __shared__ uint32_t s_c[C * ST];
+    __shared__ uint2 s_cand[SK2T_CAP + 6];      /* {key, position}: [1] left sentinel, [2 .. n + 1] the candidates, [n + 2] right sentinel;
+                                                   [0] and [n + 3 .. n + 5] are only ever over-read (values not used) */
+    __shared__ uint32_t s_bits[NBW];
+    __shared__ uint32_t s_roll[64];
+    __shared__ uint32_t s_wsum[NW];
+    __shared__ uint32_t s_flag;
+    uint2 *const s_xy = (uint2 *)s_c;
+    uint32_t *const s_so = (uint32_t *)&s_xy[2 * NX];
+    static_assert(sizeof(uint32_t) * C * ST >= sizeof(uint2) * 2 * NX + sizeof(uint32_t) * (NX + 1), "the exchange area must fit the element array");
+
+    const SketchArgs &A = B.A;
+    const int L = threadIdx.x;
+    const SketchGeom G = A.G;
+    const uint32_t per_xcd = gridDim.x >> 3; /* consecutive strips on one XCD (see sketch_mask_kernel) */
+    const uint32_t strip = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (strip >= A.nstrips) return;
+    const StripInfo I = A.strip_tab[strip];
+    if (I.seq == NTL_NONE || I.multi != 0) return; /* strips that cross non-ACGT runs: sketch_mask_kernel<.., MULTI = true> */
+    if (L < 16) { s_roll[2 * L] = (uint32_t)(A.roll_tab[L][0] >> 33); s_roll[2 * L + 1] = (uint32_t)(A.roll_tab[L][1] >> 32); }
+    if (L < NBW) s_bits[L] = 0;
+    if (L == 0) { s_flag = B.force_redo ? 1u : 0u; s_cand[0] = make_uint2(0u, 0u); s_cand[1] = make_uint2(0u, 0u); }
+
+    const int64_t e_lane = (int64_t)I.E0 + (int64_t)L * C; /* ordinal of this lane's element t = 0 */
+    const uint64_t gp = (uint64_t)((int64_t)I.base + I.P0 + (int64_t)L * C);
+
+    /* ---- phase 1a: 16-base partial hashes of the lane's own chunk (and of the chunks behind the strip) ---- */
+    const bool live = e_lane < (int64_t)I.M;
+    const bool feeds = e_lane - 16 * (int64_t)(B.q16 + 1) < (int64_t)I.M;
+    uint32_t so = 0;
+    if (feeds) {
+        so = sk2_bases16(A.T.packed, gp, B.max_word);
+        uint2 FU, P;
+        sk2_chunk(so, B.r16, B, FU, P);
+        s_xy[L] = FU;
+        s_so[L] = so;
+        if (B.r16) s_xy[NX + L] = P;
+    }
+    if (L <= B.q16) {
+        const int64_t ev = (int64_t)I.E0 + (int64_t)(NT + L) * C;
+        if (ev - 16 * (int64_t)(B.q16 + 1) < (int64_t)I.M) {
+            const uint32_t sv = sk2_bases16(A.T.packed, gp + (uint64_t)NT * C, B.max_word);
+            uint2 FU, P;
+            sk2_chunk(sv, B.r16, B, FU, P);
+            s_xy[NT + L] = FU;
+            s_so[NT + L] = sv;
+            if (B.r16) s_xy[NX + NT + L] = P;
+        }
+    }
+    __syncthreads();
+
+    /* ---- phase 1b: first k-mer's rings from the partials, then 15 rolling steps (as in sketch_fast_kernel) ---- */
+    uint32_t c[C];
+#pragma unroll
+    for (int t = 0; t < C; t++) c[t] = SK2_INF;
+    uint32_t fx = 0, ry = 0, si = 0;
+    if (live) {
+        {
+            const uint32_t lo = s_so[L + B.q16];
+            si = B.r16 ? ntl_alignbit(s_so[L + B.q16 + 1], lo, 2u * (uint32_t)B.r16) : lo;
+        }
+        uint32_t f = 0, u = 0;
+        for (int i = 0; i < B.q16; i++) {
+            if (i) { f = ring_rotl(f, 16); u = ring_rotr(u, 16); }
+            const uint2 p = s_xy[L + i];
+            f ^= p.x;
+            u ^= p.y;
+        }
+        if (B.r16) {
+            const uint32_t r = (uint32_t)B.r16;
+            if (B.q16) { f = ring_rotl(f, r); u = ring_rotr(u, r); }
+            const uint2 p = s_xy[NX + L + B.q16];
+            f ^= p.x;
+            u ^= p.y;
+        }
+        fx = f;
+        ry = u << 1;
+    }
+    __syncthreads(); /* the partial hashes have been read: s_c may take the elements */
+    if (live) {
+        c[0] = (fx << 1) + ry;
+        uint32_t wz[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const uint32_t o2 = r < 2 ? so << (3 - 2 * r) : so >> (2 * r - 3);
+            const uint32_t i2 = r < 3 ? si << (5 - 2 * r) : si >> (2 * r - 5);
+            wz[r] = (o2 & 0x18181818u) | (i2 & 0x60606060u);
+        }
+#pragma unroll
+        for (int t = 1; t < C; t++) {
+            const int b = t - 1;
+            const uint32_t off = ntl_bfe(wz[b & 3], 8u * (uint32_t)(b >> 2), 8u);
+            const uint2 sd = *(const uint2 *)((const char *)s_roll + off);
+            fx = ((fx << 1) | ((fx >> 30) & 1u)) ^ sd.x;
+            const uint32_t a = ry ^ sd.y;
+            ry = ntl_alignbit(a >> 1, a, 1);
+            c[t] = (fx << 1) + ry;
+        }
+        if (e_lane < 0 || e_lane + C > (int64_t)I.M) { /* strip edges only */
+#pragma unroll
+            for (int t = 0; t < C; t++) {
+                const int64_t e = e_lane + t;
+                if (e < 0 || e >= (int64_t)I.M) c[t] = SK2_INF;
+            }
+        }
+    }
+    if (L == 0) c[0] = SK2_INF; /* element 0 belongs to the windows of the previous strip only */
+
+    /* ---- phase 2: stage the keys; which of them are candidates, and how many (bit 15 - t of acc: element t) ---- */
+    const uint32_t tm1 = B.thresh - 1u;
+    uint32_t acc = 0;
+#pragma unroll
+    for (int t = 0; t < C; t++) {
+        s_c[t * ST + L] = c[t];
+        acc = ntl_shl1_or_le(acc, c[t], tm1);
+    }
+    uint32_t m16 = ntl_brev(acc) >> 16; /* bit t: element t */
+    const uint32_t ncl = (uint32_t)__popc(m16);
+    const uint32_t incl = ntl_wave_incl_scan(ncl);
+    if ((L & 63) == 63) s_wsum[L >> 6] = incl;
+    __syncthreads();
+    uint32_t at = incl - ncl, total = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < NW; q++) {
+        const uint32_t v = s_wsum[q];
+        if (q < ((uint32_t)L >> 6)) at += v;
+        total += v;
+    }
+    const uint32_t hi = (uint32_t)((int64_t)I.M - (int64_t)I.E0 < (int64_t)(NT * C) ? (int64_t)I.M - (int64_t)I.E0 : (int64_t)(NT * C));
+    const uint32_t n = total < (uint32_t)SK2T_CAP ? total : (uint32_t)SK2T_CAP;
+    if (L >= NT - 4) { /* the right sentinel, and defined values in the entries behind it that the chunked scan may over-read */
+        s_cand[n + 2 + (uint32_t)(NT - 1 - L)] = make_uint2(0u, hi);
+        if (L == NT - 1 && total > (uint32_t)SK2T_CAP) s_flag = 16u;
+    }
+    /* ---- phase 3: the lane's candidates into the list (its own staged keys back from LDS by index; the read of the next
+       one is in flight while the previous one is written) ---- */
+    if (m16) {
+        uint32_t t = (uint32_t)__ffs(m16) - 1u;
+        m16 &= m16 - 1u;
+        uint32_t v = s_c[t * ST + L];
+        for (;;) {
+            const uint32_t t0 = t, v0 = v;
+            const bool more = m16 != 0u;
+            if (more) {
+                t = (uint32_t)__ffs(m16) - 1u;
+                m16 &= m16 - 1u;
+                v = s_c[t * ST + L];
+            }
+            if (at < (uint32_t)SK2T_CAP) s_cand[at + 2] = make_uint2(v0, (uint32_t)(L * C) + t0);
+            at++;
+            if (!more) break;
+        }
+    }
+    __syncthreads();
+
+    /* ---- phase 4: one lane per candidate (see the header); the scans take four list entries per step ---- */
+    {
+        const uint32_t w = (uint32_t)G.w;
+        bool bad = false;
+        if (L == 0) bad = s_cand[2].y - 1u >= w; /* elements 1 .. w without a candidate */
+        for (uint32_t i = (uint32_t)L; i < n; i += NT) {
+            const uint2 me = s_cand[i + 2];
+            const uint32_t lim = me.x + SK2_NEAR;
+            bad |= lim >= B.thresh;
+            uint32_t Rp = me.y + w;
+            uint2 e;
+            {   /* to the right: the first entry that is a blocker or at least w away; ends at the right sentinel (key 0) at the latest */
+                uint32_t j = i + 3;
+                for (;;) {
+                    const uint2 q0 = s_cand[j], q1 = s_cand[j + 1], q2 = s_cand[j + 2], q3 = s_cand[j + 3];
+                    if (j == i + 3) bad |= q0.y - me.y - 1u >= w; /* a window between two candidates */
+                    const bool s0 = !(q0.y < Rp && q0.x > lim), s1 = !(q1.y < Rp && q1.x > lim);
+                    const bool s2 = !(q2.y < Rp && q2.x > lim), s3 = !(q3.y < Rp && q3.x > lim);
+                    e.x = s0 ? q0.x : (s1 ? q1.x : (s2 ? q2.x : q3.x));
+                    e.y = s0 ? q0.y : (s1 ? q1.y : (s2 ? q2.y : q3.y));
+                    if (s0 || s1 || s2 || s3) break;
+                    j += 4;
+                }
+            }
+            if (e.y < Rp) {
+                Rp = e.y;
+                bad |= e.x + SK2_NEAR >= me.x; /* within SK2_NEAR (the sentinel's key 0: only for keys <= SK2_NEAR) */
+            }
+            const int32_t need = (int32_t)Rp - (int32_t)w; /* a blocker at q < pos matters where q >= need */
+            {   /* to the left: the first entry that is a blocker or lies before `need`; ends at the left sentinel (position 0, key 0) */
+                uint32_t j = i + 1;
+                for (;;) {
+                    const uint2 q0 = s_cand[j], q1 = s_cand[j - 1];
+                    const bool s0 = !((int32_t)q0.y >= need && q0.x > lim), s1 = !((int32_t)q1.y >= need && q1.x > lim);
+                    e.x = s0 ? q0.x : q1.x;
+                    e.y = s0 ? q0.y : q1.y;
+                    if (s0 || s1) break;
+                    j -= 2;
+                }
+            }
+            const bool blocked = (int32_t)e.y >= need;
+            if (!blocked) atomicOr(&s_bits[me.y >> 5], 1u << (me.y & 31u));
+        }
+        if (bad) {
+            s_flag = 2u;
+#ifdef NTL_SIM
+            if (getenv("NTL_SK2_DEBUG")) fprintf(stderr, "strip %u lane %d: threshold pass gives up (n=%u M=%u E0=%d)\n", strip, L, n, I.M, I.E0);
+#endif
         }
     }
     __syncthreads();
