@@ -880,7 +880,19 @@ __global__ __launch_bounds__(NT) void sketch_lanes_kernel(Sketch2Args B)
  *
  * More candidates than SK2T_CAP in a strip (low T-quantile sequence): flag.
  */
-#define SK2T_CAP 404
+#define SK2T_CAP 402
+
+/* index of the first of four keys that is <= lim, 4 if none: straight-line (compare + add-with-carry per key, one v_ffbl), so
+   that the four LDS reads behind it are issued together instead of one per taken branch */
+__device__ __forceinline__ uint32_t sk2t_first_le(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, uint32_t lim)
+{
+    uint32_t acc = 1u;
+    acc = ntl_shl1_or_le(acc, k3, lim);
+    acc = ntl_shl1_or_le(acc, k2, lim);
+    acc = ntl_shl1_or_le(acc, k1, lim);
+    acc = ntl_shl1_or_le(acc, k0, lim);
+    return (uint32_t)__ffs(acc) - 1u;
+}
 
 template <int NT>
 __global__ __launch_bounds__(NT) void sketch_thresh_kernel(Sketch2Args B)
@@ -891,8 +903,8 @@ __global__ __launch_bounds__(NT) void sketch_thresh_kernel(Sketch2Args B)
     constexpr int NX = NT + SK2_QMAX + 1;
     constexpr uint32_t NW = NT / 64;
     __shared__ uint32_t s_c[C * ST];
-    __shared__ uint2 s_cand[SK2T_CAP + 6];      /* {key, position}: [1] left sentinel, [2 .. n + 1] the candidates, [n + 2] right sentinel;
-                                                   [0] and [n + 3 .. n + 5] are only ever over-read (values not used) */
+    __shared__ uint2 s_cand[SK2T_CAP + 8];      /* {key, position}: [3] left sentinel, [4 .. n + 3] the candidates, [n + 4] right sentinel;
+                                                   [0 .. 2] and [n + 5 .. n + 7]: copies of the sentinels that the four-entry scan steps read along */
     __shared__ uint32_t s_bits[NBW];
     __shared__ uint32_t s_roll[64];
     __shared__ uint32_t s_wsum[NW];
@@ -911,7 +923,8 @@ __global__ __launch_bounds__(NT) void sketch_thresh_kernel(Sketch2Args B)
     if (I.seq == NTL_NONE || I.multi != 0) return; /* strips that cross non-ACGT runs: sketch_mask_kernel<.., MULTI = true> */
     if (L < 16) { s_roll[2 * L] = (uint32_t)(A.roll_tab[L][0] >> 33); s_roll[2 * L + 1] = (uint32_t)(A.roll_tab[L][1] >> 32); }
     if (L < NBW) s_bits[L] = 0;
-    if (L == 0) { s_flag = B.force_redo ? 1u : 0u; s_cand[0] = make_uint2(0u, 0u); s_cand[1] = make_uint2(0u, 0u); }
+    if (L == 0) s_flag = B.force_redo ? 1u : 0u;
+    if (L < 4) s_cand[L] = make_uint2(0u, 0u);
 
     const int64_t e_lane = (int64_t)I.E0 + (int64_t)L * C; /* ordinal of this lane's element t = 0 */
     const uint64_t gp = (uint64_t)((int64_t)I.base + I.P0 + (int64_t)L * C);
@@ -1021,7 +1034,7 @@ __global__ __launch_bounds__(NT) void sketch_thresh_kernel(Sketch2Args B)
     const uint32_t hi = (uint32_t)((int64_t)I.M - (int64_t)I.E0 < (int64_t)(NT * C) ? (int64_t)I.M - (int64_t)I.E0 : (int64_t)(NT * C));
     const uint32_t n = total < (uint32_t)SK2T_CAP ? total : (uint32_t)SK2T_CAP;
     if (L >= NT - 4) { /* the right sentinel, and defined values in the entries behind it that the chunked scan may over-read */
-        s_cand[n + 2 + (uint32_t)(NT - 1 - L)] = make_uint2(0u, hi);
+        s_cand[n + 4 + (uint32_t)(NT - 1 - L)] = make_uint2(0u, hi);
         if (L == NT - 1 && total > (uint32_t)SK2T_CAP) s_flag = 16u;
     }
     /* ---- phase 3: the lane's candidates into the list (its own staged keys back from LDS by index; the read of the next
@@ -1038,7 +1051,7 @@ __global__ __launch_bounds__(NT) void sketch_thresh_kernel(Sketch2Args B)
                 m16 &= m16 - 1u;
                 v = s_c[t * ST + L];
             }
-            if (at < (uint32_t)SK2T_CAP) s_cand[at + 2] = make_uint2(v0, (uint32_t)(L * C) + t0);
+            if (at < (uint32_t)SK2T_CAP) s_cand[at + 4] = make_uint2(v0, (uint32_t)(L * C) + t0);
             at++;
             if (!more) break;
         }
@@ -1049,43 +1062,44 @@ __global__ __launch_bounds__(NT) void sketch_thresh_kernel(Sketch2Args B)
     {
         const uint32_t w = (uint32_t)G.w;
         bool bad = false;
-        if (L == 0) bad = s_cand[2].y - 1u >= w; /* elements 1 .. w without a candidate */
+        if (L == 0) bad = s_cand[4].y - 1u >= w; /* elements 1 .. w without a candidate */
         for (uint32_t i = (uint32_t)L; i < n; i += NT) {
-            const uint2 me = s_cand[i + 2];
+            const uint2 me = s_cand[i + 4];
             const uint32_t lim = me.x + SK2_NEAR;
             bad |= lim >= B.thresh;
             uint32_t Rp = me.y + w;
-            uint2 e;
-            {   /* to the right: the first entry that is a blocker or at least w away; ends at the right sentinel (key 0) at the latest */
-                uint32_t j = i + 3;
+            /* Positions grow along the list, so a scan only asks each entry "blocker?" and the chunk's farthest entry "still in
+               range?"; which blocker came first (fb, 4 = none) and whether it lies in range is settled behind the loop. */
+            {   /* to the right: the first blocker nearer than w; ends at the right sentinel (key 0) at the latest */
+                uint32_t j = i + 5, fb;
+                bad |= s_cand[j].y - me.y - 1u >= w; /* a window between two candidates */
                 for (;;) {
                     const uint2 q0 = s_cand[j], q1 = s_cand[j + 1], q2 = s_cand[j + 2], q3 = s_cand[j + 3];
-                    if (j == i + 3) bad |= q0.y - me.y - 1u >= w; /* a window between two candidates */
-                    const bool s0 = !(q0.y < Rp && q0.x > lim), s1 = !(q1.y < Rp && q1.x > lim);
-                    const bool s2 = !(q2.y < Rp && q2.x > lim), s3 = !(q3.y < Rp && q3.x > lim);
-                    e.x = s0 ? q0.x : (s1 ? q1.x : (s2 ? q2.x : q3.x));
-                    e.y = s0 ? q0.y : (s1 ? q1.y : (s2 ? q2.y : q3.y));
-                    if (s0 || s1 || s2 || s3) break;
+                    fb = sk2t_first_le(q0.x, q1.x, q2.x, q3.x, lim);
+                    if (fb != 4u || q3.y >= Rp) break;
                     j += 4;
                 }
-            }
-            if (e.y < Rp) {
-                Rp = e.y;
-                bad |= e.x + SK2_NEAR >= me.x; /* within SK2_NEAR (the sentinel's key 0: only for keys <= SK2_NEAR) */
-            }
-            const int32_t need = (int32_t)Rp - (int32_t)w; /* a blocker at q < pos matters where q >= need */
-            {   /* to the left: the first entry that is a blocker or lies before `need`; ends at the left sentinel (position 0, key 0) */
-                uint32_t j = i + 1;
-                for (;;) {
-                    const uint2 q0 = s_cand[j], q1 = s_cand[j - 1];
-                    const bool s0 = !((int32_t)q0.y >= need && q0.x > lim), s1 = !((int32_t)q1.y >= need && q1.x > lim);
-                    e.x = s0 ? q0.x : q1.x;
-                    e.y = s0 ? q0.y : q1.y;
-                    if (s0 || s1) break;
-                    j -= 2;
+                if (fb != 4u) {
+                    const uint2 e = s_cand[j + fb];
+                    if (e.y < Rp) {
+                        Rp = e.y;
+                        bad |= e.x + SK2_NEAR >= me.x; /* within SK2_NEAR (the sentinel's key 0: only for keys <= SK2_NEAR) */
+                    }
                 }
             }
-            const bool blocked = (int32_t)e.y >= need;
+            const int32_t need = (int32_t)Rp - (int32_t)w; /* a blocker at q < pos matters where q >= need */
+            bool blocked = false;
+            {   /* to the left: is there a blocker at or behind `need`?  Ends at the left sentinel (position 0, key 0) at the latest:
+                   the step that holds the sentinel (index 3) stops the scan, and reads no index below 0 */
+                uint32_t j = i + 3, fb;
+                for (;;) {
+                    const uint2 q0 = s_cand[j], q1 = s_cand[j - 1], q2 = s_cand[j - 2], q3 = s_cand[j - 3];
+                    fb = sk2t_first_le(q0.x, q1.x, q2.x, q3.x, lim);
+                    if (fb != 4u || (int32_t)q3.y < need) break;
+                    j -= 4;
+                }
+                if (fb != 4u) blocked = (int32_t)s_cand[j - fb].y >= need;
+            }
             if (!blocked) atomicOr(&s_bits[me.y >> 5], 1u << (me.y & 31u));
         }
         if (bad) {
