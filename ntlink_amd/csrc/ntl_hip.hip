@@ -1121,7 +1121,7 @@ static void launch_fast_r0(ntl_ctx *c, const Sketch2Args &B, unsigned strips)
            takes 5-6 % LONGER (profiles/r03*_lanes*): an experiment that is kept for the record, not the default */
         const char *le = getenv("NTL_SKETCH_LANES"); /* read per call: the tests switch it inside one process */
         const int lanes = le ? atoi(le) : 0;
-        /* NTL_SKETCH_THRESH: sketch_thresh_kernel, threshold-sparsified windows: the other experiment */
+        /* the window pass on threshold-sparsified windows where the geometry allows it (B.thresh != 0) */
         if (NT == 256 && B.thresh && B.A.G.a + 2 <= 16 && B.dbg == 0) { hipLaunchKernelGGL((sketch_thresh_kernel<256>), grid, dim3(256), 0, c->wstream, B); return; }
         if (B.A.G.a + 2 <= 16 && B.A.G.w >= 64 && B.A.G.a >= 2 && lanes && B.dbg == 0) hipLaunchKernelGGL((sketch_lanes_kernel<NT, R0>), grid, dim3(NT), 0, c->wstream, B);
         else if (B.A.G.a + 2 <= 16 && B.A.G.w >= 64) hipLaunchKernelGGL((sketch_fast_kernel<NT, R0, false>), grid, dim3(NT), 0, c->wstream, B);
@@ -1308,10 +1308,14 @@ static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const nt
             B.force_redo = 0;
             B.dbg = 0;
             B.thresh = 0;
-            {   /* NTL_SKETCH_THRESH=1 (or = candidates per window, default 12.5): sketch_thresh_kernel for 160 <= w <= 255 */
-                const char *e = getenv("NTL_SKETCH_THRESH"); /* read per call: the tests switch it inside one process */
-                double cpw = e ? atof(e) : 0.0;
-                if (cpw == 1.0) cpw = 12.5;
+            {   /* sketch_thresh_kernel (threshold-sparsified windows) where a strip's candidate list fits: keys below
+                   T = 2^32 * cpw / w are candidates, cpw = 10 of them per window -- fewer and more strips have a window without
+                   one (they take the exact pass: 0.7 % at 10, 2 % at 9), more and the list work grows (profiles/r03p_*).
+                   NTL_SKETCH_THRESH=0: sketch_fast_kernel everywhere; = x: x candidates per window.  Read per call: the tests
+                   switch it inside one process. */
+                const char *e = getenv("NTL_SKETCH_THRESH");
+                double cpw = e ? atof(e) : 10.0;
+                if (cpw == 1.0) cpw = 10.0;
                 if (cpw > 0 && nt != 128 && w <= 255 && 4096.0 * cpw / w <= 340.0)
                     B.thresh = (uint32_t)std::min(4294967295.0, 4294967296.0 * cpw / w);
             }

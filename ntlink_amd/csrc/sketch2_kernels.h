@@ -857,7 +857,7 @@ __global__ __launch_bounds__(NT) void sketch_lanes_kernel(Sketch2Args B)
  * Same strip, same keys, same contract as sketch_fast_kernel<NT, R0, false>: a bit per k-mer that is the argmin of one of the
  * windows the strip answers for, or the strip on the redo list and none of its bits.  What differs is everything behind the
  * rolling: no block minima, no 17-window pass, no search jobs.  Only the k-mers with key < T ("candidates"; T = 2^32 * c / w for
- * about c = 12.5 candidates per window) are looked at again.  They are compacted, in position order, into a list in LDS, and one
+ * about c = 10 candidates per window) are looked at again.  They are compacted, in position order, into a list in LDS, and one
  * lane per candidate decides whether it is the lone minimum of some window:
  *
  *   blocker of candidate i   a candidate with key <= key_i + SK2_NEAR (what could be the 64-bit argmin in i's place).

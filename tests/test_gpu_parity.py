@@ -226,8 +226,9 @@ def _rand_seq(rng, n):
     return bytes(synth.random_bases(rng, n))
 
 
-def test_fast_window_pass_decides_random_sequence_alone(dev):
+def test_fast_window_pass_decides_random_sequence_alone(dev, monkeypatch):
     """sketch_fast_kernel: on random sequence no strip needs the exact pass (and the sketch is the oracle's)."""
+    monkeypatch.setenv("NTL_SKETCH_THRESH", "0")  # the threshold pass gives up strips with a candidate-free window: next test
     rng = np.random.default_rng(5)
     seqs = [_rand_seq(rng, n) for n in (90000, 4200, 170000, 300, 131, 5000, 1_000_000)]
     for k, w in ((32, 100), (32, 250), (24, 100), (40, 31), (20, 16), (20, 33), (64, 64), (100, 70), (32, 1000), (17, 3000)):
@@ -235,6 +236,22 @@ def test_fast_window_pass_decides_random_sequence_alone(dev):
             # 1.3 M windows x 7 / 2^32 chances of an entering key within SK2_NEAR of the minimum: none expected
             assert sk.strips > 0 and sk.redo_strips <= 1, (k, w, sk.strips, sk.redo_strips)
         pc.check_sketch(dev, seqs, k, w)
+
+
+def test_threshold_window_pass_random_sequence(dev, monkeypatch):
+    """sketch_thresh_kernel (the default for 121 <= w <= 255): the oracle's sketch on random sequence; about N p e^(-w p) of
+    the strips (N p candidates per strip) have a window without a candidate and take the exact pass: 0.7 % at 10 candidates
+    per window, most strips at 4, none with the pass switched off."""
+    rng = np.random.default_rng(7)
+    seqs = [_rand_seq(rng, n) for n in (90000, 4200, 700000, 300, 131, 5000, 3_000_000)]
+    frac = {}
+    for cpw in ("10", "4", "13", "0"):
+        monkeypatch.setenv("NTL_SKETCH_THRESH", cpw)
+        for k, w in ((32, 250), (24, 121), (40, 255), (20, 180)):
+            with dev.batch(seqs) as b, dev.sketch(b, k, w) as sk:
+                frac[cpw, w] = sk.redo_strips / sk.strips
+            pc.check_sketch(dev, seqs, k, w)
+    assert frac["10", 250] < 0.03 and frac["4", 250] > 0.3 and frac["13", 250] < 0.005 and frac["0", 250] < 0.003, frac
 
 
 def test_fast_window_pass_hands_ties_to_the_exact_pass(dev, monkeypatch):
@@ -395,11 +412,13 @@ def test_one_stream_and_back(dev):
     pc.check_full_pipeline(dev, contigs, reads, 32, 250, z=1000, sensitive=True)
 
 
-@pytest.mark.parametrize("env", [{"NTL_SKETCH_LANES": "1"}, {"NTL_EMIT_U": "2"}, {"NTL_SKETCH_LANES": "1", "NTL_EMIT_U": "2"}],
+@pytest.mark.parametrize("env", [{"NTL_SKETCH_THRESH": "0"}, {"NTL_SKETCH_THRESH": "0", "NTL_SKETCH_LANES": "1"}, {"NTL_EMIT_U": "2"},
+                                 {"NTL_SKETCH_THRESH": "0", "NTL_SKETCH_LANES": "1", "NTL_EMIT_U": "2"}, {"NTL_SKETCH_THRESH": "5"}, {"NTL_SKETCH_THRESH": "13"}],
                          ids=lambda e: ",".join(f"{k[4:]}={v}" for k, v in e.items()))
 def test_kernel_variants_full_pipeline(dev, monkeypatch, env):
-    """sketch_lanes_kernel (the experiment of DESIGN 4.12) and the two-wide emit kernel on the GPU: scaled-down C3- and C5-like
-    workloads, full pipeline against the oracle, and the fuzz sequences."""
+    """The window passes that are not the default for 121 <= w <= 255 (sketch_fast_kernel; sketch_lanes_kernel, the experiment of
+    DESIGN 4.12), the threshold pass with other candidate densities than the default, and the two-wide emit kernel on the GPU:
+    scaled-down C3- and C5-like workloads, full pipeline against the oracle, and the fuzz sequences."""
     import fuzz_cases
     for k_, v in env.items():
         monkeypatch.setenv(k_, v)

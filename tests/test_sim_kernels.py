@@ -194,9 +194,11 @@ def _rand_seq(rng, n):
     return bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), n))
 
 
-def test_sim_fast_window_pass_decides_random_sequence_alone(dev):
+def test_sim_fast_window_pass_decides_random_sequence_alone(dev, monkeypatch):
     """sketch_fast_kernel (32-bit keys, searched change points): on random sequence no strip needs the exact pass,
-    and the result is the oracle's."""
+    and the result is the oracle's.  (The threshold pass, which gives a strip up when one of its windows has no candidate,
+    is switched off: test_sim_threshold_window_pass.)"""
+    monkeypatch.setenv("NTL_SKETCH_THRESH", "0")
     rng = np.random.default_rng(5)
     seqs = [_rand_seq(rng, n) for n in (9000, 4200, 300, 131, 5000)]
     for k, w in ((32, 100), (32, 250), (24, 100), (40, 31), (15, 16), (100, 70)):
@@ -329,16 +331,37 @@ def test_sim_one_stream_and_back(dev):
     pc.check_full_pipeline(dev, contigs, reads, 40, 100, z=1000, sensitive=True)
 
 
-@pytest.mark.parametrize("env", [{"NTL_SKETCH_LANES": "1"}, {"NTL_EMIT_U": "2"}])
+@pytest.mark.parametrize("env", [{"NTL_SKETCH_THRESH": "0"}, {"NTL_SKETCH_THRESH": "0", "NTL_SKETCH_LANES": "1"}, {"NTL_EMIT_U": "2"},
+                                 {"NTL_SKETCH_THRESH": "4"}, {"NTL_SKETCH_THRESH": "13"}])
 def test_sim_kernel_variants_full_pipeline(dev, monkeypatch, env):
-    """The window pass that walks only lanes whose minimum can change, and the emit kernel with two minimizers in flight per
-    thread: same records as the oracle on fixtures, fuzz sequences (ties, N patterns) and windows of both 20-KB ranges."""
+    """The window passes that are not the default for 121 <= w <= 255 (sketch_fast_kernel, sketch_lanes_kernel), the threshold
+    pass with few candidates per window (most strips have a window without one and take the exact pass) and with many, and the
+    emit kernel with two minimizers in flight per thread: same records as the oracle on fixtures, fuzz sequences (ties, N
+    patterns) and windows of both 20-KB ranges."""
     import fuzz_cases
     for k_, v in env.items():
         monkeypatch.setenv(k_, v)
     pc.check_full_pipeline(dev, pc.fixture_seqs("scaffolds_4.fa"), pc.fixture_seqs("long_reads_4_top5.fa"), 40, 100, z=1000)
-    for seed, k, w in ((1, 32, 100), (2, 32, 250), (3, 24, 64)):
+    for seed, k, w in ((1, 32, 100), (2, 32, 250), (3, 24, 64), (4, 40, 130)):
         pc.check_sketch(dev, fuzz_cases.fuzz_sequences(seed)[:12], k, w)
+
+
+def test_sim_threshold_window_pass(dev, monkeypatch):
+    """sketch_thresh_kernel (the default window pass for 121 <= w <= 255): random sequences of lengths around the strip and
+    window sizes at the ends of its range of w, against the oracle; with 4 candidates per window instead of 10 most strips
+    have a window without a candidate and must come back from the exact pass with the same sketch; with NTL_SKETCH_THRESH=0
+    nothing takes the threshold pass and (random sequence) nothing is redone."""
+    rng = np.random.default_rng(5)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    seqs = [bytes(acgt[rng.integers(0, 4, n)]) for n in (60000, 5000, 300, 4127, 281, 282, 3871, 8000, 0, 31)]
+    redo = {}
+    for cpw in ("10", "4", "0"):
+        monkeypatch.setenv("NTL_SKETCH_THRESH", cpw)
+        for k, w in ((32, 250), (24, 121), (40, 255)):
+            info = {}
+            assert pc.check_sketch(dev, seqs, k, w, info=info) > 0
+            redo[cpw, w] = info["redo_strips"]
+    assert redo["4", 250] > 5 * max(redo["10", 250], 1) and redo["0", 250] == 0, redo
 
 
 @pytest.mark.parametrize("form", ["fasta", "fasta_wrapped", "fastq", "fastq_wrapped", "fastq_short_quals"])

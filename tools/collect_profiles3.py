@@ -19,7 +19,7 @@ import bench  # noqa: E402  (kernel_signature only)
 tag = sys.argv[1]
 src = os.path.join(ROOT, "gpurun_out", tag)
 out = os.path.join(ROOT, "profiles")
-SKETCH = ("sketch_mask_kernel", "sketch_fast_kernel")
+SKETCH = ("sketch_mask_kernel", "sketch_fast_kernel", "sketch_thresh_kernel")
 N_SIMD = 1024
 
 
