@@ -183,6 +183,9 @@ uint64_t ntl_sketch_count(const ntl_sketch *s);
  * sequence).  The result is the same either way. */
 uint64_t ntl_sketch_strips(const ntl_sketch *s);
 uint64_t ntl_sketch_redo_strips(const ntl_sketch *s);
+/* ... and how many strips the threshold pass (71 <= w <= 255: only k-mers with a small key are looked at) handed to the
+ * block-minima pass because one of their windows had no such k-mer (about 0.7 % on random sequence). */
+uint64_t ntl_sketch_fallback_strips(const ntl_sketch *s);
 /* mx_off[nseq+1]: minimizers of sequence i are [mx_off[i], mx_off[i+1]); hash/pos/strand hold
  * ntl_sketch_count() entries (the three fields `indexlr` prints as H:pos:strand). */
 int ntl_sketch_download(const ntl_sketch *s, uint64_t *mx_off, uint64_t *hash, uint32_t *pos,

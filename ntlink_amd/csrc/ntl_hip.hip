@@ -972,7 +972,7 @@ struct ntl_index {
 };
 
 /* what emit_kernel leaves in the sketch's page-locked slot */
-struct SketchSums { uint32_t total_mx, redo_n; unsigned long long nfound; };
+struct SketchSums { uint32_t total_mx, redo_n, fb_n, pad_; unsigned long long nfound; }; /* redo_n, fb_n: one 8-byte copy */
 
 struct ntl_sketch {
     ntl_ctx *c;
@@ -980,6 +980,7 @@ struct ntl_sketch {
     uint64_t nseq = 0;
     mutable uint64_t count = 0;           /* valid once !pending */
     mutable uint64_t strips = 0, redo_strips = 0; /* diagnostics: strips of the window pass, strips that also took the exact pass */
+    mutable uint64_t fallback_strips = 0;  /* ... strips the threshold pass handed to the block-minima pass */
     mutable uint64_t nfound = 0;
     mutable DevBuf records; /* MxRecord[cap] */
     mutable DevBuf mx_off;  /* u32[nseq+1] */
@@ -1122,7 +1123,15 @@ static void launch_fast_r0(ntl_ctx *c, const Sketch2Args &B, unsigned strips)
         const char *le = getenv("NTL_SKETCH_LANES"); /* read per call: the tests switch it inside one process */
         const int lanes = le ? atoi(le) : 0;
         /* the window pass on threshold-sparsified windows where the geometry allows it (B.thresh != 0) */
-        if (NT == 256 && B.thresh && B.A.G.a + 2 <= 16 && B.dbg == 0) { hipLaunchKernelGGL((sketch_thresh_kernel<256>), grid, dim3(256), 0, c->wstream, B); return; }
+        if (NT == 256 && B.thresh && B.A.G.a + 2 <= 16 && B.dbg == 0) {
+            const char *de = getenv("NTL_SKETCH_THRESH_DIRECT"); /* 1: the variant without staged keys for the large windows too (A/B) */
+            const int direct = de ? atoi(de) : 0;
+            if (direct || 4096.0 * (double)B.thresh / 4294967296.0 > 340.0) hipLaunchKernelGGL((sketch_thresh_kernel<256, true>), grid, dim3(256), 0, c->wstream, B);
+            else hipLaunchKernelGGL((sketch_thresh_kernel<256, false>), grid, dim3(256), 0, c->wstream, B);
+            /* what it gave up (a window without a candidate: 0.7 % of the strips): the block-minima pass over that list */
+            hipLaunchKernelGGL((sketch_fast_list_kernel<256, R0>), dim3(std::min(strips, 4096u)), dim3(256), 0, c->wstream, B, (const uint32_t *)B.fb_list, (const uint32_t *)B.fb_count);
+            return;
+        }
         if (B.A.G.a + 2 <= 16 && B.A.G.w >= 64 && B.A.G.a >= 2 && lanes && B.dbg == 0) hipLaunchKernelGGL((sketch_lanes_kernel<NT, R0>), grid, dim3(NT), 0, c->wstream, B);
         else if (B.A.G.a + 2 <= 16 && B.A.G.w >= 64) hipLaunchKernelGGL((sketch_fast_kernel<NT, R0, false>), grid, dim3(NT), 0, c->wstream, B);
         else hipLaunchKernelGGL((sketch_fast_kernel<NT, R0, true>), grid, dim3(NT), 0, c->wstream, B);
@@ -1280,11 +1289,13 @@ static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const nt
         fast = C == 16 && k <= 16 * SK2_QMAX && G.a + 2 <= SK2_PAD;
         if (const char *e = getenv("NTL_SKETCH_FAST")) fast = fast && atoi(e) != 0; /* 0: exact pass only (A/B, tests) */
         if (fast) {
-            if ((rc = redo.alloc(c, (ub_strips + 2) * 4, wsid))) return rc;
-            HIPCHK(c, hipMemsetAsync(redo.p, 0, 4, ws));
+            /* [0] strips for the exact pass, [1] strips the threshold pass gave up, then the two lists */
+            if ((rc = redo.alloc(c, (2 * ub_strips + 4) * 4, wsid))) return rc;
+            HIPCHK(c, hipMemsetAsync(redo.p, 0, 8, ws));
             Sketch2Args B;
             B.A = A;
-            B.redo_count = redo.as<uint32_t>(); B.redo_list = redo.as<uint32_t>() + 1;
+            B.redo_count = redo.as<uint32_t>(); B.redo_list = redo.as<uint32_t>() + 2;
+            B.fb_count = redo.as<uint32_t>() + 1; B.fb_list = redo.as<uint32_t>() + 2 + ub_strips + 1;
             B.max_word = b->nwords_packed - 1;
             B.q16 = k / 16; B.r16 = k % 16;
             B.rev_a = (uint32_t)(k - 1) % 33u; B.rev_b = (uint32_t)(k - 1) % 31u;
@@ -1316,7 +1327,9 @@ static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const nt
                 const char *e = getenv("NTL_SKETCH_THRESH");
                 double cpw = e ? atof(e) : 10.0;
                 if (cpw == 1.0) cpw = 10.0;
-                if (cpw > 0 && nt != 128 && w <= 255 && 4096.0 * cpw / w <= 340.0)
+                /* a strip's expected 4096 cpw / w candidates must fit the list with room for their spread: 402 entries beside
+                   the staged keys (w >= 121 at 10 per window), 680 without them (sketch_thresh_kernel<.., DIRECT>: w >= 71) */
+                if (cpw > 0 && nt != 128 && w <= 255 && 4096.0 * cpw / w <= 580.0)
                     B.thresh = (uint32_t)std::min(4294967295.0, 4294967296.0 * cpw / w);
             }
             if (const char *e = getenv("NTL_SKETCH_ABLATE")) B.dbg = atoi(e); /* tools/sketch_bench.py only: results are wrong */
@@ -1334,7 +1347,7 @@ static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const nt
             if (b->any_multi) launch_mask<16>(c, A, (unsigned)ub_strips, false, true, nt);
             HIPCHK(c, hipGetLastError());
             /* the redo count travels with the window stream: `redo` never leaves it */
-            HIPCHK(c, hipMemcpyAsync(&((SketchSums *)s->slot)->redo_n, redo.p, 4, hipMemcpyDeviceToHost, ws));
+            HIPCHK(c, hipMemcpyAsync(&((SketchSums *)s->slot)->redo_n, redo.p, 8, hipMemcpyDeviceToHost, ws));
         } else {
             ProfSpan sp(c, "sketch_mask", wsid);
             if (C == 16) launch_mask<16>(c, A, (unsigned)ub_strips, true, b->any_multi, nt);
@@ -1466,7 +1479,7 @@ static int sketch_finalize(const ntl_sketch *cs)
         s->pending = false;
         if (e != hipSuccess) { s->failed = fail(c, NTL_EDEVICE, std::string("sketch: ") + hipGetErrorString(e)); break; }
         const SketchSums hs = *(const SketchSums *)s->slot;
-        s->count = hs.total_mx; s->redo_strips = hs.redo_n; s->nfound = hs.nfound;
+        s->count = hs.total_mx; s->redo_strips = hs.redo_n; s->fallback_strips = hs.fb_n; s->nfound = hs.nfound;
         if (s->count <= s->cap) break;
         if (round || !s->src) { s->failed = fail(c, NTL_EINTERNAL, "sketch: the exact-size round overflowed again"); break; }
         s->gen++;
@@ -1498,6 +1511,7 @@ extern "C" uint64_t ntl_sketch_nseq(const ntl_sketch *s) { return s ? s->nseq : 
 extern "C" uint64_t ntl_sketch_count(const ntl_sketch *s) { return s && sketch_finalize(s) == NTL_OK ? s->count : 0; }
 extern "C" uint64_t ntl_sketch_strips(const ntl_sketch *s) { return s ? s->strips : 0; }
 extern "C" uint64_t ntl_sketch_redo_strips(const ntl_sketch *s) { return s && sketch_finalize(s) == NTL_OK ? s->redo_strips : 0; }
+extern "C" uint64_t ntl_sketch_fallback_strips(const ntl_sketch *s) { return s && sketch_finalize(s) == NTL_OK ? s->fallback_strips : 0; }
 
 extern "C" int ntl_sketch_download(const ntl_sketch *s, uint64_t *mx_off, uint64_t *hash, uint32_t *pos, uint8_t *strand)
 {

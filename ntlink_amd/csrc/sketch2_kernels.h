@@ -69,6 +69,8 @@ struct Sketch2Args {
     int force_redo;        /* tests: flag every strip */
     int dbg;               /* ablation (tools/sketch_bench.py, results WRONG): 1 no search, 2 no window pass, 4 no rolling, 8 no init */
     uint32_t thresh;       /* sketch_thresh_kernel: keys below it are candidates */
+    uint32_t *fb_list;     /* sketch_thresh_kernel: the strips it gives up, for sketch_fast_list_kernel */
+    uint32_t *fb_count;
 };
 
 __device__ __forceinline__ uint32_t sk2_bases16(const uint32_t *__restrict__ packed, uint64_t gp, uint64_t max_word)
@@ -130,7 +132,7 @@ __device__ __forceinline__ void sk2_chunk(uint32_t so, int r, const Sketch2Args 
 }
 
 template <int NT, int R0, bool BIG>
-__global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
+__device__ __forceinline__ void sk2_fast_strip(const Sketch2Args &B, const uint32_t strip)
 {
     constexpr int C = 16;
     constexpr int NBW = (C * NT + 31) / 32;
@@ -163,8 +165,6 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
     const SketchArgs &A = B.A;
     const int L = threadIdx.x;
     const SketchGeom G = A.G;
-    const uint32_t per_xcd = gridDim.x >> 3; /* consecutive strips on one XCD (see sketch_mask_kernel) */
-    const uint32_t strip = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
     if (strip >= A.nstrips) return;
     const StripInfo I = A.strip_tab[strip];
     if (I.seq == NTL_NONE || I.multi != 0) return; /* strips that cross non-ACGT runs: sketch_mask_kernel<.., MULTI = true> */
@@ -474,6 +474,26 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
         }
     }
     if (L == 0 && flagged) B.redo_list[atomicAdd(B.redo_count, 1u)] = strip;
+}
+
+template <int NT, int R0, bool BIG>
+__global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
+{
+    const uint32_t per_xcd = gridDim.x >> 3; /* consecutive strips on one XCD (see sketch_mask_kernel) */
+    sk2_fast_strip<NT, R0, BIG>(B, (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3));
+}
+
+/* The same pass over a list of strips: the ones sketch_thresh_kernel gave up (a window without a candidate, mostly).  What this
+   pass cannot decide either goes on to B.redo_list, the exact pass's list.  A fixed grid walks the list, whose length is only
+   known on the device. */
+template <int NT, int R0>
+__global__ __launch_bounds__(NT) void sketch_fast_list_kernel(Sketch2Args B, const uint32_t *__restrict__ list, const uint32_t *__restrict__ count)
+{
+    const uint32_t n = *count;
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+        sk2_fast_strip<NT, R0, false>(B, list[i]);
+        __syncthreads(); /* the next strip's first writes to LDS behind this one's last reads */
+    }
 }
 
 
@@ -878,9 +898,11 @@ __global__ __launch_bounds__(NT) void sketch_lanes_kernel(Sketch2Args B)
  *   only covers what the decision needs.  (c) Otherwise i has no blocker inside W, Rp lies behind W, the start of W is
  *   <= Rp - w, and a blocker in [Rp - w, pos_i) would lie in W: there is none, the bit is set.
  *
- * More candidates than SK2T_CAP in a strip (low T-quantile sequence): flag.
+ * More candidates than the list holds in a strip: flag.  A flagged strip goes on B.fb_list: sketch_fast_list_kernel decides it with
+ * the block-minima pass, and what that cannot decide either (near ties) takes the exact pass.
  */
 #define SK2T_CAP 402
+#define SK2T_CAP_DIRECT 680
 
 /* index of the first of four keys that is <= lim, 4 if none: straight-line (compare + add-with-carry per key, one v_ffbl), so
    that the four LDS reads behind it are issued together instead of one per taken branch */
@@ -894,7 +916,7 @@ __device__ __forceinline__ uint32_t sk2t_first_le(uint32_t k0, uint32_t k1, uint
     return (uint32_t)__ffs(acc) - 1u;
 }
 
-template <int NT>
+template <int NT, bool DIRECT>
 __global__ __launch_bounds__(NT) void sketch_thresh_kernel(Sketch2Args B)
 {
     constexpr int C = 16;
@@ -902,8 +924,12 @@ __global__ __launch_bounds__(NT) void sketch_thresh_kernel(Sketch2Args B)
     constexpr int ST = NT;
     constexpr int NX = NT + SK2_QMAX + 1;
     constexpr uint32_t NW = NT / 64;
-    __shared__ uint32_t s_c[C * ST];
-    __shared__ uint2 s_cand[SK2T_CAP + 8];      /* {key, position}: [3] left sentinel, [4 .. n + 3] the candidates, [n + 4] right sentinel;
+    /* DIRECT: the candidates go from the registers to the list with sixteen predicated writes, the keys are not staged: the
+       element array shrinks to the exchange area of phase 1, one barrier goes, and the list may hold more (smaller w) */
+    constexpr uint32_t CAP = DIRECT ? SK2T_CAP_DIRECT : SK2T_CAP;
+    constexpr int XW = (int)((sizeof(uint2) * 2 * NX + sizeof(uint32_t) * (NX + 1)) / sizeof(uint32_t));
+    __shared__ uint32_t s_c[DIRECT ? XW : C * ST];
+    __shared__ uint2 s_cand[CAP + 8];      /* {key, position}: [3] left sentinel, [4 .. n + 3] the candidates, [n + 4] right sentinel;
                                                    [0 .. 2] and [n + 5 .. n + 7]: copies of the sentinels that the four-entry scan steps read along */
     __shared__ uint32_t s_bits[NBW];
     __shared__ uint32_t s_roll[64];
@@ -981,7 +1007,7 @@ __global__ __launch_bounds__(NT) void sketch_thresh_kernel(Sketch2Args B)
         fx = f;
         ry = u << 1;
     }
-    __syncthreads(); /* the partial hashes have been read: s_c may take the elements */
+    if constexpr (!DIRECT) __syncthreads(); /* the partial hashes have been read: s_c may take the elements */
     if (live) {
         c[0] = (fx << 1) + ry;
         uint32_t wz[4];
@@ -1011,12 +1037,12 @@ __global__ __launch_bounds__(NT) void sketch_thresh_kernel(Sketch2Args B)
     }
     if (L == 0) c[0] = SK2_INF; /* element 0 belongs to the windows of the previous strip only */
 
-    /* ---- phase 2: stage the keys; which of them are candidates, and how many (bit 15 - t of acc: element t) ---- */
+    /* ---- phase 2: (stage the keys;) which of them are candidates, and how many (bit 15 - t of acc: element t) ---- */
     const uint32_t tm1 = B.thresh - 1u;
     uint32_t acc = 0;
 #pragma unroll
     for (int t = 0; t < C; t++) {
-        s_c[t * ST + L] = c[t];
+        if constexpr (!DIRECT) s_c[t * ST + L] = c[t];
         acc = ntl_shl1_or_le(acc, c[t], tm1);
     }
     uint32_t m16 = ntl_brev(acc) >> 16; /* bit t: element t */
@@ -1032,14 +1058,21 @@ __global__ __launch_bounds__(NT) void sketch_thresh_kernel(Sketch2Args B)
         total += v;
     }
     const uint32_t hi = (uint32_t)((int64_t)I.M - (int64_t)I.E0 < (int64_t)(NT * C) ? (int64_t)I.M - (int64_t)I.E0 : (int64_t)(NT * C));
-    const uint32_t n = total < (uint32_t)SK2T_CAP ? total : (uint32_t)SK2T_CAP;
-    if (L >= NT - 4) { /* the right sentinel, and defined values in the entries behind it that the chunked scan may over-read */
+    const bool over = total > CAP; /* the strip is given up: an empty list (nothing is written, nothing scanned) */
+    const uint32_t n = over ? 0u : total;
+    if (L >= NT - 4) { /* the right sentinel, and copies of it behind it for the scan steps to read along */
         s_cand[n + 4 + (uint32_t)(NT - 1 - L)] = make_uint2(0u, hi);
-        if (L == NT - 1 && total > (uint32_t)SK2T_CAP) s_flag = 16u;
+        if (L == NT - 1 && over) s_flag = 16u;
     }
-    /* ---- phase 3: the lane's candidates into the list (its own staged keys back from LDS by index; the read of the next
-       one is in flight while the previous one is written) ---- */
-    if (m16) {
+    /* ---- phase 3: the lane's candidates into the list ---- */
+    if constexpr (DIRECT) {
+        if (!over) {
+            uint2 *dst = &s_cand[at + 4];
+#pragma unroll
+            for (int t = 0; t < C; t++)
+                if (c[t] <= tm1) *dst++ = make_uint2(c[t], (uint32_t)(L * C + t));
+        }
+    } else if (m16 && !over) { /* its own staged keys back from LDS by index; the read of the next one is in flight while the previous one is written */
         uint32_t t = (uint32_t)__ffs(m16) - 1u;
         m16 &= m16 - 1u;
         uint32_t v = s_c[t * ST + L];
@@ -1051,7 +1084,7 @@ __global__ __launch_bounds__(NT) void sketch_thresh_kernel(Sketch2Args B)
                 m16 &= m16 - 1u;
                 v = s_c[t * ST + L];
             }
-            if (at < (uint32_t)SK2T_CAP) s_cand[at + 4] = make_uint2(v0, (uint32_t)(L * C) + t0);
+            s_cand[at + 4] = make_uint2(v0, (uint32_t)(L * C) + t0);
             at++;
             if (!more) break;
         }
@@ -1111,7 +1144,7 @@ __global__ __launch_bounds__(NT) void sketch_thresh_kernel(Sketch2Args B)
     }
     __syncthreads();
 
-    /* ---- phase 7: proven minimizers to the global bitmask; flagged strips to the exact pass ---- */
+    /* ---- phase 7: proven minimizers to the global bitmask; flagged strips to the block-minima pass ---- */
     const uint32_t flagged = s_flag;
     if (L < NBW && !flagged) {
         const uint32_t word = s_bits[L];
@@ -1122,5 +1155,5 @@ __global__ __launch_bounds__(NT) void sketch_thresh_kernel(Sketch2Args B)
             if (sh && (word >> (32u - sh))) atomicOr(&A.mask[(g0 >> 5) + 1], word >> (32u - sh));
         }
     }
-    if (L == 0 && flagged) B.redo_list[atomicAdd(B.redo_count, 1u)] = strip;
+    if (L == 0 && flagged) B.fb_list[atomicAdd(B.fb_count, 1u)] = strip;
 }

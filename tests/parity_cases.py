@@ -19,7 +19,7 @@ def check_sketch(dev, seqs, k, w, threads=0, info=None):
     with dev.batch(seqs) as b, dev.sketch(b, k, w) as sk:
         off, h, p, s = sk.download()
         if info is not None:
-            info.update(strips=sk.strips, redo_strips=sk.redo_strips)
+            info.update(strips=sk.strips, redo_strips=sk.redo_strips, fallback_strips=sk.fallback_strips)
     ooff, oh, op, os_ = oracle.sketch_batch(b"".join(seqs), offsets_of(seqs), k, w, threads=threads)
     assert np.array_equal(off, ooff), "per-sequence minimizer counts differ"
     assert np.array_equal(p, op), "positions differ"

@@ -334,7 +334,7 @@ def test_sim_one_stream_and_back(dev):
 @pytest.mark.parametrize("env", [{"NTL_SKETCH_THRESH": "0"}, {"NTL_SKETCH_THRESH": "0", "NTL_SKETCH_LANES": "1"}, {"NTL_EMIT_U": "2"},
                                  {"NTL_SKETCH_THRESH": "4"}, {"NTL_SKETCH_THRESH": "13"}])
 def test_sim_kernel_variants_full_pipeline(dev, monkeypatch, env):
-    """The window passes that are not the default for 121 <= w <= 255 (sketch_fast_kernel, sketch_lanes_kernel), the threshold
+    """The window passes that are not the default for 71 <= w <= 255 (sketch_fast_kernel, sketch_lanes_kernel), the threshold
     pass with few candidates per window (most strips have a window without one and take the exact pass) and with many, and the
     emit kernel with two minimizers in flight per thread: same records as the oracle on fixtures, fuzz sequences (ties, N
     patterns) and windows of both 20-KB ranges."""
@@ -347,21 +347,30 @@ def test_sim_kernel_variants_full_pipeline(dev, monkeypatch, env):
 
 
 def test_sim_threshold_window_pass(dev, monkeypatch):
-    """sketch_thresh_kernel (the default window pass for 121 <= w <= 255): random sequences of lengths around the strip and
-    window sizes at the ends of its range of w, against the oracle; with 4 candidates per window instead of 10 most strips
-    have a window without a candidate and must come back from the exact pass with the same sketch; with NTL_SKETCH_THRESH=0
-    nothing takes the threshold pass and (random sequence) nothing is redone."""
+    """sketch_thresh_kernel (the default window pass for 71 <= w <= 255; without staged keys below 121): random sequences of
+    lengths around the strip and window sizes at the ends of its ranges of w, against the oracle.  With 4 candidates per window
+    instead of 10 most strips have a window without a candidate: they come back from the block-minima pass
+    (sketch_fast_list_kernel) with the same sketch, and none of them needs the exact pass; with NTL_SKETCH_THRESH=0 nothing
+    takes the threshold pass."""
     rng = np.random.default_rng(5)
     acgt = np.frombuffer(b"ACGT", np.uint8)
     seqs = [bytes(acgt[rng.integers(0, 4, n)]) for n in (60000, 5000, 300, 4127, 281, 282, 3871, 8000, 0, 31)]
-    redo = {}
+    fb = {}
     for cpw in ("10", "4", "0"):
         monkeypatch.setenv("NTL_SKETCH_THRESH", cpw)
-        for k, w in ((32, 250), (24, 121), (40, 255)):
+        for k, w in ((32, 250), (24, 121), (40, 255), (24, 100), (32, 71), (20, 120)):
             info = {}
             assert pc.check_sketch(dev, seqs, k, w, info=info) > 0
-            redo[cpw, w] = info["redo_strips"]
-    assert redo["4", 250] > 5 * max(redo["10", 250], 1) and redo["0", 250] == 0, redo
+            fb[cpw, w] = info["fallback_strips"]
+            assert info["redo_strips"] == 0, (cpw, k, w, info)
+    assert fb["4", 250] > 5 * max(fb["10", 250], 1) and fb["0", 250] == 0 and fb["4", 100] > 5 * max(fb["10", 100], 1), fb
+    monkeypatch.setenv("NTL_SKETCH_THRESH", "10")
+    monkeypatch.setenv("NTL_SKETCH_THRESH_DIRECT", "1")
+    assert pc.check_sketch(dev, seqs, 32, 250) > 0
+    monkeypatch.setenv("NTL_SKETCH_FORCE_REDO", "1")  # every strip through all three passes
+    info = {}
+    assert pc.check_sketch(dev, seqs, 32, 250, info=info) > 0
+    assert info["fallback_strips"] == info["redo_strips"] > 0
 
 
 @pytest.mark.parametrize("form", ["fasta", "fasta_wrapped", "fastq", "fastq_wrapped", "fastq_short_quals"])
