@@ -28,12 +28,15 @@ timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/
 timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/$O/pmc_write_$W -o p -- $B > /dev/null 2> $R/$O/pmc_write_$W.err
 timeout 900 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $R/$O/pmc_sq_$W -o p -- $B > $R/$O/bench_pmc_sq_$W.json 2> $R/$O/pmc_sq_$W.err
 done
-# the experiment that was not kept (sketch_lanes_kernel): its launch time and counters for the record
-export NTL_SKETCH_LANES=1
+# for the record: the block-minima window pass (sketch_fast_kernel, NTL_SKETCH_THRESH=0: the default before the threshold pass)
+# and the variant of the threshold pass without staged keys at the large window
+for V in "fast NTL_SKETCH_THRESH=0" "direct NTL_SKETCH_THRESH_DIRECT=1"; do
+set -- $V; export $2
 B="python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-e2e --no-others --serial-steps 0 --workload C3"
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/trace_C3_lanes -o kt -- $B > $R/$O/bench_trace_C3_lanes.json 2> $R/$O/trace_C3_lanes.err
-timeout 900 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $R/$O/pmc_sq_C3_lanes -o p -- $B > /dev/null 2> $R/$O/pmc_sq_C3_lanes.err
-unset NTL_SKETCH_LANES
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/trace_C3_$1 -o kt -- $B > $R/$O/bench_trace_C3_$1.json 2> $R/$O/trace_C3_$1.err
+timeout 900 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $R/$O/pmc_sq_C3_$1 -o p -- $B > /dev/null 2> $R/$O/pmc_sq_C3_$1.err
+unset ${2%%=*}
+done
 unset NTL_PIPELINE
 cd $R
 # the raw per-dispatch traces are large: keep the stats and the counter tables
