@@ -46,7 +46,10 @@
  * NTL_IO_GZ_WHOLE_MAX (compressed bytes up to which a gzip file is inflated in one go, default
  * 1/40 of the physical memory within 1..16 GiB), NTL_IO_TRACE=1 (reader diagnostics on stderr), NTL_SKETCH_C / NTL_SKETCH_NT (k-mers per
  * lane, lanes per strip of the sketch kernel), NTL_SKETCH_FAST=0 (exact 64-bit window pass only), NTL_SKETCH_FORCE_REDO=1
- * (every strip takes the 32-bit pass and the exact pass), NTL_PIPELINE=0 (one stream per context; default: a second stream for
+ * (every strip takes the 32-bit passes and the exact pass), NTL_SKETCH_THRESH (0: the block-minima window pass for every
+ * window instead of the threshold pass for 71 <= w <= 255; x: x candidates per window instead of 10), NTL_SKETCH_THRESH_DIRECT=1
+ * (the threshold pass without staged keys for the large windows too), NTL_SKETCH_LANES=1 and NTL_EMIT_U=2 (kernel variants kept
+ * for the record), NTL_PIPELINE=0 (one stream per context; default: a second stream for
  * the window stage), NTL_PIPELINE_PRIO (0 no stream priorities, 1 = default: MAIN above the window stream, 2 the reverse),
  * NTL_SKETCH_CAP_GUESS (records a sketch's arrays hold before its count is known; tests force the second round with it).
  */

@@ -343,12 +343,13 @@ def _append_part(final_path, part_path, offset):
     os.remove(part_path)
 
 
-def _map_batches(dev, ix, batches, drain, stats, t_mark, w, **map_kw):
+def _map_batches(dev, ix, batches, drain, stats, t_mark, w, first=None, **map_kw):
     """The device stage of the pair driver: read batches -> records, handed to `drain` in input order.
 
     NTL_DEVICE_STREAMS (default 2) worker threads, each with its own context on the GPU (stream, block cache, page-locked
     result buffers), take batches in turn: while one batch's kernels and record download run, the next batch's bases
-    cross PCIe.  The batches' results are committed in input order."""
+    cross PCIe.  The batches' results are committed in input order.  `first` (if given) runs on the calling thread, on `dev`,
+    once the other workers have started: work of the contig stage that the mapping does not depend on."""
     import threading
     n_workers = max(1, int(os.environ.get("NTL_DEVICE_STREAMS", "2")))
     devs = [dev] + [dev.clone() for _ in range(n_workers - 1)]
@@ -425,6 +426,14 @@ def _map_batches(dev, ix, batches, drain, stats, t_mark, w, **map_kw):
     threads = [threading.Thread(target=work, args=(d,), daemon=True) for d in devs[1:]]
     for t in threads:
         t.start()
+    if first is not None:
+        try:
+            first()
+        except BaseException as exc:
+            with commit:
+                if state["error"] is None:
+                    state["error"] = exc
+                commit.notify_all()
     work(devs[0])
     for t in threads:
         t.join()
@@ -500,17 +509,21 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
             t_ctg_up = time.perf_counter()
             with dev.sketch(cb, k, w) as csk:
                 t_ctg_sk = time.perf_counter()
-                if tsv_drain:
-                    tsv_drain.put(*csk.download())  # <target>.k<k>.w<w>.tsv is written while the reads are mapped
-                t_ctg_dl = time.perf_counter()
                 with dev.index(csk, ctg_len) as ix:
                     stats["index_size"] = len(ix)
                     t_mark = time.perf_counter()
                     stats["t_contigs"] = t_mark - t_start
                     stats["t_contigs_parts"] = {"parse": round(t_ctg_parsed - t_start, 4), "upload_pack": round(t_ctg_up - t_ctg_parsed, 4),
-                                                "sketch": round(t_ctg_sk - t_ctg_up, 4), "download_for_tsv": round(t_ctg_dl - t_ctg_sk, 4),
-                                                "index": round(t_mark - t_ctg_dl, 4)}
-                    _map_batches(dev, ix, batches, drain, stats, t_mark, w, k=k, z=z, x=x, sensitive=sensitive, repeat_filter=repeats)
+                                                "sketch": round(t_ctg_sk - t_ctg_up, 4), "index": round(t_mark - t_ctg_sk, 4)}
+
+                    def contig_tsv():
+                        # <target>.k<k>.w<w>.tsv: its records come off the device while the other workers already map reads,
+                        # and are written while the reads are mapped
+                        t0 = time.perf_counter()
+                        tsv_drain.put(*csk.download())
+                        stats["t_contigs_parts"]["download_for_tsv_beside_mapping"] = round(time.perf_counter() - t0, 4)
+                    _map_batches(dev, ix, batches, drain, stats, t_mark, w, first=contig_tsv if tsv_drain else None,
+                                 k=k, z=z, x=x, sensitive=sensitive, repeat_filter=repeats)
         t_fin = time.perf_counter()
         drain.close()
         for d in stats.pop("_extra_devices", []):
