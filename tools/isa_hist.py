@@ -76,7 +76,7 @@ def classify(mn, table):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("pattern", nargs="?", default=r"sketch_thresh_kernel<256, (false|true)>|sketch_fast_list_kernel<256, 10>|sketch_fast_kernel<256, 10, false>|sketch_fast_kernel<256, 4, false>|emit_kernel<[12]>|map_kernel<512, 128>|map_kernel<256, 64>")
+    ap.add_argument("pattern", nargs="?", default=r"sketch_thresh_kernel<256, (false|true)>|sketch_fast_list_kernel<256, 10>|sketch_fast_kernel<256, 10, false>|sketch_fast_kernel<256, 4, false>|emit_kernel<[12], 1>|map_kernel<512, 128, 1>|map_kernel<256, 64, 0>|map_kernel<1024, 128, 2>")
     ap.add_argument("-o", "--out", default=None)
     ap.add_argument("--asm", default=None)
     a = ap.parse_args()
