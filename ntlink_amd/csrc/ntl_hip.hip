@@ -1123,7 +1123,7 @@ static void launch_fast_r0(ntl_ctx *c, const Sketch2Args &B, unsigned strips)
         const char *le = getenv("NTL_SKETCH_LANES"); /* read per call: the tests switch it inside one process */
         const int lanes = le ? atoi(le) : 0;
         /* the window pass on threshold-sparsified windows where the geometry allows it (B.thresh != 0) */
-        if (NT == 256 && B.thresh && B.A.G.a + 2 <= 16 && B.dbg == 0) {
+        if (NT == 256 && B.thresh && B.A.G.a + 2 <= 16 && (B.dbg & ~24) == 0) { /* (ablation bits 8 and 16 exist in this kernel too) */
             const char *de = getenv("NTL_SKETCH_THRESH_DIRECT"); /* 1: the variant without staged keys for the large windows too (A/B) */
             const int direct = de ? atoi(de) : 0;
             if (direct || 4096.0 * (double)B.thresh / 4294967296.0 > 340.0) hipLaunchKernelGGL((sketch_thresh_kernel<256, true>), grid, dim3(256), 0, c->wstream, B);
@@ -1308,13 +1308,16 @@ static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const nt
                         c->g8k.clear();
                     }
                     void *t = nullptr;
-                    if (hipMalloc(&t, (size_t)2 * 65536 * sizeof(uint2)) != hipSuccess) return fail(c, NTL_ENOMEM, "hipMalloc failed");
+                    if (hipMalloc(&t, (size_t)(2 * 65536 + 1024) * sizeof(uint2)) != hipSuccess) return fail(c, NTL_ENOMEM, "hipMalloc failed");
                     hipLaunchKernelGGL(g8k_build_kernel, dim3(256), dim3(256), 0, ws, (const uint64_t (*)[2])c->g8, (uint2 *)t,
                                        B.rev_a, B.rev_b);
+                    hipLaunchKernelGGL(g4k_build_kernel, dim3(1), dim3(256), 0, ws, (const uint64_t (*)[2])c->g4, (uint2 *)t + 2 * 65536,
+                                       B.rev_a, B.rev_b); /* the four-base form of the same, behind it */
                     HIPCHK(c, hipGetLastError());
                     it = c->g8k.emplace(k, t).first;
                 }
                 B.g8k = (const uint2 *)it->second;
+                B.g4k = B.g8k + 2 * 65536;
             }
             B.force_redo = 0;
             B.dbg = 0;
@@ -1386,7 +1389,7 @@ static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const nt
         EmitArgs E;
         E.packed = T.packed; E.seq_base = T.seq_base; E.nseq = (uint32_t)nseq; E.mask = (uint32_t *)mask.p;
         E.nwords = nmask; E.tile_off = tile.as<uint32_t>(); E.tile_seq = tile_seq.as<uint32_t>(); E.mx_off = s->mx_off.as<uint32_t>();
-        E.out = s->records.as<MxRecord>(); E.out_cap = (uint32_t)cap;
+        E.out = s->records.as<MxRecord>(); E.out_cap = (uint32_t)cap; E.ntiles = (uint32_t)tiles;
         E.k = k; E.mult = 1ull ^ ((uint64_t)k * 0x90b45d39fb6da1faull);
         uint64_t roll[16][2];
         make_tables(k, roll, E.seed_tab);
@@ -1400,11 +1403,14 @@ static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const nt
         /* the emit kernel is the last reader of the bitmask and clears the words it read: the mask goes back clean */
         const char *eu = getenv("NTL_EMIT_U"); /* minimizers in flight per thread; read per call: the tests switch it inside one process */
         const int emit_u = eu ? atoi(eu) : 1;
+        /* NTL_EMIT_GRID=n: at most n workgroups walk the tiles (0 = default: one workgroup per tile) */
+        const char *eg = getenv("NTL_EMIT_GRID");
+        const unsigned emit_grid = eg && atoi(eg) > 0 ? (unsigned)std::min<uint64_t>(tiles, (uint64_t)atoi(eg)) : (unsigned)tiles;
         if (probe == 0) hipLaunchKernelGGL((emit_kernel<0, 1>), dim3((unsigned)tiles), dim3(EMIT_NT), 0, ms, E);
-        else if (probe == 1 && emit_u >= 2) hipLaunchKernelGGL((emit_kernel<1, 2>), dim3((unsigned)tiles), dim3(EMIT_NT), 0, ms, E);
-        else if (probe == 1) hipLaunchKernelGGL((emit_kernel<1, 1>), dim3((unsigned)tiles), dim3(EMIT_NT), 0, ms, E);
-        else if (emit_u >= 2) hipLaunchKernelGGL((emit_kernel<2, 2>), dim3((unsigned)tiles), dim3(EMIT_NT), 0, ms, E);
-        else hipLaunchKernelGGL((emit_kernel<2, 1>), dim3((unsigned)tiles), dim3(EMIT_NT), 0, ms, E);
+        else if (probe == 1 && emit_u >= 2) hipLaunchKernelGGL((emit_kernel<1, 2>), dim3(emit_grid), dim3(EMIT_NT), 0, ms, E);
+        else if (probe == 1) hipLaunchKernelGGL((emit_kernel<1, 1>), dim3(emit_grid), dim3(EMIT_NT), 0, ms, E);
+        else if (emit_u >= 2) hipLaunchKernelGGL((emit_kernel<2, 2>), dim3(emit_grid), dim3(EMIT_NT), 0, ms, E);
+        else hipLaunchKernelGGL((emit_kernel<2, 1>), dim3(emit_grid), dim3(EMIT_NT), 0, ms, E);
         HIPCHK(c, hipGetLastError());
         mask.clean = sev_get(c);
         if (mask.clean) HIPCHK(c, hipEventRecord(mask.clean, ms));

@@ -69,6 +69,7 @@ struct Sketch2Args {
     int force_redo;        /* tests: flag every strip */
     int dbg;               /* ablation (tools/sketch_bench.py, results WRONG): 1 no search, 2 no window pass, 4 no rolling, 8 no init */
     uint32_t thresh;       /* sketch_thresh_kernel: keys below it are candidates */
+    const uint2 *g4k;      /* sketch_thresh_kernel: k-dependent four-base ring tables (g4k_build_kernel), [256 j + byte] for the j-th four bases of a chunk */
     uint32_t *fb_list;     /* sketch_thresh_kernel: the strips it gives up, for sketch_fast_list_kernel */
     uint32_t *fb_count;
 };
@@ -101,6 +102,25 @@ __global__ __launch_bounds__(256) void g8k_build_kernel(const uint64_t (*__restr
     const uint64_t f = g8[w][0], u = g8[w][1];
     g8k[w] = make_uint2(ring_of(srot_h(f, 8, 8)), ring_of(srot_u(srot_h(u, 25, 23), rev_a, rev_b)));
     g8k[65536u + w] = make_uint2(ring_of(f), ring_of(srot_u(u, rev_a, rev_b)));
+}
+
+/* The same partial hashes from four lookups in tables small enough for LDS (8 KB): G[j][byte] = the contribution of the j-th four
+ * bases of a sixteen-base chunk, rotated into place -- {srol^(4(3-j))(f4), R(sror^(4(3-j))(u4))}, rings only -- so that
+ *   T0[w0] ^ T1[w1] = G[0][b0] ^ G[1][b1] ^ G[2][b2] ^ G[3][b3]     and    T1[w0] = G[2][b0] ^ G[3][b1]   (k % 16 == 8).
+ * sketch_thresh_kernel copies them into LDS at the start of a strip, beside its load of the base words: the table lookups of the
+ * eight-base form are a SECOND dependent global load per strip (a 1-MB table: L2 at best), which costs the kernel 13 % of its time
+ * alone and twice that next to the emit kernel's random traffic (profiles/r03y). */
+__global__ __launch_bounds__(256) void g4k_build_kernel(const uint64_t (*__restrict__ g4)[2], uint2 *__restrict__ g4k,
+                                                        uint32_t rev_a, uint32_t rev_b)
+{
+    const uint32_t b = threadIdx.x;
+    const uint64_t f = g4[b][0], u = g4[b][1];
+    for (uint32_t j = 0; j < 4; j++) {
+        const uint32_t sh = 4u * (3u - j);
+        const uint64_t fs = sh ? srot_h(f, sh, sh) : f;
+        const uint64_t us = sh ? srot_h(u, 33u - sh, 31u - sh) : u;
+        g4k[256u * j + b] = make_uint2(ring_of(fs), ring_of(srot_u(us, rev_a, rev_b)));
+    }
 }
 
 /* partial hashes (rings) of one 16-base chunk: Horner forms over its 16 bases FU = {F, R(U)} and over its first r bases P = {PF, R(PU)} */
@@ -928,7 +948,11 @@ __global__ __launch_bounds__(NT) void sketch_thresh_kernel(Sketch2Args B)
        element array shrinks to the exchange area of phase 1, one barrier goes, and the list may hold more (smaller w) */
     constexpr uint32_t CAP = DIRECT ? SK2T_CAP_DIRECT : SK2T_CAP;
     constexpr int XW = (int)((sizeof(uint2) * 2 * NX + sizeof(uint32_t) * (NX + 1)) / sizeof(uint32_t));
-    __shared__ uint32_t s_c[DIRECT ? XW : C * ST];
+    /* the four-base tables (2048 words) live behind the exchange area while phase 1a needs them: in the second half of the element
+       array, which only takes the staged keys two barriers later, or -- DIRECT -- in words of their own */
+    constexpr int TOFF = DIRECT ? ((XW + 3) & ~3) : (C * ST) / 2;
+    static_assert(TOFF >= XW && (DIRECT || TOFF + 2048 <= C * ST), "the tables must not overlap the exchange area");
+    __shared__ __attribute__((aligned(16))) uint32_t s_c[DIRECT ? TOFF + 2048 : C * ST];
     __shared__ uint2 s_cand[CAP + 8];      /* {key, position}: [3] left sentinel, [4 .. n + 3] the candidates, [n + 4] right sentinel;
                                                    [0 .. 2] and [n + 5 .. n + 7]: copies of the sentinels that the four-entry scan steps read along */
     __shared__ uint32_t s_bits[NBW];
@@ -955,28 +979,57 @@ __global__ __launch_bounds__(NT) void sketch_thresh_kernel(Sketch2Args B)
     const int64_t e_lane = (int64_t)I.E0 + (int64_t)L * C; /* ordinal of this lane's element t = 0 */
     const uint64_t gp = (uint64_t)((int64_t)I.base + I.P0 + (int64_t)L * C);
 
-    /* ---- phase 1a: 16-base partial hashes of the lane's own chunk (and of the chunks behind the strip) ---- */
+    /* ---- phase 1a: 16-base partial hashes of the lane's own chunk (and of the chunks behind the strip).  The base words and the
+       workgroup's copy of the four-base tables are requested together; the lookups then stay inside the CU. ---- */
     const bool live = e_lane < (int64_t)I.M;
     const bool feeds = e_lane - 16 * (int64_t)(B.q16 + 1) < (int64_t)I.M;
-    uint32_t so = 0;
-    if (feeds) {
-        so = sk2_bases16(A.T.packed, gp, B.max_word);
+    const bool feeds2 = L <= B.q16 && (int64_t)I.E0 + (int64_t)(NT + L) * C - 16 * (int64_t)(B.q16 + 1) < (int64_t)I.M; /* chunks NT .. NT+q16 feed the last lanes */
+    uint2 *const s_g4k = (uint2 *)&s_c[TOFF];
+    {
+        static_assert(NT == 256, "one 32-byte piece of the 8-KB tables per lane");
+        const uint4 *src = (const uint4 *)B.g4k;
+        const uint4 t0 = src[2 * L], t1 = src[2 * L + 1];
+        uint4 *dst = (uint4 *)s_g4k;
+        dst[2 * L] = t0;
+        dst[2 * L + 1] = t1;
+    }
+    uint32_t so = 0, sv = 0;
+    if (feeds && !SK2_DBG(B, 8)) so = sk2_bases16(A.T.packed, gp, B.max_word);
+    if (feeds2) sv = sk2_bases16(A.T.packed, gp + (uint64_t)NT * C, B.max_word);
+    __syncthreads();
+    auto chunk = [&](const uint32_t w, uint2 &FU, uint2 &P) {
+        const uint2 g0 = s_g4k[w & 255u], g1 = s_g4k[256u + ((w >> 8) & 255u)], g2 = s_g4k[512u + ((w >> 16) & 255u)], g3 = s_g4k[768u + (w >> 24)];
+        FU = make_uint2(g0.x ^ g1.x ^ g2.x ^ g3.x, g0.y ^ g1.y ^ g2.y ^ g3.y);
+        P = make_uint2(0u, 0u);
+        if (B.r16 == 8) {
+            const uint2 p0 = s_g4k[512u + (w & 255u)], p1 = s_g4k[768u + ((w >> 8) & 255u)];
+            P = make_uint2(p0.x ^ p1.x, p0.y ^ p1.y);
+        } else if (B.r16) {
+            uint2 fu;
+            sk2_chunk(w, B.r16, B, fu, P); /* k % 16 not in {0, 8}: the first r bases on the plain 64-bit tables */
+        }
+#ifdef NTL_SIM
+        {
+            uint2 fu, pp;
+            sk2_chunk(w, B.r16, B, fu, pp);
+            if (fu.x != FU.x || fu.y != FU.y || (B.r16 && (pp.x != P.x || pp.y != P.y))) { fprintf(stderr, "g4k tables disagree with g8k (k %% 16 = %d)\n", B.r16); abort(); }
+        }
+#endif
+    };
+    if (feeds && !SK2_DBG(B, 8)) {
         uint2 FU, P;
-        sk2_chunk(so, B.r16, B, FU, P);
+        if (SK2_DBG(B, 16)) { FU = make_uint2(so * 2654435761u, so ^ 0x9E3779B9u); P = FU; } /* ablation: no table lookups */
+        else chunk(so, FU, P);
         s_xy[L] = FU;
         s_so[L] = so;
         if (B.r16) s_xy[NX + L] = P;
     }
-    if (L <= B.q16) {
-        const int64_t ev = (int64_t)I.E0 + (int64_t)(NT + L) * C;
-        if (ev - 16 * (int64_t)(B.q16 + 1) < (int64_t)I.M) {
-            const uint32_t sv = sk2_bases16(A.T.packed, gp + (uint64_t)NT * C, B.max_word);
-            uint2 FU, P;
-            sk2_chunk(sv, B.r16, B, FU, P);
-            s_xy[NT + L] = FU;
-            s_so[NT + L] = sv;
-            if (B.r16) s_xy[NX + NT + L] = P;
-        }
+    if (feeds2) {
+        uint2 FU, P;
+        chunk(sv, FU, P);
+        s_xy[NT + L] = FU;
+        s_so[NT + L] = sv;
+        if (B.r16) s_xy[NX + NT + L] = P;
     }
     __syncthreads();
 

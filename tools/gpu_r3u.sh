@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 3: emit kernel on a fewer workgroups per CU (NTL_EMIT_LDS: unused dynamic LDS) beside the window kernel, C3 / C5
+# round 3: emit kernel on a a resident-size grid walking the tiles (NTL_EMIT_GRID) beside the window kernel, C3 / C5
 TAG=${1:-r03u}
 O=gpurun_out/$TAG; mkdir -p $O
 python __graft_entry__.py > $O/build.log 2>&1 || { tail -20 $O/build.log; exit 1; }
@@ -13,5 +13,5 @@ for l in open(sys.argv[1]):
 PY
 tail -2 $O/bench_$name.err
 }
-for g in 0 20000 40000 60000 100000; do run c3_g$g NTL_EMIT_LDS=$g -- --steps 6 --warmup 1; done
-for g in 0 40000 60000; do run c5_g$g NTL_EMIT_LDS=$g -- --workload C5 --steps 3 --warmup 1; done
+for g in 0 4096 2048 1536 1024 512; do run c3_g$g NTL_EMIT_GRID=$g -- --steps 6 --warmup 1; done
+for g in 0 4096 2048 1024; do run c5_g$g NTL_EMIT_GRID=$g -- --workload C5 --steps 3 --warmup 1; done
