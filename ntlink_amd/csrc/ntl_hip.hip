@@ -1389,7 +1389,7 @@ static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const nt
         EmitArgs E;
         E.packed = T.packed; E.seq_base = T.seq_base; E.nseq = (uint32_t)nseq; E.mask = (uint32_t *)mask.p;
         E.nwords = nmask; E.tile_off = tile.as<uint32_t>(); E.tile_seq = tile_seq.as<uint32_t>(); E.mx_off = s->mx_off.as<uint32_t>();
-        E.out = s->records.as<MxRecord>(); E.out_cap = (uint32_t)cap; E.ntiles = (uint32_t)tiles;
+        E.out = s->records.as<MxRecord>(); E.out_cap = (uint32_t)cap;
         E.k = k; E.mult = 1ull ^ ((uint64_t)k * 0x90b45d39fb6da1faull);
         uint64_t roll[16][2];
         make_tables(k, roll, E.seed_tab);
@@ -1403,14 +1403,11 @@ static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const nt
         /* the emit kernel is the last reader of the bitmask and clears the words it read: the mask goes back clean */
         const char *eu = getenv("NTL_EMIT_U"); /* minimizers in flight per thread; read per call: the tests switch it inside one process */
         const int emit_u = eu ? atoi(eu) : 1;
-        /* NTL_EMIT_GRID=n: at most n workgroups walk the tiles (0 = default: one workgroup per tile) */
-        const char *eg = getenv("NTL_EMIT_GRID");
-        const unsigned emit_grid = eg && atoi(eg) > 0 ? (unsigned)std::min<uint64_t>(tiles, (uint64_t)atoi(eg)) : (unsigned)tiles;
         if (probe == 0) hipLaunchKernelGGL((emit_kernel<0, 1>), dim3((unsigned)tiles), dim3(EMIT_NT), 0, ms, E);
-        else if (probe == 1 && emit_u >= 2) hipLaunchKernelGGL((emit_kernel<1, 2>), dim3(emit_grid), dim3(EMIT_NT), 0, ms, E);
-        else if (probe == 1) hipLaunchKernelGGL((emit_kernel<1, 1>), dim3(emit_grid), dim3(EMIT_NT), 0, ms, E);
-        else if (emit_u >= 2) hipLaunchKernelGGL((emit_kernel<2, 2>), dim3(emit_grid), dim3(EMIT_NT), 0, ms, E);
-        else hipLaunchKernelGGL((emit_kernel<2, 1>), dim3(emit_grid), dim3(EMIT_NT), 0, ms, E);
+        else if (probe == 1 && emit_u >= 2) hipLaunchKernelGGL((emit_kernel<1, 2>), dim3((unsigned)tiles), dim3(EMIT_NT), 0, ms, E);
+        else if (probe == 1) hipLaunchKernelGGL((emit_kernel<1, 1>), dim3((unsigned)tiles), dim3(EMIT_NT), 0, ms, E);
+        else if (emit_u >= 2) hipLaunchKernelGGL((emit_kernel<2, 2>), dim3((unsigned)tiles), dim3(EMIT_NT), 0, ms, E);
+        else hipLaunchKernelGGL((emit_kernel<2, 1>), dim3((unsigned)tiles), dim3(EMIT_NT), 0, ms, E);
         HIPCHK(c, hipGetLastError());
         mask.clean = sev_get(c);
         if (mask.clean) HIPCHK(c, hipEventRecord(mask.clean, ms));

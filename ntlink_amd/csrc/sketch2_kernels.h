@@ -969,6 +969,8 @@ __global__ __launch_bounds__(NT) void sketch_thresh_kernel(Sketch2Args B)
     const uint32_t per_xcd = gridDim.x >> 3; /* consecutive strips on one XCD (see sketch_mask_kernel) */
     const uint32_t strip = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
     if (strip >= A.nstrips) return;
+    static_assert(NT == 256, "one 32-byte piece of the 8-KB tables per lane");
+    const uint4 tb0 = ((const uint4 *)B.g4k)[2 * L], tb1 = ((const uint4 *)B.g4k)[2 * L + 1];
     const StripInfo I = A.strip_tab[strip];
     if (I.seq == NTL_NONE || I.multi != 0) return; /* strips that cross non-ACGT runs: sketch_mask_kernel<.., MULTI = true> */
     if (L < 16) { s_roll[2 * L] = (uint32_t)(A.roll_tab[L][0] >> 33); s_roll[2 * L + 1] = (uint32_t)(A.roll_tab[L][1] >> 32); }
@@ -985,17 +987,11 @@ __global__ __launch_bounds__(NT) void sketch_thresh_kernel(Sketch2Args B)
     const bool feeds = e_lane - 16 * (int64_t)(B.q16 + 1) < (int64_t)I.M;
     const bool feeds2 = L <= B.q16 && (int64_t)I.E0 + (int64_t)(NT + L) * C - 16 * (int64_t)(B.q16 + 1) < (int64_t)I.M; /* chunks NT .. NT+q16 feed the last lanes */
     uint2 *const s_g4k = (uint2 *)&s_c[TOFF];
-    {
-        static_assert(NT == 256, "one 32-byte piece of the 8-KB tables per lane");
-        const uint4 *src = (const uint4 *)B.g4k;
-        const uint4 t0 = src[2 * L], t1 = src[2 * L + 1];
-        uint4 *dst = (uint4 *)s_g4k;
-        dst[2 * L] = t0;
-        dst[2 * L + 1] = t1;
-    }
     uint32_t so = 0, sv = 0;
     if (feeds && !SK2_DBG(B, 8)) so = sk2_bases16(A.T.packed, gp, B.max_word);
     if (feeds2) sv = sk2_bases16(A.T.packed, gp + (uint64_t)NT * C, B.max_word);
+    ((uint4 *)s_g4k)[2 * L] = tb0;
+    ((uint4 *)s_g4k)[2 * L + 1] = tb1;
     __syncthreads();
     auto chunk = [&](const uint32_t w, uint2 &FU, uint2 &P) {
         const uint2 g0 = s_g4k[w & 255u], g1 = s_g4k[256u + ((w >> 8) & 255u)], g2 = s_g4k[512u + ((w >> 16) & 255u)], g3 = s_g4k[768u + (w >> 24)];

@@ -454,7 +454,6 @@ struct EmitArgs {
     uint32_t *mx_off;         /* [nseq+1] minimizers before each sequence start = offsets of the per-sequence lists */
     MxRecord *out;
     uint32_t out_cap;         /* records `out` can hold (it is sized before the count is known) */
-    uint32_t ntiles;          /* tiles of 65536 base positions */
     int k;
     uint64_t mult;            /* 1 ^ (k * MULTISEED) */
     uint64_t seed_tab[4][2];
@@ -498,138 +497,126 @@ __global__ __launch_bounds__(EMIT_NT) void emit_kernel(EmitArgs A)
     if (t < 4) { s_seed[t][0] = A.seed_tab[t][0]; s_seed[t][1] = A.seed_tab[t][1]; }
     s_g4[t][0] = A.g4[t][0];
     s_g4[t][1] = A.g4[t][1];
-    /* A.ntiles tiles over gridDim.x workgroups: one tile each when the grid is the tile count; a smaller, resident-size grid
-       walks them (fewer wavefront slots taken from the window kernel of the next sub-batch that runs beside this one) */
-    /* (PROBE == 0, the contig stage's launch, always gets one workgroup per tile: as a loop that instantiation trips an
-       "illegal instruction" check of this hipcc's backend) */
-    auto one_tile = [&](const uint32_t tile) {
-        const uint64_t tile_w0 = (uint64_t)tile * EMIT_TILE;
-        /* Sequences that overlap this tile of 65536 base positions: from the one its first position lies in to the one the next
-           tile's first position lies in (tile_seq_kernel); their starts are cached in LDS.  More than EMIT_SEQ_CAP of them (tiny
-           sequences) falls back to binary searches in global memory. */
-        const uint32_t s_lo = A.nseq ? A.tile_seq[tile] : 0u;
-        const uint32_t s_hi = A.nseq ? A.tile_seq[tile + 1] + 1u : 0u; /* candidates [s_lo, s_hi) */
-        const uint64_t gp_last = tile_w0 * 32 + (uint64_t)EMIT_TILE * 32 - 1;
-        const bool cached = s_hi - s_lo <= EMIT_SEQ_CAP;
-        const uint32_t ncache = cached ? s_hi - s_lo : EMIT_SEQ_CAP;
-        for (uint32_t i = t; i < ncache; i += EMIT_NT) s_base[i] = A.seq_base[s_lo + i];
-        /* (the barriers of the scan below stand between these stores and their readers) */
-        const uint64_t w0 = tile_w0 + (uint64_t)t * EMIT_WPT;
-        uint32_t words[EMIT_WPT];
-        uint32_t c = 0;
-        if (w0 + EMIT_WPT <= A.nwords) {
-            const uint4 a = *reinterpret_cast<const uint4 *>(A.mask + w0), b = *reinterpret_cast<const uint4 *>(A.mask + w0 + 4);
-            words[0] = a.x; words[1] = a.y; words[2] = a.z; words[3] = a.w; words[4] = b.x; words[5] = b.y; words[6] = b.z; words[7] = b.w;
-        } else {
-    #pragma unroll
-            for (int i = 0; i < EMIT_WPT; i++) words[i] = w0 + i < A.nwords ? A.mask[w0 + i] : 0u;
+    const uint64_t tile_w0 = (uint64_t)blockIdx.x * EMIT_TILE;
+    /* Sequences that overlap this tile of 65536 base positions: from the one its first position lies in to the one the next
+       tile's first position lies in (tile_seq_kernel); their starts are cached in LDS.  More than EMIT_SEQ_CAP of them (tiny
+       sequences) falls back to binary searches in global memory. */
+    const uint32_t s_lo = A.nseq ? A.tile_seq[blockIdx.x] : 0u;
+    const uint32_t s_hi = A.nseq ? A.tile_seq[blockIdx.x + 1] + 1u : 0u; /* candidates [s_lo, s_hi) */
+    const uint64_t gp_last = tile_w0 * 32 + (uint64_t)EMIT_TILE * 32 - 1;
+    const bool cached = s_hi - s_lo <= EMIT_SEQ_CAP;
+    const uint32_t ncache = cached ? s_hi - s_lo : EMIT_SEQ_CAP;
+    for (uint32_t i = t; i < ncache; i += EMIT_NT) s_base[i] = A.seq_base[s_lo + i];
+    /* (the barriers of the scan below stand between these stores and their readers) */
+    const uint64_t w0 = tile_w0 + (uint64_t)t * EMIT_WPT;
+    uint32_t words[EMIT_WPT];
+    uint32_t c = 0;
+    if (w0 + EMIT_WPT <= A.nwords) {
+        const uint4 a = *reinterpret_cast<const uint4 *>(A.mask + w0), b = *reinterpret_cast<const uint4 *>(A.mask + w0 + 4);
+        words[0] = a.x; words[1] = a.y; words[2] = a.z; words[3] = a.w; words[4] = b.x; words[5] = b.y; words[6] = b.z; words[7] = b.w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < EMIT_WPT; i++) words[i] = w0 + i < A.nwords ? A.mask[w0 + i] : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < EMIT_WPT; i++) c += (uint32_t)__popc(words[i]);
+    uint32_t total;
+    const uint32_t excl = block_excl_scan<EMIT_NT>(c, s_tmp, total);
+    const uint32_t tile_base = A.tile_off[blockIdx.x];
+    {
+        uint32_t r = excl;
+#pragma unroll
+        for (int i = 0; i < EMIT_WPT; i++) {
+            s_wrank[t * EMIT_WPT + i] = (uint16_t)r; /* < 65536: at most 65504 bits precede a word of the tile */
+            r += (uint32_t)__popc(words[i]);
         }
-    #pragma unroll
-        for (int i = 0; i < EMIT_WPT; i++) c += (uint32_t)__popc(words[i]);
-        uint32_t total;
-        const uint32_t excl = block_excl_scan<EMIT_NT>(c, s_tmp, total);
-        const uint32_t tile_base = A.tile_off[tile];
-        {
-            uint32_t r = excl;
-    #pragma unroll
-            for (int i = 0; i < EMIT_WPT; i++) {
-                s_wrank[t * EMIT_WPT + i] = (uint16_t)r; /* < 65536: at most 65504 bits precede a word of the tile */
-                r += (uint32_t)__popc(words[i]);
+    }
+    __syncthreads();
+    /* offsets of the per-sequence lists: the rank of every sequence start that lies in this tile (the end of the last
+       sequence, seq_base[nseq], counts as one: it receives the total) */
+    {
+        const uint64_t gp0 = tile_w0 * 32;
+        for (uint32_t s = s_lo + (uint32_t)t; s <= A.nseq; s += EMIT_NT) {
+            const uint64_t g = s - s_lo < ncache ? s_base[s - s_lo] : A.seq_base[s];
+            if (g > gp_last) break; /* starts are sorted: nothing further for this thread */
+            if (g < gp0) continue;  /* s_lo itself may start before the tile */
+            const uint32_t wl = (uint32_t)((g >> 5) - tile_w0), b = (uint32_t)g & 31u;
+            const uint32_t word = tile_w0 + wl < A.nwords ? A.mask[tile_w0 + wl] : 0u;
+            A.mx_off[s] = tile_base + s_wrank[wl] + (uint32_t)__popc(word & ((1u << b) - 1u));
+        }
+    }
+    for (uint32_t r0 = 0; r0 < total; r0 += EMIT_CAP) {
+        uint32_t r = excl;
+#pragma unroll
+        for (int i = 0; i < EMIT_WPT; i++) {
+            uint32_t m = words[i];
+            while (m) {
+                const int b = __ffs(m) - 1;
+                m &= m - 1;
+                if (r >= r0 && r < r0 + EMIT_CAP) s_list[r - r0] = (uint16_t)((t * EMIT_WPT + i) * 32 + b);
+                r++;
             }
         }
         __syncthreads();
-        /* offsets of the per-sequence lists: the rank of every sequence start that lies in this tile (the end of the last
-           sequence, seq_base[nseq], counts as one: it receives the total) */
-        {
-            const uint64_t gp0 = tile_w0 * 32;
-            for (uint32_t s = s_lo + (uint32_t)t; s <= A.nseq; s += EMIT_NT) {
-                const uint64_t g = s - s_lo < ncache ? s_base[s - s_lo] : A.seq_base[s];
-                if (g > gp_last) break; /* starts are sorted: nothing further for this thread */
-                if (g < gp0) continue;  /* s_lo itself may start before the tile */
-                const uint32_t wl = (uint32_t)((g >> 5) - tile_w0), b = (uint32_t)g & 31u;
-                const uint32_t word = tile_w0 + wl < A.nwords ? A.mask[tile_w0 + wl] : 0u;
-                A.mx_off[s] = tile_base + s_wrank[wl] + (uint32_t)__popc(word & ((1u << b) - 1u));
+        const uint32_t n = total - r0 < EMIT_CAP ? total - r0 : EMIT_CAP;
+        /* U minimizers per thread and step, in straight-line code: their base-word loads, and then their first index loads, are
+           in flight together (the kernel's time is the latency of these dependent random accesses, not its arithmetic) */
+        for (uint32_t i0 = t; i0 < n; i0 += U * EMIT_NT) {
+            uint64_t tt[U];
+            MxRecord R[U];
+            bool ok[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t i = i0 + (uint32_t)u * EMIT_NT;
+                const uint32_t ic = i < n ? i : i0; /* past the end: the first one again, result dropped */
+                const uint64_t gp = tile_w0 * 32 + s_list[ic];
+                const uint32_t sq = cached ? s_lo + seq_of(s_base, 0, s_hi - s_lo, gp) : seq_of(A.seq_base, s_lo, s_hi, gp);
+                const uint64_t sb = cached ? s_base[sq - s_lo] : A.seq_base[sq];
+                uint64_t fwd, rev;
+                hash_init_g4(A.packed, gp, A.k, s_g4, s_seed, fwd, rev);
+                uint64_t h = (fwd + rev) * A.mult;
+                h ^= h >> 27;
+                tt[u] = h;
+                R[u].hash = h;
+                R[u].pos = (uint32_t)(gp - sb);
+                R[u].meta = (sq << 1) | (fwd <= rev ? 1u : 0u);
+                ok[u] = i < n && tile_base + r0 + i < A.out_cap;
             }
-        }
-        for (uint32_t r0 = 0; r0 < total; r0 += EMIT_CAP) {
-            uint32_t r = excl;
-    #pragma unroll
-            for (int i = 0; i < EMIT_WPT; i++) {
-                uint32_t m = words[i];
-                while (m) {
-                    const int b = __ffs(m) - 1;
-                    m &= m - 1;
-                    if (r >= r0 && r < r0 + EMIT_CAP) s_list[r - r0] = (uint16_t)((t * EMIT_WPT + i) * 32 + b);
-                    r++;
-                }
-            }
-            __syncthreads();
-            const uint32_t n = total - r0 < EMIT_CAP ? total - r0 : EMIT_CAP;
-            /* U minimizers per thread and step, in straight-line code: their base-word loads, and then their first index loads, are
-               in flight together (the kernel's time is the latency of these dependent random accesses, not its arithmetic) */
-            for (uint32_t i0 = t; i0 < n; i0 += U * EMIT_NT) {
-                uint64_t tt[U];
-                MxRecord R[U];
-                bool ok[U];
-    #pragma unroll
+            if (PROBE) {
+                IndexProbe<PROBE == 1> pr[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) pr[u].start(tt[u], A.slots, A.tags, A.ix_bits);
+#pragma unroll
                 for (int u = 0; u < U; u++) {
-                    const uint32_t i = i0 + (uint32_t)u * EMIT_NT;
-                    const uint32_t ic = i < n ? i : i0; /* past the end: the first one again, result dropped */
-                    const uint64_t gp = tile_w0 * 32 + s_list[ic];
-                    const uint32_t sq = cached ? s_lo + seq_of(s_base, 0, s_hi - s_lo, gp) : seq_of(A.seq_base, s_lo, s_hi, gp);
-                    const uint64_t sb = cached ? s_base[sq - s_lo] : A.seq_base[sq];
-                    uint64_t fwd, rev;
-                    hash_init_g4(A.packed, gp, A.k, s_g4, s_seed, fwd, rev);
-                    uint64_t h = (fwd + rev) * A.mult;
-                    h ^= h >> 27;
-                    tt[u] = h;
-                    R[u].hash = h;
-                    R[u].pos = (uint32_t)(gp - sb);
-                    R[u].meta = (sq << 1) | (fwd <= rev ? 1u : 0u);
-                    ok[u] = i < n && tile_base + r0 + i < A.out_cap;
+                    if (!ok[u]) continue;
+                    const uint32_t at = tile_base + r0 + i0 + (uint32_t)u * EMIT_NT;
+                    A.out[at] = R[u];
+                    const Cand cd = pr[u].finish(tt[u], A.slots, A.tags, A.special, ((uint64_t)1 << A.ix_bits) - 1);
+                    A.cand[at] = cd;
+                    found += cd.meta & 1u;
                 }
-                if (PROBE) {
-                    IndexProbe<PROBE == 1> pr[U];
-    #pragma unroll
-                    for (int u = 0; u < U; u++) pr[u].start(tt[u], A.slots, A.tags, A.ix_bits);
-    #pragma unroll
-                    for (int u = 0; u < U; u++) {
-                        if (!ok[u]) continue;
-                        const uint32_t at = tile_base + r0 + i0 + (uint32_t)u * EMIT_NT;
-                        A.out[at] = R[u];
-                        const Cand cd = pr[u].finish(tt[u], A.slots, A.tags, A.special, ((uint64_t)1 << A.ix_bits) - 1);
-                        A.cand[at] = cd;
-                        found += cd.meta & 1u;
-                    }
-                } else {
-    #pragma unroll
-                    for (int u = 0; u < U; u++)
-                        if (ok[u]) A.out[tile_base + r0 + i0 + (uint32_t)u * EMIT_NT] = R[u];
-                }
-            }
-            __syncthreads();
-        }
-        /* every read of this tile's mask words is behind a barrier by now (the offsets loop reads other threads' words): clear
-           what was set, so that the next window pass finds the bitmask zero-filled without a fill pass of its own */
-        __syncthreads();
-        if (c) {
-            if (w0 + EMIT_WPT <= A.nwords) {
-                const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-                *reinterpret_cast<uint4 *>(A.mask + w0) = z;
-                *reinterpret_cast<uint4 *>(A.mask + w0 + 4) = z;
             } else {
-    #pragma unroll
-                for (int i = 0; i < EMIT_WPT; i++)
-                    if (words[i]) A.mask[w0 + i] = 0u;
+#pragma unroll
+                for (int u = 0; u < U; u++)
+                    if (ok[u]) A.out[tile_base + r0 + i0 + (uint32_t)u * EMIT_NT] = R[u];
             }
         }
-    };
-    if constexpr (PROBE == 0) one_tile(blockIdx.x);
-    else
-        for (uint32_t tile = blockIdx.x; tile < A.ntiles; tile += gridDim.x) {
-            one_tile(tile);
-            __syncthreads(); /* the next tile's LDS writes behind this tile's last reads */
+        __syncthreads();
+    }
+    /* every read of this tile's mask words is behind a barrier by now (the offsets loop reads other threads' words): clear
+       what was set, so that the next window pass finds the bitmask zero-filled without a fill pass of its own */
+    __syncthreads();
+    if (c) {
+        if (w0 + EMIT_WPT <= A.nwords) {
+            const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+            *reinterpret_cast<uint4 *>(A.mask + w0) = z;
+            *reinterpret_cast<uint4 *>(A.mask + w0 + 4) = z;
+        } else {
+#pragma unroll
+            for (int i = 0; i < EMIT_WPT; i++)
+                if (words[i]) A.mask[w0 + i] = 0u;
         }
+    }
     if (PROBE) { /* one atomic per workgroup */
         __syncthreads();
         if (t == 0) s_range[0] = 0;
