@@ -635,10 +635,20 @@ def end_to_end(dev, wl, W, args):
             for f in os.listdir(d):
                 if f.startswith("cold."):
                     os.remove(os.path.join(d, f))
-            t0 = time.perf_counter()
-            st = pipeline.run_pair(dev, "asm.fa", " ".join(files), k=W["k"], w=W["w"], paf=True, pairs_tsv=True,
-                                   sensitive=W["sensitive"])
-            dt = time.perf_counter() - t0
+            # three timed runs, the fastest reported and all three listed: the GPU box grants the process 16 of its cores and
+            # shares the rest of the host with other tenants -- the same build measured 14.7 and 18.7 Gbases/s on two boxes
+            runs, st, dt = [], None, None
+            for _ in range(3):
+                for f in os.listdir(d):
+                    if f.startswith("asm.fa."):
+                        os.remove(os.path.join(d, f))
+                t0 = time.perf_counter()
+                st_i = pipeline.run_pair(dev, "asm.fa", " ".join(files), k=W["k"], w=W["w"], paf=True, pairs_tsv=True,
+                                         sensitive=W["sensitive"])
+                dt_i = time.perf_counter() - t0
+                runs.append(round(dt_i, 3))
+                if dt is None or dt_i < dt:
+                    st, dt = st_i, dt_i
         finally:
             os.chdir(cwd)
         out_bytes = sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d) if f.startswith("asm.fa."))
@@ -647,7 +657,8 @@ def end_to_end(dev, wl, W, args):
             gz = gz_forms(dev, d, files[0], W, cwd)
         except Exception as exc:
             gz = {"error": f"{type(exc).__name__}: {exc}"}
-        return {"value": round(st["read_bases"] / dt / 1e9, 3), "unit": "Gbases/s", "seconds": round(dt, 3), "compressed_inputs": gz,
+        return {"value": round(st["read_bases"] / dt / 1e9, 3), "unit": "Gbases/s", "seconds": round(dt, 3), "runs_s": runs,
+                "runs_note": "value = the fastest of the three warm runs (stage times below are that run's)", "compressed_inputs": gz,
                 "host_cpu": dict(zip(("cpus_visible", "cpu_quota_cores"), cpu_budget())),
                 "first_run_cold": {"value": round(st0["read_bases"] / dt0 / 1e9, 3), "unit": "Gbases/s", "seconds": round(dt0, 3), "read_bases": st0["read_bases"],
                                    "what": "the same driver on the first reads file only, first call in this process"},
