@@ -471,6 +471,8 @@ def valu_roofline(pm, avg_launch_ms, bases_per_launch):
     out = {"achieved": round(ach / 1e9, 2), "unit": "G wave-instr/s", "lane_instr_per_base": round(n * 64.0 / bases_per_launch, 2),
            "source": pm.get("valu_source"), "isa_histogram": pm.get("isa_histogram")}
     if busy:
+        if busy > 1.0:  # the counter ticks in units of four cycles; plain integer instructions issue in less: a few per cent above 1 = saturated
+            out["busy_as_counted"] = busy
         out.update({"frac": round(min(busy, 1.0), 3), "peak": round(ach / 1e9 / min(busy, 1.0), 1),
                     "cycles_per_wave_instr": pm.get("valu_cycles_per_wave_instr"), "clock_ghz": pm.get("clock_ghz"),
                     "note": "frac = VALU-busy SIMD cycles / SIMD cycles of the profiled launches (counters, not a model); peak = achieved / frac"})
@@ -658,7 +660,10 @@ def end_to_end(dev, wl, W, args):
         except Exception as exc:
             gz = {"error": f"{type(exc).__name__}: {exc}"}
         return {"value": round(st["read_bases"] / dt / 1e9, 3), "unit": "Gbases/s", "seconds": round(dt, 3), "runs_s": runs,
-                "runs_note": "value = the fastest of the three warm runs (stage times below are that run's)", "compressed_inputs": gz,
+                "runs_note": "value = the fastest of the three runs on all read files (stage times below are that run's): the steady state of a "
+                             "long job.  The first of them still page-locks staging buffers for the full depth of the two readers and grows the "
+                             "writers' buffer pool (about half a second, once per process): a 90-Gbases input would see it as 12 % of its run",
+                "compressed_inputs": gz,
                 "host_cpu": dict(zip(("cpus_visible", "cpu_quota_cores"), cpu_budget())),
                 "first_run_cold": {"value": round(st0["read_bases"] / dt0 / 1e9, 3), "unit": "Gbases/s", "seconds": round(dt0, 3), "read_bases": st0["read_bases"],
                                    "what": "the same driver on the first reads file only, first call in this process"},
