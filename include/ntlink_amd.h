@@ -40,7 +40,7 @@
  * position order), exactly as the reference emits them.
  *
  * Environment (tuning and tests; none is needed): NTL_IO_THREADS (parser threads, default
- * min(cores, 32)), NTL_IO_MIN_CHUNK (bytes per parser thread below which fewer threads are used),
+ * min(cores, 32), or one and a half per core of the process's cgroup CPU quota when that is less), NTL_IO_MIN_CHUNK (bytes per parser thread below which fewer threads are used),
  * NTL_IO_NO_MMAP=1 (stream every input through zlib on one thread), NTL_IO_PREAD=1 (plain files through staged preads
  * instead of a mapping), NTL_IO_NO_LIBDEFLATE=1, NTL_POOL_MAX_BYTES (bound of the cache of device blocks, default half the device memory),
  * NTL_IO_GZ_WHOLE_MAX (compressed bytes up to which a gzip file is inflated in one go, default

@@ -20,7 +20,7 @@ import numpy as np
 from . import capi, formats, pairing, seqio
 
 TSV_BLOCK_BYTES = 256 << 20  # text of the read-minimizer TSV parsed per device batch (operator B2)
-DEFAULT_BATCH_BASES = 256_000_000  # read bases per device batch (packed: 64 MB); the next batch is parsed meanwhile
+DEFAULT_BATCH_BASES = 512_000_000  # read bases per device batch (packed: 128 MB); the next batches are parsed meanwhile (256 M: 7 % slower file to file)
 
 
 _TRACE = [] if os.environ.get("NTL_PIPE_TRACE") else None  # (seconds, thread, what, batch): a timeline of the pair driver, dumped at the end

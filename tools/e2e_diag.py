@@ -39,24 +39,25 @@ def prepare(d, bases, workload):
     return files
 
 
-def run_once(d, batch, files=None):
+def run_once(d, batch, files=None, repeat=1):
     from ntlink_amd import capi, pipeline
     plan = json.load(open(os.path.join(d, "plan.json")))
     files = files or plan["files"]
     dev = capi.Device(0)
     os.chdir(d)
-    for f in os.listdir(d):
-        if f.startswith("asm.fa."):
-            os.remove(f)
-    t0 = time.perf_counter()
-    st = pipeline.run_pair(dev, "asm.fa", " ".join(files), k=plan["k"], w=plan["w"], paf=True, pairs_tsv=True, sensitive=plan["sensitive"],
-                           batch_bases=batch)
-    dt = time.perf_counter() - t0
-    dev.close()
     keep = ("t_contigs", "t_contigs_parts", "t_ingest", "t_device", "t_device_parts", "t_handover", "t_drain_tail", "t_graph", "t_write", "t_tally", "reader")
-    print(json.dumps({"Gbases_per_s": round(st["read_bases"] / dt / 1e9, 3), "seconds": round(dt, 3), "read_bases": st["read_bases"],
-                      "batch_bases": batch, "env": {k: v for k, v in os.environ.items() if k.startswith("NTL_")},
-                      **{k: (round(st[k], 4) if isinstance(st.get(k), float) else st.get(k)) for k in keep}}), flush=True)
+    for rep in range(repeat):  # the second and later passes of one process: staging buffers and buffer pools exist (the steady state)
+        for f in os.listdir(d):
+            if f.startswith("asm.fa."):
+                os.remove(f)
+        t0 = time.perf_counter()
+        st = pipeline.run_pair(dev, "asm.fa", " ".join(files), k=plan["k"], w=plan["w"], paf=True, pairs_tsv=True, sensitive=plan["sensitive"],
+                               **({"batch_bases": batch} if batch else {}))  # 0: the driver's default
+        dt = time.perf_counter() - t0
+        print(json.dumps({"Gbases_per_s": round(st["read_bases"] / dt / 1e9, 3), "seconds": round(dt, 3), "pass": rep, "read_bases": st["read_bases"],
+                          "batch_bases": batch, "env": {k: v for k, v in os.environ.items() if k.startswith("NTL_")},
+                          **{k: (round(st[k], 4) if isinstance(st.get(k), float) else st.get(k)) for k in keep}}), flush=True)
+    dev.close()
 
 
 def main():
@@ -66,10 +67,11 @@ def main():
     ap.add_argument("--run", default=None)
     ap.add_argument("--batch", type=int, default=256_000_000)
     ap.add_argument("--files", default=None)
+    ap.add_argument("--repeat", type=int, default=1)
     ap.add_argument("--forms", action="store_true", help="also time gzip / FASTQ.gz forms of (a part of) the same reads")
     a = ap.parse_args()
     if a.run:
-        run_once(a.run, a.batch, a.files.split(",") if a.files else None)
+        run_once(a.run, a.batch, a.files.split(",") if a.files else None, a.repeat)
         return
     import tempfile
     d = tempfile.mkdtemp(prefix="ntl_e2ed_", dir="/dev/shm")
@@ -81,6 +83,22 @@ def main():
             for i in range(2):
                 subprocess.run([sys.executable, os.path.abspath(__file__), "--run", d, "--batch", "256000000"],
                                env=dict(os.environ, NTL_PIPE_TRACE=os.environ["NTL_E2E_TRACE_ONLY"] + f".{i}", NTL_IO_TRACE="1"), check=False)
+            return
+        if os.environ.get("NTL_E2E_SWEEP5"):  # the defaults, twice
+            for _ in range(2):
+                subprocess.run([sys.executable, os.path.abspath(__file__), "--run", d, "--batch", "0", "--repeat", "3"], env=dict(os.environ), check=False)
+            return
+        if os.environ.get("NTL_E2E_SWEEP4"):
+            for env, batch in (({}, 512_000_000), ({"NTL_IO_THREADS": "24"}, 512_000_000), ({"NTL_IO_THREADS": "20"}, 512_000_000), ({}, 1_000_000_000),
+                               ({"NTL_IO_THREADS": "24"}, 1_000_000_000), ({"NTL_IO_THREADS": "24"}, 384_000_000), ({"NTL_IO_THREADS": "28"}, 512_000_000),
+                               ({"NTL_IO_THREADS": "24", "NTL_IO_READERS": "3"}, 512_000_000)):
+                subprocess.run([sys.executable, os.path.abspath(__file__), "--run", d, "--batch", str(batch), "--repeat", "3"], env=dict(os.environ, **env), check=False)
+            return
+        if os.environ.get("NTL_E2E_SWEEP3"):  # three passes per process: the last ones are the steady state
+            for env, batch in (({}, 256_000_000), ({"NTL_IO_READERS": "3"}, 256_000_000), ({"NTL_IO_THREADS": "16"}, 256_000_000),
+                               ({"NTL_IO_THREADS": "24"}, 256_000_000), ({"NTL_DEVICE_STREAMS": "3"}, 256_000_000), ({}, 512_000_000),
+                               ({"NTL_IO_READERS": "3", "NTL_DEVICE_STREAMS": "3"}, 256_000_000), ({"NTL_IO_READERS": "1"}, 256_000_000)):
+                subprocess.run([sys.executable, os.path.abspath(__file__), "--run", d, "--batch", str(batch), "--repeat", "3"], env=dict(os.environ, **env), check=False)
             return
         if os.environ.get("NTL_E2E_SWEEP2"):
             for env in ({}, {}, {"NTL_IO_ONE_PASS": "0"}, {"NTL_IO_THREADS": "8"}, {"NTL_IO_THREADS": "16"}, {"NTL_IO_THREADS": "16", "NTL_IO_READERS": "1"},
