@@ -258,7 +258,7 @@ def load(paths, max_bases=None, alloc=None, ahead=None, stats=None, packed=False
     SeqSets of about that many bases; several files are concatenated in the order given and a batch
     never spans two files.  alloc(nbytes) -> uint8 array supplies the sequence buffers (the pair
     driver passes the device's page-locked pool); default numpy.  Opening a gzip file inflates it, so
-    the next `ahead` files (default min(32, cores/4), at most 2 GiB of compressed input) are opened by
+    the next `ahead` files (default min(32, cores), at most 2 GiB of compressed input) are opened by
     background threads while the current one is consumed: many .fq.gz files decode in parallel.  An entry of `paths` may
     be (path, lo, hi): the records of a plain file that start in that byte range (shard_plan).  stats["parsed_bytes"]
     accumulates the input bytes consumed (file bytes of plain files and ranges, compressed bytes of gzip files).
@@ -273,7 +273,7 @@ def load(paths, max_bases=None, alloc=None, ahead=None, stats=None, packed=False
         paths = [paths]
     trace = bool(os.environ.get("NTL_IO_TRACE"))
     one_pass = packed and max_bases is not None and os.environ.get("NTL_IO_ONE_PASS", "1") != "0"
-    n_ahead = ahead if ahead is not None else min(32, max(1, (os.cpu_count() or 1) // 4))
+    n_ahead = ahead if ahead is not None else min(32, max(2, os.cpu_count() or 1))  # opening a gzip file inflates it: one thread per file
     whole = []
     pending = collections.deque()  # (path, future of an open handle, compressed bytes)
     todo = iter(paths)
@@ -390,7 +390,13 @@ def load_parallel(paths, readers=None, chunk_bytes=None, max_bases=None, stats=N
     for p in paths:
         path, lo, hi = p if isinstance(p, tuple) else (p, 0, None)
         if not _splittable(path):
-            chunks.append(p)
+            # consecutive files that cannot be cut (gzip streams) form ONE chunk: `load` opens -- inflates -- the next files of its
+            # list ahead on a pool of threads, which a reader that is handed one file at a time cannot do (16 .fq.gz files on the
+            # GPU box: 1.3 Gbases/s one file per reader, 4.0 as one list; profiles/r03ah_gz_diag.txt)
+            if chunks and isinstance(chunks[-1], list):
+                chunks[-1].append(p)
+            else:
+                chunks.append([p])
             continue
         hi = os.path.getsize(path) if hi is None else int(hi)
         n = max(1, -(-(hi - int(lo)) // chunk_bytes))
@@ -401,6 +407,7 @@ def load_parallel(paths, readers=None, chunk_bytes=None, max_bases=None, stats=N
             a, b = int(lo) + (hi - int(lo)) * i // n, int(lo) + (hi - int(lo)) * (i + 1) // n
             if a < b:
                 chunks.append((path, a, b))
+    chunks = [c[0] if isinstance(c, list) and len(c) == 1 else c for c in chunks]
     if len(chunks) <= 1:
         yield from load(paths, max_bases=max_bases, stats=stats, **kw)
         return
@@ -422,7 +429,7 @@ def load_parallel(paths, readers=None, chunk_bytes=None, max_bases=None, stats=N
                 return
             st = {}
             try:
-                for ss in load([chunks[i]], max_bases=max_bases, stats=st, **kw):
+                for ss in load(chunks[i] if isinstance(chunks[i], list) else [chunks[i]], max_bases=max_bases, stats=st, **kw):
                     qs[i].put(ss)
                     if stop.is_set():
                         break
