@@ -736,14 +736,20 @@ def gz_forms(dev, d, fasta, W, cwd, max_bases=2_000_000_000):
     os.chdir(d)
     try:
         for name, reads in (("16_fq_gz_files", " ".join(f"fq_{i:02d}.fq.gz" for i in range(nfiles))), ("one_bgzf_fq_gz", "all.fq.bgz.gz")):
-            for f in os.listdir(d):
-                if f.startswith("gzrun."):
-                    os.remove(os.path.join(d, f))
-            t0 = time.perf_counter()
-            st = pipeline.run_pair(dev, "asm.fa", reads, prefix="gzrun", k=W["k"], w=W["w"], paf=True, pairs_tsv=True, sensitive=W["sensitive"],
-                                   write_contig_tsv=False)
-            dt = time.perf_counter() - t0
-            out[name] = {"value": round(st["read_bases"] / dt / 1e9, 3), "unit": "Gbases/s", "seconds": round(dt, 3), "read_bases": st["read_bases"],
+            runs, st, dt = [], None, None
+            for _ in range(2):  # as in end_to_end: the faster of two runs, both listed (2 Gbases: 0.25 s of every run is the contig stage)
+                for f in os.listdir(d):
+                    if f.startswith("gzrun."):
+                        os.remove(os.path.join(d, f))
+                t0 = time.perf_counter()
+                st_i = pipeline.run_pair(dev, "asm.fa", reads, prefix="gzrun", k=W["k"], w=W["w"], paf=True, pairs_tsv=True, sensitive=W["sensitive"],
+                                         write_contig_tsv=False)
+                dt_i = time.perf_counter() - t0
+                runs.append(round(dt_i, 3))
+                if dt is None or dt_i < dt:
+                    st, dt = st_i, dt_i
+            out[name] = {"value": round(st["read_bases"] / dt / 1e9, 3), "unit": "Gbases/s", "seconds": round(dt, 3), "runs_s": runs, "read_bases": st["read_bases"],
+                         "t_contig_stage": round(st["t_contigs"], 3),
                          "compressed_bytes": sum(os.path.getsize(os.path.join(d, x)) for x in reads.split())}
     finally:
         os.chdir(cwd)
