@@ -573,3 +573,18 @@ def test_parallel_readers_keep_the_input_order(tmp_path):
     next(g)
     g.close()
     assert threading.active_count() <= before + 1
+    # several gzip streams in a row are one chunk (inflated ahead by one reader's `load`), plain files between and behind them
+    # are cut as before: same records, same order
+    gz = []
+    for f in range(5):
+        q = tmp_path / f"s{f}.fq.gz"
+        with gzip.open(q, "wt") as fh:
+            for i in range(40):
+                sq = "".join(rng.choice(list("ACGT"), int(rng.integers(1, 3000))))
+                fh.write(f"@s{f}_{i}\n{sq}\n+\n{'I' * len(sq)}\n")
+        gz.append(str(q))
+    mixed = gz[:3] + [paths[0]] + gz[3:] + [paths[-1]]
+    want = _records(list(seqio.load(mixed, max_bases=30_000)))
+    for readers in (2, 3):
+        assert _records(list(seqio.load_parallel(mixed, readers=readers, chunk_bytes=100_000, max_bases=30_000))) == want
+    assert _records(list(seqio.load_parallel(gz, readers=2, max_bases=30_000))) == _records(list(seqio.load(gz, max_bases=30_000)))
