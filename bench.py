@@ -78,13 +78,18 @@ def spawn_ranks(args):
 
 
 def kernel_signature():
-    """Identifies the kernel sources a PMC pass was taken on (profiles/traffic.json is stale after an edit)."""
+    """Identifies the kernel sources a PMC pass was taken on (profiles/traffic.json is stale after an edit of the code; comments
+    and white space do not count)."""
+    import re
     h = hashlib.sha1()
     d = os.path.join(ROOT, "ntlink_amd", "csrc")
     for f in ("sketch_kernels.h", "sketch2_kernels.h", "dev_common.h", "map_kernels.h", "index_common.h"):
         p = os.path.join(d, f)
         if os.path.exists(p):
-            h.update(open(p, "rb").read())
+            text = open(p, "r", errors="replace").read()
+            text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)   # block comments
+            text = re.sub(r"(?m)(^|[^:\"'])//[^\n]*", r"\1", text)  # line comments (not `://` inside a string)
+            h.update(" ".join(text.split()).encode())
     return h.hexdigest()[:12]
 
 
