@@ -892,10 +892,10 @@ __global__ __launch_bounds__(NT) void sketch_lanes_kernel(Sketch2Args B)
 
 
 /*
- * sketch_thresh_kernel: the window pass on threshold-sparsified windows (VERDICT r2 item 2b's structural experiment).
+ * sketch_thresh_kernel: the window pass on threshold-sparsified windows -- the default for 71 <= w <= 255.
  *
  * Same strip, same keys, same contract as sketch_fast_kernel<NT, R0, false>: a bit per k-mer that is the argmin of one of the
- * windows the strip answers for, or the strip on the redo list and none of its bits.  What differs is everything behind the
+ * windows the strip answers for, or the strip on a list for another pass and none of its bits.  What differs is everything behind the
  * rolling: no block minima, no 17-window pass, no search jobs.  Only the k-mers with key < T ("candidates"; T = 2^32 * c / w for
  * about c = 10 candidates per window) are looked at again.  They are compacted, in position order, into a list in LDS, and one
  * lane per candidate decides whether it is the lone minimum of some window:
