@@ -13,9 +13,25 @@ import os
 import sys
 
 
+def cpu_quota_cores():
+    """CPU time the process's cgroup is granted, in cores, or None (cpu.max of cgroup v2, cfs_quota_us / cfs_period_us of v1): a
+    container often sees every CPU of its host and is granted a fraction of them."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            return q / per if q > 0 else None
+        except (OSError, ValueError):
+            return None
+
+
 def pin_rank(local_rank, local_world):
     """Several ranks on one host: each keeps to its own contiguous slice of the cores, and its parser / emitter thread pools
-    (NTL_IO_THREADS, unless the caller set it) are sized to that slice -- eight ranks must not start eight full-size pools
+    (NTL_IO_THREADS, unless the caller set it) are sized to that slice -- or to its share of the cgroup's CPU quota, one and a half
+    threads per granted core as in the single-process default, when that is less: eight ranks must not start eight full-size pools
     and two device workers each on top of one another.  NTL_PIN=0 leaves the affinity alone.  -> cores of this rank, or None."""
     if local_world <= 1 or os.environ.get("NTL_PIN", "1") == "0" or not hasattr(os, "sched_getaffinity"):
         return None
@@ -26,7 +42,11 @@ def pin_rank(local_rank, local_world):
         os.sched_setaffinity(0, mine)
     except OSError:
         return None
-    os.environ.setdefault("NTL_IO_THREADS", str(max(2, min(64, len(mine)))))
+    threads = min(64, len(mine))
+    quota = cpu_quota_cores()
+    if quota:
+        threads = min(threads, int(1.5 * quota / local_world + 0.5))
+    os.environ.setdefault("NTL_IO_THREADS", str(max(2, threads)))
     return len(mine)
 
 
