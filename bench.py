@@ -422,7 +422,7 @@ def main():
     if world == 1 and rank == 0 and not args.no_others and args.scale == 1.0:
         # the other single-GPU configurations of BASELINE.json under the same clock (fewer steps; same definitions)
         others = {}
-        for name, st in (("C2", 40), ("C5", 3)):
+        for name, st in (("C2", 200), ("C5", 3)):
             if name == args.workload:
                 continue
             try:
