@@ -92,6 +92,35 @@ def test_sim_pair_driver_files(dev, tmp_path):
     assert os.path.exists(pre + ".n1.scaffold.dot")
 
 
+def test_sim_pair_driver_several_gzip_read_files(dev, tmp_path, monkeypatch):
+    """`reads='a.fa.gz b.fa.gz c.fa.gz'` (ntLink:222: `gzip -cd -f FILES`) with two parallel readers: the run of gzip files is one
+    chunk of theirs (inflated ahead, a thread per file) -- same files as from one plain FASTA."""
+    import gzip
+    import os
+    import shutil
+    from helpers import REF, read_text
+    from ntlink_amd import pipeline
+    for n in ("scaffolds_4.fa", "long_reads_4_top5.fa"):
+        shutil.copy(os.path.join(REF, n), tmp_path / n)
+    recs = open(tmp_path / "long_reads_4_top5.fa").read().split(">")[1:]
+    assert len(recs) == 5
+    for i, part in enumerate((recs[:2], recs[2:3], recs[3:])):
+        with gzip.open(tmp_path / f"part{i}.fa.gz", "wt") as fh:
+            fh.write("".join(">" + r for r in part))
+    monkeypatch.setenv("NTL_IO_READERS", "2")
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        pipeline.run_pair(dev, "scaffolds_4.fa", "long_reads_4_top5.fa", k=40, w=100, paf=True, pairs_tsv=True, prefix="plain", write_contig_tsv=False)
+        st = pipeline.run_pair(dev, "scaffolds_4.fa", "part0.fa.gz part1.fa.gz part2.fa.gz", k=40, w=100, paf=True, pairs_tsv=True,
+                               prefix="gz", batch_bases=20_000, write_contig_tsv=False)
+        assert st["reads"] == 5
+    finally:
+        os.chdir(cwd)
+    for ext in (".verbose_mapping.tsv", ".paf", ".pairs.tsv"):
+        assert read_text(str(tmp_path / "gz") + ext) == read_text(str(tmp_path / "plain") + ext), ext
+
+
 def test_sim_pair_driver_error_removes_partial_outputs(dev, tmp_path):
     """bin/ntlink_pair.py:608-613: on an error nothing half-written stays behind; the reader thread's
     exception surfaces in the driver."""
