@@ -20,8 +20,9 @@ profiles/ hold); the durations measured inside the pipelined steps are reported 
 
 N > 1: one process per GPU (the driver launches `python -m torch.distributed.run ... bench.py --gpus N`;
 a bare `python bench.py --gpus N` starts those N ranks itself as a child process).  Reads shard, the contig
-index is rebuilt on every GPU, no data-path collective; RCCL carries the barrier and the max.  Default
-weak scaling (every rank maps its own 90 Gbases); --strong splits the same 90 Gbases N ways (configs[3]).
+index is rebuilt on every GPU, no data-path collective; RCCL carries the barrier and the max.  Default for N > 1:
+STRONG scaling, BASELINE.json configs[3] -- the same 90 Gbases split N ways, a rank's share in at least --min-batches
+sub-batches; --weak gives every rank a whole read set of its own instead.
 
 Prints ONE JSON line on rank 0.
 """
@@ -45,7 +46,9 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=14)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="C3", help="C3 (default: 3 Gbp + 90 Gbases ONT, k32 w250), C2, C5")
-    ap.add_argument("--strong", action="store_true", help="strong scaling: the workload's read set is split over the ranks")
+    ap.add_argument("--strong", action="store_true", help="strong scaling: the workload's read set is split over the ranks (configs[3]; the default for --gpus N > 1)")
+    ap.add_argument("--weak", action="store_true", help="weak scaling: every rank maps a whole read set of its own (N > 1 only; reported as \"scaling\": \"weak\")")
+    ap.add_argument("--min-batches", type=int, default=8, help="strong scaling: a rank's share is cut into at least this many sub-batches, so that the two-stream pipeline has depth")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debugging only; reported)")
     ap.add_argument("--batch-bases", type=float, default=3.95e9, help="read bases per device batch")
     ap.add_argument("--serial-steps", type=int, default=2, help="steps of the kernels-alone pass behind the timed region (0 = none)")
@@ -158,6 +161,13 @@ class Comm:
         self.dist.all_gather(out, t)
         return [float(x.item()) for x in out]
 
+    def gather_obj(self, obj):
+        if self.dist is None:
+            return [obj]
+        out = [None] * self.dist.get_world_size()
+        self.dist.all_gather_object(out, obj)
+        return out
+
     def close(self):
         if self.dist is not None:
             self.dist.destroy_process_group()
@@ -172,8 +182,11 @@ def run_workload(dev, comm, name, args, steps, warmup, rank, world, serial_steps
     k, w = W["k"], W["w"]
     total_read_bases = W["read_bases"]
     my_bases = total_read_bases // world if args.strong else total_read_bases
+    batch_bases = int(args.batch_bases)
+    if args.strong and world > 1:  # a rank's share of configs[3] is 3 sub-batches of the N = 1 size: too few for window(i+1) beside emit(i)
+        batch_bases = max(1, min(batch_bases, -(-my_bases // max(1, args.min_batches))))
     t0 = time.perf_counter()
-    wl = synth.DeviceWorkload(dev, name, args.scale, read_bases=my_bases, batch_bases=int(args.batch_bases),
+    wl = synth.DeviceWorkload(dev, name, args.scale, read_bases=my_bases, batch_bases=batch_bases,
                               read_seed=(2 + rank) if not args.strong else (2, rank))
     dev.sync()
     gen_s = time.perf_counter() - t0
@@ -286,13 +299,16 @@ def run_workload(dev, comm, name, args, steps, warmup, rank, world, serial_steps
     for d in devs[1:]:
         d.close()
     per_rank_ms = [x / steps * 1e3 for x in comm.gather(elapsed)]
+    ranks_seen = int(round(comm.sum(1)))
+    ranks = comm.gather_obj({"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "device": dev.name,
+                             "backend": ("rccl" if comm.use_cuda else "gloo") if comm.dist is not None else None})
     per_rank_bases = comm.gather(wl.read_bases)
     elapsed_max = comm.max(elapsed)
     total_bases = comm.sum(wl.read_bases)
     return dict(name=name, W=W, wl=wl, ix=ix, csk=csk, params=params, stats=stats, gen_s=gen_s, contig_stage_ms=contig_stage_ms,
                 contig_prof=contig_prof, contig_mx=contig_mx, index_size=index_size, elapsed=elapsed_max, total_bases=total_bases,
                 prof=prof, serial=serial, pipelined=pipelined, per_rank_ms=per_rank_ms, per_rank_bases=per_rank_bases, steps=steps,
-                n_streams=n_streams)
+                n_streams=n_streams, ranks_seen=ranks_seen, ranks=ranks, batch_bases=batch_bases)
 
 
 def summarize(R, args, world, dev_name):
@@ -369,6 +385,9 @@ def summarize(R, args, world, dev_name):
 
 def main():
     args = parse_args()
+    if args.strong and args.weak:
+        sys.exit("--strong and --weak exclude each other")
+    args.strong = not args.weak  # total work fixed at the workload's read set whatever N: configs[3]; at N = 1 the two are the same run
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
@@ -386,7 +405,7 @@ def main():
         dist.destroy_process_group()
         return
     sys.path.insert(0, ROOT)
-    from ntlink_amd.dist_pair import pin_rank
+    from ntlink_amd.dist_pair import pin_rank, LAST_PIN
     cores_mine = pin_rank(local_rank, local_world)
     import torch
     from ntlink_amd import capi
@@ -408,9 +427,12 @@ def main():
             "config": cfg, "roofline": roof,
             "per_rank_ms_per_step": [round(x, 3) for x in R["per_rank_ms"]],
             "per_rank_bases_per_step": [int(x) for x in R["per_rank_bases"]],
+            "world_size": world, "rccl_ranks_seen": R["ranks_seen"], "ranks": R["ranks"],
+            "sub_batches_per_rank": len(R["wl"].read_batches), "batch_bases": R["batch_bases"],
         }
         if cores_mine:
             out["cores_per_rank"] = cores_mine
+            out["pin_rank0"] = dict(LAST_PIN)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dev, R["wl"], R["W"], R["params"])
         if world == 1 and not args.no_e2e and use_cuda:

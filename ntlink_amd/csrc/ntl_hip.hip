@@ -73,6 +73,7 @@ struct Zombie {
     int kind = 0;      /* 1 sketch (w[0] low = minimizer total vs cap), 2 map result (w[1] low = invariant flag) */
     uint64_t cap = 0;
     std::shared_ptr<std::atomic<float>> hitf; /* 2: where the batch's hit fraction goes (MapSums: nfound / nmx) */
+    const struct ntl_index *ix = nullptr; /* the index the queued kernels read: its reference is dropped when they have run */
 };
 
 struct ntl_ctx {
@@ -181,6 +182,7 @@ static hipError_t main_wait(ntl_ctx *c)
 }
 
 static PinSlot *slot_get(ntl_ctx *c);
+static void index_unref(const struct ntl_index *ix, ntl_ctx *by);
 static void slot_put(ntl_ctx *c, PinSlot *p) { if (p) c->slot_free.push_back((uint32_t)(p - c->slots)); }
 
 /* zombies whose work has finished: check what they carried, recycle event and slot.  block: wait for the oldest one. */
@@ -207,6 +209,7 @@ static void reap(ntl_ctx *c, bool block)
         }
         sev_put(c, z.done);
         slot_put(c, z.slot);
+        index_unref(z.ix, c);
         c->zombies.pop_front();
     }
 }
@@ -426,7 +429,9 @@ extern "C" int ntl_ctx_create(int device, ntl_ctx **out)
             delete c;
             return NTL_EDEVICE;
         }
-        for (uint32_t i = 0; i < NTL_NSLOTS; i++) c->slot_free.push_back(NTL_NSLOTS - 1 - i);
+        uint32_t nslots = NTL_NSLOTS; /* NTL_NSLOTS (tests): fewer, so that a handful of handles reaches the bound */
+        if (const char *e = getenv("NTL_NSLOTS")) nslots = (uint32_t)std::min<long>(NTL_NSLOTS, std::max<long>(2, atol(e)));
+        for (uint32_t i = 0; i < nslots; i++) c->slot_free.push_back(nslots - 1 - i);
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
@@ -956,6 +961,9 @@ static std::atomic<uint64_t> g_index_gen{1};
 
 struct ntl_index {
     ntl_ctx *c;
+    /* the caller's + one per PENDING sketch / map result that was queued against it: their kernels read the table, and an
+       overflowed sketch is made again from it (sketch_finalize, mapres_finalize).  ntl_index_destroy only drops the caller's. */
+    mutable std::atomic<int> refs{1};
     uint64_t gen = 0;                    /* identity of this index: a sketch made for it remembers the number, not the address */
     int bits = 0;
     uint64_t nslots = 0;
@@ -1003,6 +1011,24 @@ struct ntl_sketch {
 
 static int sketch_finalize(const ntl_sketch *s);
 
+/* The last reference to an index goes.  Dropped by the context that built it: its device blocks return to that context's cache.
+ * Dropped by ANOTHER context (a worker context completing or reaping work that outlived the caller's ntl_index_destroy): the
+ * owner's cache and event lists belong to the owner's thread, so the blocks are freed outright (hipFree waits for the device). */
+static void index_unref(const ntl_index *cix, ntl_ctx *by)
+{
+    ntl_index *ix = const_cast<ntl_index *>(cix);
+    if (!ix || --ix->refs != 0) return;
+    (void)hipSetDevice(ix->c->device);
+    if (by != ix->c) {
+        for (DevBuf *b : {&ix->slots, &ix->special, &ix->ctg_len, &ix->cnt, &ix->tags}) {
+            if (b->p) (void)hipFree(b->p);
+            b->p = nullptr; b->bytes = 0;
+        }
+        if (ix->built) (void)hipEventDestroy(ix->built);
+    } else sev_put(ix->c, ix->built);
+    delete ix;
+}
+
 static void sketch_unref(const ntl_sketch *cs)
 {
     ntl_sketch *s = const_cast<ntl_sketch *>(cs);
@@ -1011,11 +1037,12 @@ static void sketch_unref(const ntl_sketch *cs)
     (void)hipSetDevice(c->device);
     if (s->pending) { /* nobody asked: the device blocks go back now (stream-ordered), event and slot when the work is done */
         Zombie z;
-        z.done = s->done; z.slot = s->slot; z.kind = 1; z.cap = s->cap;
+        z.done = s->done; z.slot = s->slot; z.kind = 1; z.cap = s->cap; z.ix = s->src_ix;
         c->zombies.push_back(z);
     } else {
         sev_put(c, s->done);
         slot_put(c, s->slot);
+        index_unref(s->src_ix, c);
     }
     if (s->src) batch_unref(s->src);
     delete s;
@@ -1447,6 +1474,7 @@ static int sketch_run_impl(ntl_ctx *c, const ntl_batch *b, int k, int w, const n
     if ((rc = sketch_geometry(c, k, w, G, C, nt))) return rc;
     ntl_sketch *s = new ntl_sketch();
     s->c = c; s->nseq = b->nseq; s->k = k; s->w = w; s->src_ix = ix;
+    if (ix) ix->refs++;
     s->done = sev_get(c);
     s->slot = slot_get(c);
     if (!s->done || !s->slot) { sketch_unref(s); return fail(c, NTL_EDEVICE, "out of events / page-locked slots"); }
@@ -1491,6 +1519,11 @@ static int sketch_finalize(const ntl_sketch *cs)
         if (rc) { (void)sync_both(c); s->pending = false; s->failed = rc; break; }
     }
     if (s->src) { batch_unref(s->src); s->src = nullptr; }
+    /* complete: what only a pending sketch needs goes back now, not when the handle is destroyed -- a context has NTL_NSLOTS
+       page-locked slots, and callers keep thousands of completed sketches alive */
+    index_unref(s->src_ix, c); s->src_ix = nullptr;
+    sev_put(c, s->done); s->done = nullptr;
+    slot_put(c, s->slot); s->slot = nullptr;
     return s->failed;
 }
 
@@ -1725,10 +1758,7 @@ extern "C" int ntl_index_build(ntl_ctx *c, const ntl_sketch *ctg, const uint32_t
 
 extern "C" void ntl_index_destroy(ntl_index *ix)
 {
-    if (!ix) return;
-    (void)hipSetDevice(ix->c->device);
-    sev_put(ix->c, ix->built);
-    delete ix;
+    if (ix) index_unref(ix, ix->c); /* sketches and map results still pending against it keep it until their work has run */
 }
 
 extern "C" uint64_t ntl_index_size(const ntl_index *ix)
@@ -1861,11 +1891,12 @@ static void mapres_free(ntl_mapres *R)
     (void)hipSetDevice(c->device);
     if (R->pending) {
         Zombie z;
-        z.done = R->done; z.slot = R->slot; z.kind = 2; z.hitf = R->hitf;
+        z.done = R->done; z.slot = R->slot; z.kind = 2; z.hitf = R->hitf; z.ix = R->ix;
         c->zombies.push_back(z);
     } else {
         sev_put(c, R->done);
         slot_put(c, R->slot);
+        index_unref(R->ix, c);
     }
     if (R->reads) sketch_unref(R->reads);
     delete R;
@@ -1898,6 +1929,9 @@ static int mapres_finalize(const ntl_mapres *cR)
         break;
     }
     if (R->reads) { sketch_unref(R->reads); R->reads = nullptr; }
+    index_unref(R->ix, c); R->ix = nullptr;
+    sev_put(c, R->done); R->done = nullptr;
+    slot_put(c, R->slot); R->slot = nullptr;
     return R->failed;
 }
 
@@ -1914,6 +1948,7 @@ extern "C" int ntl_map_run(ntl_ctx *c, const ntl_index *ix, const ntl_sketch *re
     const uint64_t nreads = reads->nseq;
     ntl_mapres *R = new ntl_mapres();
     R->c = c; R->ix = ix; R->params = *params; R->hitf = ix->hit_fraction;
+    ix->refs++;
     R->done = sev_get(c);
     R->slot = slot_get(c);
     if (!R->done || !R->slot) { mapres_free(R); return fail(c, NTL_EDEVICE, "out of events / page-locked slots"); }

@@ -135,6 +135,54 @@ def check_full_pipeline(dev, contigs, reads, k, w, **kw):
     return got
 
 
+def check_handles_outlive_their_inputs(dev, contigs, reads, k, w, n_live=700, tiny_len=None, **kw):
+    """Two promises of the header's "Asynchrony" paragraph: (1) completed handles cost no page-locked slot -- more
+    than the context's 512 slots' worth of completed sketches and map results stay alive side by side; (2) an index may be
+    destroyed as soon as the calls that took it have returned -- also when the read sketch then turns out to have overflowed its
+    record array and both it and the mapping are made AGAIN from that index when the result is finally asked for (the caller
+    forces that with NTL_SKETCH_CAP_GUESS)."""
+    ctg_len = np.array([len(s) for s in contigs], np.uint32)
+    rlen = np.array([len(s) for s in reads], np.uint32)
+    ooff, oh, op, os_ = oracle.sketch_batch(b"".join(contigs), offsets_of(contigs), k, w)
+    oix = oracle.Index(oh, contig_ids(ooff), op, os_)
+    qoff, qh, qp, qs = oracle.sketch_batch(b"".join(reads), offsets_of(reads), k, w)
+    exp = oracle.map_reads(oix, ctg_len, qoff, rlen, qh, qp, qs, k=k, threads=0, **kw)
+    # (2) first: index, contig sketch and read batch all gone before anything is asked
+    cb = dev.batch(contigs)
+    csk = dev.sketch(cb, k, w)
+    ix = dev.index(csk, ctg_len)
+    rb = dev.batch(reads)
+    rsk = dev.sketch(rb, k, w, index=ix)
+    res = dev.map(ix, rsk, rlen, k=k, **kw)
+    ix.close(); csk.close(); cb.close(); rb.close()
+    junk = [dev.batch([b"ACGT" * 300]) for _ in range(8)]  # whatever the freed blocks are handed out for next
+    got = res.download()
+    assert_same_records(got, exp)
+    assert rsk.count == len(qh)
+    res.close(); rsk.close()
+    for j in junk:
+        j.close()
+    # (1) n_live completed sketches + map results alive at once
+    with dev.batch(contigs) as cb, dev.sketch(cb, k, w) as csk, dev.index(csk, ctg_len) as ix:
+        tiny = [reads[0][:tiny_len]] if tiny_len else reads[:1]
+        tl = np.array([len(tiny[0])], np.uint32)
+        toff, th, tp, ts = oracle.sketch_batch(tiny[0], offsets_of(tiny), k, w)
+        live = []
+        with dev.batch(tiny) as tb:
+            for i in range(n_live):
+                sk = dev.sketch(tb, k, w, index=ix)
+                mr = dev.map(ix, sk, tl, k=k, **kw)
+                assert sk.count == len(th) and mr.counts()[0] >= 0  # completes both: their slots and events go back here
+                live.append((sk, mr))
+        first = live[0][1].download()
+        last = live[-1][1].download()
+        assert_same_records(first, last)
+        for sk, mr in live:
+            mr.close(); sk.close()
+    dev.sync()
+    return len(got["maps"])
+
+
 def fixture_seqs(fname):
     return [s for _, s in oracle.read_fastx(os.path.join(REF, fname))]
 

@@ -38,7 +38,7 @@ def test_bench_line_on_the_simt_mock(tmp_path):
 
 
 def test_two_ranks_strong_scaling_line_on_the_simt_mock():
-    """`bench.py --gpus 2 --strong` end to end on CPU: the launcher starts two gloo ranks, each maps its half of the read
+    """`bench.py --gpus 2` (strong scaling is the default for N > 1: BASELINE.json configs[3]) end to end on CPU: the launcher starts two gloo ranks, each maps its half of the read
     set on the SIMT mock, rank 0 prints one line with n_gpus = 2, the max-over-ranks time and the summed bases."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from sim import simlib
@@ -46,34 +46,39 @@ def test_two_ranks_strong_scaling_line_on_the_simt_mock():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     base = [sys.executable, os.path.join(ROOT, "bench.py"), "--lib", lib, "--workload", "C2", "--scale", "0.0004", "--steps", "1",
             "--warmup", "1", "--no-e2e", "--no-cpu-baseline", "--batch-bases", "100000"]
-    p = subprocess.run(base + ["--gpus", "2", "--strong"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    p = subprocess.run(base + ["--gpus", "2", "--min-batches", "2"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)  # bare --gpus N = configs[3]
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     two = json.loads(lines[0])
     assert two["n_gpus"] == 2 and two["scaling"] == "strong"
+    assert two["world_size"] == 2 and two["rccl_ranks_seen"] == 2
+    assert [(r["rank"], r["local_rank"], r["backend"]) for r in two["ranks"]] == [(0, 0, "gloo"), (1, 1, "gloo")] and all(r["device"] for r in two["ranks"])
     per_rank = int(two["config"]["workload"].split(" read bases per GPU")[0].split("+ ")[-1])
     assert abs(2 * per_rank - 200_000) < 40_000  # C2 at scale 0.0004 is 200 kbases of reads: split two ways (a few 10-kb reads each)
     assert two["ms_per_step"] > 0 and two["config"]["index_size"] > 0 and two["config"]["mappings_hits_pafs_per_step"][0] > 0
 
 
 def test_eight_ranks_strong_scaling_line_on_the_simt_mock():
-    """configs[3]'s shape: `bench.py --gpus 8 --strong` -- eight gloo ranks, each with an eighth of the read set; the line
+    """configs[3]'s shape: a bare `bench.py --gpus 8` -- eight gloo ranks, each with an eighth of the read set; the line
     carries every rank's time and bases so that an imbalance would show."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from sim import simlib
     lib = simlib.build()
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--lib", lib, "--workload", "C2", "--scale", "0.0008", "--steps", "1",
-                        "--warmup", "1", "--no-e2e", "--no-cpu-baseline", "--batch-bases", "100000", "--serial-steps", "0", "--gpus", "8", "--strong"],
+                        "--warmup", "1", "--no-e2e", "--no-cpu-baseline", "--batch-bases", "100000", "--serial-steps", "0", "--gpus", "8", "--min-batches", "4"],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 8 and out["scaling"] == "strong"
+    assert out["n_gpus"] == 8 and out["scaling"] == "strong" and out["world_size"] == 8 and out["rccl_ranks_seen"] == 8
+    assert [r["local_rank"] for r in out["ranks"]] == list(range(8))
+    assert out["sub_batches_per_rank"] >= 4  # a rank's share is cut into sub-batches of its own (--min-batches), not the N = 1 size
     assert len(out["per_rank_ms_per_step"]) == 8 and len(out["per_rank_bases_per_step"]) == 8
-    assert abs(sum(out["per_rank_bases_per_step"]) - 400_000) < 100_000  # C2 at scale 0.0008: 400 kbases of reads over all ranks
+    # C2 at scale 0.0008: 400 kbases of reads over all ranks; a sub-batch of 12.5 kbases is rounded up to two whole 10-kb reads
+    assert 400_000 <= sum(out["per_rank_bases_per_step"]) <= 700_000
     assert max(out["per_rank_ms_per_step"]) == pytest_approx(out["ms_per_step"])
 
 

@@ -84,8 +84,13 @@ def test_byte_range_readers_see_every_record_once(tmp_path, fastq, wrap):
             assert max(parsed) < total / world + 8000  # a rank's share + at most one record and the small gzip file
 
 
-def _run_ranks(tmp_path, world, port, args):
+def _run_ranks(tmp_path, world, port, args, extra_env=None):
     env = dict(os.environ, OMP_NUM_THREADS="1", NTLINK_AMD_LIB=simlib.build(), NTL_IO_THREADS="2")
+    for key, val in (extra_env or {}).items():
+        if val is None:
+            env.pop(key, None)
+        else:
+            env[key] = val
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"), "pair"] + args
     assert subprocess.call(cmd, cwd=tmp_path, env=env, timeout=900) == 0
@@ -138,9 +143,36 @@ def test_three_ranks_many_reads_and_files(tmp_path):
     assert read_text(pre + ".pairs.tsv") == read_text(os.path.join(REF, "expected_outputs", "scaffolds_1.fa.k32.w250.z1000.pairs.tsv"))
 
 
+def _fake_host(root, gpus_per_node=(4, 4), cpus_per_node=64, cpu_max="1600000 100000"):
+    """A made-up /sys for dist_pair.pin_rank: NUMA nodes with `cpus_per_node` CPUs each, GPUs hanging off them (KFD topology
+    nodes behind one CPU node per NUMA node, render minors 128..), and the cgroup's cpu.max."""
+    def put(path, text):
+        os.makedirs(os.path.dirname(root + path), exist_ok=True)
+        with open(root + path, "w") as fh:
+            fh.write(text)
+    n_nodes = len(gpus_per_node)
+    put("/sys/fs/cgroup/cpu.max", cpu_max + "\n")
+    put("/sys/devices/system/cpu/online", f"0-{n_nodes * cpus_per_node - 1}\n")
+    kfd, minor = 0, 128
+    for nd in range(n_nodes):
+        put(f"/sys/devices/system/node/node{nd}/cpulist", f"{nd * cpus_per_node}-{(nd + 1) * cpus_per_node - 1}\n")
+        put(f"/sys/class/kfd/kfd/topology/nodes/{kfd}/properties", "cpu_cores_count 64\nsimd_count 0\ndrm_render_minor 0\n")
+        kfd += 1
+    for nd, n in enumerate(gpus_per_node):
+        for _ in range(n):
+            put(f"/sys/class/kfd/kfd/topology/nodes/{kfd}/properties", f"cpu_cores_count 0\nsimd_count 1024\ndrm_render_minor {minor}\n")
+            put(f"/sys/class/drm/renderD{minor}/device/numa_node", f"{nd}\n")
+            kfd += 1
+            minor += 1
+
+
 def test_eight_ranks_many_reads_and_files(tmp_path):
     """BASELINE.json configs[3] in miniature: eight ranks (one node's worth) share test 1's reads, given as three plain files;
-    every rank parses about an eighth of the bytes, the outputs are those of one process, no part file is left behind."""
+    every rank parses about an eighth of the bytes, the outputs are those of one process, no part file is left behind.
+    The ranks see a made-up host -- two NUMA nodes of 64 CPUs with four GPUs each, 16 cores granted by cpu.max, as on the GPU
+    boxes of this project: every rank takes cores of its GPU's node and, at two granted cores per rank, one reader, one device
+    worker and three parser threads."""
+    _fake_host(str(tmp_path / "fakesys"))
     shutil.copy(os.path.join(REF, "scaffolds_1.fa"), tmp_path / "scaffolds_1.fa")
     recs = list(__import__("oracle").read_fastx(os.path.join(REF, "long_reads_1.fa")))
     cuts = [0, len(recs) // 3, len(recs) * 2 // 3, len(recs)]
@@ -149,7 +181,8 @@ def test_eight_ranks_many_reads_and_files(tmp_path):
         with open(tmp_path / n, "wt") as fh:
             for name, seq in recs[a:b]:
                 fh.write(f">{name}\n{seq.decode() if isinstance(seq, bytes) else seq}\n")
-    _run_ranks(tmp_path, 8, 29575, ["target=scaffolds_1.fa", "reads=" + " ".join(names), "k=32", "w=250", "paf=True", "ntlink_pairs_tsv=True", "v=1"])
+    _run_ranks(tmp_path, 8, 29575, ["target=scaffolds_1.fa", "reads=" + " ".join(names), "k=32", "w=250", "paf=True", "ntlink_pairs_tsv=True", "v=1"],
+               extra_env={"NTL_SYSFS_ROOT": str(tmp_path / "fakesys"), "NTL_IO_THREADS": None, "NTL_IO_READERS": None, "NTL_DEVICE_STREAMS": None})
     pre = str(tmp_path / "scaffolds_1.fa.k32.w250.z1000")
     d = os.path.join(GEN, "fixtures", "t1_k32_w250")
     for ext in (".verbose_mapping.tsv", ".paf", ".pairs.tsv"):
@@ -161,6 +194,10 @@ def test_eight_ranks_many_reads_and_files(tmp_path):
     assert len(per) == 8 and sum(per) == total
     longest = max(len(s) for _, s in recs) + 200
     assert all(abs(b - total / 8) <= longest for b in per)
+    pins = json.loads(rep["ntlink_amd pin_per_rank"])
+    assert [p["numa_node"] for p in pins] == [0, 0, 0, 0, 1, 1, 1, 1]
+    assert [p["first_core"] for p in pins] == [0, 16, 32, 48, 64, 80, 96, 112] and all(p["cores"] == 16 for p in pins)
+    assert all(p["cpu_quota_cores"] == 16.0 and p["io_threads"] == 3 and p["io_readers"] == "1" and p["device_streams"] == "1" for p in pins)
 
 
 def test_a_dead_run_leaves_no_checkpoint(tmp_path):
@@ -218,3 +255,38 @@ def test_bgzf_member_ranges_see_every_record_once(tmp_path, fastq, block):
         assert sum(parsed) == total
         if 1 < world <= 8:
             assert max(parsed) < total / world + 0x10000 + 64  # a rank's share + at most one member
+
+
+def test_pin_rank_choices_on_made_up_hosts(tmp_path, monkeypatch):
+    """dist_pair.pin_rank without any process group: NUMA-local cores when the kernel names the GPUs' nodes, contiguous slices
+    when it does not, two readers / device workers kept where a rank has four cores or more, HIP_VISIBLE_DEVICES re-mapping."""
+    from ntlink_amd import dist_pair
+    for var in ("NTL_IO_THREADS", "NTL_IO_READERS", "NTL_DEVICE_STREAMS", "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+
+    def pin(root, rank, world):
+        monkeypatch.setenv("NTL_SYSFS_ROOT", root)
+        for var in ("NTL_IO_THREADS", "NTL_IO_READERS", "NTL_DEVICE_STREAMS"):
+            monkeypatch.delenv(var, raising=False)
+        dist_pair.pin_rank(rank, world)
+        return dict(dist_pair.LAST_PIN)
+
+    a = str(tmp_path / "a")  # an uneven host: 6 GPUs on node 0, 2 on node 1, no CPU quota
+    _fake_host(a, gpus_per_node=(6, 2), cpus_per_node=48, cpu_max="max 100000")
+    assert dist_pair.gpu_numa_nodes.__call__() is not None
+    pins = [pin(a, r, 8) for r in range(8)]
+    assert [p["numa_node"] for p in pins] == [0] * 6 + [1] * 2
+    assert [p["cores"] for p in pins] == [8] * 6 + [24] * 2 and pins[6]["first_core"] == 48 and pins[7]["first_core"] == 72
+    assert all(p["io_readers"] is None and p["device_streams"] is None and p["cpu_quota_cores"] is None for p in pins)
+    assert pins[0]["io_threads"] == 8 and pins[7]["io_threads"] == 24
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "7,0")  # two ranks on the last and the first GPU
+    assert [pin(a, r, 2)["numa_node"] for r in range(2)] == [1, 0]
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    b = str(tmp_path / "b")  # the kernel does not say (numa_node -1): contiguous slices of the CPUs
+    _fake_host(b, gpus_per_node=(8,), cpus_per_node=64, cpu_max="3200000 100000")
+    for m in range(128, 136):
+        open(f"{b}/sys/class/drm/renderD{m}/device/numa_node", "w").write("-1\n")
+    pins = [pin(b, r, 8) for r in range(8)]
+    assert all(p["how"] == "contiguous slice" and p["cores"] == 8 for p in pins) and [p["first_core"] for p in pins] == list(range(0, 64, 8))
+    assert all(p["io_threads"] == 6 and p["io_readers"] is None for p in pins)  # 32 granted cores / 8 ranks = 4 each: both pairs kept
+    assert dist_pair.pin_rank(0, 1) is None and dist_pair.LAST_PIN == {}

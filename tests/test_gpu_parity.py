@@ -409,6 +409,18 @@ def test_async_order_and_unseen_results(dev, monkeypatch):
     dev.sync()
 
 
+def test_handles_outlive_their_inputs(dev, monkeypatch):
+    """ADVICE r3 on the device: the index, the contig sketch and both batches are destroyed before the result of a read sketch
+    that overflowed its record array is asked for (sketch and mapping are then made again from that index), and 700 completed
+    sketches + 700 completed map results stay alive at once on a context with 512 page-locked slots."""
+    chroms, cbuf, coff, names, _ = synth.make_assembly(3, 1, 10, 200_000)
+    rbuf, roff, _ = synth.make_reads(4, chroms, 3_000_000, 12_000, 0.02, 0.015, 0.015, lognormal_sigma=0.4)
+    contigs = [cbuf[int(coff[i]):int(coff[i + 1])].tobytes() for i in range(len(coff) - 1)]
+    reads = [rbuf[int(roff[i]):int(roff[i + 1])].tobytes() for i in range(len(roff) - 1)]
+    monkeypatch.setenv("NTL_SKETCH_CAP_GUESS", "1000")
+    assert pc.check_handles_outlive_their_inputs(dev, contigs, reads, 32, 100, z=1000, n_live=700) > 50
+
+
 def test_one_stream_and_back(dev):
     contigs = pc.fixture_seqs("scaffolds_1.fa")
     reads = pc.fixture_seqs("long_reads_4_top5.fa")

@@ -347,6 +347,20 @@ def test_sim_async_order_and_unseen_results(dev, monkeypatch):
     dev.sync()  # reported once
 
 
+def test_sim_handles_outlive_their_inputs(monkeypatch):
+    """the index destroyed before an overflowed sketch is made again from it; more live completed handles than the
+    context has page-locked slots (a context of its own with four of them: the mock takes seconds per sketch)."""
+    contigs = pc.fixture_seqs("scaffolds_4.fa")[:6]
+    reads = pc.fixture_seqs("long_reads_4_top5.fa")[:2]
+    monkeypatch.setenv("NTL_SKETCH_CAP_GUESS", "40")
+    monkeypatch.setenv("NTL_NSLOTS", "4")
+    d = simlib.device()
+    try:
+        pc.check_handles_outlive_their_inputs(d, contigs, reads, 40, 100, z=1000, n_live=6, tiny_len=700)
+    finally:
+        d.close()
+
+
 def test_sim_one_stream_and_back(dev):
     """ntl_ctx_set_pipeline: the window stage back on the one stream at a quiet point, and out again: same records."""
     contigs = pc.fixture_seqs("scaffolds_4.fa")
