@@ -162,8 +162,15 @@ int ntl_batch_download(const ntl_batch *b, char *seqs, uint64_t *offsets);
  * the device then, and ntl_sketch_wait / ntl_mapres_wait do only that and return the status.  A caller that queues batch
  * i+1 before it asks for the results of batch i lets the window kernels of i+1 run beside the lookup and map kernels of i
  * (the reference's pipe between `indexlr` and `ntlink_pair.py` overlaps the same two stages, ntLink:221-225).  Inputs may be
- * destroyed as soon as the call that took them has returned: the library keeps what it still needs.  Destroying a handle
- * that was never asked for anything is allowed; if its work then fails, the next ntl_ctx_sync reports it. */
+ * destroyed as soon as the call that took them has returned: the library keeps what it still needs by reference count -- the
+ * batch a sketch was made from, the sketch a map result was made from, and the INDEX both were queued against (their kernels
+ * read it, and a sketch that overflowed its record array is made again from it when its count is asked for); ntl_index_destroy
+ * and the other destroy calls only drop the caller's reference.  Destroying a handle that was never asked for anything is
+ * allowed; if its work then fails, the next ntl_ctx_sync reports it.
+ * Limits: a context holds 512 page-locked result slots, one per PENDING sketch or map result (queued, not yet completed by an
+ * accessor or a wait; handles destroyed while pending count until their work has run).  A call that finds none waits for the
+ * oldest destroyed-while-pending handle and otherwise fails with NTL_EDEVICE; the library itself never runs more than eight
+ * sketches ahead of the device.  COMPLETED handles hold no slot: any number of them may stay alive. */
 
 /* Computes the (k,w) minimizers of every sequence of the batch on the device; the result stays
  * in device memory.  Replaces `indexlr --long --pos --strand -k K -w W` (ntLink:199,223):
@@ -173,7 +180,7 @@ int ntl_sketch_run(ntl_ctx *ctx, const ntl_batch *b, int k, int w, ntl_sketch **
 /* The same sketch made FOR one contig index (read batches of the pair stage): every minimizer is looked up in `ix` while it is
  * emitted, and ntl_map_run(ix, this sketch) skips its own lookup pass over the 16-byte records -- per-read lookup of
  * bin/ntlink_pair.py:364-367 fused into the emitter of `indexlr`.  Minimizers and mappings are those of the two-call form;
- * the index must outlive the sketch. */
+ * the index may be destroyed once this call has returned (see "Asynchrony"). */
 int ntl_sketch_run_indexed(ntl_ctx *ctx, const ntl_batch *b, int k, int w, const ntl_index *ix, ntl_sketch **out);
 void ntl_sketch_destroy(ntl_sketch *s);
 /* Waits until the sketch is complete; 0 or the error its completion met. */
