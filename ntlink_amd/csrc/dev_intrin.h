@@ -123,3 +123,30 @@ __device__ __forceinline__ uint32_t ntl_wave_incl_scan(uint32_t v)
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false); /* row_bcast:31 -> rows 2, 3 */
     return v;
 }
+
+/* Wave-synchronous hand-off through LDS: LDS operations of one wavefront execute in program order, so lanes of a wavefront may
+   exchange data through LDS without a workgroup barrier -- the compiler only has to keep the accesses in order (no instruction). */
+__device__ __forceinline__ void ntl_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+/* the value of the first active lane in every lane (an SGPR): v_readfirstlane_b32 */
+__device__ __forceinline__ uint32_t ntl_readfirstlane(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+/* four consecutive words from a pointer that is only 4-byte aligned: one global_load_dwordx4 */
+struct __attribute__((packed, aligned(4))) ntl_u32x4_a4 { uint32_t x, y, z, w; };
+__device__ __forceinline__ uint4 ntl_load4_a4(const uint32_t *p)
+{
+    const ntl_u32x4_a4 v = *(const ntl_u32x4_a4 *)p;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+/* an 8-byte LDS read that stays where the source puts it (volatile: the optimiser would sink it next to its first use) */
+__device__ __forceinline__ uint2 ntl_lds_load2_ordered(const uint2 *p)
+{
+    const uint64_t v = *(const volatile uint64_t *)p;
+    return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+}

@@ -491,6 +491,17 @@ extern "C" int ntl_ctx_set_pipeline(ntl_ctx *c, int on)
     if (on && !c->wstream_own) return fail(c, NTL_EINVAL, "this context was created without a window stream (NTL_PIPELINE=0)");
     c->pipelined = on != 0;
     c->wstream = on ? c->wstream_own : c->stream;
+    /* Everything queued has run (both streams were drained above), so every cached block is free on either stream: they all
+       move to MAIN's cache.  Switching off, sid() maps every request to MAIN and the window-stage blocks would otherwise lie
+       stranded in pool[SID_W] (counted, never handed out: the next step allocated its temporaries anew); switching on, the
+       window stage's first requests miss its own cache once and are served from then on. */
+    for (auto &kv : c->pool[SID_W]) c->pool[SID_MAIN].insert(kv);
+    c->pool[SID_W].clear();
+    for (auto &kv : c->xpool) {
+        c->pool[SID_MAIN].insert({kv.first, kv.second.p});
+        sev_put(c, kv.second.ev[0]); sev_put(c, kv.second.ev[1]);
+    }
+    c->xpool.clear();
     return NTL_OK;
 }
 
@@ -1151,6 +1162,20 @@ static void launch_fast_r0(ntl_ctx *c, const Sketch2Args &B, unsigned strips)
         const int lanes = le ? atoi(le) : 0;
         /* the window pass on threshold-sparsified windows where the geometry allows it (B.thresh != 0) */
         if (NT == 256 && B.thresh && B.A.G.a + 2 <= 16 && (B.dbg & ~24) == 0) { /* (ablation bits 8 and 16 exist in this kernel too) */
+            /* one wavefront per strip, 64 k-mers per lane (sketch_wave_kernel, round 4) where a lane's first k-mer lies in its own
+               64 bases and a strip's candidates fit its list; NTL_SKETCH_WAVE=0: the workgroup-per-strip form (A/B, tests) */
+            const char *we = getenv("NTL_SKETCH_WAVE");
+            const int wave = we ? atoi(we) : 1;
+            if (wave && B.A.G.k <= 64 && 4096.0 * (double)B.thresh / 4294967296.0 <= 175.0) {
+                const unsigned wpg = wave == 8 || wave == 9 ? 8u : 4u;
+                const unsigned wgs = (((strips + wpg - 1u) / wpg) + 7u) & ~7u;
+                if (wave == 2) hipLaunchKernelGGL((sketch_wave_kernel<4, 11>), dim3(wgs), dim3(256), 0, c->wstream, B);
+                else if (wave == 8) hipLaunchKernelGGL((sketch_wave_kernel<8, 12>), dim3(wgs), dim3(512), 0, c->wstream, B);
+                else if (wave == 9) hipLaunchKernelGGL((sketch_wave_kernel<8, 10>), dim3(wgs), dim3(512), 0, c->wstream, B);
+                else hipLaunchKernelGGL((sketch_wave_kernel<4, 12>), dim3(wgs), dim3(256), 0, c->wstream, B);
+                hipLaunchKernelGGL((sketch_fast_list_kernel<256, R0>), dim3(std::min(strips, 4096u)), dim3(256), 0, c->wstream, B, (const uint32_t *)B.fb_list, (const uint32_t *)B.fb_count);
+                return;
+            }
             const char *de = getenv("NTL_SKETCH_THRESH_DIRECT"); /* 1: the variant without staged keys for the large windows too (A/B) */
             const int direct = de ? atoi(de) : 0;
             if (direct || 4096.0 * (double)B.thresh / 4294967296.0 > 340.0) hipLaunchKernelGGL((sketch_thresh_kernel<256, true>), grid, dim3(256), 0, c->wstream, B);

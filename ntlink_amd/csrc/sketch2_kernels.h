@@ -1206,3 +1206,235 @@ __global__ __launch_bounds__(NT) void sketch_thresh_kernel(Sketch2Args B)
     }
     if (L == 0 && flagged) B.fb_list[atomicAdd(B.fb_count, 1u)] = strip;
 }
+
+
+/*
+ * sketch_wave_kernel: the threshold pass (see sketch_thresh_kernel above for the algorithm and its proof) with ONE WAVEFRONT PER
+ * STRIP and 64 k-mers per lane -- round 4.
+ *
+ * Same strips (4096 consecutive valid-k-mer ordinals, strip_table_kernel's geometry for NT = 256, C = 16), same keys, same
+ * candidates, same decision per candidate, same lists for the passes behind it; so a strip it gives up is taken over by
+ * sketch_fast_list_kernel exactly as before.  What differs is who does the work:
+ *
+ *   - a lane owns 64 consecutive k-mers instead of 16: the first k-mer's hash (the table lookups, the combination of the 16-base
+ *     partial hashes) is paid once per 64 k-mers, and for k <= 64 it is made from the lane's OWN bases -- no exchange of partial
+ *     hashes or base words between lanes, no exchange area in LDS;
+ *   - the keys are never stored: each key is tested against the threshold as it leaves the rolling step, and a candidate is
+ *     written at once into the lane's own staging slots {key, position} (S per lane: a lane holds 64 p = 2.6 candidates on
+ *     average at ten per window); one pass then copies the staged candidates, in position order, into the strip's list;
+ *   - the four wavefronts of a workgroup share nothing but the read-only tables (the four-base ring tables and the rolling
+ *     seeds, copied into LDS once per workgroup), so after the one barrier behind that copy NO barrier is left: a wavefront
+ *     walks through load -> first k-mers -> rolling -> list -> scans -> bits at its own pace, and the wavefronts of a CU are in
+ *     different phases at any time (issue-bound rolling of one beside the LDS-latency-bound scans of another).  The phases of
+ *     sketch_thresh_kernel were separated by six workgroup barriers.
+ *   - hand-offs between lanes (the list, the sentinels) are wave-synchronous LDS traffic (ntl_wave_sync: ordering only).
+ *
+ * Elements: local position p = 64 L + t of the strip is ordinal E0 + p; p = 0 belongs to the previous strip's windows only
+ * and positions >= hi = min(4096, M - E0) lie behind the sequence: candidates found there are dropped when the list is made.
+ * Gives the strip up (B.fb_list) when a lane stages more than S candidates, the list would hold more than SKW_CAP, or the scans say
+ * so (a window without a candidate, a near tie, a key within SK2_NEAR of the threshold).
+ */
+#define SKW_CAP 248u /* candidates per strip the list holds (164 expected at ten per window of 250, +6.5 sigma) */
+
+template <int WAVES, int S>
+__global__ __launch_bounds__(64 * WAVES) void sketch_wave_kernel(Sketch2Args B)
+{
+    constexpr int C = 64;
+    constexpr uint32_t STAGE = 64u * (uint32_t)S;  /* staging slots of a wavefront */
+    constexpr uint32_t LIST = SKW_CAP + 8u;        /* [3] left sentinel, [4 .. n + 3] candidates, [n + 4] right sentinel, copies around them (see sketch_thresh_kernel) */
+    static_assert(LIST >= (uint32_t)(C - S), "what lane 63 writes beyond its slots must stay inside the wavefront's own list area");
+    __shared__ __attribute__((aligned(16))) uint2 s_g4k[1024];
+    __shared__ __attribute__((aligned(16))) uint32_t s_roll[32];
+    __shared__ __attribute__((aligned(16))) uint2 s_wave[WAVES][STAGE + LIST];
+
+    const SketchArgs &A = B.A;
+    const int tid = threadIdx.x, L = tid & 63;
+    const uint32_t wv = ntl_readfirstlane((uint32_t)tid >> 6);
+    for (int i = tid; i < 512; i += 64 * WAVES) ((uint4 *)s_g4k)[i] = ((const uint4 *)B.g4k)[i];
+    if (tid < 16) { s_roll[2 * tid] = (uint32_t)(A.roll_tab[tid][0] >> 33); s_roll[2 * tid + 1] = (uint32_t)(A.roll_tab[tid][1] >> 32); }
+
+    const uint32_t per_xcd = gridDim.x >> 3; /* consecutive strips on one XCD */
+    const uint32_t strip = ((blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3)) * (uint32_t)WAVES + wv;
+    StripInfo I;
+    I.seq = NTL_NONE;
+    if (strip < A.nstrips) I = A.strip_tab[strip];
+    const bool active = I.seq != NTL_NONE && I.multi == 0; /* strips that cross non-ACGT runs: sketch_mask_kernel<.., MULTI = true> */
+
+    /* ---- the lane's bases: 64 that leave (so) and the 64 that enter (si), k bases further on ---- */
+    uint32_t so[4] = {0u, 0u, 0u, 0u}, si[4] = {0u, 0u, 0u, 0u};
+    if (active) {
+        const uint64_t gp = (uint64_t)((int64_t)I.base + I.P0 + (int64_t)L * C);
+        const uint32_t wmax = (uint32_t)B.max_word - 9u; /* over-reads behind the last sequence: values never used */
+        const uint64_t gq = gp + (uint64_t)A.G.k;
+        uint32_t wi = (uint32_t)(gp >> 4), wq = (uint32_t)(gq >> 4);
+        wi = wi < wmax ? wi : wmax;
+        wq = wq < wmax ? wq : wmax;
+        const uint4 o0 = ntl_load4_a4(A.T.packed + wi), i0 = ntl_load4_a4(A.T.packed + wq);
+        const uint32_t o4 = A.T.packed[wi + 4], i4 = A.T.packed[wq + 4];
+        const uint32_t ao = 2u * ((uint32_t)gp & 15u), ai = 2u * ((uint32_t)gq & 15u);
+        so[0] = ntl_alignbit(o0.y, o0.x, ao); so[1] = ntl_alignbit(o0.z, o0.y, ao); so[2] = ntl_alignbit(o0.w, o0.z, ao); so[3] = ntl_alignbit(o4, o0.w, ao);
+        si[0] = ntl_alignbit(i0.y, i0.x, ai); si[1] = ntl_alignbit(i0.z, i0.y, ai); si[2] = ntl_alignbit(i0.w, i0.z, ai); si[3] = ntl_alignbit(i4, i0.w, ai);
+    }
+    __syncthreads(); /* the tables are in LDS; the only workgroup barrier of the kernel */
+    if (!active) return;
+
+    uint2 *const stage = &s_wave[wv][0];
+    uint2 *const list = &s_wave[wv][STAGE];
+    const uint32_t hi = (uint32_t)((int64_t)I.M - (int64_t)I.E0 < (int64_t)(64 * C) ? (int64_t)I.M - (int64_t)I.E0 : (int64_t)(64 * C));
+    const uint32_t lane_pos = (uint32_t)(L * C);
+    const uint32_t tm1 = lane_pos < hi ? B.thresh - 1u : 0u; /* lanes behind the sequence's last k-mer roll over whatever follows it: nothing of theirs is a candidate */
+
+    /* ---- the first k-mer's rings from the lane's own bases: 16-base partial hashes out of the four-base tables ---- */
+    uint32_t fx, ry;
+    {
+        uint32_t f = 0, u = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { /* k <= 64 */
+            if (i >= B.q16) break;
+            if (i) { f = ring_rotl(f, 16); u = ring_rotr(u, 16); }
+            const uint32_t w = so[i];
+            const uint2 g0 = s_g4k[w & 255u], g1 = s_g4k[256u + ((w >> 8) & 255u)], g2 = s_g4k[512u + ((w >> 16) & 255u)], g3 = s_g4k[768u + (w >> 24)];
+            f ^= g0.x ^ g1.x ^ g2.x ^ g3.x;
+            u ^= g0.y ^ g1.y ^ g2.y ^ g3.y;
+        }
+        if (B.r16) {
+            const uint32_t r = (uint32_t)B.r16;
+            if (B.q16) { f = ring_rotl(f, r); u = ring_rotr(u, r); }
+            const uint32_t w = B.q16 == 0 ? so[0] : (B.q16 == 1 ? so[1] : (B.q16 == 2 ? so[2] : so[3]));
+            uint2 P;
+            if (B.r16 == 8) {
+                const uint2 p0 = s_g4k[512u + (w & 255u)], p1 = s_g4k[768u + ((w >> 8) & 255u)];
+                P = make_uint2(p0.x ^ p1.x, p0.y ^ p1.y);
+            } else {
+                uint2 fu;
+                sk2_chunk(w, B.r16, B, fu, P); /* k % 16 not in {0, 8}: the first r bases on the plain 64-bit tables */
+            }
+            f ^= P.x;
+            u ^= P.y;
+        }
+        fx = f;
+        ry = u << 1; /* the tables carry the reverse strand's final rotation */
+    }
+
+    /* ---- rolling; every key is tested as it is made, candidates go to the lane's staging slots ---- */
+    uint2 *dst = stage + (uint32_t)L * (uint32_t)S;
+    {
+        uint32_t key = (fx << 1) + ry;
+        if (key <= tm1) *dst++ = make_uint2(key, lane_pos);
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            uint32_t wz[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const uint32_t o2 = r < 2 ? so[m] << (3 - 2 * r) : so[m] >> (2 * r - 3);
+                const uint32_t i2 = r < 3 ? si[m] << (5 - 2 * r) : si[m] >> (2 * r - 5);
+                wz[r] = (o2 & 0x18181818u) | (i2 & 0x60606060u);
+            }
+            /* the sixteen seed pairs of this word's steps are requested together, in front of the steps: every step ends in a
+               predicated write (a basic block of its own), and a read issued inside a step would be waited for inside it */
+            uint2 sd[16];
+#pragma unroll
+            for (int b = 0; b < 16; b++) {
+                const uint32_t off = ntl_bfe(wz[b & 3], 8u * (uint32_t)(b >> 2), 8u);
+                sd[b] = ntl_lds_load2_ordered((const uint2 *)((const char *)s_roll + off));
+            }
+#pragma unroll
+            for (int b = 0; b < 16; b++) {
+                const int t = 16 * m + b + 1;
+                if (t >= C) break;
+                fx = ((fx << 1) | ((fx >> 30) & 1u)) ^ sd[b].x;
+                const uint32_t a = ry ^ sd[b].y;
+                ry = ntl_alignbit(a >> 1, a, 1);
+                key = (fx << 1) + ry;
+                if (key <= tm1) *dst++ = make_uint2(key, lane_pos + (uint32_t)t);
+            }
+        }
+    }
+    uint32_t cnt = (uint32_t)(dst - (stage + (uint32_t)L * (uint32_t)S));
+    bool bad = cnt > (uint32_t)S; /* (what it wrote beyond its slots lies in the next lane's, or in the list area: the strip is given up) */
+
+    /* ---- the staged candidates that are elements of the strip's windows, in position order, into the list ---- */
+    const uint2 *src = stage + (uint32_t)L * (uint32_t)S;
+    if (cnt > (uint32_t)S) cnt = (uint32_t)S;
+    if (L == 0 && cnt && src[0].y == 0u) { src++; cnt--; } /* element 0 belongs to the windows of the previous strip only */
+    if (hi < (uint32_t)(64 * C)) { /* the sequence ends inside the strip: positions >= hi are not elements */
+        uint32_t keep = 0;
+        for (uint32_t j = 0; j < (uint32_t)S; j++)
+            if (j < cnt && src[j].y < hi) keep++;
+        cnt = keep;
+    }
+    const uint32_t incl = ntl_wave_incl_scan(cnt);
+    const uint32_t total = ntl_readfirstlane((uint32_t)__shfl((int)incl, 63));
+    uint32_t at = incl - cnt;
+    const bool over = total > SKW_CAP;
+    const uint32_t n = over ? 0u : total;
+    if (!over) {
+        for (uint32_t j = 0; __ballot(j < cnt) != 0ull; j++)
+            if (j < cnt) list[at + 4u + j] = src[j];
+    }
+    if (L < 4) {
+        list[L] = make_uint2(0u, 0u);          /* the left sentinel (position 0, key 0) and copies of it in front */
+        list[n + 4u + (uint32_t)L] = make_uint2(0u, hi); /* the right sentinel at the end of the strip's elements and copies behind it */
+    }
+    ntl_wave_sync();
+
+    /* ---- one lane per candidate (sketch_thresh_kernel, phase 4), four list entries per step ---- */
+    const uint32_t w = (uint32_t)A.G.w;
+    uint32_t found[4] = {SK2_INF, SK2_INF, SK2_INF, SK2_INF};
+    if (L == 0) bad |= list[4].y - 1u >= w; /* elements 1 .. w without a candidate */
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const uint32_t i = (uint32_t)L + 64u * (uint32_t)r;
+        if (i < n) {
+            const uint2 me = list[i + 4u];
+            const uint32_t lim = me.x + SK2_NEAR;
+            bad |= lim >= B.thresh;
+            uint32_t Rp = me.y + w;
+            {
+                uint32_t j = i + 5u, fb;
+                bad |= list[j].y - me.y - 1u >= w; /* a window between two candidates */
+                for (;;) {
+                    const uint2 q0 = list[j], q1 = list[j + 1], q2 = list[j + 2], q3 = list[j + 3];
+                    fb = sk2t_first_le(q0.x, q1.x, q2.x, q3.x, lim);
+                    if (fb != 4u || q3.y >= Rp) break;
+                    j += 4;
+                }
+                if (fb != 4u) {
+                    const uint2 e = list[j + fb];
+                    if (e.y < Rp) {
+                        Rp = e.y;
+                        bad |= e.x + SK2_NEAR >= me.x;
+                    }
+                }
+            }
+            const int32_t need = (int32_t)Rp - (int32_t)w;
+            bool blocked = false;
+            {
+                uint32_t j = i + 3u, fb;
+                for (;;) {
+                    const uint2 q0 = list[j], q1 = list[j - 1], q2 = list[j - 2], q3 = list[j - 3];
+                    fb = sk2t_first_le(q0.x, q1.x, q2.x, q3.x, lim);
+                    if (fb != 4u || (int32_t)q3.y < need) break;
+                    j -= 4;
+                }
+                if (fb != 4u) blocked = (int32_t)list[j - fb].y >= need;
+            }
+            if (!blocked) found[r] = me.y;
+        }
+    }
+
+    /* ---- proven minimizers to the global bitmask; a strip that was given up writes none and goes to the block-minima pass ---- */
+    const bool flagged = B.force_redo || over || __ballot(bad) != 0ull;
+    if (flagged) {
+        if (L == 0) B.fb_list[atomicAdd(B.fb_count, 1u)] = strip;
+        return;
+    }
+    const uint64_t g0 = (uint64_t)((int64_t)I.base + I.P0);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        if (found[r] != SK2_INF) {
+            const uint64_t g = g0 + found[r];
+            atomicOr(&A.mask[g >> 5], 1u << ((uint32_t)g & 31u));
+        }
+    }
+}

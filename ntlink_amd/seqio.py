@@ -412,7 +412,19 @@ def load_parallel(paths, readers=None, chunk_bytes=None, max_bases=None, stats=N
         yield from load(paths, max_bases=max_bases, stats=stats, **kw)
         return
     END = object()
-    qs = [queue.Queue() for _ in chunks]
+    # bounded: a chunk that cannot be cut (a list of gzip files) may hold any number of batches, and every batch is a
+    # page-locked buffer -- a reader parks (stop-aware) once `depth` of its batches wait for the consumer
+    depth = max(2, int(os.environ.get("NTL_IO_QUEUE_DEPTH", "4")))
+    qs = [queue.Queue(maxsize=depth) for _ in chunks]
+
+    def put(q, item):
+        while True:
+            try:
+                q.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                if stop.is_set():
+                    return False
     claim = itertools.count()
     lock, stop = threading.Lock(), threading.Event()
     go = threading.Semaphore(readers)  # a reader starts a new chunk only when fewer than `readers` chunks are unconsumed
@@ -430,12 +442,11 @@ def load_parallel(paths, readers=None, chunk_bytes=None, max_bases=None, stats=N
             st = {}
             try:
                 for ss in load(chunks[i] if isinstance(chunks[i], list) else [chunks[i]], max_bases=max_bases, stats=st, **kw):
-                    qs[i].put(ss)
-                    if stop.is_set():
+                    if not put(qs[i], ss) or stop.is_set():
                         break
-                qs[i].put(END)
+                put(qs[i], END)
             except BaseException as exc:  # re-raised by the consumer at this chunk's place
-                qs[i].put(exc)
+                put(qs[i], exc)
             with lock:
                 part_stats.append(st)
 

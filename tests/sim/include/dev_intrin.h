@@ -92,3 +92,8 @@ inline uint32_t ntl_wave_incl_scan(uint32_t v)
     }
     return v;
 }
+
+inline void ntl_wave_sync() { pthread_barrier_wait(&sim::cur->wbar[sim::tid >> 6]); }
+inline uint32_t ntl_readfirstlane(uint32_t v) { return __shfl(v, 0); }
+inline uint4 ntl_load4_a4(const uint32_t *p) { return make_uint4(p[0], p[1], p[2], p[3]); }
+inline uint2 ntl_lds_load2_ordered(const uint2 *p) { return *p; }

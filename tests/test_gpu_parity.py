@@ -433,7 +433,9 @@ def test_one_stream_and_back(dev):
 
 
 @pytest.mark.parametrize("env", [{"NTL_SKETCH_THRESH": "0"}, {"NTL_SKETCH_THRESH": "0", "NTL_SKETCH_LANES": "1"}, {"NTL_EMIT_U": "2"},
-                                 {"NTL_SKETCH_THRESH": "0", "NTL_SKETCH_LANES": "1", "NTL_EMIT_U": "2"}, {"NTL_SKETCH_THRESH": "5"}, {"NTL_SKETCH_THRESH": "13"}],
+                                 {"NTL_SKETCH_THRESH": "0", "NTL_SKETCH_LANES": "1", "NTL_EMIT_U": "2"}, {"NTL_SKETCH_THRESH": "5"}, {"NTL_SKETCH_THRESH": "13"},
+                                 {"NTL_SKETCH_WAVE": "0"}, {"NTL_SKETCH_WAVE": "2"}, {"NTL_SKETCH_WAVE": "8"}, {"NTL_SKETCH_WAVE": "9"},
+                                 {"NTL_SKETCH_WAVE": "0", "NTL_SKETCH_THRESH": "5"}],
                          ids=lambda e: ",".join(f"{k[4:]}={v}" for k, v in e.items()))
 def test_kernel_variants_full_pipeline(dev, monkeypatch, env):
     """The window passes that are not the default for 71 <= w <= 255 (sketch_fast_kernel; sketch_lanes_kernel, the experiment of
