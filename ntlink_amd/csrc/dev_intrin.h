@@ -147,6 +147,44 @@ __device__ __forceinline__ uint4 ntl_load4_a4(const uint32_t *p)
 /* an 8-byte LDS read that stays where the source puts it (volatile: the optimiser would sink it next to its first use) */
 __device__ __forceinline__ uint2 ntl_lds_load2_ordered(const uint2 *p)
 {
-    const uint64_t v = *(const volatile uint64_t *)p;
+    typedef __attribute__((address_space(3))) const volatile uint64_t lds_u64; /* said to be LDS: a volatile access through a generic pointer is a FLAT load */
+    const uint64_t v = *(lds_u64 *)p;
     return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+}
+
+/* hides a value's origin from the optimiser (no instruction) */
+#define NTL_OPAQUE(v) asm volatile("" : "+v"(v))
+
+/* *p++ = (v & ~mask) | T for a pointer into LDS and a constant T <= 64, as the three instructions it is: v_bfi_b32 with T as an
+   inline constant, ds_write_b32, v_add_u32 (the compiler makes a v_mov of the constant, a temporary of the incremented pointer
+   and a v_mov of that).  The write is not in the compiler's count of outstanding LDS operations; LDS operations of a wavefront
+   complete in order, so a wait the compiler computes for one of ITS reads can only come out stricter, never laxer. */
+template <int T>
+__device__ __forceinline__ void ntl_lds_push_tagged(uint32_t *&p, uint32_t mask, uint32_t v)
+{
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    lds_u32 *q = (lds_u32 *)p;
+    uint32_t tmp;
+    asm volatile("v_bfi_b32 %1, %2, %3, %4\n\tds_write_b32 %0, %1\n\tv_add_u32 %0, 4, %0" : "+v"(q), "=&v"(tmp) : "v"(mask), "n"(T), "v"(v) : "memory");
+    p = (uint32_t *)q;
+}
+
+/* minimum of three: v_min3_u32 */
+__device__ __forceinline__ uint32_t ntl_min3(uint32_t a, uint32_t b, uint32_t c)
+{
+    const uint32_t m = a < b ? a : b;
+    return m < c ? m : c;
+}
+
+/* bit i: k_i <= lim, bit 4 set: four compare + add-with-carry pairs as ONE asm statement (between separate statements the compiler
+   pads with s_nop) */
+__device__ __forceinline__ uint32_t ntl_le4_mask(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, uint32_t lim)
+{
+    uint32_t acc = 1u;
+    asm("v_cmp_le_u32 vcc, %1, %5\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+        "v_cmp_le_u32 vcc, %2, %5\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+        "v_cmp_le_u32 vcc, %3, %5\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+        "v_cmp_le_u32 vcc, %4, %5\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+        : "+v"(acc) : "v"(k3), "v"(k2), "v"(k1), "v"(k0), "v"(lim) : "vcc");
+    return acc;
 }

@@ -85,6 +85,8 @@ struct ntl_ctx {
     std::string err;
     std::string async_err;         /* first failure of work whose handle was already gone: reported by ntl_ctx_sync */
     std::string devname;
+    int n_cu = 1;                  /* compute units of the device: the grid of a kernel whose wavefronts stay resident */
+    std::map<const void *, int> occ; /* kernel -> workgroups one CU holds (hipOccupancyMaxActiveBlocksPerMultiprocessor, asked once) */
     bool prof = false;
     std::map<std::string, ProfEntry> profs;
     std::vector<hipEvent_t> ev_free;    /* timing events (profiling spans) */
@@ -441,6 +443,7 @@ extern "C" int ntl_ctx_create(int device, ntl_ctx **out)
         snprintf(buf, sizeof buf, "%s %s %d CUs %.0f GiB", prop.name, prop.gcnArchName, prop.multiProcessorCount,
                  (double)prop.totalGlobalMem / (1024.0 * 1024.0 * 1024.0));
         c->devname = buf;
+        c->n_cu = prop.multiProcessorCount;
     }
     *out = c;
     return NTL_OK;
@@ -1148,6 +1151,20 @@ static void launch_mask(ntl_ctx *c, const SketchArgs &A, unsigned strips, bool s
     else launch_mask_r0<C, SK_NT, 0>(c, A, strips, single, multi);
 }
 
+/* workgroups of `threads` lanes of a kernel that one CU holds at once */
+template <typename K>
+static int occupancy_blocks(K kern, int threads)
+{
+#ifdef NTL_SIM
+    (void)kern; (void)threads;
+    return 2;
+#else
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, threads, 0) != hipSuccess || n < 1) n = 1;
+    return n;
+#endif
+}
+
 /* fast 32-bit pass over the single-run strips (sketch2_kernels.h) */
 template <int NT, int R0>
 static void launch_fast_r0(ntl_ctx *c, const Sketch2Args &B, unsigned strips)
@@ -1166,13 +1183,29 @@ static void launch_fast_r0(ntl_ctx *c, const Sketch2Args &B, unsigned strips)
                64 bases and a strip's candidates fit its list; NTL_SKETCH_WAVE=0: the workgroup-per-strip form (A/B, tests) */
             const char *we = getenv("NTL_SKETCH_WAVE");
             const int wave = we ? atoi(we) : 1;
-            if (wave && B.A.G.k <= 64 && 4096.0 * (double)B.thresh / 4294967296.0 <= 175.0) {
-                const unsigned wpg = wave == 8 || wave == 9 ? 8u : 4u;
-                const unsigned wgs = (((strips + wpg - 1u) / wpg) + 7u) & ~7u;
-                if (wave == 2) hipLaunchKernelGGL((sketch_wave_kernel<4, 11>), dim3(wgs), dim3(256), 0, c->wstream, B);
-                else if (wave == 8) hipLaunchKernelGGL((sketch_wave_kernel<8, 12>), dim3(wgs), dim3(512), 0, c->wstream, B);
-                else if (wave == 9) hipLaunchKernelGGL((sketch_wave_kernel<8, 10>), dim3(wgs), dim3(512), 0, c->wstream, B);
-                else hipLaunchKernelGGL((sketch_wave_kernel<4, 12>), dim3(wgs), dim3(256), 0, c->wstream, B);
+            const double per_strip = 4096.0 * (double)B.thresh / 4294967296.0; /* candidates a strip is expected to hold */
+            if (wave && B.A.G.k <= 64 && per_strip <= 440.0) {
+                /* resident wavefronts that walk over their strips: as many workgroups as the device holds at once (a multiple of 8:
+                   one share of the strips per XCD).  <wavefronts per workgroup, staging slots per lane, scan rounds>: the slots hold a
+                   lane's 64 p candidates + 4.5 sigma, the list (64 per round) a strip's 4096 p + 4 sigma; what does not fit is given up */
+                auto go = [&](auto kern, unsigned threads) {
+                    int &per_cu = c->occ[(const void *)kern];
+                    if (!per_cu) per_cu = occupancy_blocks(kern, (int)threads);
+                    unsigned wgs = (unsigned)std::max(1, per_cu) * (unsigned)std::max(1, c->n_cu);
+                    wgs = std::min(wgs, (strips + threads / 64u - 1u) / (threads / 64u));
+                    wgs = (wgs + 7u) & ~7u;
+                    hipLaunchKernelGGL(kern, dim3(wgs), dim3(threads), 0, c->wstream, B);
+                };
+                if (per_strip <= 175.0) { /* w >= 235 at ten candidates per window */
+                    if (wave == 4) go(sketch_wave_kernel<4, 11, 4>, 256u);
+                    else if (wave == 16) go(sketch_wave_kernel<16, 11, 4>, 1024u);
+                    else go(sketch_wave_kernel<8, 11, 4>, 512u);
+                } else if (per_strip <= 300.0) { /* w >= 137 */
+                    go(sketch_wave_kernel<8, 15, 6>, 512u);
+                } else {                         /* w >= 94 */
+                    if (wave == 4) go(sketch_wave_kernel<4, 19, 8>, 256u);
+                    else go(sketch_wave_kernel<8, 19, 8>, 512u);
+                }
                 hipLaunchKernelGGL((sketch_fast_list_kernel<256, R0>), dim3(std::min(strips, 4096u)), dim3(256), 0, c->wstream, B, (const uint32_t *)B.fb_list, (const uint32_t *)B.fb_count);
                 return;
             }
@@ -1310,6 +1343,8 @@ static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const nt
     }
     if (ub_strips >= 0x7FFFFFFFull) return fail(c, NTL_EINVAL, "batch too large: too many strips");
     if ((rc = strip_tab.alloc(c, (ub_strips + 1) * sizeof(StripInfo), wsid))) return rc;
+    DevBuf strip_lite;
+    if ((rc = strip_lite.alloc(c, (ub_strips + 1) * sizeof(StripLite), wsid))) return rc;
     SketchSums *dsums = s->sums.as<SketchSums>();
     HIPCHK(c, hipMemsetAsync(dsums, 0, sizeof(SketchSums), ms));
     {
@@ -1324,7 +1359,7 @@ static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const nt
             hipLaunchKernelGGL(strip_table_kernel, dim3((unsigned)((ub_strips + 255) / 256 + 1)), dim3(256), 0, ws, T,
                                (const uint32_t *)run_n.as<uint32_t>(), (const uint32_t *)run_ord.as<uint32_t>(),
                                (const uint32_t *)seq_M.as<uint32_t>(), (const uint32_t *)strip_first.as<uint32_t>(), G.NWO,
-                               C * nt, strip_tab.as<StripInfo>(), (uint32_t)ub_strips + 1u);
+                               C * nt, strip_tab.as<StripInfo>(), (uint32_t)ub_strips + 1u, strip_lite.as<StripLite>());
             HIPCHK(c, hipGetLastError());
         }
     }
@@ -1332,6 +1367,7 @@ static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const nt
         SketchArgs A;
         A.T = T;
         A.run_n = run_n.as<uint32_t>(); A.run_ord = run_ord.as<uint32_t>(); A.seq_M = seq_M.as<uint32_t>();
+        A.strip_lite = strip_lite.as<StripLite>();
         A.strip_tab = strip_tab.as<StripInfo>(); A.nstrips = (uint32_t)ub_strips; A.mask = (uint32_t *)mask.p; A.G = G;
         make_tables(k, A.roll_tab, A.seed_tab);
         A.g4 = (const uint64_t (*)[2])c->g4;

@@ -43,6 +43,7 @@
  *   F = XOR_i rotl^(k-16(i+1))(F16[L+i]) ^ (first k%16 bases of chunk L+k/16),   same for rev with rotr.
  */
 #pragma once
+#include <utility>
 #include "sketch_kernels.h"
 
 #define SK2_JOBCAP 512 /* searched windows per strip; more (pathological sequence) hands the strip to the exact pass */
@@ -928,12 +929,7 @@ __global__ __launch_bounds__(NT) void sketch_lanes_kernel(Sketch2Args B)
    that the four LDS reads behind it are issued together instead of one per taken branch */
 __device__ __forceinline__ uint32_t sk2t_first_le(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, uint32_t lim)
 {
-    uint32_t acc = 1u;
-    acc = ntl_shl1_or_le(acc, k3, lim);
-    acc = ntl_shl1_or_le(acc, k2, lim);
-    acc = ntl_shl1_or_le(acc, k1, lim);
-    acc = ntl_shl1_or_le(acc, k0, lim);
-    return (uint32_t)__ffs(acc) - 1u;
+    return (uint32_t)__ffs(ntl_le4_mask(k0, k1, k2, k3, lim)) - 1u;
 }
 
 template <int NT, bool DIRECT>
@@ -1210,7 +1206,7 @@ __global__ __launch_bounds__(NT) void sketch_thresh_kernel(Sketch2Args B)
 
 /*
  * sketch_wave_kernel: the threshold pass (see sketch_thresh_kernel above for the algorithm and its proof) with ONE WAVEFRONT PER
- * STRIP and 64 k-mers per lane -- round 4.
+ * STRIP, 64 k-mers per lane, and wavefronts that stay resident and walk over their strips -- round 4.
  *
  * Same strips (4096 consecutive valid-k-mer ordinals, strip_table_kernel's geometry for NT = 256, C = 16), same keys, same
  * candidates, same decision per candidate, same lists for the passes behind it; so a strip it gives up is taken over by
@@ -1220,32 +1216,90 @@ __global__ __launch_bounds__(NT) void sketch_thresh_kernel(Sketch2Args B)
  *     partial hashes) is paid once per 64 k-mers, and for k <= 64 it is made from the lane's OWN bases -- no exchange of partial
  *     hashes or base words between lanes, no exchange area in LDS;
  *   - the keys are never stored: each key is tested against the threshold as it leaves the rolling step, and a candidate is
- *     written at once into the lane's own staging slots {key, position} (S per lane: a lane holds 64 p = 2.6 candidates on
- *     average at ten per window); one pass then copies the staged candidates, in position order, into the strip's list;
- *   - the four wavefronts of a workgroup share nothing but the read-only tables (the four-base ring tables and the rolling
- *     seeds, copied into LDS once per workgroup), so after the one barrier behind that copy NO barrier is left: a wavefront
- *     walks through load -> first k-mers -> rolling -> list -> scans -> bits at its own pace, and the wavefronts of a CU are in
+ *     written at once into the lane's own staging slots (S per lane: a lane holds 64 p = 2.6 candidates on average at ten per
+ *     window of 250) as ONE word: the key with its six low bits replaced by the step t it was made in (SKW_NEAR below); the lanes
+ *     then take their staged candidates into registers and write them back, in position order, over the same words -- staging
+ *     area and list of keys are one array -- with the positions 64 L + t as words at a constant distance behind them: 4 KB of LDS
+ *     per wavefront, so that a CU holds 32 of them;
+ *   - the wavefronts of a workgroup share nothing but the read-only tables (the four-base ring tables and the rolling seeds,
+ *     copied into LDS once per workgroup LIFETIME), so after the one barrier behind that copy no barrier is left: a wavefront
+ *     walks through first k-mers -> rolling -> list -> scans -> bits at its own pace, and the wavefronts of a CU are in
  *     different phases at any time (issue-bound rolling of one beside the LDS-latency-bound scans of another).  The phases of
- *     sketch_thresh_kernel were separated by six workgroup barriers.
+ *     sketch_thresh_kernel were separated by six workgroup barriers;
+ *   - a wavefront is given every (number of wavefronts)-th strip of its XCD's share and asks for the strip table entry two
+ *     strips ahead and for the base words one strip ahead (vector loads: a scalar load would sit in the same counter as the LDS
+ *     reads of the rolling loop), so that no strip starts with a chain of dependent global loads;
  *   - hand-offs between lanes (the list, the sentinels) are wave-synchronous LDS traffic (ntl_wave_sync: ordering only).
  *
  * Elements: local position p = 64 L + t of the strip is ordinal E0 + p; p = 0 belongs to the previous strip's windows only
  * and positions >= hi = min(4096, M - E0) lie behind the sequence: candidates found there are dropped when the list is made.
- * Gives the strip up (B.fb_list) when a lane stages more than S candidates, the list would hold more than SKW_CAP, or the scans say
- * so (a window without a candidate, a near tie, a key within SK2_NEAR of the threshold).
+ * Gives the strip up (B.fb_list) when a lane stages more than S candidates, the list would hold more than 64 ROUNDS - 8, or the
+ * scans say so (a window without a candidate, a near tie, a key within SK2_NEAR of the threshold).
  */
-#define SKW_CAP 248u /* candidates per strip the list holds (164 expected at ten per window of 250, +6.5 sigma) */
+struct SkwWords { uint4 o0, i0; uint32_t o4, i4, ao, ai; };
 
-template <int WAVES, int S>
-__global__ __launch_bounds__(64 * WAVES) void sketch_wave_kernel(Sketch2Args B)
+__device__ __forceinline__ uint4 skw_strip_load(const StripLite *tab, uint32_t strip, uint32_t end)
+{
+    uint4 v = make_uint4(0u, 0u, 0u, 0u); /* {g0 lo, g0 hi, hi, -}; hi = 0: nothing to do */
+    if (strip < end) v = *(const uint4 *)&tab[strip];
+    return v;
+}
+
+__device__ __forceinline__ SkwWords skw_words_load(const uint32_t *__restrict__ packed, const uint4 I, int L, int k, uint32_t wmax)
+{
+    SkwWords W;
+    const uint64_t gp = (((uint64_t)I.y << 32) | I.x) + (uint64_t)(L * 64);
+    const uint64_t gq = gp + (uint64_t)k;
+    uint32_t wi = (uint32_t)(gp >> 4), wq = (uint32_t)(gq >> 4);
+    wi = wi < wmax ? wi : wmax; /* over-reads behind the last sequence: values never used */
+    wq = wq < wmax ? wq : wmax;
+    W.o0 = ntl_load4_a4(packed + wi); W.o4 = packed[wi + 4];
+    W.i0 = ntl_load4_a4(packed + wq); W.i4 = packed[wq + 4];
+    W.ao = 2u * ((uint32_t)gp & 15u); W.ai = 2u * ((uint32_t)gq & 15u);
+    return W;
+}
+
+/* A staged key carries the step it was made in in its six low bits: k' = (key & ~63) | t.  Two such words order their k-mers' hashes
+   when they are more than SKW_NEAR apart: k'_j - k'_i > SKW_NEAR  =>  key_j - key_i > SKW_NEAR - 126 >= SK2_NEAR  =>  h0_i < h0_j
+   ("exact" in the header of this file); closer pairs are the near ties that give a strip up -- 2^-23 per window instead of 2^-29. */
+#define SKW_NEAR 131u
+static_assert(SKW_NEAR >= 126u + SK2_NEAR, "see above");
+
+/* rolling step T (the k-mer at position T of the lane's block from the one before it) and its candidate test */
+template <int T>
+__device__ __forceinline__ void skw_step(uint32_t &fx, uint32_t &ry, uint32_t &fd, const uint2 sd, uint32_t tm1, uint32_t low6, uint32_t *&dst)
+{
+    fx = ntl_alignbit(fx, fd, 31) ^ sd.x; /* srol1 on the ring: (fx << 1) | ring bit 30, which is the top bit of fd = fx << 1 */
+    const uint32_t a = ry ^ sd.y;
+    ry = ntl_alignbit(a >> 1, a, 1);      /* sror1: ring bit 0 (bit 1 of a) -> bit 31 */
+    fd = fx << 1;
+    const uint32_t key = fd + ry;
+    if (key <= tm1) ntl_lds_push_tagged<T>(dst, low6, key);
+}
+
+template <int T0, int... J>
+__device__ __forceinline__ void skw_steps(std::integer_sequence<int, J...>, uint32_t &fx, uint32_t &ry, uint32_t &fd, const uint2 (&sd)[8], uint32_t tm1,
+                                          uint32_t low6, uint32_t *&dst)
+{
+    (skw_step<T0 + J>(fx, ry, fd, sd[J], tm1, low6, dst), ...);
+}
+
+template <int WAVES, int S, int ROUNDS>
+__global__ __launch_bounds__(64 * WAVES, WAVES >= 8 ? 8 : 7) void sketch_wave_kernel(Sketch2Args B)
 {
     constexpr int C = 64;
-    constexpr uint32_t STAGE = 64u * (uint32_t)S;  /* staging slots of a wavefront */
-    constexpr uint32_t LIST = SKW_CAP + 8u;        /* [3] left sentinel, [4 .. n + 3] candidates, [n + 4] right sentinel, copies around them (see sketch_thresh_kernel) */
-    static_assert(LIST >= (uint32_t)(C - S), "what lane 63 writes beyond its slots must stay inside the wavefront's own list area");
+    constexpr uint32_t SLOTS = 64u * (uint32_t)S;      /* words of a wavefront's key array: staging slots, then the list's keys in place */
+    constexpr uint32_t NLIST = 64u * (uint32_t)ROUNDS; /* list entries: [3] left sentinel, [4 .. n + 3] candidates, [n + 4] right sentinel, copies around them */
+    constexpr uint32_t CAP = NLIST - 8u;               /* candidates the list holds */
+    static_assert(NLIST <= SLOTS, "the list's keys live in the staging slots");
+    static_assert(S & 1, "odd S: the lanes' slots start S words apart, and a ds_write_b32 of 32 lanes is conflict-free only for odd S");
     __shared__ __attribute__((aligned(16))) uint2 s_g4k[1024];
     __shared__ __attribute__((aligned(16))) uint32_t s_roll[32];
-    __shared__ __attribute__((aligned(16))) uint2 s_wave[WAVES][STAGE + LIST];
+    /* the list's positions are words at a constant distance KP from their keys (one address register serves both), in the upper part
+       of the same array: once the staged keys are in registers only the list lives there */
+    constexpr uint32_t KP = NLIST;
+    constexpr uint32_t NWORDS = SLOTS + (uint32_t)(C - S) > 2u * NLIST ? SLOTS + (uint32_t)(C - S) : 2u * NLIST; /* the slots + what lane 63 may write beyond them */
+    __shared__ __attribute__((aligned(16))) uint32_t s_keys[WAVES][NWORDS];
 
     const SketchArgs &A = B.A;
     const int tid = threadIdx.x, L = tid & 63;
@@ -1253,188 +1307,214 @@ __global__ __launch_bounds__(64 * WAVES) void sketch_wave_kernel(Sketch2Args B)
     for (int i = tid; i < 512; i += 64 * WAVES) ((uint4 *)s_g4k)[i] = ((const uint4 *)B.g4k)[i];
     if (tid < 16) { s_roll[2 * tid] = (uint32_t)(A.roll_tab[tid][0] >> 33); s_roll[2 * tid + 1] = (uint32_t)(A.roll_tab[tid][1] >> 32); }
 
-    const uint32_t per_xcd = gridDim.x >> 3; /* consecutive strips on one XCD */
-    const uint32_t strip = ((blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3)) * (uint32_t)WAVES + wv;
-    StripInfo I;
-    I.seq = NTL_NONE;
-    if (strip < A.nstrips) I = A.strip_tab[strip];
-    const bool active = I.seq != NTL_NONE && I.multi == 0; /* strips that cross non-ACGT runs: sketch_mask_kernel<.., MULTI = true> */
+    /* the strips of this wavefront: XCD x (workgroups x, x + 8, ...: they share an L2) takes the x-th eighth of the strips, and its
+       wavefronts walk through it side by side -- neighbouring strips share their halo bases and strip-table lines */
+    const uint32_t per_xcd = (A.nstrips + 7u) >> 3;
+    const uint32_t stride = (gridDim.x >> 3) * (uint32_t)WAVES;
+    const uint32_t lo = (blockIdx.x & 7u) * per_xcd;
+    const uint32_t end = lo + per_xcd < A.nstrips ? lo + per_xcd : A.nstrips;
+    uint32_t strip = lo + (blockIdx.x >> 3) * (uint32_t)WAVES + wv;
+    const uint32_t wmax = (uint32_t)B.max_word - 9u;
+    const int k = A.G.k;
 
-    /* ---- the lane's bases: 64 that leave (so) and the 64 that enter (si), k bases further on ---- */
-    uint32_t so[4] = {0u, 0u, 0u, 0u}, si[4] = {0u, 0u, 0u, 0u};
-    if (active) {
-        const uint64_t gp = (uint64_t)((int64_t)I.base + I.P0 + (int64_t)L * C);
-        const uint32_t wmax = (uint32_t)B.max_word - 9u; /* over-reads behind the last sequence: values never used */
-        const uint64_t gq = gp + (uint64_t)A.G.k;
-        uint32_t wi = (uint32_t)(gp >> 4), wq = (uint32_t)(gq >> 4);
-        wi = wi < wmax ? wi : wmax;
-        wq = wq < wmax ? wq : wmax;
-        const uint4 o0 = ntl_load4_a4(A.T.packed + wi), i0 = ntl_load4_a4(A.T.packed + wq);
-        const uint32_t o4 = A.T.packed[wi + 4], i4 = A.T.packed[wq + 4];
-        const uint32_t ao = 2u * ((uint32_t)gp & 15u), ai = 2u * ((uint32_t)gq & 15u);
-        so[0] = ntl_alignbit(o0.y, o0.x, ao); so[1] = ntl_alignbit(o0.z, o0.y, ao); so[2] = ntl_alignbit(o0.w, o0.z, ao); so[3] = ntl_alignbit(o4, o0.w, ao);
-        si[0] = ntl_alignbit(i0.y, i0.x, ai); si[1] = ntl_alignbit(i0.z, i0.y, ai); si[2] = ntl_alignbit(i0.w, i0.z, ai); si[3] = ntl_alignbit(i4, i0.w, ai);
-    }
+    uint4 I = skw_strip_load(A.strip_lite, strip, end);
+    uint4 I1 = skw_strip_load(A.strip_lite, strip + stride, end);
+    SkwWords W = skw_words_load(A.T.packed, I, L, k, wmax);
     __syncthreads(); /* the tables are in LDS; the only workgroup barrier of the kernel */
-    if (!active) return;
 
-    uint2 *const stage = &s_wave[wv][0];
-    uint2 *const list = &s_wave[wv][STAGE];
-    const uint32_t hi = (uint32_t)((int64_t)I.M - (int64_t)I.E0 < (int64_t)(64 * C) ? (int64_t)I.M - (int64_t)I.E0 : (int64_t)(64 * C));
-    const uint32_t lane_pos = (uint32_t)(L * C);
-    const uint32_t tm1 = lane_pos < hi ? B.thresh - 1u : 0u; /* lanes behind the sequence's last k-mer roll over whatever follows it: nothing of theirs is a candidate */
-
-    /* ---- the first k-mer's rings from the lane's own bases: 16-base partial hashes out of the four-base tables ---- */
-    uint32_t fx, ry;
-    {
-        uint32_t f = 0, u = 0;
-#pragma unroll
-        for (int i = 0; i < 4; i++) { /* k <= 64 */
-            if (i >= B.q16) break;
-            if (i) { f = ring_rotl(f, 16); u = ring_rotr(u, 16); }
-            const uint32_t w = so[i];
-            const uint2 g0 = s_g4k[w & 255u], g1 = s_g4k[256u + ((w >> 8) & 255u)], g2 = s_g4k[512u + ((w >> 16) & 255u)], g3 = s_g4k[768u + (w >> 24)];
-            f ^= g0.x ^ g1.x ^ g2.x ^ g3.x;
-            u ^= g0.y ^ g1.y ^ g2.y ^ g3.y;
-        }
-        if (B.r16) {
-            const uint32_t r = (uint32_t)B.r16;
-            if (B.q16) { f = ring_rotl(f, r); u = ring_rotr(u, r); }
-            const uint32_t w = B.q16 == 0 ? so[0] : (B.q16 == 1 ? so[1] : (B.q16 == 2 ? so[2] : so[3]));
-            uint2 P;
-            if (B.r16 == 8) {
-                const uint2 p0 = s_g4k[512u + (w & 255u)], p1 = s_g4k[768u + ((w >> 8) & 255u)];
-                P = make_uint2(p0.x ^ p1.x, p0.y ^ p1.y);
-            } else {
-                uint2 fu;
-                sk2_chunk(w, B.r16, B, fu, P); /* k % 16 not in {0, 8}: the first r bases on the plain 64-bit tables */
-            }
-            f ^= P.x;
-            u ^= P.y;
-        }
-        fx = f;
-        ry = u << 1; /* the tables carry the reverse strand's final rotation */
-    }
-
-    /* ---- rolling; every key is tested as it is made, candidates go to the lane's staging slots ---- */
-    uint2 *dst = stage + (uint32_t)L * (uint32_t)S;
-    {
-        uint32_t key = (fx << 1) + ry;
-        if (key <= tm1) *dst++ = make_uint2(key, lane_pos);
-#pragma unroll
-        for (int m = 0; m < 4; m++) {
-            uint32_t wz[4];
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const uint32_t o2 = r < 2 ? so[m] << (3 - 2 * r) : so[m] >> (2 * r - 3);
-                const uint32_t i2 = r < 3 ? si[m] << (5 - 2 * r) : si[m] >> (2 * r - 5);
-                wz[r] = (o2 & 0x18181818u) | (i2 & 0x60606060u);
-            }
-            /* the sixteen seed pairs of this word's steps are requested together, in front of the steps: every step ends in a
-               predicated write (a basic block of its own), and a read issued inside a step would be waited for inside it */
-            uint2 sd[16];
-#pragma unroll
-            for (int b = 0; b < 16; b++) {
-                const uint32_t off = ntl_bfe(wz[b & 3], 8u * (uint32_t)(b >> 2), 8u);
-                sd[b] = ntl_lds_load2_ordered((const uint2 *)((const char *)s_roll + off));
-            }
-#pragma unroll
-            for (int b = 0; b < 16; b++) {
-                const int t = 16 * m + b + 1;
-                if (t >= C) break;
-                fx = ((fx << 1) | ((fx >> 30) & 1u)) ^ sd[b].x;
-                const uint32_t a = ry ^ sd[b].y;
-                ry = ntl_alignbit(a >> 1, a, 1);
-                key = (fx << 1) + ry;
-                if (key <= tm1) *dst++ = make_uint2(key, lane_pos + (uint32_t)t);
-            }
-        }
-    }
-    uint32_t cnt = (uint32_t)(dst - (stage + (uint32_t)L * (uint32_t)S));
-    bool bad = cnt > (uint32_t)S; /* (what it wrote beyond its slots lies in the next lane's, or in the list area: the strip is given up) */
-
-    /* ---- the staged candidates that are elements of the strip's windows, in position order, into the list ---- */
-    const uint2 *src = stage + (uint32_t)L * (uint32_t)S;
-    if (cnt > (uint32_t)S) cnt = (uint32_t)S;
-    if (L == 0 && cnt && src[0].y == 0u) { src++; cnt--; } /* element 0 belongs to the windows of the previous strip only */
-    if (hi < (uint32_t)(64 * C)) { /* the sequence ends inside the strip: positions >= hi are not elements */
-        uint32_t keep = 0;
-        for (uint32_t j = 0; j < (uint32_t)S; j++)
-            if (j < cnt && src[j].y < hi) keep++;
-        cnt = keep;
-    }
-    const uint32_t incl = ntl_wave_incl_scan(cnt);
-    const uint32_t total = ntl_readfirstlane((uint32_t)__shfl((int)incl, 63));
-    uint32_t at = incl - cnt;
-    const bool over = total > SKW_CAP;
-    const uint32_t n = over ? 0u : total;
-    if (!over) {
-        for (uint32_t j = 0; __ballot(j < cnt) != 0ull; j++)
-            if (j < cnt) list[at + 4u + j] = src[j];
-    }
-    if (L < 4) {
-        list[L] = make_uint2(0u, 0u);          /* the left sentinel (position 0, key 0) and copies of it in front */
-        list[n + 4u + (uint32_t)L] = make_uint2(0u, hi); /* the right sentinel at the end of the strip's elements and copies behind it */
-    }
-    ntl_wave_sync();
-
-    /* ---- one lane per candidate (sketch_thresh_kernel, phase 4), four list entries per step ---- */
+    uint32_t *const keys = &s_keys[wv][0];
+    uint32_t *const pos = keys + KP;
     const uint32_t w = (uint32_t)A.G.w;
-    uint32_t found[4] = {SK2_INF, SK2_INF, SK2_INF, SK2_INF};
-    if (L == 0) bad |= list[4].y - 1u >= w; /* elements 1 .. w without a candidate */
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const uint32_t i = (uint32_t)L + 64u * (uint32_t)r;
-        if (i < n) {
-            const uint2 me = list[i + 4u];
-            const uint32_t lim = me.x + SK2_NEAR;
-            bad |= lim >= B.thresh;
-            uint32_t Rp = me.y + w;
-            {
-                uint32_t j = i + 5u, fb;
-                bad |= list[j].y - me.y - 1u >= w; /* a window between two candidates */
-                for (;;) {
-                    const uint2 q0 = list[j], q1 = list[j + 1], q2 = list[j + 2], q3 = list[j + 3];
-                    fb = sk2t_first_le(q0.x, q1.x, q2.x, q3.x, lim);
-                    if (fb != 4u || q3.y >= Rp) break;
-                    j += 4;
-                }
-                if (fb != 4u) {
-                    const uint2 e = list[j + fb];
-                    if (e.y < Rp) {
-                        Rp = e.y;
-                        bad |= e.x + SK2_NEAR >= me.x;
-                    }
-                }
-            }
-            const int32_t need = (int32_t)Rp - (int32_t)w;
-            bool blocked = false;
-            {
-                uint32_t j = i + 3u, fb;
-                for (;;) {
-                    const uint2 q0 = list[j], q1 = list[j - 1], q2 = list[j - 2], q3 = list[j - 3];
-                    fb = sk2t_first_le(q0.x, q1.x, q2.x, q3.x, lim);
-                    if (fb != 4u || (int32_t)q3.y < need) break;
-                    j -= 4;
-                }
-                if (fb != 4u) blocked = (int32_t)list[j - fb].y >= need;
-            }
-            if (!blocked) found[r] = me.y;
-        }
-    }
+    for (; strip < end; strip += stride) {
+        /* two strips ahead: the table entry; one strip ahead: the base words */
+        const uint4 I2 = skw_strip_load(A.strip_lite, strip + 2u * stride, end);
+        const SkwWords W1 = skw_words_load(A.T.packed, I1, L, k, wmax);
+        const uint4 Ic = I;
+        const SkwWords Wc = W;
+        I = I1; I1 = I2; W = W1;
+        const uint32_t hi = ntl_readfirstlane(Ic.z);
+        if (hi == 0u) continue; /* past the last strip, or a strip that crosses non-ACGT runs: sketch_mask_kernel<.., MULTI = true> */
 
-    /* ---- proven minimizers to the global bitmask; a strip that was given up writes none and goes to the block-minima pass ---- */
-    const bool flagged = B.force_redo || over || __ballot(bad) != 0ull;
-    if (flagged) {
-        if (L == 0) B.fb_list[atomicAdd(B.fb_count, 1u)] = strip;
-        return;
-    }
-    const uint64_t g0 = (uint64_t)((int64_t)I.base + I.P0);
+        /* ---- the lane's bases: 64 that leave (so) and the 64 that enter (si), k bases further on ---- */
+        uint32_t so[4], si[4];
+        so[0] = ntl_alignbit(Wc.o0.y, Wc.o0.x, Wc.ao); so[1] = ntl_alignbit(Wc.o0.z, Wc.o0.y, Wc.ao); so[2] = ntl_alignbit(Wc.o0.w, Wc.o0.z, Wc.ao); so[3] = ntl_alignbit(Wc.o4, Wc.o0.w, Wc.ao);
+        si[0] = ntl_alignbit(Wc.i0.y, Wc.i0.x, Wc.ai); si[1] = ntl_alignbit(Wc.i0.z, Wc.i0.y, Wc.ai); si[2] = ntl_alignbit(Wc.i0.w, Wc.i0.z, Wc.ai); si[3] = ntl_alignbit(Wc.i4, Wc.i0.w, Wc.ai);
+
+        const uint32_t lane_pos = (uint32_t)(L * C);
+        const uint32_t tm1 = lane_pos < hi ? B.thresh - 1u : 0u; /* lanes behind the sequence's last k-mer roll over whatever follows it: nothing of theirs is a candidate */
+        uint32_t low6 = 63u;
+        NTL_OPAQUE(low6); /* a register, not a literal per step; and not loop-invariant for the optimiser */
+
+        /* ---- the first k-mer's rings from the lane's own bases: 16-base partial hashes out of the four-base tables ---- */
+        uint32_t fx, ry;
+        {
+            uint32_t f = 0, u = 0;
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        if (found[r] != SK2_INF) {
-            const uint64_t g = g0 + found[r];
-            atomicOr(&A.mask[g >> 5], 1u << ((uint32_t)g & 31u));
+            for (int i = 0; i < 4; i++) { /* k <= 64 */
+                if (i >= B.q16) break;
+                if (i) { f = ring_rotl(f, 16); u = ring_rotr(u, 16); }
+                const uint32_t x = so[i];
+                const uint2 g0 = s_g4k[x & 255u], g1 = s_g4k[256u + ((x >> 8) & 255u)], g2 = s_g4k[512u + ((x >> 16) & 255u)], g3 = s_g4k[768u + (x >> 24)];
+                f ^= g0.x ^ g1.x ^ g2.x ^ g3.x;
+                u ^= g0.y ^ g1.y ^ g2.y ^ g3.y;
+            }
+            if (B.r16) {
+                const uint32_t r = (uint32_t)B.r16;
+                if (B.q16) { f = ring_rotl(f, r); u = ring_rotr(u, r); }
+                const uint32_t x = B.q16 == 0 ? so[0] : (B.q16 == 1 ? so[1] : (B.q16 == 2 ? so[2] : so[3]));
+                uint2 P;
+                if (B.r16 == 8) {
+                    const uint2 p0 = s_g4k[512u + (x & 255u)], p1 = s_g4k[768u + ((x >> 8) & 255u)];
+                    P = make_uint2(p0.x ^ p1.x, p0.y ^ p1.y);
+                } else {
+                    uint2 fu;
+                    sk2_chunk(x, B.r16, B, fu, P); /* k % 16 not in {0, 8}: the first r bases on the plain 64-bit tables */
+                }
+                f ^= P.x;
+                u ^= P.y;
+            }
+            fx = f;
+            ry = u << 1; /* the tables carry the reverse strand's final rotation */
         }
+
+        /* ---- rolling; every key is tested as it is made, candidates go to the lane's staging slots ---- */
+        uint32_t *const slots = keys + (uint32_t)L * (uint32_t)S;
+        uint32_t *dst = slots;
+        {
+            uint32_t fd = fx << 1;
+            if (fd + ry <= tm1) ntl_lds_push_tagged<0>(dst, low6, fd + ry);
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                uint32_t wz[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const uint32_t o2 = r < 2 ? so[m] << (3 - 2 * r) : so[m] >> (2 * r - 3);
+                    const uint32_t i2 = r < 3 ? si[m] << (5 - 2 * r) : si[m] >> (2 * r - 5);
+                    wz[r] = (o2 & 0x18181818u) | (i2 & 0x60606060u);
+                }
+                /* the seed pairs of eight steps are requested together, in front of the steps: every step ends in a predicated
+                   write (a basic block of its own), and a read issued inside a step would be waited for inside it */
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    uint2 sd[8];
+#pragma unroll
+                    for (int b = 8 * h; b < 8 * h + 8; b++) {
+                        const uint32_t off = ntl_bfe(wz[b & 3], 8u * (uint32_t)(b >> 2), 8u);
+                        sd[b & 7] = ntl_lds_load2_ordered((const uint2 *)((const char *)s_roll + off));
+                    }
+                    if (m == 0 && h == 0) skw_steps<1>(std::make_integer_sequence<int, 8>(), fx, ry, fd, sd, tm1, low6, dst);
+                    else if (m == 0) skw_steps<9>(std::make_integer_sequence<int, 8>(), fx, ry, fd, sd, tm1, low6, dst);
+                    else if (m == 1 && h == 0) skw_steps<17>(std::make_integer_sequence<int, 8>(), fx, ry, fd, sd, tm1, low6, dst);
+                    else if (m == 1) skw_steps<25>(std::make_integer_sequence<int, 8>(), fx, ry, fd, sd, tm1, low6, dst);
+                    else if (m == 2 && h == 0) skw_steps<33>(std::make_integer_sequence<int, 8>(), fx, ry, fd, sd, tm1, low6, dst);
+                    else if (m == 2) skw_steps<41>(std::make_integer_sequence<int, 8>(), fx, ry, fd, sd, tm1, low6, dst);
+                    else if (h == 0) skw_steps<49>(std::make_integer_sequence<int, 8>(), fx, ry, fd, sd, tm1, low6, dst);
+                    else skw_steps<57>(std::make_integer_sequence<int, 7>(), fx, ry, fd, sd, tm1, low6, dst);
+                }
+            }
+        }
+        uint32_t cnt = (uint32_t)(dst - slots);
+        bool bad = cnt > (uint32_t)S; /* (what it wrote beyond its slots lies in the next lane's, or behind the array: the strip is given up) */
+
+        /* ---- the staged candidates that are elements of the strip's windows into registers, then back in position order: the list ---- */
+        if (cnt > (uint32_t)S) cnt = (uint32_t)S;
+        uint32_t mine[S];
+#pragma unroll
+        for (int j = 0; j < S; j++) mine[j] = (uint32_t)j < cnt ? slots[j] : SK2_INF;
+        uint32_t first = 0;
+        if (L == 0 && cnt && (mine[0] & 63u) == 0u) { first = 1; cnt--; } /* element 0 belongs to the windows of the previous strip only */
+        if (hi < (uint32_t)(64 * C)) { /* the sequence ends inside the strip: positions >= hi are not elements */
+            uint32_t keep = 0;
+#pragma unroll
+            for (int j = 0; j < S; j++)
+                if ((uint32_t)j >= first && (uint32_t)j < first + cnt && lane_pos + (mine[j] & 63u) < hi) keep++;
+            cnt = keep;
+        }
+        const uint32_t incl = ntl_wave_incl_scan(cnt);
+        const uint32_t total = ntl_readfirstlane((uint32_t)__shfl((int)incl, 63));
+        const uint32_t at = incl - cnt + 4u - first;
+        const bool over = total > CAP;
+        const uint32_t n = over ? 0u : total;
+        ntl_wave_sync(); /* every lane holds its candidates: the slots may be overwritten */
+        if (!over) {
+#pragma unroll
+            for (int j = 0; j < S; j++)
+                if ((uint32_t)j >= first && (uint32_t)j < first + cnt) {
+                    keys[at + (uint32_t)j] = mine[j];
+                    pos[at + (uint32_t)j] = lane_pos + (mine[j] & 63u);
+                }
+        }
+        if (L < 4) {
+            keys[L] = 0u; pos[L] = 0;                                       /* the left sentinel (position 0, key 0) and copies of it in front */
+            keys[n + 4u + (uint32_t)L] = 0u; pos[n + 4u + (uint32_t)L] = hi; /* the right sentinel at the end of the strip's elements and copies behind it */
+        }
+        ntl_wave_sync();
+
+        /* ---- one lane per candidate (sketch_thresh_kernel, phase 4), four list entries per step.  Every branch is uniform over the
+           wavefront: a lane whose scan has ended reads its last four entries again until the slowest lane's has (the wavefront
+           pays for the slowest lane either way, and without diverging lanes there are no execution masks to juggle); a lane
+           without a candidate in the last round works on the last candidate again and drops the answer. ---- */
+        uint32_t found = 0; /* bit r: this lane's candidate of round r is a minimizer */
+        if (L == 0) bad |= pos[4] - 1u >= w; /* elements 1 .. w without a candidate */
+        for (uint32_t r = 0; r * 64u < n; r++) {
+            const uint32_t i0 = (uint32_t)L + 64u * r;
+            const bool real = i0 < n;
+            const uint32_t i = real ? i0 : n - 1u;
+            const uint32_t mk = keys[i + 4u], mp = pos[i + 4u];
+            const uint32_t lim = mk + SKW_NEAR;
+            bool b = lim >= B.thresh;
+            uint32_t Rp = mp + w;
+            b |= pos[i + 5u] - mp - 1u >= w; /* a window between two candidates */
+            uint32_t q0, q1, q2, q3;
+            {   /* to the right: the first blocker nearer than w; ends at the right sentinel (key 0) at the latest */
+                const uint32_t *kp = keys + i + 5u;
+                for (;;) { /* a step only asks "any blocker among the four?" (two minima, one compare); which one is settled once, behind the loop */
+                    q0 = kp[0]; q1 = kp[1]; q2 = kp[2]; q3 = kp[3];
+                    const uint32_t p3 = kp[KP + 3];
+                    const bool go = (ntl_min3(q0, q1, q2 < q3 ? q2 : q3) > lim) & (p3 < Rp); /* (no short circuit: the reads are issued together) */
+                    if (__ballot(go) == 0ull) break;
+                    kp += go ? 4 : 0;
+                }
+                const uint32_t fb = sk2t_first_le(q0, q1, q2, q3, lim);
+                const uint32_t *ke = kp + (fb != 4u ? fb : 3u);
+                const uint32_t ek = ke[0], ep = ke[KP];
+                const bool take = fb != 4u && ep < Rp;
+                b |= take && ek + SKW_NEAR >= mk; /* within the tolerance of the candidate's own key (the sentinel's key 0: only for keys <= SKW_NEAR) */
+                Rp = take ? ep : Rp;
+            }
+            const int32_t need = (int32_t)Rp - (int32_t)w; /* a blocker at q < pos matters where q >= need */
+            bool blocked;
+            {   /* to the left: is there a blocker at or behind `need`?  Ends at the left sentinel (index 3: position 0, key 0) at the latest */
+                const uint32_t *kp = keys + i; /* the chunk [i .. i + 3], nearest entry last */
+                for (;;) {
+                    q0 = kp[3]; q1 = kp[2]; q2 = kp[1]; q3 = kp[0];
+                    const int32_t p3 = (int32_t)kp[KP];
+                    const bool go = (ntl_min3(q0, q1, q2 < q3 ? q2 : q3) > lim) & (p3 >= need);
+                    if (__ballot(go) == 0ull) break;
+                    kp -= go ? 4 : 0;
+                }
+                const uint32_t fb = sk2t_first_le(q0, q1, q2, q3, lim);
+                blocked = fb != 4u && (int32_t)kp[KP + 3u - (fb != 4u ? fb : 3u)] >= need;
+            }
+            if (real) {
+                bad |= b;
+                if (!blocked) found |= 1u << r;
+            }
+        }
+
+        /* ---- proven minimizers to the global bitmask; a strip that was given up writes none and goes to the block-minima pass ---- */
+        const bool flagged = B.force_redo || over || __ballot(bad) != 0ull;
+        if (flagged) {
+            if (L == 0) B.fb_list[atomicAdd(B.fb_count, 1u)] = strip;
+        } else {
+            const uint64_t g0 = ((uint64_t)Ic.y << 32) | Ic.x;
+            while (found) {
+                const uint32_t r = (uint32_t)__ffs(found) - 1u;
+                found &= found - 1u;
+                const uint64_t g = g0 + pos[(uint32_t)L + 64u * r + 4u];
+                atomicOr(&A.mask[g >> 5], 1u << ((uint32_t)g & 31u));
+            }
+        }
+        ntl_wave_sync(); /* the list has been read: the next strip may stage over it */
     }
 }

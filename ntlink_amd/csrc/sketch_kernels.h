@@ -83,12 +83,23 @@ struct StripInfo {
  * that a strip's workgroup starts from a single 40-byte load instead of a chain of dependent ones.
  * strip_first[s] + i -> strip i of sequence s, first ordinal i*NWO - 1.
  */
+/* what sketch_wave_kernel needs of a strip, in one 16-byte load: the global base index of element 0, and the number of elements that
+   lie in the sequence (0: not a strip of its kind -- past the last strip, or across non-ACGT runs) */
+struct __attribute__((aligned(16))) StripLite {
+    uint64_t g0;
+    uint32_t hi, pad_;
+};
+
 __global__ void strip_table_kernel(SeqTables T, const uint32_t *run_n, const uint32_t *run_ord, const uint32_t *seq_M,
-                                   const uint32_t *strip_first, int NWO, int strip_elems, StripInfo *tab, uint32_t cap)
+                                   const uint32_t *strip_first, int NWO, int strip_elems, StripInfo *tab, uint32_t cap, StripLite *lite)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; /* one thread per strip */
     if (i >= cap) return;
-    if (i >= strip_first[T.nseq]) { tab[i].seq = NTL_NONE; return; } /* the grid of the sketch kernel is an upper bound */
+    if (i >= strip_first[T.nseq]) { /* the grid of the sketch kernel is an upper bound */
+        tab[i].seq = NTL_NONE;
+        if (lite) { lite[i].g0 = 0; lite[i].hi = 0; lite[i].pad_ = 0; }
+        return;
+    }
     uint32_t lo = 0, hi = T.nseq; /* largest s with strip_first[s] <= i */
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
@@ -116,6 +127,12 @@ __global__ void strip_table_kernel(SeqTables T, const uint32_t *run_n, const uin
     I.multi = (e_hi > run_ord[rl] + run_n[rl]) ? 1 : 0;
     I.P0 = (int64_t)T.run_start[rl] - (int64_t)run_ord[rl] + (int64_t)I.E0;
     tab[i] = I;
+    if (lite) {
+        const int64_t left = (int64_t)I.M - (int64_t)I.E0;
+        lite[i].g0 = (uint64_t)((int64_t)I.base + I.P0);
+        lite[i].hi = I.multi ? 0u : (uint32_t)(left < (int64_t)strip_elems ? left : (int64_t)strip_elems);
+        lite[i].pad_ = 0;
+    }
 }
 
 struct SketchArgs {
@@ -129,6 +146,7 @@ struct SketchArgs {
     uint64_t seed_tab[4][2];     /* [c] = {seed[c], seed[3-c]} */
     const uint64_t (*g4)[2];     /* [256] four-base init table (dev_common.h hash_init) */
     const uint64_t (*g8)[2];     /* [65536] eight-base init table */
+    const struct StripLite *strip_lite; /* [nstrips + 1] the same for sketch_wave_kernel */
     const uint32_t *redo_list;   /* not NULL: process exactly these strips (flagged by sketch_fast_kernel), looping */
     const uint32_t *redo_count;
 };

@@ -1,16 +1,19 @@
 #!/bin/bash
-# round 4, A/B of the window pass: build, sketch parity tests, sketch stage alone at the C3 (and C5/C2) points for every variant of
+# round 4, A/B of the window pass: build, sketch parity tests, sketch stage alone at the C3 / C5 / w=150 points for the variants of
 # NTL_SKETCH_WAVE, SQ counters of the default
 TAG=${1:-r04a}
-VARIANTS=${VARIANTS:-"0 1 2 8 9"}
+VARIANTS=${VARIANTS:-"0 1 4 16"}
 mkdir -p gpurun_out/$TAG
 python __graft_entry__.py > gpurun_out/$TAG/build.log 2>&1 || { tail -20 gpurun_out/$TAG/build.log; exit 1; }
 timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "sketch or fast or fuzz or edge or golden or thresh" 2>&1 | tail -4 | tee gpurun_out/$TAG/pytest_sketch.log
 for v in $VARIANTS; do
   NTL_SKETCH_WAVE=$v python tools/sketch_bench.py | tee -a gpurun_out/$TAG/sk_c3.jsonl
 done
-for v in 0 1; do
+for v in 0 1 4; do
   NTL_SKETCH_WAVE=$v python tools/sketch_bench.py --w 100 --k 24 --read-len 20000 --bases 3.9e9 | tee -a gpurun_out/$TAG/sk_c5.jsonl
+done
+for v in 0 1; do
+  NTL_SKETCH_WAVE=$v python tools/sketch_bench.py --w 150 --k 32 --read-len 15000 --bases 3.9e9 | tee -a gpurun_out/$TAG/sk_w150.jsonl
 done
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
