@@ -188,3 +188,12 @@ __device__ __forceinline__ uint32_t ntl_le4_mask(uint32_t k0, uint32_t k1, uint3
         : "+v"(acc) : "v"(k3), "v"(k2), "v"(k1), "v"(k0), "v"(lim) : "vcc");
     return acc;
 }
+
+/* Wavefront issue priority 0..3 (s_setprio).  The latency-bound kernels of the MAIN stream (index lookup, mapping, gathers) raise
+   theirs: beside the window stage's resident, issue-bound wavefronts their few instructions between two memory round trips
+   should not queue behind a stream of rolling steps. */
+#ifndef NTL_NO_SETPRIO
+#define NTL_PRIO_LATENCY_BOUND() asm volatile("s_setprio 3")
+#else
+#define NTL_PRIO_LATENCY_BOUND() ((void)0)
+#endif

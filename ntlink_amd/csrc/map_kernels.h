@@ -655,6 +655,7 @@ __device__ __forceinline__ int map_class_of(uint32_t nmx) { return nmx <= 256u ?
 template <int MAP_CAPH, int MAP_CAPR, int CLASS>
 __global__ __launch_bounds__(MAP_NT) void map_kernel(MapArgs A)
 {
+    NTL_PRIO_LATENCY_BOUND();
     __shared__ uint32_t s_h32[3][MAP_CAPH];
     __shared__ uint32_t s_h16[MAP_CAPH];      /* two uint16 arrays (run, ord), on a word boundary for the flag atomics */
     __shared__ uint32_t s_r32[3][MAP_CAPR];
@@ -686,6 +687,7 @@ __global__ __launch_bounds__(MAP_NT) void map_kernel(MapArgs A)
 /* the reads map_kernel could not stage in LDS, on their regions of the global scratch arrays */
 __global__ __launch_bounds__(MAP_NT) void map_overflow_kernel(MapArgs A)
 {
+    NTL_PRIO_LATENCY_BOUND();
     if (map_sketch_overflowed(A)) return;
     const uint32_t n = *A.over_count;
     for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {

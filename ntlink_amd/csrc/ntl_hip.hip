@@ -1191,7 +1191,13 @@ static void launch_fast_r0(ntl_ctx *c, const Sketch2Args &B, unsigned strips)
                 auto go = [&](auto kern, unsigned threads) {
                     int &per_cu = c->occ[(const void *)kern];
                     if (!per_cu) per_cu = occupancy_blocks(kern, (int)threads);
-                    unsigned wgs = (unsigned)std::max(1, per_cu) * (unsigned)std::max(1, c->n_cu);
+                    /* Beside the other stream's kernels (two streams: the lookup / map kernels of the previous batch) the resident wavefronts
+                       take HALF the CU's 32 slots: with more, those kernels' workgroups wait for slots that never come free before the
+                       launch ends, and the step is as long as on one stream (C3, profiles/r04_window_grid_sweep.json: 16 wavefronts per
+                       CU 77.6 ms per step, 24 89.5, 32 89.4; alone the launch takes 2.65 ms at 16 against 2.09 at 32). */
+                    int use = c->pipelined ? std::min(per_cu, (int)(16u / (threads / 64u))) : per_cu;
+                    if (const char *e = getenv("NTL_SKW_WGS_PER_CU")) use = std::max(1, std::min(per_cu, atoi(e))); /* tuning */
+                    unsigned wgs = (unsigned)std::max(1, use) * (unsigned)std::max(1, c->n_cu);
                     wgs = std::min(wgs, (strips + threads / 64u - 1u) / (threads / 64u));
                     wgs = (wgs + 7u) & ~7u;
                     hipLaunchKernelGGL(kern, dim3(wgs), dim3(threads), 0, c->wstream, B);
@@ -1378,12 +1384,16 @@ static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const nt
         if (const char *e = getenv("NTL_SKETCH_FAST")) fast = fast && atoi(e) != 0; /* 0: exact pass only (A/B, tests) */
         if (fast) {
             /* [0] strips for the exact pass, [1] strips the threshold pass gave up, then the two lists */
-            if ((rc = redo.alloc(c, (2 * ub_strips + 4) * 4, wsid))) return rc;
+            /* ... and behind them the eight chunk counters of sketch_wave_kernel (one per XCD's share of the strips), 64 bytes apart */
+            const uint64_t redo_words = 2 * ub_strips + 4;
+            if ((rc = redo.alloc(c, (redo_words + 8 * 16) * 4, wsid))) return rc;
             HIPCHK(c, hipMemsetAsync(redo.p, 0, 8, ws));
+            HIPCHK(c, hipMemsetAsync(redo.as<uint32_t>() + redo_words, 0, 8 * 16 * 4, ws));
             Sketch2Args B;
             B.A = A;
             B.redo_count = redo.as<uint32_t>(); B.redo_list = redo.as<uint32_t>() + 2;
             B.fb_count = redo.as<uint32_t>() + 1; B.fb_list = redo.as<uint32_t>() + 2 + ub_strips + 1;
+            B.chunk_next = redo.as<uint32_t>() + redo_words;
             B.max_word = b->nwords_packed - 1;
             B.q16 = k / 16; B.r16 = k % 16;
             B.rev_a = (uint32_t)(k - 1) % 33u; B.rev_b = (uint32_t)(k - 1) % 31u;

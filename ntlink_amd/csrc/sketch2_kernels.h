@@ -73,6 +73,7 @@ struct Sketch2Args {
     const uint2 *g4k;      /* sketch_thresh_kernel: k-dependent four-base ring tables (g4k_build_kernel), [256 j + byte] for the j-th four bases of a chunk */
     uint32_t *fb_list;     /* sketch_thresh_kernel: the strips it gives up, for sketch_fast_list_kernel */
     uint32_t *fb_count;
+    uint32_t *chunk_next;  /* sketch_wave_kernel: [16 x] = the next chunk of strips of XCD x's share that nobody has taken yet (zeroed per launch) */
 };
 
 __device__ __forceinline__ uint32_t sk2_bases16(const uint32_t *__restrict__ packed, uint64_t gp, uint64_t max_word)
@@ -1262,6 +1263,7 @@ __device__ __forceinline__ SkwWords skw_words_load(const uint32_t *__restrict__ 
 /* A staged key carries the step it was made in in its six low bits: k' = (key & ~63) | t.  Two such words order their k-mers' hashes
    when they are more than SKW_NEAR apart: k'_j - k'_i > SKW_NEAR  =>  key_j - key_i > SKW_NEAR - 126 >= SK2_NEAR  =>  h0_i < h0_j
    ("exact" in the header of this file); closer pairs are the near ties that give a strip up -- 2^-23 per window instead of 2^-29. */
+#define SKW_CHUNK 4u /* strips a wavefront takes from its XCD's counter at a time */
 #define SKW_NEAR 131u
 static_assert(SKW_NEAR >= 126u + SK2_NEAR, "see above");
 
@@ -1307,31 +1309,51 @@ __global__ __launch_bounds__(64 * WAVES, WAVES >= 8 ? 8 : 7) void sketch_wave_ke
     for (int i = tid; i < 512; i += 64 * WAVES) ((uint4 *)s_g4k)[i] = ((const uint4 *)B.g4k)[i];
     if (tid < 16) { s_roll[2 * tid] = (uint32_t)(A.roll_tab[tid][0] >> 33); s_roll[2 * tid + 1] = (uint32_t)(A.roll_tab[tid][1] >> 32); }
 
-    /* the strips of this wavefront: XCD x (workgroups x, x + 8, ...: they share an L2) takes the x-th eighth of the strips, and its
-       wavefronts walk through it side by side -- neighbouring strips share their halo bases and strip-table lines */
+    /* The strips of this wavefront: XCD x (workgroups x, x + 8, ...: they share an L2) takes the x-th eighth of the strips, and its
+       wavefronts take CHUNKS of SKW_CHUNK consecutive strips from a counter as they go (neighbouring strips share their halo bases
+       and strip-table lines).  Taken, not dealt out in advance: beside the lookup and map kernels of the other stream a part of the
+       workgroups starts late, and with fixed shares the launch would end when the last of them has worked off a full share. */
     const uint32_t per_xcd = (A.nstrips + 7u) >> 3;
-    const uint32_t stride = (gridDim.x >> 3) * (uint32_t)WAVES;
     const uint32_t lo = (blockIdx.x & 7u) * per_xcd;
     const uint32_t end = lo + per_xcd < A.nstrips ? lo + per_xcd : A.nstrips;
-    uint32_t strip = lo + (blockIdx.x >> 3) * (uint32_t)WAVES + wv;
+    uint32_t *const counter = B.chunk_next + 16u * (blockIdx.x & 7u);
     const uint32_t wmax = (uint32_t)B.max_word - 9u;
     const int k = A.G.k;
-
-    uint4 I = skw_strip_load(A.strip_lite, strip, end);
-    uint4 I1 = skw_strip_load(A.strip_lite, strip + stride, end);
+    /* s0 is the strip at work, s1 and s2 the two behind it (0xFFFFFFFF: none); `chunk` holds the chunk s2 walks through and
+       `ahead` -- in lane 0's register until it is needed -- the number of the one after it */
+    uint32_t ahead = 0;
+    if (L == 0) ahead = atomicAdd(counter, 2u);
+    uint32_t chunk = lo + SKW_CHUNK * ntl_readfirstlane(ahead), sub = 0;
+    ahead = chunk + SKW_CHUNK; /* (the first take covered two chunks) */
+    auto next_strip = [&]() -> uint32_t {
+        if (sub == SKW_CHUNK) {
+            chunk = ntl_readfirstlane(ahead);
+            sub = 0;
+            if (L == 0) ahead = lo + SKW_CHUNK * atomicAdd(counter, 1u); /* asked for a whole chunk before it is needed */
+        }
+        const uint32_t s = chunk + sub;
+        sub++;
+        return s < end ? s : 0xFFFFFFFFu;
+    };
+    uint32_t s0 = next_strip(), s1 = next_strip();
+    uint4 I = skw_strip_load(A.strip_lite, s0, end);
+    uint4 I1 = skw_strip_load(A.strip_lite, s1, end);
     SkwWords W = skw_words_load(A.T.packed, I, L, k, wmax);
     __syncthreads(); /* the tables are in LDS; the only workgroup barrier of the kernel */
 
     uint32_t *const keys = &s_keys[wv][0];
     uint32_t *const pos = keys + KP;
     const uint32_t w = (uint32_t)A.G.w;
-    for (; strip < end; strip += stride) {
+    while (s0 != 0xFFFFFFFFu) {
         /* two strips ahead: the table entry; one strip ahead: the base words */
-        const uint4 I2 = skw_strip_load(A.strip_lite, strip + 2u * stride, end);
+        const uint32_t s2 = next_strip();
+        const uint4 I2 = skw_strip_load(A.strip_lite, s2, end);
         const SkwWords W1 = skw_words_load(A.T.packed, I1, L, k, wmax);
         const uint4 Ic = I;
         const SkwWords Wc = W;
+        const uint32_t strip = s0;
         I = I1; I1 = I2; W = W1;
+        s0 = s1; s1 = s2;
         const uint32_t hi = ntl_readfirstlane(Ic.z);
         if (hi == 0u) continue; /* past the last strip, or a strip that crosses non-ACGT runs: sketch_mask_kernel<.., MULTI = true> */
 

@@ -541,6 +541,7 @@ __global__ __launch_bounds__(EMIT_NT) void emit_kernel(EmitArgs A)
     uint32_t total;
     const uint32_t excl = block_excl_scan<EMIT_NT>(c, s_tmp, total);
     const uint32_t tile_base = A.tile_off[blockIdx.x];
+    NTL_PRIO_LATENCY_BOUND(); /* (behind the scan: in front of the shared arrays' first use it trips the compiler's address-space lowering) */
     {
         uint32_t r = excl;
 #pragma unroll
