@@ -80,6 +80,21 @@ def spawn_ranks(args):
     return p.returncode if p.returncode else (0 if line else 1)
 
 
+class stdout_to_stderr:
+    """file descriptor 1 -> 2 for a block (native code and child threads included)"""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def kernel_signature():
     """Identifies the kernel sources a PMC pass was taken on (profiles/traffic.json is stale after an edit of the code; comments
     and white space do not count)."""
@@ -441,7 +456,8 @@ def main():
             for h in R["wl"].read_batches:
                 h.close()
             R["wl"].read_batches = []
-            out["end_to_end"] = end_to_end(dev, R["wl"], R["W"], args)
+            with stdout_to_stderr():  # the driver logs its steps on stdout as the reference does (bin/ntlink_pair.py:540-606); stdout is the JSON line's
+                out["end_to_end"] = end_to_end(dev, R["wl"], R["W"], args)
     R["ix"].close(); R["csk"].close(); R["wl"].close()
     if world == 1 and rank == 0 and not args.no_others and args.scale == 1.0:
         # the other single-GPU configurations of BASELINE.json under the same clock (fewer steps; same definitions)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Randomised differential soak of the threshold window pass (sketch_thresh_kernel + sketch_fast_list_kernel) on the GPU: product
+"""Randomised differential soak of the threshold window pass (sketch_wave_kernel / sketch_thresh_kernel + sketch_fast_list_kernel) on the GPU: product
 vs oracle over random k, w in 71..255, candidates per window, staged / direct list form, on adversarial and on long random
 sequences, for a given number of seconds.  Usage: tests/gpu_thresh_soak.py [seconds] [seed0]"""
 import os
@@ -29,6 +29,7 @@ while time.time() - t0 < budget:
     cpw = str(rng.choice(["10", "10", "6", "8", "13", "4"]))
     os.environ["NTL_SKETCH_THRESH"] = cpw
     os.environ["NTL_SKETCH_THRESH_DIRECT"] = str(int(rng.integers(0, 2)))
+    os.environ["NTL_SKETCH_WAVE"] = str(rng.choice(["1", "1", "4", "16", "0"]))  # sketch_wave_kernel's shapes (k <= 64) / sketch_thresh_kernel
     seqs = fuzz_cases.fuzz_sequences(seed, n=int(rng.integers(5, 40)), max_len=int(rng.choice([3000, 9000, 30000])))
     for _ in range(int(rng.integers(1, 4))):  # long random sequences: full strips, hundreds of candidates each
         seqs.append(bytes(acgt[rng.integers(0, 4, int(rng.integers(20_000, 400_000)))]))
@@ -36,7 +37,7 @@ while time.time() - t0 < budget:
     try:
         pc.check_sketch(dev, seqs, k, w, info=info)
     except AssertionError as e:
-        print("SKETCH MISMATCH seed", seed, "k", k, "w", w, "cpw", cpw, "direct", os.environ["NTL_SKETCH_THRESH_DIRECT"], e)
+        print("SKETCH MISMATCH seed", seed, "k", k, "w", w, "cpw", cpw, "direct", os.environ["NTL_SKETCH_THRESH_DIRECT"], "wave", os.environ["NTL_SKETCH_WAVE"], e)
         sys.exit(1)
     n += 1
     fb += info["fallback_strips"]
