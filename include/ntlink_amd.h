@@ -350,6 +350,29 @@ void ntl_tsv_sizes(const ntl_tsv *r, uint64_t *nrec, uint64_t *nmx, uint64_t *na
 int ntl_tsv_copy(const ntl_tsv *r, char *names, uint64_t *name_off, uint32_t *lengths, uint64_t *mx_off,
                  uint64_t *hash, uint32_t *pos, uint8_t *strand);
 
+/* ---- the text of the mapping outputs, made on the device ------------------------------------
+ * Replaces the formatting loops of bin/ntlink_pair.py:308-313,382-388 (<prefix>.verbose_mapping.tsv) and
+ * bin/ntlink_paf_output.py:131-135 (<prefix>.paf): the lines are laid out and written by kernels from the dense records of a map
+ * result and two name tables that live on the device; what crosses PCIe is the text itself, the mappings, and -- all the pair tally
+ * needs of the hits (bin/ntlink_pair.py:394-406) -- the first and the last hit of every mapping.  The bytes are those of
+ * ntl_write_verbose / ntl_write_paf on the same records. */
+typedef struct ntl_names ntl_names;
+typedef struct ntl_text ntl_text;
+/* Name i is names[off[i] .. off[i+1]); len (may be NULL) the sequences' lengths: both tables of ntl_mapres_format need them
+ * (PAF columns 2 and 7).  The arrays are copied; they are the caller's again when the call returns. */
+int ntl_names_create(ntl_ctx *ctx, const char *names, const uint64_t *off, const uint32_t *len, uint64_t n, ntl_names **out);
+void ntl_names_destroy(ntl_names *t);
+/* Completes the result (waits for it), then formats: verbose != 0 the lines of .verbose_mapping.tsv, paf != 0 those of .paf.
+ * One more host wait inside (the byte totals size the text arrays).  NTL_ERANGE for more than 4 GB of text in one batch.
+ * The result must outlive the text's download. */
+int ntl_mapres_format(const ntl_mapres *r, const ntl_names *reads, const ntl_names *contigs, int verbose, int paf, ntl_text **out);
+void ntl_text_sizes(const ntl_text *t, uint64_t *verbose_bytes, uint64_t *paf_bytes, uint64_t *n_mappings);
+/* Any destination may be NULL.  ends: 2 * n_mappings hits, {first, last} per mapping (ntl_tally_add_ends). */
+int ntl_text_download(const ntl_text *t, char *verbose, char *paf, ntl_mapping *maps, ntl_hit *ends);
+void ntl_text_destroy(ntl_text *t);
+/* n bytes at the end of fd (O_APPEND or not: the position is taken once), written by the I/O worker pool in parallel pieces. */
+int ntl_write_blob(int fd, const char *p, uint64_t n);
+
 /* ---- host-side pair tally (no GPU involved) ------------------------------------------------- */
 
 /* The contig-pair bookkeeping of bin/ntlink_pair.py (tally_pairs_from_mappings :416-435, add_pair
@@ -365,6 +388,8 @@ int ntl_tally_create(const char *ctg_names, const uint64_t *ctg_name_off, const 
                      int k, int f, ntl_tally **out);
 void ntl_tally_destroy(ntl_tally *t);
 int ntl_tally_add(ntl_tally *t, const ntl_mapping *maps, uint64_t n_maps, const ntl_hit *hits, const uint32_t *read_len);
+/* The same from the first and last hit of every mapping alone (ends[2 i], ends[2 i + 1]: ntl_text_download). */
+int ntl_tally_add_ends(ntl_tally *t, const ntl_mapping *maps, uint64_t n_maps, const ntl_hit *ends, const uint32_t *read_len);
 uint64_t ntl_tally_npairs(const ntl_tally *t);
 uint64_t ntl_tally_ngaps(const ntl_tally *t);
 int ntl_tally_export(const ntl_tally *t, uint32_t *src, uint8_t *src_ori, uint32_t *tgt, uint8_t *tgt_ori,

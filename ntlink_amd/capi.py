@@ -31,6 +31,8 @@ SYMBOLS = [
     "ntl_tsv_open", "ntl_tsv_close", "ntl_tsv_error", "ntl_tsv_next", "ntl_tsv_sizes", "ntl_tsv_copy",
     "ntl_tally_create", "ntl_tally_destroy", "ntl_tally_add", "ntl_tally_npairs", "ntl_tally_ngaps", "ntl_tally_export", "ntl_tally_merge",
     "ntl_liftover",
+    "ntl_names_create", "ntl_names_destroy", "ntl_mapres_format", "ntl_text_sizes", "ntl_text_download", "ntl_text_destroy", "ntl_write_blob",
+    "ntl_tally_add_ends",
 ]
 
 MAPPING_DT = np.dtype([("read", "<u4"), ("ctg", "<u4"), ("n_hits", "<u4"), ("pad", "<u4"), ("hit_off", "<u8")])
@@ -162,6 +164,17 @@ def load(path=None):
     L.ntl_tally_destroy.argtypes = [vp]
     L.ntl_tally_destroy.restype = None
     L.ntl_tally_add.argtypes = [vp, vp, C.c_uint64, vp, u32p]
+    L.ntl_tally_add_ends.argtypes = [vp, vp, C.c_uint64, vp, u32p]
+    L.ntl_names_create.argtypes = [vp, vp, u64p, u32p, C.c_uint64, C.POINTER(vp)]
+    L.ntl_names_destroy.argtypes = [vp]
+    L.ntl_names_destroy.restype = None
+    L.ntl_mapres_format.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.POINTER(vp)]
+    L.ntl_text_sizes.argtypes = [vp, u64p, u64p, u64p]
+    L.ntl_text_sizes.restype = None
+    L.ntl_text_download.argtypes = [vp, vp, vp, vp, vp]
+    L.ntl_text_destroy.argtypes = [vp]
+    L.ntl_text_destroy.restype = None
+    L.ntl_write_blob.argtypes = [C.c_int, vp, C.c_uint64]
     for nm in ("npairs", "ngaps"):
         f = getattr(L, "ntl_tally_" + nm)
         f.argtypes = [vp]
@@ -310,6 +323,45 @@ class MapResult(_Handle):
         maps = np.empty(nm, MAPPING_DT); hits = np.empty(nh, HIT_DT); pafs = np.empty(npf, PAF_DT)
         self.dev._chk(self.dev.L.ntl_mapres_download(self.ptr, maps.ctypes.data, hits.ctypes.data, pafs.ctypes.data))
         return {"maps": maps, "hits": hits, "pafs": pafs}
+
+    def format(self, read_names, ctg_names, verbose=True, paf=True):
+        """The text of this result's lines, made on the device (ntl_mapres_format): read_names / ctg_names are NameTables
+        (Device.names) with lengths.  The result must stay open until the Text has been downloaded."""
+        p = C.c_void_p()
+        self.dev._chk(self.dev.L.ntl_mapres_format(self.ptr, read_names.ptr, ctg_names.ptr, int(bool(verbose)), int(bool(paf)), C.byref(p)))
+        return Text(self.dev, p)
+
+
+class NameTable(_Handle):
+    """A name table (+ sequence lengths) resident on the device: the strings the text kernels copy into their lines."""
+    _destroy = "ntl_names_destroy"
+
+
+class Text(_Handle):
+    """The lines of .verbose_mapping.tsv / .paf of one map result, formatted on the device."""
+    _destroy = "ntl_text_destroy"
+
+    def sizes(self):
+        v, p, n = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self.dev.L.ntl_text_sizes(self.ptr, C.byref(v), C.byref(p), C.byref(n))
+        return int(v.value), int(p.value), int(n.value)
+
+    def download(self):
+        """dict(verbose=bytes as uint8, paf=..., maps=, ends= [2 per mapping: first and last hit]) in ONE page-locked buffer of
+        the device's pool; hand dict["_pinned"] to Device.pinned_release() when it has been written out."""
+        nv, npf, nm = self.sizes()
+        sizes = [nv, npf, nm * MAPPING_DT.itemsize, 2 * nm * HIT_DT.itemsize]
+        offs, at = [], 0
+        for sz in sizes:
+            offs.append(at)
+            at = (at + sz + 63) & ~63
+        base = self.dev.pinned_empty(at + 64)
+        verbose = base[offs[0]:offs[0] + nv]
+        paf = base[offs[1]:offs[1] + npf]
+        maps = base[offs[2]:offs[2] + sizes[2]].view(MAPPING_DT)
+        ends = base[offs[3]:offs[3] + sizes[3]].view(HIT_DT)
+        self.dev._chk(self.dev.L.ntl_text_download(self.ptr, verbose.ctypes.data, paf.ctypes.data, maps.ctypes.data, ends.ctypes.data))
+        return {"verbose": verbose, "paf": paf, "maps": maps, "ends": ends, "_pinned": base, "_owner": self.dev}
 
 
 class Device:
@@ -497,6 +549,20 @@ class Device:
         self._chk(self.L.ntl_overlap_filter(self.ptr, sketch.ptr, _ptr(ro, C.c_uint64), _ptr(rs, C.c_uint32), _ptr(re, C.c_uint32),
                                             C.byref(p)))
         return Sketch(self, p)
+
+    def names(self, names, lengths):
+        """Device copy of a name table (seqio.Names or a list of str / bytes) with the sequences' lengths."""
+        from .seqio import Names
+        nm = Names.of(names)
+        blob = np.ascontiguousarray(nm.blob)
+        off = np.ascontiguousarray(nm.off, np.uint64)
+        ln = np.ascontiguousarray(lengths, np.uint32)
+        if len(ln) != len(nm):
+            raise ValueError("one length per name")
+        p = C.c_void_p()
+        self._chk(self.L.ntl_names_create(self.ptr, blob.ctypes.data if len(blob) else None, _ptr(off, C.c_uint64),
+                                          _ptr(ln, C.c_uint32) if len(ln) else None, len(nm), C.byref(p)))
+        return NameTable(self, p)
 
     def index(self, contig_sketch, ctg_len):
         cl = np.ascontiguousarray(ctg_len, np.uint32)

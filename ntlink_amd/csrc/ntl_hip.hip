@@ -27,6 +27,7 @@
 #include "pack_kernels.h"
 #include "synth_kernels.h"
 #include "overlap_kernels.h"
+#include "format_kernels.h"
 
 #define NTL_END_PAD 4096u /* bases of padding behind the last sequence (rolling over-reads) */
 #define SK_NT 256
@@ -2075,4 +2076,128 @@ extern "C" int ntl_mapres_download(const ntl_mapres *r, ntl_mapping *maps, ntl_h
     if (pafs && r->n_pafs) HIPCHK(c, hipMemcpyAsync(pafs, r->pafs.p, r->n_pafs * sizeof(PafRec), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, main_wait(c));
     return NTL_OK;
+}
+
+/* ------------------------------------------------------------------ text on the device ---- */
+
+struct ntl_names {
+    ntl_ctx *c;
+    uint64_t n = 0;
+    DevBuf blob, off, len; /* bytes, u64[n + 1], u32[n] (or none) */
+};
+
+extern "C" int ntl_names_create(ntl_ctx *c, const char *blob, const uint64_t *off, const uint32_t *len, uint64_t n, ntl_names **out)
+{
+    if (!c || !out || (n && (!blob || !off))) return NTL_EINVAL;
+    *out = nullptr;
+    (void)hipSetDevice(c->device);
+    std::unique_ptr<ntl_names> t(new ntl_names());
+    t->c = c; t->n = n;
+    const uint64_t zero = 0;
+    const uint64_t bytes = n ? off[n] : 0;
+    int rc;
+    if ((rc = t->blob.alloc(c, bytes + 16)) || (rc = t->off.alloc(c, (n + 1) * 8)) || (len && (rc = t->len.alloc(c, (n + 1) * 4)))) return rc;
+    if (bytes) HIPCHK(c, hipMemcpyAsync(t->blob.p, blob, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(t->off.p, n ? (const void *)off : (const void *)&zero, (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    if (len && n) HIPCHK(c, hipMemcpyAsync(t->len.p, len, n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, main_wait(c)); /* the caller's arrays are free again */
+    *out = t.release();
+    return NTL_OK;
+}
+
+extern "C" void ntl_names_destroy(ntl_names *t)
+{
+    if (!t) return;
+    (void)hipSetDevice(t->c->device);
+    delete t;
+}
+
+struct ntl_text {
+    ntl_ctx *c;
+    uint64_t verbose_bytes = 0, paf_bytes = 0, n_maps = 0;
+    DevBuf verbose, paf, ends;
+    const ntl_mapres *res = nullptr; /* the mappings themselves stay in the result: it must outlive the text's download */
+};
+
+/* Makes the text of a map result on the device.  One host wait: the three byte totals decide the size of the text arrays. */
+extern "C" int ntl_mapres_format(const ntl_mapres *r, const ntl_names *reads, const ntl_names *contigs, int want_verbose, int want_paf,
+                                 ntl_text **out)
+{
+    if (!r || !reads || !contigs || !out) return NTL_EINVAL;
+    *out = nullptr;
+    ntl_ctx *c = r->c;
+    (void)hipSetDevice(c->device);
+    if (int frc = mapres_finalize(r)) return frc;
+    if (!reads->len.p || !contigs->len.p) return fail(c, NTL_EINVAL, "ntl_mapres_format: both name tables need their lengths");
+    if (r->n_hits >= 0xFFFFFF00ull || r->n_maps >= 0xFFFFFF00ull) return fail(c, NTL_ERANGE, "ntl_mapres_format: too many records for one text");
+    /* 32-bit offsets: a token is at most 27 bytes, a name at most what the tables hold */
+    const uint64_t bound = r->n_hits * 27 + (r->n_maps + r->n_pafs) * 64 + (r->n_maps + r->n_pafs) * 2 * 4096;
+    if (bound >= 0xFFFFFFFFull && r->n_hits * 27 >= 0xF0000000ull) return fail(c, NTL_ERANGE, "ntl_mapres_format: more than 4 GB of text in one batch");
+    std::unique_ptr<ntl_text> t(new ntl_text());
+    t->c = c; t->res = r; t->n_maps = r->n_maps;
+    const uint32_t nm = (uint32_t)r->n_maps, nh = want_verbose ? (uint32_t)r->n_hits : 0u, np = want_paf ? (uint32_t)r->n_pafs : 0u;
+    DevBuf tok, hdr, pl;
+    int rc;
+    if ((rc = tok.alloc(c, ((uint64_t)nh + 1) * 4)) || (rc = hdr.alloc(c, ((uint64_t)nm + 1) * 4)) || (rc = pl.alloc(c, ((uint64_t)np + 1) * 4)) ||
+        (rc = t->ends.alloc(c, ((uint64_t)r->n_maps * 2 + 1) * sizeof(HitRec))))
+        return rc;
+    FmtArgs A;
+    A.maps = r->maps.as<MapRec>(); A.hits = r->hits.as<HitRec>(); A.pafs = r->pafs.as<PafRec>();
+    A.n_maps = nm; A.n_hits = nh; A.n_pafs = np; A.do_verbose = want_verbose ? 1 : 0;
+    A.read_name_off = reads->off.as<uint64_t>(); A.read_names = reads->blob.as<char>();
+    A.ctg_name_off = contigs->off.as<uint64_t>(); A.ctg_names = contigs->blob.as<char>();
+    A.read_len = reads->len.as<uint32_t>(); A.ctg_len = contigs->len.as<uint32_t>();
+    A.tok_len = tok.as<uint32_t>(); A.hdr_len = hdr.as<uint32_t>(); A.paf_len = pl.as<uint32_t>();
+    A.verbose = nullptr; A.paf = nullptr; A.ends = t->ends.as<HitRec>();
+    const uint64_t most = std::max<uint64_t>(std::max<uint64_t>(nh, nm), np);
+    uint32_t tot[3] = {0, 0, 0};
+    if (most) {
+        ProfSpan sp(c, "format");
+        const unsigned grid = (unsigned)((most + 255) / 256);
+        hipLaunchKernelGGL(fmt_len_kernel, dim3(grid), dim3(256), 0, c->stream, A);
+        if (!want_verbose) HIPCHK(c, hipMemsetAsync(A.hdr_len, 0, ((uint64_t)nm + 1) * 4, c->stream));
+        if ((rc = device_scan(c, A.tok_len, A.tok_len, nh, nullptr)) || (rc = device_scan(c, A.hdr_len, A.hdr_len, nm, nullptr)) ||
+            (rc = device_scan(c, A.paf_len, A.paf_len, np, nullptr)))
+            return rc;
+        HIPCHK(c, hipMemcpyAsync(&tot[0], A.tok_len + nh, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(&tot[1], A.hdr_len + nm, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(&tot[2], A.paf_len + np, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, main_wait(c));
+        t->verbose_bytes = (uint64_t)tot[0] + tot[1];
+        t->paf_bytes = tot[2];
+        if (t->verbose_bytes >= 0xFFFFFFFFull) return fail(c, NTL_ERANGE, "ntl_mapres_format: more than 4 GB of text in one batch");
+        if ((rc = t->verbose.alloc(c, t->verbose_bytes + 16)) || (rc = t->paf.alloc(c, t->paf_bytes + 16))) return rc;
+        A.verbose = t->verbose.as<char>(); A.paf = t->paf.as<char>();
+        hipLaunchKernelGGL(fmt_fill_kernel, dim3(grid), dim3(256), 0, c->stream, A);
+        HIPCHK(c, hipGetLastError());
+    }
+    *out = t.release();
+    return NTL_OK;
+}
+
+extern "C" void ntl_text_sizes(const ntl_text *t, uint64_t *verbose_bytes, uint64_t *paf_bytes, uint64_t *n_maps)
+{
+    if (verbose_bytes) *verbose_bytes = t ? t->verbose_bytes : 0;
+    if (paf_bytes) *paf_bytes = t ? t->paf_bytes : 0;
+    if (n_maps) *n_maps = t ? t->n_maps : 0;
+}
+
+extern "C" int ntl_text_download(const ntl_text *t, char *verbose, char *paf, ntl_mapping *maps, ntl_hit *ends)
+{
+    if (!t) return NTL_EINVAL;
+    ntl_ctx *c = t->c;
+    (void)hipSetDevice(c->device);
+    if (verbose && t->verbose_bytes) HIPCHK(c, hipMemcpyAsync(verbose, t->verbose.p, t->verbose_bytes, hipMemcpyDeviceToHost, c->stream));
+    if (paf && t->paf_bytes) HIPCHK(c, hipMemcpyAsync(paf, t->paf.p, t->paf_bytes, hipMemcpyDeviceToHost, c->stream));
+    if (maps && t->n_maps) HIPCHK(c, hipMemcpyAsync(maps, t->res->maps.p, t->n_maps * sizeof(MapRec), hipMemcpyDeviceToHost, c->stream));
+    if (ends && t->n_maps) HIPCHK(c, hipMemcpyAsync(ends, t->ends.p, t->n_maps * 2 * sizeof(HitRec), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, main_wait(c));
+    return NTL_OK;
+}
+
+extern "C" void ntl_text_destroy(ntl_text *t)
+{
+    if (!t) return;
+    (void)hipSetDevice(t->c->device);
+    delete t;
 }

@@ -65,9 +65,13 @@ extern "C" void ntl_tally_destroy(ntl_tally *t) { delete t; }
 
 /* One batch of mappings (reads in order; read_len is indexed by ntl_mapping.read).  Returns NTL_ERANGE
  * when an overhang of an evaluated pair comes out negative -- the reference's "Gap distance estimation less than 0". */
-extern "C" int ntl_tally_add(ntl_tally *t, const ntl_mapping *maps, uint64_t n_maps, const ntl_hit *hits, const uint32_t *read_len)
+/* ENDS: `hits` holds two entries per mapping, its first and its last hit (ntl_text_download), instead of all of them */
+template <bool ENDS>
+static int tally_add(ntl_tally *t, const ntl_mapping *maps, uint64_t n_maps, const ntl_hit *hits, const uint32_t *read_len)
 {
     if (!t || (n_maps && (!maps || !hits || !read_len))) return NTL_EINVAL;
+    auto first_of = [&](uint64_t i) -> const ntl_hit & { return ENDS ? hits[2 * i] : hits[maps[i].hit_off]; };
+    auto last_of = [&](uint64_t i) -> const ntl_hit & { return ENDS ? hits[2 * i + 1] : hits[maps[i].hit_off + maps[i].n_hits - 1]; };
     if (n_maps < 2) return NTL_OK;
     const int64_t k = t->k;
     /* per mapping: overhang behind its terminal hit when it is the source of a pair (a), in front of its
@@ -77,7 +81,7 @@ extern "C" int ntl_tally_add(ntl_tally *t, const ntl_mapping *maps, uint64_t n_m
     for (uint64_t i = 0; i < n_maps; i++) {
         const ntl_mapping &m = maps[i];
         if (m.ctg >= t->ctg_len.size() || m.n_hits == 0) return NTL_EINVAL;
-        const ntl_hit &hf = hits[m.hit_off], &hl = hits[m.hit_off + m.n_hits - 1];
+        const ntl_hit &hf = first_of(i), &hl = last_of(i);
         const int64_t clen = t->ctg_len[m.ctg];
         sp[i] = hl.read_strand == hl.ctg_strand;
         tp[i] = hf.read_strand == hf.ctg_strand;
@@ -98,7 +102,7 @@ extern "C" int ntl_tally_add(ntl_tally *t, const ntl_mapping *maps, uint64_t n_m
                                       pairs it evaluates, before the |gap| > read length test */
             auto add = [&](uint64_t i, uint64_t j, const std::unordered_set<uint64_t> *check) -> uint64_t {
                 if (a[i] < 0 || b[j] < 0) { negative = true; return 0; }
-                const ntl_hit &hf = hits[maps[j].hit_off], &hl = hits[maps[i].hit_off + maps[i].n_hits - 1];
+                const ntl_hit &hf = first_of(j), &hl = last_of(i);
                 const int64_t gap = (int64_t)hf.read_pos - (int64_t)hl.read_pos - a[i] - b[j];
                 uint32_t ci = maps[i].ctg, cj = maps[j].ctg;
                 uint32_t so = sp[i], to = tp[j];
@@ -140,6 +144,16 @@ extern "C" int ntl_tally_add(ntl_tally *t, const ntl_mapping *maps, uint64_t n_m
         s0 = s1;
     }
     return NTL_OK;
+}
+
+extern "C" int ntl_tally_add(ntl_tally *t, const ntl_mapping *maps, uint64_t n_maps, const ntl_hit *hits, const uint32_t *read_len)
+{
+    return tally_add<false>(t, maps, n_maps, hits, read_len);
+}
+
+extern "C" int ntl_tally_add_ends(ntl_tally *t, const ntl_mapping *maps, uint64_t n_maps, const ntl_hit *ends, const uint32_t *read_len)
+{
+    return tally_add<true>(t, maps, n_maps, ends, read_len);
 }
 
 extern "C" uint64_t ntl_tally_npairs(const ntl_tally *t) { return t ? t->pairs.size() : 0; }

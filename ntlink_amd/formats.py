@@ -34,6 +34,19 @@ def _native():
     return capi.load()
 
 
+def write_blob(fh, text):
+    """Text made elsewhere (capi.Text.download: uint8 array) behind what the file holds."""
+    if not len(text):
+        return
+    fd = _fd(fh)
+    if fd is None:
+        fh.write(bytes(text).decode())
+        return
+    t = np.ascontiguousarray(text)
+    if _native().ntl_write_blob(fd, t.ctypes.data, len(t)) != 0:
+        raise OSError("write failed")
+
+
 def write_indexlr(fh, names, lengths, mx_off, mx_hash, pos, strand, with_len, with_strand=True):
     """Every record prints its id even without minimizers (such lines are skipped by the consumers,
     bin/ntlink_pair.py:200,357)."""

@@ -53,6 +53,17 @@ class PairTally:
             out[name] = arr[name]
         return out
 
+    def add_batch_ends(self, maps, ends, read_len):
+        """The same from the first and last hit of every mapping (capi.Text.download: ends[2 i], ends[2 i + 1])."""
+        maps, ends = self._as(maps, self._maps_dt), self._as(ends, self._hits_dt)
+        rl = np.ascontiguousarray(read_len, np.uint32)
+        rc = self._L.ntl_tally_add_ends(self._h, maps.ctypes.data, len(maps), ends.ctypes.data, rl.ctypes.data_as(C.POINTER(C.c_uint32)))
+        self._pairs = None
+        if rc == -5:
+            raise AssertionError("Gap distance estimation less than 0")
+        if rc != 0:
+            raise ValueError(f"ntl_tally_add_ends failed with {rc}")
+
     def add_batch(self, res, read_len):
         maps, hits = self._as(res["maps"], self._maps_dt), self._as(res["hits"], self._hits_dt)
         rl = np.ascontiguousarray(read_len, np.uint32)

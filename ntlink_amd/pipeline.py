@@ -51,6 +51,26 @@ class PairOutputs:
 
     def add(self, res, read_names, read_len):
         t0 = time.perf_counter()
+        if "verbose" in res:  # the lines were made on the device (capi.MapResult.format): they are written as they are
+            paf_job = None
+            if self.paf_fh and len(res["paf"]):
+                import threading
+                paf_job = threading.Thread(target=self._guard, args=(formats.write_blob, self.paf_fh, res["paf"]))
+                paf_job.start()
+            try:
+                if self.verbose_fh:
+                    formats.write_blob(self.verbose_fh, res["verbose"])
+                t1 = time.perf_counter()
+                self.tally.add_batch_ends(res["maps"], res["ends"], read_len)
+            finally:
+                if paf_job:
+                    paf_job.join()
+            if self._exc is not None:
+                exc, self._exc = self._exc, None
+                raise exc
+            self.t_write += t1 - t0
+            self.t_tally += time.perf_counter() - t1
+            return
         paf_job = None
         if self.paf_fh:  # the two files are independent: the PAF is written next to the verbose mapping
             import threading
@@ -343,7 +363,7 @@ def _append_part(final_path, part_path, offset):
     os.remove(part_path)
 
 
-def _map_batches(dev, ix, batches, drain, stats, t_mark, w, first=None, **map_kw):
+def _map_batches(dev, ix, batches, drain, stats, t_mark, w, first=None, text=None, **map_kw):
     """The device stage of the pair driver: read batches -> records, handed to `drain` in input order.
 
     NTL_DEVICE_STREAMS (default 2) worker threads, each with its own context on the GPU (stream, block cache, page-locked
@@ -391,7 +411,11 @@ def _map_batches(dev, ix, batches, drain, stats, t_mark, w, first=None, **map_kw
                         t_sk = time.perf_counter()
                         with wdev.map(ix, rsk, rl, **map_kw) as res:
                             t_mp = time.perf_counter()
-                            pres = res.download(pinned=True)
+                            if text is not None:  # (contig name table, verbose, paf): the lines are formatted on the device
+                                with wdev.names(rs_.names, rl) as rn, res.format(rn, text[0], text[1], text[2]) as txt:
+                                    pres = txt.download()
+                            else:
+                                pres = res.download(pinned=True)
                             n_mx, n_hit = rsk.count, res.n_index_hits
                 t_done = time.perf_counter()
                 _mark("dev_done", seq)
@@ -522,8 +546,15 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
                         t0 = time.perf_counter()
                         tsv_drain.put(*csk.download())
                         stats["t_contigs_parts"]["download_for_tsv_beside_mapping"] = round(time.perf_counter() - t0, 4)
-                    _map_batches(dev, ix, batches, drain, stats, t_mark, w, first=contig_tsv if tsv_drain else None,
-                                 k=k, z=z, x=x, sensitive=sensitive, repeat_filter=repeats)
+                    # NTL_DEVICE_TEXT=0: records cross PCIe and the host's emitter threads format them (ntl_write_verbose / _paf)
+                    ctg_tab = dev.names(ctg.names, ctg_len) if os.environ.get("NTL_DEVICE_TEXT", "1") != "0" else None
+                    try:
+                        _map_batches(dev, ix, batches, drain, stats, t_mark, w, first=contig_tsv if tsv_drain else None,
+                                     text=(ctg_tab, verbose, paf) if ctg_tab is not None else None,
+                                     k=k, z=z, x=x, sensitive=sensitive, repeat_filter=repeats)
+                    finally:
+                        if ctg_tab is not None:
+                            ctg_tab.close()
         t_fin = time.perf_counter()
         drain.close()
         for d in stats.pop("_extra_devices", []):

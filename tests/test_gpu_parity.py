@@ -421,6 +421,20 @@ def test_handles_outlive_their_inputs(dev, monkeypatch):
     assert pc.check_handles_outlive_their_inputs(dev, contigs, reads, 32, 100, z=1000, n_live=700) > 50
 
 
+@pytest.mark.parametrize("k,w,rl,sens,err", [(32, 250, 15000, False, (0.02, 0.015, 0.015)), (24, 100, 20000, True, (0.001, 0.0005, 0.0005))],
+                         ids=["C3_like", "C5_like"])
+def test_text_made_on_the_device(dev, k, w, rl, sens, err):
+    """ntl_mapres_format on scaled-down C3- and C5-like workloads (thousands of mappings, 10^5 .. 10^6 hits, names of different
+    lengths): the device's bytes == the host emitters' == the oracle's; the pair tally's hit ends == the records'."""
+    chroms, cbuf, coff, names, _ = synth.make_assembly(5, 2, 8, 250_000)
+    contigs = [cbuf[int(coff[i]):int(coff[i + 1])].tobytes() for i in range(len(coff) - 1)]
+    rbuf, roff, _ = synth.make_reads(6, chroms, 20_000_000, rl, *err, lognormal_sigma=0.4)
+    reads = [rbuf[int(roff[i]):int(roff[i + 1])].tobytes() for i in range(len(roff) - 1)]
+    n, nv, npf = pc.check_device_text(dev, contigs, reads, k, w, z=1000, sensitive=sens)
+    assert n > 500 and nv > 100_000 and npf > 10_000
+    assert pc.check_device_text(dev, contigs[:2], [b"ACGT" * 500, b""], k, w, z=1000) == (0, 0, 0)
+
+
 def test_one_stream_and_back(dev):
     contigs = pc.fixture_seqs("scaffolds_1.fa")
     reads = pc.fixture_seqs("long_reads_4_top5.fa")

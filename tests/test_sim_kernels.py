@@ -361,6 +361,16 @@ def test_sim_handles_outlive_their_inputs(monkeypatch):
         d.close()
 
 
+def test_sim_text_made_on_the_device(dev):
+    """ntl_mapres_format under the mock: the verbose and PAF lines of test 7's five reads == the host emitters' == the oracle's;
+    and a batch without any mapping gives two empty texts."""
+    contigs = pc.fixture_seqs("scaffolds_4.fa")
+    reads = pc.fixture_seqs("long_reads_4_top5.fa")
+    n, nv, npf = pc.check_device_text(dev, contigs, reads, 40, 100, z=1000)
+    assert n >= 6 and nv > 100 and npf > 100
+    assert pc.check_device_text(dev, contigs[:3], [b"ACGT" * 200, b"", b"N" * 300], 40, 100, z=1000) == (0, 0, 0)
+
+
 def test_sim_one_stream_and_back(dev):
     """ntl_ctx_set_pipeline: the window stage back on the one stream at a quiet point, and out again: same records."""
     contigs = pc.fixture_seqs("scaffolds_4.fa")
