@@ -680,10 +680,14 @@ def end_to_end(dev, wl, W, args):
                 for f in os.listdir(d):
                     if f.startswith("asm.fa."):
                         os.remove(os.path.join(d, f))
+                pin0, mal0 = (dev.pin_alloc_s, dev.pin_alloc_bytes), dev.prof_get("hipMalloc")
                 t0 = time.perf_counter()
                 st_i = pipeline.run_pair(dev, "asm.fa", " ".join(files), k=W["k"], w=W["w"], paf=True, pairs_tsv=True,
                                          sensitive=W["sensitive"])
                 runs.append(round(time.perf_counter() - t0, 3))
+                mal1 = dev.prof_get("hipMalloc")
+                st_i["one_time"] = {"page_lock_s": round(dev.pin_alloc_s - pin0[0], 3), "page_locked_MB": round((dev.pin_alloc_bytes - pin0[1]) / 1e6),
+                                    "hipMalloc_s_main_context": round((mal1[0] - mal0[0]) / 1e3, 3), "hipMalloc_calls_main_context": int(mal1[1] - mal0[1])}
                 stats_all.append(st_i)
             st, dt = stats_all[0], runs[0]
             best = min(range(3), key=lambda i: runs[i])
@@ -704,6 +708,7 @@ def end_to_end(dev, wl, W, args):
                              "and thread pools are made on the way; stage times below are that run's); steady_state = the faster of the two passes behind it",
                 "steady_state": {"value": round(stats_all[best]["read_bases"] / runs[best] / 1e9, 3), "unit": "Gbases/s", "seconds": runs[best],
                                  "run": best, **stage_times(stats_all[best])},
+                "one_time_costs_per_run": [x.get("one_time") for x in stats_all],
                 "text_formatted_on": "device (ntl_mapres_format)" if os.environ.get("NTL_DEVICE_TEXT", "1") != "0" else "host (ntl_write_verbose / ntl_write_paf)",
                 "compressed_inputs": gz,
                 "host_cpu": dict(zip(("cpus_visible", "cpu_quota_cores"), cpu_budget())),

@@ -97,7 +97,8 @@ int ntl_ctx_set_pipeline(ntl_ctx *ctx, int on);
 /* Kernel timing with HIP events on the context's stream.  When enabled, every launch of the
  * named kernel groups is bracketed by events; ntl_prof_get returns the accumulated time and
  * launch count since the last ntl_prof_reset.  Names: "sketch_mask", "sketch_emit", "index",
- * "probe", "map", "compact". */
+ * "probe", "map", "compact", "format".  "hipMalloc" (always counted, HOST milliseconds): the misses of the context's cache of
+ * device blocks. */
 int ntl_prof_enable(ntl_ctx *ctx, int on);
 int ntl_prof_reset(ntl_ctx *ctx);
 int ntl_prof_get(ntl_ctx *ctx, const char *name, double *total_ms, uint64_t *launches);

@@ -10,6 +10,7 @@ import weakref
 import os
 
 import numpy as np
+from time import perf_counter as _now
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "libntlink_hip.so")
@@ -379,6 +380,15 @@ class Device:
         self._live = weakref.WeakSet()
         self._pinned_free, self._pinned_all, self._pinned_out = [], [], {}  # (address, capacity) of page-locked buffers
         self._pinned_lock = threading.Lock()  # the reader thread takes buffers, the device thread returns them
+        self.pin_alloc_s, self.pin_alloc_bytes, self.pin_alloc_caps = 0.0, 0, []
+
+    def workers(self, n):
+        """n - 1 further contexts on the same GPU, kept for the life of this Device: the pair driver's device workers.  Their block
+        caches and page-locked result buffers survive from one run_pair call to the next."""
+        pool = self.__dict__.setdefault("_workers", [])
+        while len(pool) < n - 1:
+            pool.append(self.clone())
+        return pool[:max(0, n - 1)]
 
     def clone(self):
         """Another context (stream, block cache, staging pool) on the same GPU: a second worker thread of the pair driver
@@ -387,6 +397,8 @@ class Device:
 
     def close(self):
         if self.ptr:
+            for wk in self.__dict__.pop("_workers", []):
+                wk.close()
             for h in list(self._live):  # device objects die before their context
                 h.close()
             for addr, _cap in self._pinned_all:
@@ -446,7 +458,11 @@ class Device:
             if pick is None:
                 cap = max(int(nbytes * 1.125) + 4096, 1 << 20)
                 p = C.c_void_p()
+                t0 = _now()
                 self._chk(self.L.ntl_host_alloc(self.ptr, cap, C.byref(p)))
+                self.pin_alloc_s += _now() - t0  # page-locking is the expensive part of a process's first pass
+                self.pin_alloc_bytes += cap
+                self.pin_alloc_caps.append(cap)
                 addr = p.value
                 self._pinned_all.append((addr, cap))
             else:

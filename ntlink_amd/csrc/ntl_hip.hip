@@ -13,6 +13,7 @@
 #include <chrono>
 #include <deque>
 #include <map>
+#include <mutex>
 #include <memory>
 #include <string>
 #include <thread>
@@ -99,6 +100,12 @@ struct ntl_ctx {
     std::multimap<size_t, XBlock> xpool;   /* ... and those that were used on both */
     size_t pool_bytes = 0;
     size_t pool_cap = (size_t)32 << 30; /* upper bound of pool_bytes */
+    /* Blocks up to NTL_SLAB_MAX_REQ are cut from slabs of NTL_SLAB_BYTES (a bump pointer; the cache above recycles them): a
+       hipMalloc costs 4-9 ms of host time whatever its size, and a context's first read batch asked for seventy of them -- 0.6 s
+       per context of a process's first pass (profiles/r04_first_pass.txt).  A slab block that the cache drops is not reused. */
+    std::vector<std::pair<char *, size_t>> slabs;
+    char *slab_cur = nullptr, *slab_end = nullptr;
+    std::mutex slab_mu; /* (dev_free may be asked about another context's block: index_unref) */
     std::deque<CleanMask> masks;
     void *host_tmp = nullptr;           /* page-locked bounce buffer for record downloads (grows, never shrinks) */
     size_t host_tmp_cap = 0;
@@ -227,14 +234,31 @@ static PinSlot *slot_get(ntl_ctx *c)
     return p;
 }
 
+#define NTL_SLAB_BYTES ((size_t)1 << 30)
+#define NTL_SLAB_MAX_REQ ((size_t)192 << 20)
+
+static bool in_slab(ntl_ctx *c, const void *p)
+{
+    std::lock_guard<std::mutex> g(c->slab_mu);
+    for (auto &sl : c->slabs)
+        if ((const char *)p >= sl.first && (const char *)p < sl.first + sl.second) return true;
+    return false;
+}
+
+/* gives a block of dev_alloc back to the driver (a slab block: nothing to do, its slab goes with the context) */
+static void dev_free(ntl_ctx *c, void *p)
+{
+    if (p && !in_slab(c, p)) (void)hipFree(p);
+}
+
 static void pool_drop_all(ntl_ctx *c)
 {
     for (int i = 0; i < 2; i++) {
-        for (auto &kv : c->pool[i]) (void)hipFree(kv.second);
+        for (auto &kv : c->pool[i]) dev_free(c, kv.second);
         c->pool[i].clear();
     }
     for (auto &kv : c->xpool) {
-        (void)hipFree(kv.second.p);
+        dev_free(c, kv.second.p);
         sev_put(c, kv.second.ev[0]); sev_put(c, kv.second.ev[1]);
     }
     c->xpool.clear();
@@ -245,8 +269,38 @@ static const bool g_pool_trace = getenv("NTL_POOL_TRACE") != nullptr; /* diagnos
 
 static int dev_alloc(ntl_ctx *c, size_t bytes, void **out)
 {
+#ifdef NTL_SIM
+    static const bool use_slabs = false; /* the mock's blocks stay single allocations: the CPU sanitizers see every array's ends */
+#else
+    static const bool use_slabs = [] { const char *e = getenv("NTL_SLABS"); return !e || atoi(e) != 0; }();
+#endif
+    if (use_slabs && bytes <= NTL_SLAB_MAX_REQ) {
+        const size_t need = (bytes + 255) & ~(size_t)255;
+        if (!c->slab_cur || (size_t)(c->slab_end - c->slab_cur) < need) {
+            void *sl = nullptr;
+            const auto ts = std::chrono::steady_clock::now();
+            if (hipMalloc(&sl, NTL_SLAB_BYTES) == hipSuccess) {
+                ProfEntry &pe = c->profs["hipMalloc"];
+                pe.done_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts).count();
+                pe.launches++;
+                std::lock_guard<std::mutex> g(c->slab_mu);
+                c->slabs.push_back({(char *)sl, NTL_SLAB_BYTES});
+                c->slab_cur = (char *)sl; c->slab_end = (char *)sl + NTL_SLAB_BYTES;
+            } else (void)hipGetLastError(); /* no room for a slab: single blocks as before */
+        }
+        if (c->slab_cur && (size_t)(c->slab_end - c->slab_cur) >= need) {
+            *out = c->slab_cur;
+            c->slab_cur += need;
+            return NTL_OK;
+        }
+    }
     const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(out, bytes);
+    {   /* host time of the block cache's misses: ntl_prof_get(ctx, "hipMalloc") -- what a process's first pass pays once */
+        ProfEntry &pe = c->profs["hipMalloc"];
+        pe.done_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        pe.launches++;
+    }
     if (g_pool_trace)
         fprintf(stderr, "ntl pool: hipMalloc %.1f MB -> %s in %.3f ms (cached %.1f MB of %.1f)\n", bytes / 1e6, e == hipSuccess ? "ok" : "FAILED",
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), c->pool_bytes / 1e6, c->pool_cap / 1e6);
@@ -340,12 +394,12 @@ struct DevBuf {
                 if (big && (c->xpool.empty() || std::prev(big->end())->first >= std::prev(c->xpool.end())->first)) {
                     auto it = std::prev(big->end());
                     if (g_pool_trace) fprintf(stderr, "ntl pool: over the bound, hipFree %.1f MB\n", it->first / 1e6);
-                    (void)hipFree(it->second); /* waits for the device: safe whatever is still queued */
+                    dev_free(c, it->second); /* waits for the device: safe whatever is still queued */
                     c->pool_bytes -= it->first;
                     big->erase(it);
                 } else if (!c->xpool.empty()) {
                     auto it = std::prev(c->xpool.end());
-                    (void)hipFree(it->second.p);
+                    dev_free(c, it->second.p);
                     sev_put(c, it->second.ev[0]); sev_put(c, it->second.ev[1]);
                     c->pool_bytes -= it->first;
                     c->xpool.erase(it);
@@ -464,10 +518,12 @@ extern "C" void ntl_ctx_destroy(ntl_ctx *c)
     (void)sync_both(c);
     reap(c, true);
     pool_drop_all(c);
-    for (auto &m : c->masks) { (void)hipFree(m.p); sev_put(c, m.clean); }
+    for (auto &m : c->masks) { dev_free(c, m.p); sev_put(c, m.clean); }
     (void)hipFree(c->g4);
     (void)hipFree(c->g8);
     for (auto &kv : c->g8k) (void)hipFree(kv.second);
+    for (auto &sl : c->slabs) (void)hipFree(sl.first);
+    c->slabs.clear();
     if (c->host_tmp) (void)hipHostFree(c->host_tmp);
     if (c->slots) (void)hipHostFree(c->slots);
     for (auto &kv : c->profs)
@@ -1036,7 +1092,7 @@ static void index_unref(const ntl_index *cix, ntl_ctx *by)
     (void)hipSetDevice(ix->c->device);
     if (by != ix->c) {
         for (DevBuf *b : {&ix->slots, &ix->special, &ix->ctg_len, &ix->cnt, &ix->tags}) {
-            if (b->p) (void)hipFree(b->p);
+            if (b->p) dev_free(ix->c, b->p);
             b->p = nullptr; b->bytes = 0;
         }
         if (ix->built) (void)hipEventDestroy(ix->built);
@@ -1253,7 +1309,7 @@ static int mask_take(ntl_ctx *c, size_t bytes, int sid, CleanMask *out)
         }
     }
     while (c->masks.size() > 4) { /* other batch sizes came and went */
-        (void)hipFree(c->masks.front().p);
+        dev_free(c, c->masks.front().p);
         sev_put(c, c->masks.front().clean);
         c->masks.pop_front();
     }
@@ -1334,7 +1390,7 @@ static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const nt
     if ((rc = mask_take(c, nmask * 4, wsid, &mask))) return rc;
     struct MaskGuard { /* error paths: the mask is not known to be clean any more */
         ntl_ctx *c; CleanMask *m;
-        ~MaskGuard() { if (m->p) { (void)hipFree(m->p); m->p = nullptr; } }
+        ~MaskGuard() { if (m->p) { dev_free(c, m->p); m->p = nullptr; } }
     } mask_guard{c, &mask};
     batch_on_wstream(c, b);
     SeqTables T;

@@ -372,7 +372,7 @@ def _map_batches(dev, ix, batches, drain, stats, t_mark, w, first=None, text=Non
     once the other workers have started: work of the contig stage that the mapping does not depend on."""
     import threading
     n_workers = max(1, int(os.environ.get("NTL_DEVICE_STREAMS", "2")))
-    devs = [dev] + [dev.clone() for _ in range(n_workers - 1)]
+    devs = [dev] + dev.workers(n_workers)  # kept by `dev` from one call to the next
     it = iter(batches)
     lock, commit = threading.Lock(), threading.Condition()
     state = {"next_seq": 0, "commit_seq": 0, "error": None, "t_mark": t_mark}
@@ -461,9 +461,8 @@ def _map_batches(dev, ix, batches, drain, stats, t_mark, w, first=None, text=Non
     work(devs[0])
     for t in threads:
         t.join()
-    # Results of the cloned contexts may still sit in the writer's queue (or be in its hands), as views into their page-locked
-    # buffers: the contexts are closed by run_pair only after the writer thread has been joined -- on the error path too.
-    stats.setdefault("_extra_devices", []).extend(devs[1:])
+    # (Results of the worker contexts may still sit in the writer's queue as views into their page-locked buffers: the contexts
+    # live as long as `dev` does.)
     if state["error"] is not None:
         raise state["error"]
 
@@ -557,8 +556,6 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
                             ctg_tab.close()
         t_fin = time.perf_counter()
         drain.close()
-        for d in stats.pop("_extra_devices", []):
-            d.close()
         if tsv_drain:
             tsv_drain.close()
         out.close()
@@ -604,8 +601,6 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
                     d.close()
             except BaseException:
                 pass
-        for d in stats.pop("_extra_devices", []):
-            d.close()
         out.remove_partial()
         batches.stop()
         raise
