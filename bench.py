@@ -234,6 +234,7 @@ def run_workload(dev, comm, name, args, steps, warmup, rank, world, serial_steps
             while len(held) > n_keep:
                 rsk, res = held.pop(0)
                 acc["read_mx"] += rsk.count
+                acc["strips"] = acc.get("strips", 0) + rsk.strips
                 acc["index_hits"] += res.n_index_hits
                 acc["counts"] = [a + b for a, b in zip(acc["counts"], res.counts())]
                 res.close()
@@ -257,7 +258,7 @@ def run_workload(dev, comm, name, args, steps, warmup, rank, world, serial_steps
 
     def step(collect=False):
         if collect:
-            stats.update(read_mx=0, index_hits=0, counts=[0, 0, 0])
+            stats.update(read_mx=0, index_hits=0, counts=[0, 0, 0], strips=0)
         items = list(zip(wl.read_batches, wl.read_lens))
         if n_streams == 1:
             run_batches(dev, items, collect, stats)
@@ -364,7 +365,7 @@ def summarize(R, args, world, dev_name):
                        f"k={k} w={w} z=1000 x=0 sensitive={W['sensitive']} paf=True verbose=True",
            "scale": args.scale, "hit_fraction": round(hfrac, 4),
            "read_minimizers_per_step": stats["read_mx"], "contig_minimizers": R["contig_mx"],
-           "index_size": R["index_size"], "mappings_hits_pafs_per_step": list(stats["counts"]),
+           "index_size": R["index_size"], "mappings_hits_pafs_per_step": list(stats["counts"]), "window_strips_per_step": stats.get("strips"),
            "device": dev_name, "gen_s": round(R["gen_s"], 2),
            "contig_stage_ms": round(R["contig_stage_ms"], 2),
            "contig_stage_kernels_ms": {nm: round(v[0], 3) for nm, v in R["contig_prof"].items() if v[1]},
@@ -396,7 +397,8 @@ def summarize(R, args, world, dev_name):
                            "achieved": round(whole_gbs, 1), "unit": "GB/s per GPU", "frac": round(whole_gbs / HBM_PEAK_GBS, 5)},
             "note": "integer/VALU-bound kernel (SURVEY 7): the 60 % HBM target of north_star is out of reach for a rolling hash (about 100 integer "
                     "operations per algorithmic byte); the roof that binds is VALU issue, in `valu`",
-            "valu": valu_roofline(pm, avg_alone, bases_per_launch)}
+            "valu": valu_roofline(dict(pm, strips_per_launch=(stats.get("strips") or 0) / max(nb, 1) or None,
+                                       scan_rounds_per_strip=float(-(-int(4096 * 10 / w) // 64))), avg_alone, bases_per_launch)}
     return value, ms_per_step, cfg, roof
 
 
@@ -498,30 +500,61 @@ def pmc_summary(workload, scale, bases_per_launch):
         return {"traffic": None, "traffic_source": "stale: profiles/traffic.json was taken on other kernel sources or launch sizes"}
     return {"traffic": t["bytes_per_launch"], "traffic_source": t["source"], "kernel": t.get("kernel"),
             "valu_wave_instr_per_launch": t.get("valu_wave_instr_per_launch"), "valu_source": t.get("valu_source"),
-            "valu_busy_frac": t.get("valu_busy_frac"), "valu_cycles_per_wave_instr": t.get("valu_cycles_per_wave_instr"),
-            "clock_ghz": t.get("clock_ghz"), "isa_histogram": t.get("isa_histogram")}
+            "measured_cycles_per_wave_instr": t.get("measured_cycles_per_wave_instr"),
+            "clock_ghz": t.get("clock_ghz"), "isa_mix": t.get("isa_mix")}
 
 
 def valu_roofline(pm, avg_launch_ms, bases_per_launch):
-    """The roof that binds the window kernel: VALU issue.  `frac` = the fraction of SIMD cycles in which the kernel's wavefronts
-    had a VALU instruction executing, from the counters of the PMC pass (SQ_ACTIVE_INST_VALU x 4 / (SIMDs x GRBM_GUI_ACTIVE / XCDs)):
-    a measured utilisation, never above 1.  `peak` = the instruction rate at which that fraction would be 1 with this kernel's
-    own mix (achieved / frac); the per-class issue costs behind the mix are in profiles/valu_cycles.json and the kernel's class
-    histogram in the file named by isa_histogram."""
+    """The roof that binds the window kernel: VALU issue.
+      measured  SIMD cycles per VALU wave-instruction of the profiled launches = 1024 SIMDs x (GRBM_GUI_ACTIVE / 8 XCDs) / SQ_INSTS_VALU
+                (PMC pass of this same command, profiles/traffic.json) -- every cycle of every SIMD, busy or not, per instruction;
+      priced    what the instructions would cost if each issued at its calibrated class cost (profiles/valu_cycles.json: 2.4 cycles for
+                the plain two-operand integer ops, 4.0-4.4 for the rest) with the kernel's own mix: the compiler's assembly, basic blocks
+                weighted by loop depth (tools/isa_mix.py: depth 1 = once per strip, depth 2 = the scan rounds of a strip, depth 3 = the
+                scan steps, fitted so that the total is the instruction count the profiler saw);
+      frac      = priced / measured: the share of the SIMD cycles that the kernel's own instruction stream accounts for.  No clamp.
+      peak      = 1024 SIMDs x clock / priced (G wave-instr/s), achieved = instructions / THIS run's launch time."""
     n = pm.get("valu_wave_instr_per_launch")
-    busy = pm.get("valu_busy_frac")
+    meas = pm.get("measured_cycles_per_wave_instr")
     if not n or avg_launch_ms <= 0:
         return None
     ach = n / (avg_launch_ms * 1e-3)
     out = {"achieved": round(ach / 1e9, 2), "unit": "G wave-instr/s", "lane_instr_per_base": round(n * 64.0 / bases_per_launch, 2),
-           "source": pm.get("valu_source"), "isa_histogram": pm.get("isa_histogram")}
-    if busy:
-        if busy > 1.0:  # the counter ticks in units of four cycles; plain integer instructions issue in less: a few per cent above 1 = saturated
-            out["busy_as_counted"] = busy
-        out.update({"frac": round(min(busy, 1.0), 3), "peak": round(ach / 1e9 / min(busy, 1.0), 1),
-                    "cycles_per_wave_instr": pm.get("valu_cycles_per_wave_instr"), "clock_ghz": pm.get("clock_ghz"),
-                    "note": "frac = VALU-busy SIMD cycles / SIMD cycles of the profiled launches (counters, not a model); peak = achieved / frac"})
+           "source": pm.get("valu_source")}
+    priced = priced_cycles(pm, n)
+    if meas and priced:
+        clock = pm.get("clock_ghz") or 0.0
+        out.update({"measured_cycles_per_wave_instr": meas, "priced_cycles_per_wave_instr": priced["cycles"], "frac": round(priced["cycles"] / meas, 3),
+                    "peak": round(N_SIMD * clock / priced["cycles"], 1), "clock_ghz": clock,
+                    "this_run_cycles_per_wave_instr": round(N_SIMD * clock * 1e9 * avg_launch_ms * 1e-3 / n, 3),
+                    "priced_from": priced["how"], "isa_mix": pm.get("isa_mix"),
+                    "note": "frac = priced / measured SIMD cycles per VALU wave-instruction (no clamp); SQ_ACTIVE_INST_VALU is not used: in these "
+                            "counter files it equals SQ_INSTS_VALU"})
     return out
+
+
+def priced_cycles(pm, n_instr):
+    """Class-priced cycles per wave-instruction of the profiled kernel from its loop-depth-weighted ISA mix (tools/isa_mix.py)."""
+    path = pm.get("isa_mix")
+    if not path or not os.path.exists(os.path.join(ROOT, path)):
+        return None
+    mix = json.load(open(os.path.join(ROOT, path)))["kernels"]
+    kern = next((v for k, v in mix.items() if (pm.get("kernel") or "").replace("void ", "").strip() in k), None)
+    if kern is None:
+        return None
+    d = {int(k): v for k, v in kern["by_depth"].items()}
+    strips = pm.get("strips_per_launch")
+    per_strip = n_instr * 64.0 / 64.0 / strips if strips else None  # wave-instructions per strip (one wavefront per strip)
+    rounds = pm.get("scan_rounds_per_strip") or 3.0
+    w = {0: 0.0, 1: 1.0, 2: rounds, 3: 0.0}
+    fixed = sum(w[k] * d[k]["valu"] for k in d if k in w and k != 3)
+    how = f"depth 1 x 1, depth 2 x {rounds} rounds"
+    if per_strip and 3 in d and d[3]["valu"]:
+        w[3] = max(0.0, (per_strip - fixed) / d[3]["valu"])  # what is left of the counted instructions is scan steps
+        how += f", depth 3 x {w[3]:.1f} (fitted to {per_strip:.0f} VALU wave-instructions per strip)"
+    tot_i = sum(w.get(k, 0.0) * d[k]["valu"] for k in d)
+    tot_c = sum(w.get(k, 0.0) * d[k]["priced_cycles"] for k in d)
+    return {"cycles": round(tot_c / tot_i, 3), "how": how} if tot_i else None
 
 
 def cpu_budget():

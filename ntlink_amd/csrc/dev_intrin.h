@@ -197,3 +197,10 @@ __device__ __forceinline__ uint32_t ntl_le4_mask(uint32_t k0, uint32_t k1, uint3
 #else
 #define NTL_PRIO_LATENCY_BOUND() ((void)0)
 #endif
+
+/* eight bytes from any address: one global_load_dwordx2 (the target's unaligned access mode) */
+__device__ __forceinline__ uint64_t ntl_load_u64_a1(const uint8_t *p)
+{
+    typedef uint64_t __attribute__((aligned(1))) u64_a1;
+    return *(const __attribute__((address_space(1))) u64_a1 *)p; /* said to be global memory: through a generic pointer it is a FLAT load */
+}

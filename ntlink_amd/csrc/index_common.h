@@ -39,14 +39,14 @@ struct Cand {
 template <bool TAGS>
 struct IndexProbe {
     uint64_t s;
-    uint8_t t;
+    uint64_t t8; /* TAGS: the tags of slots s .. s + 7 (the array carries a copy of its first eight bytes behind its end) */
     IndexSlot e0;
     __device__ __forceinline__ void start(uint64_t key, const IndexSlot *slots, const uint8_t *tags, int bits)
     {
         s = index_home(key, bits);
-        t = 0;
+        t8 = 0;
         if (key == NTL_INF) return;
-        if (TAGS) t = tags[s];
+        if (TAGS) t8 = ntl_load_u64_a1(tags + s);
         else e0 = slots[s];
     }
     __device__ __forceinline__ Cand finish(uint64_t key, const IndexSlot *slots, const uint8_t *tags, const IndexSpecial *special,
@@ -57,20 +57,44 @@ struct IndexProbe {
         if (key == NTL_INF) {
             if (special->cnt == 1) { c.cpos = special->pos; c.meta = (special->meta & ~1u) | 1u; }
         } else if (TAGS) {
+            /* Eight tags in one load: the probe sequence of nearly every lookup (an empty slot ends it; the table is at most half
+               full) lies inside them, so a lookup that ends on the tags costs ONE memory round trip, not one per probed slot.
+               Zero bytes and bytes equal to the key's tag by the subtract-and-mask test; its lowest flagged byte is exact, higher
+               ones may be false alarms (borrows), so only the lowest is ever trusted and a refuted match is blanked out. */
+            const uint64_t ones = 0x0101010101010101ull, high = 0x8080808080808080ull;
             const uint8_t tg = index_tag(key);
-            uint64_t q = s;
-            uint8_t tq = t;
+            const uint64_t x = t8;
+            const uint64_t z = (x - ones) & ~x & high;
+            const uint32_t iz = z ? (uint32_t)(__ffsll((long long)z) - 1) >> 3 : 8u; /* first empty slot among the eight */
+            uint64_t y = x ^ (ones * tg);
+            bool done = false;
             for (;;) {
-                if (tq == 0) break; /* empty slot ends the probe sequence */
-                if (tq == tg) {
-                    const IndexSlot e = slots[q];
-                    if (e.key == key) {
-                        if (!(e.meta & 1u)) { c.cpos = e.pos; c.meta = e.meta | 1u; }
-                        break;
-                    }
+                const uint64_t m = (y - ones) & ~y & high;
+                const uint32_t im = m ? (uint32_t)(__ffsll((long long)m) - 1) >> 3 : 8u;
+                if (im >= iz) break; /* no (further) match in front of the empty slot */
+                const IndexSlot e = slots[(s + im) & mask];
+                if (e.key == key) {
+                    if (!(e.meta & 1u)) { c.cpos = e.pos; c.meta = e.meta | 1u; }
+                    done = true;
+                    break;
                 }
-                q = (q + 1) & mask;
-                tq = tags[q];
+                y |= 0xFFull << (8u * im); /* another key with the same tag */
+            }
+            if (!done && iz == 8u) { /* eight occupied slots without the key: on, slot by slot */
+                uint64_t q = (s + 8) & mask;
+                uint8_t tq = tags[q];
+                for (;;) {
+                    if (tq == 0) break;
+                    if (tq == tg) {
+                        const IndexSlot e = slots[q];
+                        if (e.key == key) {
+                            if (!(e.meta & 1u)) { c.cpos = e.pos; c.meta = e.meta | 1u; }
+                            break;
+                        }
+                    }
+                    q = (q + 1) & mask;
+                    tq = tags[q];
+                }
             }
         } else {
             uint64_t q = s;

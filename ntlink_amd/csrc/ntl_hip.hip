@@ -1245,14 +1245,14 @@ static void launch_fast_r0(ntl_ctx *c, const Sketch2Args &B, unsigned strips)
                 /* resident wavefronts that walk over their strips: as many workgroups as the device holds at once (a multiple of 8:
                    one share of the strips per XCD).  <wavefronts per workgroup, staging slots per lane, scan rounds>: the slots hold a
                    lane's 64 p candidates + 4.5 sigma, the list (64 per round) a strip's 4096 p + 4 sigma; what does not fit is given up */
-                auto go = [&](auto kern, unsigned threads) {
+                auto go = [&](auto kern, unsigned threads, unsigned beside = 16u) {
                     int &per_cu = c->occ[(const void *)kern];
                     if (!per_cu) per_cu = occupancy_blocks(kern, (int)threads);
                     /* Beside the other stream's kernels (two streams: the lookup / map kernels of the previous batch) the resident wavefronts
                        take HALF the CU's 32 slots: with more, those kernels' workgroups wait for slots that never come free before the
                        launch ends, and the step is as long as on one stream (C3, profiles/r04_window_grid_sweep.json: 16 wavefronts per
                        CU 77.6 ms per step, 24 89.5, 32 89.4; alone the launch takes 2.65 ms at 16 against 2.09 at 32). */
-                    int use = c->pipelined ? std::min(per_cu, (int)(16u / (threads / 64u))) : per_cu;
+                    int use = c->pipelined ? std::min(per_cu, (int)(beside / (threads / 64u))) : per_cu;
                     if (const char *e = getenv("NTL_SKW_WGS_PER_CU")) use = std::max(1, std::min(per_cu, atoi(e))); /* tuning */
                     unsigned wgs = (unsigned)std::max(1, use) * (unsigned)std::max(1, c->n_cu);
                     wgs = std::min(wgs, (strips + threads / 64u - 1u) / (threads / 64u));
@@ -1266,7 +1266,9 @@ static void launch_fast_r0(ntl_ctx *c, const Sketch2Args &B, unsigned strips)
                 } else if (per_strip <= 300.0) { /* w >= 137 */
                     go(sketch_wave_kernel<8, 15, 6>, 512u);
                 } else {                         /* w >= 94 */
-                    if (wave == 4) go(sketch_wave_kernel<4, 19, 8>, 256u);
+                    /* (dense sketches: the other stream's lookup and map kernels are the longer half of a step, and twelve resident
+                       wavefronts per CU beside them make the shortest step -- C5: 8 / 12 / 16 / 24: 304.6 / 288.5 / 315.1 / 318.7 ms) */
+                    if (wave == 4 || (c->pipelined && wave != 8)) go(sketch_wave_kernel<4, 19, 8>, 256u, 12u);
                     else go(sketch_wave_kernel<8, 19, 8>, 512u);
                 }
                 hipLaunchKernelGGL((sketch_fast_list_kernel<256, R0>), dim3(std::min(strips, 4096u)), dim3(256), 0, c->wstream, B, (const uint32_t *)B.fb_list, (const uint32_t *)B.fb_count);
@@ -1858,7 +1860,7 @@ extern "C" int ntl_index_build(ntl_ctx *c, const ntl_sketch *ctg, const uint32_t
     int rc;
     DevBuf &cnt = ix->cnt;
     if ((rc = ix->slots.alloc(c, ix->nslots * sizeof(IndexSlot))) || (rc = ix->special.alloc(c, sizeof(IndexSpecial))) ||
-        (rc = ix->ctg_len.alloc(c, ((uint64_t)n_ctg + 1) * 4)) || (rc = cnt.alloc(c, 8)) || (rc = ix->tags.alloc(c, ix->nslots))) return rc;
+        (rc = ix->ctg_len.alloc(c, ((uint64_t)n_ctg + 1) * 4)) || (rc = cnt.alloc(c, 8)) || (rc = ix->tags.alloc(c, ix->nslots + 16))) return rc;
     unsigned long long size = 0;
     {
         ProfSpan sp(c, "index");
@@ -1877,6 +1879,8 @@ extern "C" int ntl_index_build(ntl_ctx *c, const ntl_sketch *ctg, const uint32_t
                            ix->slots.as<IndexSlot>(), ix->nslots, (const IndexSpecial *)ix->special.as<IndexSpecial>(),
                            (const uint32_t *)dup.as<uint32_t>(), ix->tags.as<uint8_t>(), cnt.as<unsigned long long>());
         HIPCHK(c, hipGetLastError());
+        /* the lookups read eight tags at a time from any slot: the first eight again behind the last (the probe sequence wraps) */
+        HIPCHK(c, hipMemcpyAsync(ix->tags.as<uint8_t>() + ix->nslots, ix->tags.p, 8, hipMemcpyDeviceToDevice, c->stream));
     }
     (void)size;
     if ((ix->built = sev_get(c))) HIPCHK(c, hipEventRecord(ix->built, c->stream));
