@@ -365,7 +365,7 @@ int ntl_names_create(ntl_ctx *ctx, const char *names, const uint64_t *off, const
 void ntl_names_destroy(ntl_names *t);
 /* Completes the result (waits for it), then formats: verbose != 0 the lines of .verbose_mapping.tsv, paf != 0 those of .paf.
  * One more host wait inside (the byte totals size the text arrays).  NTL_ERANGE for more than 4 GB of text in one batch.
- * The result must outlive the text's download. */
+ * The text keeps what it needs: the result may be destroyed once this call has returned. */
 int ntl_mapres_format(const ntl_mapres *r, const ntl_names *reads, const ntl_names *contigs, int verbose, int paf, ntl_text **out);
 void ntl_text_sizes(const ntl_text *t, uint64_t *verbose_bytes, uint64_t *paf_bytes, uint64_t *n_mappings);
 /* Any destination may be NULL.  ends: 2 * n_mappings hits, {first, last} per mapping (ntl_tally_add_ends). */

@@ -24,6 +24,8 @@
 
 struct FmtArgs {
     const MapRec *maps; const HitRec *hits; const PafRec *pafs;
+    const uint32_t *hit_doff; /* [n_maps + 1]: hits of the mappings in front of each one = the DENSE number of its first hit; the hits
+                                 themselves lie in per-read regions, mapping m's at hits[maps[m].hit_off ..] (map_gather_kernel) */
     uint32_t n_maps, n_hits, n_pafs; /* n_hits = 0 and do_verbose = 0: no verbose text (the ends are made either way) */
     int do_verbose;
     const uint64_t *read_name_off; const char *read_names; /* device copies of the batch's name table */
@@ -32,6 +34,7 @@ struct FmtArgs {
     uint32_t *tok_len, *hdr_len, *paf_len; /* n + 1 entries each: lengths, then (scanned in place) offsets with the total behind them */
     char *verbose, *paf;                   /* fill: the text */
     HitRec *ends;                          /* [2 n_maps] */
+    MapRec *maps_out;                      /* [n_maps] the mappings with hit_off in the dense numbering, as ntl_mapres_download hands them out */
 };
 
 __device__ __forceinline__ uint32_t fmt_digits(uint32_t v)
@@ -69,8 +72,13 @@ __device__ __forceinline__ uint32_t fmt_digits64(uint64_t v)
 __global__ void fmt_len_kernel(FmtArgs A)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < A.n_hits) {
-        const HitRec h = A.hits[i];
+    if (i < A.n_hits) { /* dense hit i: of the last mapping whose first dense number is <= i */
+        uint32_t lo = 0, hi = A.n_maps;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (A.hit_doff[mid] <= i) lo = mid; else hi = mid;
+        }
+        const HitRec h = A.hits[A.maps[lo].hit_off + (i - A.hit_doff[lo])];
         A.tok_len[i] = fmt_digits(h.ctg_pos) + fmt_digits(h.read_pos) + 6u;
     }
     if (i < A.n_maps && A.do_verbose) {
@@ -92,14 +100,14 @@ __global__ void fmt_fill_kernel(FmtArgs A)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < A.n_hits) {
-        /* the mapping of hit i: the last one whose hit_off <= i */
+        /* the mapping of dense hit i */
         uint32_t lo = 0, hi = A.n_maps;
         while (hi - lo > 1) {
             const uint32_t mid = (lo + hi) >> 1;
-            if (A.maps[mid].hit_off <= i) lo = mid; else hi = mid;
+            if (A.hit_doff[mid] <= i) lo = mid; else hi = mid;
         }
         const MapRec m = A.maps[lo];
-        const HitRec h = A.hits[i];
+        const HitRec h = A.hits[m.hit_off + (i - A.hit_doff[lo])];
         char *p = A.verbose + (uint64_t)A.hdr_len[lo + 1] + A.tok_len[i];
         const uint32_t dc = fmt_digits(h.ctg_pos), dr = fmt_digits(h.read_pos);
         fmt_put_u32(p + dc, h.ctg_pos);
@@ -108,16 +116,19 @@ __global__ void fmt_fill_kernel(FmtArgs A)
         fmt_put_u32(p + 3 + dr, h.read_pos);
         p += 3 + dr;
         p[0] = ':'; p[1] = h.read_strand ? '+' : '-';
-        p[2] = i + 1 == m.hit_off + m.n_hits ? '\n' : ' ';
+        p[2] = i + 1 == A.hit_doff[lo] + m.n_hits ? '\n' : ' ';
     }
     if (i < A.n_maps) {
         const MapRec m = A.maps[i];
         A.ends[2 * i] = A.hits[m.hit_off];
         A.ends[2 * i + 1] = A.hits[m.hit_off + m.n_hits - 1];
+        MapRec d = m;
+        d.hit_off = A.hit_doff[i];
+        A.maps_out[i] = d;
     }
     if (i < A.n_maps && A.do_verbose) {
         const MapRec m = A.maps[i];
-        char *p = A.verbose + (uint64_t)A.hdr_len[i] + A.tok_len[m.hit_off];
+        char *p = A.verbose + (uint64_t)A.hdr_len[i] + A.tok_len[A.hit_doff[i]];
         const uint64_t r0 = A.read_name_off[m.read], r1 = A.read_name_off[m.read + 1];
         for (uint64_t j = r0; j < r1; j++) *p++ = A.read_names[j];
         *p++ = '\t';

@@ -698,21 +698,41 @@ __global__ __launch_bounds__(MAP_NT) void map_overflow_kernel(MapArgs A)
 
 /* ---------------------------------------------------------------------------- gather ------ */
 
-/* dense, read-ordered result arrays from the per-read regions */
-__global__ void map_gather_kernel(MapArgs A, const uint32_t *off_maps, const uint32_t *off_hits,
-                                  const uint32_t *off_pafs, MapRec *d_maps, HitRec *d_hits, PafRec *d_pafs)
+/* Dense, read-ordered mappings and PAF records from the per-read regions.  The HITS stay where map_read wrote them -- read r's at
+   [mx_off[r], mx_off[r] + n_hits[r]) of the region array -- and a dense mapping's hit_off points there: every consumer on the
+   device reaches the hits through hit_off (the text kernels, the tally's first / last hits), and copying 12 bytes per hit a
+   second time was most of this kernel (C5: 0.85 GB read + 0.85 GB written per sub-batch, 0.33 ms of it).  ntl_mapres_download
+   makes the dense copy it hands to the host when it is asked (map_densify_kernel). */
+__global__ void map_gather_kernel(MapArgs A, const uint32_t *off_maps, const uint32_t *off_pafs, MapRec *d_maps, PafRec *d_pafs)
 {
     if (map_sketch_overflowed(A)) return;
     const uint32_t r = blockIdx.x;
     const uint32_t m0 = A.mx_off[r];
     if (r == 0 && threadIdx.x == 0) *A.nmx_out = A.mx_off[A.nreads];
-    const uint32_t nm = A.n_maps[r], nh = A.n_hits[r], npf = A.n_pafs[r];
-    const uint32_t om = off_maps[r], oh = off_hits[r], op = off_pafs[r];
+    const uint32_t nm = A.n_maps[r], npf = A.n_pafs[r];
+    const uint32_t om = off_maps[r], op = off_pafs[r];
     for (uint32_t i = threadIdx.x; i < nm; i += blockDim.x) {
         MapRec M = A.maps[m0 + i];
-        M.hit_off += oh;
+        M.hit_off += m0;
         d_maps[om + i] = M;
     }
-    for (uint32_t i = threadIdx.x; i < nh; i += blockDim.x) d_hits[oh + i] = A.hits[m0 + i];
     for (uint32_t i = threadIdx.x; i < npf; i += blockDim.x) d_pafs[op + i] = A.pafs[m0 + i];
+}
+
+/* n_hits of every mapping as a u32 array (the input of the scan that numbers the hits densely) */
+__global__ void map_nhits_kernel(const MapRec *maps, uint32_t n_maps, uint32_t *out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_maps) out[i] = maps[i].n_hits;
+}
+
+/* the dense copy for the host: mapping m's hits to [doff[m], doff[m] + n_hits), its hit_off rewritten to match */
+__global__ void map_densify_kernel(const MapRec *maps, uint32_t n_maps, const HitRec *hits, const uint32_t *doff, MapRec *d_maps, HitRec *d_hits)
+{
+    const uint32_t m = blockIdx.x;
+    if (m >= n_maps) return;
+    MapRec M = maps[m];
+    const uint32_t o = doff[m];
+    for (uint32_t i = threadIdx.x; i < M.n_hits; i += blockDim.x) d_hits[o + i] = hits[M.hit_off + i];
+    if (threadIdx.x == 0) { M.hit_off = o; d_maps[m] = M; }
 }

@@ -1916,7 +1916,10 @@ static_assert(sizeof(MapSums) <= sizeof(PinSlot), "the sums must fit a page-lock
 struct ntl_mapres {
     ntl_ctx *c;
     mutable uint64_t n_maps = 0, n_hits = 0, n_pafs = 0, n_index_hits = 0;
-    mutable DevBuf maps, hits, pafs; /* dense, read order; sized from the sketch's capacity, filled to n_* */
+    mutable DevBuf maps, pafs;       /* dense, read order; sized from the sketch's capacity, filled to n_* */
+    mutable DevBuf hits;             /* per-read regions (read r's hits from mx_off[r] on); maps[].hit_off points into them */
+    mutable DevBuf maps_dense, hits_dense, hit_doff; /* made on demand: the dense copy ntl_mapres_download hands out; u32[n_maps + 1] dense offsets */
+    mutable bool dense_made = false, doff_made = false;
     /* lazy completion */
     mutable bool pending = false;
     mutable hipEvent_t done = nullptr;
@@ -1943,10 +1946,11 @@ static int map_enqueue(ntl_ctx *c, const ntl_index *ix, const ntl_sketch *reads,
     const ntl_map_params *params = &R->params;
     int rc;
     hipStream_t ms = c->stream;
-    DevBuf cand, smaps, shits, spafs, n3, off3, scr, sums, over;
+    DevBuf cand, smaps, spafs, n3, off3, scr, sums, over;
+    R->dense_made = R->doff_made = false;
     const uint64_t cap = nmx ? nmx : 1;
     if ((!have_cand && (rc = cand.alloc(c, cap * sizeof(Cand)))) ||
-        (rc = smaps.alloc(c, cap * sizeof(MapRec))) || (rc = shits.alloc(c, cap * sizeof(HitRec))) ||
+        (rc = smaps.alloc(c, cap * sizeof(MapRec))) ||
         (rc = spafs.alloc(c, cap * sizeof(PafRec))) || (rc = n3.alloc(c, 3 * (nreads + 1) * 4)) ||
         (rc = off3.alloc(c, 3 * (nreads + 1) * 4)) || (rc = scr.alloc(c, (uint64_t)(MAP_NHA + MAP_NRA) * cap * 4)) ||
         (rc = sums.alloc(c, sizeof(MapSums))) || (rc = over.alloc(c, (nreads + 1) * 4)) ||
@@ -1980,7 +1984,7 @@ static int map_enqueue(ntl_ctx *c, const ntl_index *ix, const ntl_sketch *reads,
     A.read_len = d_rlen; A.ctg_len = ix->ctg_len.as<uint32_t>(); A.nreads = (uint32_t)nreads;
     A.P.k = params->k; A.P.z = params->z; A.P.x = params->x; A.P.sensitive = params->sensitive;
     A.P.repeat_filter = params->repeat_filter;
-    A.maps = smaps.as<MapRec>(); A.hits = shits.as<HitRec>(); A.pafs = spafs.as<PafRec>();
+    A.maps = smaps.as<MapRec>(); A.hits = R->hits.as<HitRec>(); A.pafs = spafs.as<PafRec>();
     A.n_maps = n3.as<uint32_t>(); A.n_hits = A.n_maps + (nreads + 1); A.n_pafs = A.n_hits + (nreads + 1);
     A.scr = scr.as<uint32_t>(); A.scr_stride = cap; A.err = &dsums->err;
     A.over_list = over.as<uint32_t>(); A.over_count = &dsums->n_over;
@@ -2005,8 +2009,7 @@ static int map_enqueue(ntl_ctx *c, const ntl_index *ix, const ntl_sketch *reads,
         uint32_t *o = off3.as<uint32_t>();
         if ((rc = device_scan(c, n3.as<uint32_t>(), o, nreads, nullptr, 3, dsums->tot))) return rc;
         hipLaunchKernelGGL(map_gather_kernel, dim3((unsigned)nreads), dim3(64), 0, ms, A, (const uint32_t *)o,
-                           (const uint32_t *)(o + (nreads + 1)), (const uint32_t *)(o + 2 * (nreads + 1)),
-                           R->maps.as<MapRec>(), R->hits.as<HitRec>(), R->pafs.as<PafRec>());
+                           (const uint32_t *)(o + 2 * (nreads + 1)), R->maps.as<MapRec>(), R->pafs.as<PafRec>());
         HIPCHK(c, hipGetLastError());
     }
     HIPCHK(c, hipMemcpyAsync(R->slot, sums.p, sizeof(MapSums), hipMemcpyDeviceToHost, ms));
@@ -2123,6 +2126,41 @@ extern "C" uint64_t ntl_mapres_n_hits(const ntl_mapres *r) { return r && mapres_
 extern "C" uint64_t ntl_mapres_n_pafs(const ntl_mapres *r) { return r && mapres_finalize(r) == NTL_OK ? r->n_pafs : 0; }
 extern "C" uint64_t ntl_mapres_n_index_hits(const ntl_mapres *r) { return r && mapres_finalize(r) == NTL_OK ? r->n_index_hits : 0; }
 
+/* hit_doff[m] = hits of the mappings before m (the dense numbering of the hits); needs a completed result */
+static int mapres_dense_offsets(const ntl_mapres *r)
+{
+    if (r->doff_made) return NTL_OK;
+    ntl_ctx *c = r->c;
+    int rc;
+    if ((rc = r->hit_doff.alloc(c, (r->n_maps + 1) * 4))) return rc;
+    if (r->n_maps) {
+        hipLaunchKernelGGL(map_nhits_kernel, dim3((unsigned)((r->n_maps + 255) / 256)), dim3(256), 0, c->stream, (const MapRec *)r->maps.as<MapRec>(),
+                           (uint32_t)r->n_maps, r->hit_doff.as<uint32_t>());
+        if ((rc = device_scan(c, r->hit_doff.as<uint32_t>(), r->hit_doff.as<uint32_t>(), r->n_maps, nullptr))) return rc;
+    } else HIPCHK(c, hipMemsetAsync(r->hit_doff.p, 0, 4, c->stream));
+    HIPCHK(c, hipGetLastError());
+    r->doff_made = true;
+    return NTL_OK;
+}
+
+/* the dense copy of mappings and hits that the host receives (the device keeps the hits in their per-read regions) */
+static int mapres_densify(const ntl_mapres *r)
+{
+    if (r->dense_made) return NTL_OK;
+    ntl_ctx *c = r->c;
+    int rc;
+    if ((rc = mapres_dense_offsets(r)) || (rc = r->maps_dense.alloc(c, (r->n_maps + 1) * sizeof(MapRec))) ||
+        (rc = r->hits_dense.alloc(c, (r->n_hits + 1) * sizeof(HitRec))))
+        return rc;
+    if (r->n_maps)
+        hipLaunchKernelGGL(map_densify_kernel, dim3((unsigned)r->n_maps), dim3(64), 0, c->stream, (const MapRec *)r->maps.as<MapRec>(), (uint32_t)r->n_maps,
+                           (const HitRec *)r->hits.as<HitRec>(), (const uint32_t *)r->hit_doff.as<uint32_t>(), r->maps_dense.as<MapRec>(),
+                           r->hits_dense.as<HitRec>());
+    HIPCHK(c, hipGetLastError());
+    r->dense_made = true;
+    return NTL_OK;
+}
+
 extern "C" int ntl_mapres_download(const ntl_mapres *r, ntl_mapping *maps, ntl_hit *hits, ntl_paf *pafs)
 {
     if (!r) return NTL_EINVAL;
@@ -2131,8 +2169,11 @@ extern "C" int ntl_mapres_download(const ntl_mapres *r, ntl_mapping *maps, ntl_h
     if (int frc = mapres_finalize(r)) return frc;
     static_assert(sizeof(ntl_mapping) == sizeof(MapRec) && sizeof(ntl_hit) == sizeof(HitRec) && sizeof(ntl_paf) == sizeof(PafRec),
                   "ABI records must match the device records");
-    if (maps && r->n_maps) HIPCHK(c, hipMemcpyAsync(maps, r->maps.p, r->n_maps * sizeof(MapRec), hipMemcpyDeviceToHost, c->stream));
-    if (hits && r->n_hits) HIPCHK(c, hipMemcpyAsync(hits, r->hits.p, r->n_hits * sizeof(HitRec), hipMemcpyDeviceToHost, c->stream));
+    if ((maps || hits) && r->n_maps) {
+        if (int drc = mapres_densify(r)) return drc;
+        if (maps) HIPCHK(c, hipMemcpyAsync(maps, r->maps_dense.p, r->n_maps * sizeof(MapRec), hipMemcpyDeviceToHost, c->stream));
+        if (hits && r->n_hits) HIPCHK(c, hipMemcpyAsync(hits, r->hits_dense.p, r->n_hits * sizeof(HitRec), hipMemcpyDeviceToHost, c->stream));
+    }
     if (pafs && r->n_pafs) HIPCHK(c, hipMemcpyAsync(pafs, r->pafs.p, r->n_pafs * sizeof(PafRec), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, main_wait(c));
     return NTL_OK;
@@ -2175,8 +2216,7 @@ extern "C" void ntl_names_destroy(ntl_names *t)
 struct ntl_text {
     ntl_ctx *c;
     uint64_t verbose_bytes = 0, paf_bytes = 0, n_maps = 0;
-    DevBuf verbose, paf, ends;
-    const ntl_mapres *res = nullptr; /* the mappings themselves stay in the result: it must outlive the text's download */
+    DevBuf verbose, paf, ends, maps;
 };
 
 /* Makes the text of a map result on the device.  One host wait: the three byte totals decide the size of the text arrays. */
@@ -2194,21 +2234,23 @@ extern "C" int ntl_mapres_format(const ntl_mapres *r, const ntl_names *reads, co
     const uint64_t bound = r->n_hits * 27 + (r->n_maps + r->n_pafs) * 64 + (r->n_maps + r->n_pafs) * 2 * 4096;
     if (bound >= 0xFFFFFFFFull && r->n_hits * 27 >= 0xF0000000ull) return fail(c, NTL_ERANGE, "ntl_mapres_format: more than 4 GB of text in one batch");
     std::unique_ptr<ntl_text> t(new ntl_text());
-    t->c = c; t->res = r; t->n_maps = r->n_maps;
+    t->c = c; t->n_maps = r->n_maps;
     const uint32_t nm = (uint32_t)r->n_maps, nh = want_verbose ? (uint32_t)r->n_hits : 0u, np = want_paf ? (uint32_t)r->n_pafs : 0u;
     DevBuf tok, hdr, pl;
     int rc;
     if ((rc = tok.alloc(c, ((uint64_t)nh + 1) * 4)) || (rc = hdr.alloc(c, ((uint64_t)nm + 1) * 4)) || (rc = pl.alloc(c, ((uint64_t)np + 1) * 4)) ||
-        (rc = t->ends.alloc(c, ((uint64_t)r->n_maps * 2 + 1) * sizeof(HitRec))))
+        (rc = t->ends.alloc(c, ((uint64_t)r->n_maps * 2 + 1) * sizeof(HitRec))) || (rc = t->maps.alloc(c, ((uint64_t)r->n_maps + 1) * sizeof(MapRec))))
         return rc;
+    if ((rc = mapres_dense_offsets(r))) return rc;
     FmtArgs A;
+    A.hit_doff = r->hit_doff.as<uint32_t>();
     A.maps = r->maps.as<MapRec>(); A.hits = r->hits.as<HitRec>(); A.pafs = r->pafs.as<PafRec>();
     A.n_maps = nm; A.n_hits = nh; A.n_pafs = np; A.do_verbose = want_verbose ? 1 : 0;
     A.read_name_off = reads->off.as<uint64_t>(); A.read_names = reads->blob.as<char>();
     A.ctg_name_off = contigs->off.as<uint64_t>(); A.ctg_names = contigs->blob.as<char>();
     A.read_len = reads->len.as<uint32_t>(); A.ctg_len = contigs->len.as<uint32_t>();
     A.tok_len = tok.as<uint32_t>(); A.hdr_len = hdr.as<uint32_t>(); A.paf_len = pl.as<uint32_t>();
-    A.verbose = nullptr; A.paf = nullptr; A.ends = t->ends.as<HitRec>();
+    A.verbose = nullptr; A.paf = nullptr; A.ends = t->ends.as<HitRec>(); A.maps_out = t->maps.as<MapRec>();
     const uint64_t most = std::max<uint64_t>(std::max<uint64_t>(nh, nm), np);
     uint32_t tot[3] = {0, 0, 0};
     if (most) {
@@ -2249,7 +2291,7 @@ extern "C" int ntl_text_download(const ntl_text *t, char *verbose, char *paf, nt
     (void)hipSetDevice(c->device);
     if (verbose && t->verbose_bytes) HIPCHK(c, hipMemcpyAsync(verbose, t->verbose.p, t->verbose_bytes, hipMemcpyDeviceToHost, c->stream));
     if (paf && t->paf_bytes) HIPCHK(c, hipMemcpyAsync(paf, t->paf.p, t->paf_bytes, hipMemcpyDeviceToHost, c->stream));
-    if (maps && t->n_maps) HIPCHK(c, hipMemcpyAsync(maps, t->res->maps.p, t->n_maps * sizeof(MapRec), hipMemcpyDeviceToHost, c->stream));
+    if (maps && t->n_maps) HIPCHK(c, hipMemcpyAsync(maps, t->maps.p, t->n_maps * sizeof(MapRec), hipMemcpyDeviceToHost, c->stream));
     if (ends && t->n_maps) HIPCHK(c, hipMemcpyAsync(ends, t->ends.p, t->n_maps * 2 * sizeof(HitRec), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, main_wait(c));
     return NTL_OK;
