@@ -101,7 +101,7 @@ def kernel_signature():
     import re
     h = hashlib.sha1()
     d = os.path.join(ROOT, "ntlink_amd", "csrc")
-    for f in ("sketch_kernels.h", "sketch2_kernels.h", "dev_common.h", "map_kernels.h", "index_common.h"):
+    for f in ("sketch_kernels.h", "sketch2_kernels.h", "dev_common.h", "dev_intrin.h", "map_kernels.h", "index_common.h"):
         p = os.path.join(d, f)
         if os.path.exists(p):
             text = open(p, "r", errors="replace").read()
@@ -549,9 +549,14 @@ def priced_cycles(pm, n_instr):
     w = {0: 0.0, 1: 1.0, 2: rounds, 3: 0.0}
     fixed = sum(w[k] * d[k]["valu"] for k in d if k in w and k != 3)
     how = f"depth 1 x 1, depth 2 x {rounds} rounds"
-    if per_strip and 3 in d and d[3]["valu"]:
-        w[3] = max(0.0, (per_strip - fixed) / d[3]["valu"])  # what is left of the counted instructions is scan steps
-        how += f", depth 3 x {w[3]:.1f} (fitted to {per_strip:.0f} VALU wave-instructions per strip)"
+    if 3 in d and d[3]["valu"]:
+        fit = (per_strip - fixed) / d[3]["valu"] if per_strip else -1.0  # what is left of the counted instructions would be scan steps
+        if fit > 0:
+            w[3] = fit
+            how += f", depth 3 x {w[3]:.1f} (fitted to {per_strip:.0f} VALU wave-instructions per strip)"
+        else:  # the straight-line count already exceeds what was counted (blocks of other k, of a sequence's last strip ... are skipped)
+            w[3] = rounds * 5.5
+            how += f", depth 3 x {w[3]:.1f} (5.5 scan steps per round and side; the profiler counted {per_strip or 0:.0f} VALU wave-instructions per strip, fewer than the straight-line code holds: only the RATIO of the weights enters)"
     tot_i = sum(w.get(k, 0.0) * d[k]["valu"] for k in d)
     tot_c = sum(w.get(k, 0.0) * d[k]["priced_cycles"] for k in d)
     return {"cycles": round(tot_c / tot_i, 3), "how": how} if tot_i else None
