@@ -48,6 +48,7 @@ def parse_args(argv=None):
     ap.add_argument("--workload", default="C3", help="C3 (default: 3 Gbp + 90 Gbases ONT, k32 w250), C2, C5")
     ap.add_argument("--strong", action="store_true", help="strong scaling: the workload's read set is split over the ranks (configs[3]; the default for --gpus N > 1)")
     ap.add_argument("--weak", action="store_true", help="weak scaling: every rank maps a whole read set of its own (N > 1 only; reported as \"scaling\": \"weak\")")
+    ap.add_argument("--emulate-world", type=int, default=0, help="debugging: this ONE rank takes the share (and the sub-batch size) it would have in a world of that size; reported in config")
     ap.add_argument("--min-batches", type=int, default=8, help="strong scaling: a rank's share is cut into at least this many sub-batches, so that the two-stream pipeline has depth")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debugging only; reported)")
     ap.add_argument("--batch-bases", type=float, default=3.95e9, help="read bases per device batch")
@@ -196,9 +197,10 @@ def run_workload(dev, comm, name, args, steps, warmup, rank, world, serial_steps
     W = synth.workload(name, args.scale)
     k, w = W["k"], W["w"]
     total_read_bases = W["read_bases"]
-    my_bases = total_read_bases // world if args.strong else total_read_bases
+    share_of = args.emulate_world if (args.emulate_world > 1 and world == 1) else world
+    my_bases = total_read_bases // share_of if args.strong else total_read_bases
     batch_bases = int(args.batch_bases)
-    if args.strong and world > 1:  # a rank's share of configs[3] is 3 sub-batches of the N = 1 size: too few for window(i+1) beside emit(i)
+    if args.strong and share_of > 1:  # a rank's share of configs[3] is 3 sub-batches of the N = 1 size: too few for window(i+1) beside emit(i)
         batch_bases = max(1, min(batch_bases, -(-my_bases // max(1, args.min_batches))))
     t0 = time.perf_counter()
     wl = synth.DeviceWorkload(dev, name, args.scale, read_bases=my_bases, batch_bases=batch_bases,
@@ -363,7 +365,7 @@ def summarize(R, args, world, dev_name):
                        f"contig_stage_ms) + {read_bases} read bases per GPU per step ({int(sum(len(x) for x in wl.read_lens))} reads, mean {W['read_len']} bp, "
                        f"lognormal; generated on the device, {nb} distinct HBM-resident sub-batches), "
                        f"k={k} w={w} z=1000 x=0 sensitive={W['sensitive']} paf=True verbose=True",
-           "scale": args.scale, "hit_fraction": round(hfrac, 4),
+           "scale": args.scale, "emulated_world": args.emulate_world or None, "hit_fraction": round(hfrac, 4),
            "read_minimizers_per_step": stats["read_mx"], "contig_minimizers": R["contig_mx"],
            "index_size": R["index_size"], "mappings_hits_pafs_per_step": list(stats["counts"]), "window_strips_per_step": stats.get("strips"),
            "device": dev_name, "gen_s": round(R["gen_s"], 2),
