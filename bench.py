@@ -21,7 +21,7 @@ profiles/ hold); the durations measured inside the pipelined steps are reported 
 N > 1: one process per GPU (the driver launches `python -m torch.distributed.run ... bench.py --gpus N`;
 a bare `python bench.py --gpus N` starts those N ranks itself as a child process).  Reads shard, the contig
 index is rebuilt on every GPU, no data-path collective; RCCL carries the barrier and the max.  Default for N > 1:
-STRONG scaling, BASELINE.json configs[3] -- the same 90 Gbases split N ways, a rank's share in at least --min-batches
+STRONG scaling, BASELINE.json configs[3] -- the same 90 Gbases split N ways, a rank's share in at least --min-batches (4)
 sub-batches; --weak gives every rank a whole read set of its own instead.
 
 Prints ONE JSON line on rank 0.
@@ -49,7 +49,8 @@ def parse_args(argv=None):
     ap.add_argument("--strong", action="store_true", help="strong scaling: the workload's read set is split over the ranks (configs[3]; the default for --gpus N > 1)")
     ap.add_argument("--weak", action="store_true", help="weak scaling: every rank maps a whole read set of its own (N > 1 only; reported as \"scaling\": \"weak\")")
     ap.add_argument("--emulate-world", type=int, default=0, help="debugging: this ONE rank takes the share (and the sub-batch size) it would have in a world of that size; reported in config")
-    ap.add_argument("--min-batches", type=int, default=8, help="strong scaling: a rank's share is cut into at least this many sub-batches, so that the two-stream pipeline has depth")
+    ap.add_argument("--min-batches", type=int, default=4, help="strong scaling: a rank's share is cut into at least this many sub-batches (the two-stream pipeline needs a few; "
+                    "more and smaller ones cost more than they hide: profiles/r04_strong_share_sweep.txt)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debugging only; reported)")
     ap.add_argument("--batch-bases", type=float, default=3.95e9, help="read bases per device batch")
     ap.add_argument("--serial-steps", type=int, default=2, help="steps of the kernels-alone pass behind the timed region (0 = none)")
