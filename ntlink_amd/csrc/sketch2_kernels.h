@@ -1227,15 +1227,18 @@ __global__ __launch_bounds__(NT) void sketch_thresh_kernel(Sketch2Args B)
  *     walks through first k-mers -> rolling -> list -> scans -> bits at its own pace, and the wavefronts of a CU are in
  *     different phases at any time (issue-bound rolling of one beside the LDS-latency-bound scans of another).  The phases of
  *     sketch_thresh_kernel were separated by six workgroup barriers;
- *   - a wavefront is given every (number of wavefronts)-th strip of its XCD's share and asks for the strip table entry two
- *     strips ahead and for the base words one strip ahead (vector loads: a scalar load would sit in the same counter as the LDS
+ *   - a wavefront TAKES its strips, SKW_CHUNK consecutive ones at a time, from a counter of its XCD's share of the strips
+ *     (dealt out in advance the launch ends with the slowest share: 2.55 ms per C3 launch against 2.09 taken), and asks for
+ *     the 16-byte strip table entry two strips ahead and for the base words one strip ahead (vector loads: a scalar load would sit in the same counter as the LDS
  *     reads of the rolling loop), so that no strip starts with a chain of dependent global loads;
  *   - hand-offs between lanes (the list, the sentinels) are wave-synchronous LDS traffic (ntl_wave_sync: ordering only).
  *
  * Elements: local position p = 64 L + t of the strip is ordinal E0 + p; p = 0 belongs to the previous strip's windows only
  * and positions >= hi = min(4096, M - E0) lie behind the sequence: candidates found there are dropped when the list is made.
  * Gives the strip up (B.fb_list) when a lane stages more than S candidates, the list would hold more than 64 ROUNDS - 8, or the
- * scans say so (a window without a candidate, a near tie, a key within SK2_NEAR of the threshold).
+ * scans say so (a window without a candidate, a near tie, a key within SKW_NEAR of the threshold).  Soaked against the oracle on
+ * 24 Gbases and 985 random (k, w, candidates per window) configurations (profiles/r04s_*.log), and in every `pytest -m gpu` run
+ * on 25 Gbases more (tests/test_gpu_soak.py).
  */
 struct SkwWords { uint4 o0, i0; uint32_t o4, i4, ao, ai; };
 
