@@ -204,3 +204,15 @@ __device__ __forceinline__ uint64_t ntl_load_u64_a1(const uint8_t *p)
     typedef uint64_t __attribute__((aligned(1))) u64_a1;
     return *(const __attribute__((address_space(1))) u64_a1 *)p; /* said to be global memory: through a generic pointer it is a FLAT load */
 }
+
+/* four bytes from / eight bytes to any address of global memory */
+__device__ __forceinline__ uint32_t ntl_load_u32_a1(const uint8_t *p)
+{
+    typedef uint32_t __attribute__((aligned(1))) u32_a1;
+    return *(const __attribute__((address_space(1))) u32_a1 *)p;
+}
+__device__ __forceinline__ void ntl_store_u64_a1(uint8_t *p, uint64_t v)
+{
+    typedef uint64_t __attribute__((aligned(1))) u64_a1;
+    *(__attribute__((address_space(1))) u64_a1 *)p = v;
+}
