@@ -428,7 +428,11 @@ def main():
         return
     sys.path.insert(0, ROOT)
     from ntlink_amd.dist_pair import pin_rank, LAST_PIN
-    cores_mine = pin_rank(local_rank, local_world)
+    try:
+        cores_mine = pin_rank(local_rank, local_world)
+    except Exception as exc:  # pinning is an optimisation: an unexpected /sys layout must not cost the run
+        print(f"bench: pin_rank failed ({type(exc).__name__}: {exc}); running unpinned", file=sys.stderr)
+        cores_mine = None
     import torch
     from ntlink_amd import capi
     use_cuda = args.lib is None

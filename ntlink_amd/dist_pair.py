@@ -166,7 +166,10 @@ def main(argv=None):
         print("usage: ... -m ntlink_amd.dist_pair pair target=<fa> reads='<files>' [k= w= ...]", file=sys.stderr)
         return 2
     cli.apply_threads(kv, given)
-    pin_rank(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))
+    try:
+        pin_rank(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))
+    except Exception as exc:  # pinning is an optimisation: an unexpected /sys layout must not cost the run
+        print(f"dist_pair: pin_rank failed ({type(exc).__name__}: {exc}); running unpinned", file=sys.stderr)
     import time
     t0 = time.perf_counter()
     comm = DistComm("gloo")  # a few host objects only; the device work needs no collective
