@@ -416,7 +416,9 @@ class Device:
 
     def _chk(self, rc):
         if rc != 0:
-            raise NtlError(f"error {rc}: {self.L.ntl_last_error(self.ptr).decode()}")
+            exc = NtlError(f"error {rc}: {self.L.ntl_last_error(self.ptr).decode()}")
+            exc.code = rc
+            raise exc
 
     @property
     def name(self):

@@ -441,6 +441,8 @@ struct ProfSpan {
 static void make_g4(uint64_t g4[256][2]);
 static void make_g8(std::vector<uint64_t> &g8);
 
+static void ctx_prime(ntl_ctx *c); /* behind the kernels' launch helpers */
+
 extern "C" int ntl_ctx_create(int device, ntl_ctx **out)
 {
     if (!out) return NTL_EINVAL;
@@ -501,6 +503,7 @@ extern "C" int ntl_ctx_create(int device, ntl_ctx **out)
         c->devname = buf;
         c->n_cu = prop.multiProcessorCount;
     }
+    ctx_prime(c);
     *out = c;
     return NTL_OK;
 }
@@ -1220,6 +1223,26 @@ static int occupancy_blocks(K kern, int threads)
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, threads, 0) != hipSuccess || n < 1) n = 1;
     return n;
+#endif
+}
+
+/* What a context would otherwise do inside its first sketch call, done when it is made: the first slab of device memory and
+   the occupancy figures of the resident window kernels (the query loads the library's code object onto the device: some
+   ten milliseconds, once per process).  Best effort: whatever fails here is tried again where it is needed. */
+static void ctx_prime(ntl_ctx *c)
+{
+#ifndef NTL_SIM
+    {
+        DevBuf first;
+        (void)first.alloc(c, 1 << 20);
+    }
+    c->occ[(const void *)sketch_wave_kernel<8, 11, 4>] = occupancy_blocks(sketch_wave_kernel<8, 11, 4>, 512);
+    c->occ[(const void *)sketch_wave_kernel<8, 15, 6>] = occupancy_blocks(sketch_wave_kernel<8, 15, 6>, 512);
+    c->occ[(const void *)sketch_wave_kernel<8, 19, 8>] = occupancy_blocks(sketch_wave_kernel<8, 19, 8>, 512);
+    c->occ[(const void *)sketch_wave_kernel<4, 19, 8>] = occupancy_blocks(sketch_wave_kernel<4, 19, 8>, 256);
+    c->err.clear();
+#else
+    (void)c;
 #endif
 }
 

@@ -411,10 +411,15 @@ def _map_batches(dev, ix, batches, drain, stats, t_mark, w, first=None, text=Non
                         t_sk = time.perf_counter()
                         with wdev.map(ix, rsk, rl, **map_kw) as res:
                             t_mp = time.perf_counter()
+                            pres = None
                             if text is not None:  # (contig name table, verbose, paf): the lines are formatted on the device
-                                with wdev.names(rs_.names, rl) as rn, res.format(rn, text[0], text[1], text[2]) as txt:
-                                    pres = txt.download()
-                            else:
+                                try:
+                                    with wdev.names(rs_.names, rl) as rn, res.format(rn, text[0], text[1], text[2]) as txt:
+                                        pres = txt.download()
+                                except capi.NtlError as exc:
+                                    if getattr(exc, "code", 0) != capi.NTL_ERANGE:  # more than 4 GB of text in one batch: the host's emitters take it
+                                        raise
+                            if pres is None:
                                 pres = res.download(pinned=True)
                             n_mx, n_hit = rsk.count, res.n_index_hits
                 t_done = time.perf_counter()
