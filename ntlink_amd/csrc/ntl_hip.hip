@@ -1229,9 +1229,14 @@ static int occupancy_blocks(K kern, int threads)
 /* What a context would otherwise do inside its first sketch call, done when it is made: the first slab of device memory and
    the occupancy figures of the resident window kernels (the query loads the library's code object onto the device: some
    ten milliseconds, once per process).  Best effort: whatever fails here is tried again where it is needed. */
+__global__ void ntl_noop_kernel() {}
+
 static void ctx_prime(ntl_ctx *c)
 {
 #ifndef NTL_SIM
+    hipLaunchKernelGGL(ntl_noop_kernel, dim3(1), dim3(64), 0, c->stream); /* the library's code object goes onto the device with its first launch */
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipGetLastError();
     {
         DevBuf first;
         (void)first.alloc(c, 1 << 20);
