@@ -509,8 +509,13 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
     # this rank's share of the read files is opened, inflated and parsed from now on, behind the contig stage
     packed = os.environ.get("NTL_HOST_PACK", "1") != "0"  # the parser threads pack to 2 bits per base: a quarter of the PCIe bytes
     batches = Prefetch(seqio.load_parallel(plan, max_bases=batch_bases, alloc=dev.pinned_empty, stats=io_stats, packed=packed))
+    # the device workers' contexts (streams, tables, a first slab of device memory each) are made while the contig file is parsed
+    import threading
+    make_workers = threading.Thread(target=dev.workers, args=(max(1, int(os.environ.get("NTL_DEVICE_STREAMS", "2"))),), daemon=True)
+    make_workers.start()
     ctg = seqio.load_all([target], packed=packed)  # used once: page-locking a buffer for it would cost more than the staged copy
     ctg_len = ctg.lengths
+    make_workers.join()
     t_ctg_parsed = time.perf_counter()
     # Several ranks: EVERY rank (0 too) writes part files; the final names appear only by a rename after all parts are in
     # place -- a run that dies half way leaves no well-formed <prefix>.verbose_mapping.tsv with a fraction of the reads,
