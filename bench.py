@@ -508,6 +508,7 @@ def pmc_summary(workload, scale, bases_per_launch):
     return {"traffic": t["bytes_per_launch"], "traffic_source": t["source"], "kernel": t.get("kernel"),
             "valu_wave_instr_per_launch": t.get("valu_wave_instr_per_launch"), "valu_source": t.get("valu_source"),
             "measured_cycles_per_wave_instr": t.get("measured_cycles_per_wave_instr"),
+            "profiled_launch_ms": t.get("profiled_launch_ms"),
             "clock_ghz": t.get("clock_ghz"), "isa_mix": t.get("isa_mix")}
 
 
@@ -520,20 +521,23 @@ def valu_roofline(pm, avg_launch_ms, bases_per_launch):
                 weighted by loop depth (tools/isa_mix.py: depth 1 = once per strip, depth 2 = the scan rounds of a strip, depth 3 = the
                 scan steps, fitted so that the total is the instruction count the profiler saw);
       frac      = priced / measured: the share of the SIMD cycles that the kernel's own instruction stream accounts for.  No clamp.
-      peak      = 1024 SIMDs x clock / priced (G wave-instr/s), achieved = instructions / THIS run's launch time."""
+      peak      = 1024 SIMDs x clock / priced (G wave-instr/s), achieved = instructions / launch time, both of the profiled launches
+                (so that achieved / peak = frac); this run's unprofiled launch time beside them."""
     n = pm.get("valu_wave_instr_per_launch")
     meas = pm.get("measured_cycles_per_wave_instr")
     if not n or avg_launch_ms <= 0:
         return None
-    ach = n / (avg_launch_ms * 1e-3)
+    t_prof = pm.get("profiled_launch_ms") or avg_launch_ms
+    ach = n / (t_prof * 1e-3)  # of the PROFILED launches: their clock is the one that is known (GRBM_GUI_ACTIVE), so achieved / peak = frac
     out = {"achieved": round(ach / 1e9, 2), "unit": "G wave-instr/s", "lane_instr_per_base": round(n * 64.0 / bases_per_launch, 2),
-           "source": pm.get("valu_source")}
+           "source": pm.get("valu_source"), "profiled_launch_ms": t_prof,
+           "this_run": {"avg_launch_ms": round(avg_launch_ms, 4), "achieved": round(n / (avg_launch_ms * 1e-3) / 1e9, 2),
+                        "note": "unprofiled launches of this run: the chip holds a higher clock without the profiler (MI355X_MICROARCH.md, DVFS), which this process cannot read"}}
     priced = priced_cycles(pm, n)
     if meas and priced:
         clock = pm.get("clock_ghz") or 0.0
         out.update({"measured_cycles_per_wave_instr": meas, "priced_cycles_per_wave_instr": priced["cycles"], "frac": round(priced["cycles"] / meas, 3),
                     "peak": round(N_SIMD * clock / priced["cycles"], 1), "clock_ghz": clock,
-                    "this_run_cycles_per_wave_instr": round(N_SIMD * clock * 1e9 * avg_launch_ms * 1e-3 / n, 3),
                     "priced_from": priced["how"], "isa_mix": pm.get("isa_mix"),
                     "note": "frac = priced / measured SIMD cycles per VALU wave-instruction (no clamp); SQ_ACTIVE_INST_VALU is not used: in these "
                             "counter files it equals SQ_INSTS_VALU"})
