@@ -183,6 +183,14 @@ int ntl_sketch_run(ntl_ctx *ctx, const ntl_batch *b, int k, int w, ntl_sketch **
  * bin/ntlink_pair.py:364-367 fused into the emitter of `indexlr`.  Minimizers and mappings are those of the two-call form;
  * the index may be destroyed once this call has returned (see "Asynchrony"). */
 int ntl_sketch_run_indexed(ntl_ctx *ctx, const ntl_batch *b, int k, int w, const ntl_index *ix, ntl_sketch **out);
+/* ... and made ONLY to be mapped against `ix` (what the pair stage does with a read batch, whose minimizers the reference
+ * never keeps either: bin/ntlink_pair.py:352-367 reads indexlr's lines off a pipe): the 16-byte records are not written.  A
+ * minimizer leaves its position in the read and its candidate, 12 bytes instead of 24 written by the emitter and read by the map
+ * kernels.  ntl_sketch_count / _wait / _nseq and ntl_map_run(ix, this sketch) work; ntl_sketch_download with a record column,
+ * ntl_index_build, ntl_overlap_filter and a map against another index answer NTL_EINVAL.  Mappings are those of the other forms. */
+int ntl_sketch_run_for_map(ntl_ctx *ctx, const ntl_batch *b, int k, int w, const ntl_index *ix, ntl_sketch **out);
+/* 0 for a sketch made by ntl_sketch_run_for_map. */
+int ntl_sketch_has_records(const ntl_sketch *s);
 void ntl_sketch_destroy(ntl_sketch *s);
 /* Waits until the sketch is complete; 0 or the error its completion met. */
 int ntl_sketch_wait(const ntl_sketch *s);

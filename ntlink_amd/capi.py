@@ -21,7 +21,7 @@ SYMBOLS = [
     "ntl_prof_enable", "ntl_prof_reset", "ntl_prof_get",
     "ntl_batch_create", "ntl_batch_create_packed", "ntl_batch_create_packed_at", "ntl_packed_words", "ntl_batch_destroy", "ntl_batch_nseq", "ntl_batch_bases", "ntl_host_alloc", "ntl_host_free",
     "ntl_synth_genome", "ntl_synth_slices", "ntl_batch_download",
-    "ntl_sketch_run", "ntl_sketch_run_indexed", "ntl_sketch_destroy", "ntl_sketch_nseq", "ntl_sketch_count", "ntl_sketch_download",
+    "ntl_sketch_run", "ntl_sketch_run_indexed", "ntl_sketch_run_for_map", "ntl_sketch_has_records", "ntl_sketch_destroy", "ntl_sketch_nseq", "ntl_sketch_count", "ntl_sketch_download",
     "ntl_sketch_strips", "ntl_sketch_redo_strips", "ntl_sketch_fallback_strips", "ntl_sketch_wait", "ntl_mapres_wait",
     "ntl_sketch_from_host", "ntl_overlap_filter",
     "ntl_index_build", "ntl_index_destroy", "ntl_index_size",
@@ -103,6 +103,8 @@ def load(path=None):
     L.ntl_batch_download.argtypes = [vp, vp, u64p]
     L.ntl_sketch_run.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]
     L.ntl_sketch_run_indexed.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
+    L.ntl_sketch_run_for_map.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
+    L.ntl_sketch_has_records.argtypes = [vp]
     L.ntl_sketch_destroy.argtypes = [vp]
     L.ntl_sketch_destroy.restype = None
     L.ntl_sketch_nseq.argtypes = [vp]
@@ -535,12 +537,15 @@ class Device:
                                           float(sub), float(ins), float(dele), C.byref(p)))
         return Batch(self, p)
 
-    def sketch(self, batch, k, w, index=None):
+    def sketch(self, batch, k, w, index=None, records=True):
         """index: the contig Index the sketch will be mapped against -- its minimizers are then looked up while they are emitted
-        and Device.map(index, sketch, ...) skips its lookup pass (same records either way)."""
+        and Device.map(index, sketch, ...) skips its lookup pass (same records either way).  records=False (with an index): the
+        sketch is made only for that map (ntl_sketch_run_for_map): no records to download."""
         p = C.c_void_p()
         if index is None:
             self._chk(self.L.ntl_sketch_run(self.ptr, batch.ptr, int(k), int(w), C.byref(p)))
+        elif not records:
+            self._chk(self.L.ntl_sketch_run_for_map(self.ptr, batch.ptr, int(k), int(w), index.ptr, C.byref(p)))
         else:
             self._chk(self.L.ntl_sketch_run_indexed(self.ptr, batch.ptr, int(k), int(w), index.ptr, C.byref(p)))
         return Sketch(self, p)

@@ -152,6 +152,12 @@ __device__ __forceinline__ uint2 ntl_lds_load2_ordered(const uint2 *p)
     return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
 }
 
+/* a read-only u64 array that is SAID to live in LDS: where a kernel reads the same table from LDS or from global memory by a uniform
+   flag, the compiler may merge the two reads into one through a selected generic pointer and then fails to lower its own cast
+   ("Illegal instruction detected ... $src_shared_base", ROCm 7.2) -- pointers of two address spaces cannot be merged */
+typedef __attribute__((address_space(3))) const uint64_t ntl_lds_cu64;
+#define NTL_LDS_CU64(p) ((ntl_lds_cu64 *)(p))
+
 /* hides a value's origin from the optimiser (no instruction) */
 #define NTL_OPAQUE(v) asm volatile("" : "+v"(v))
 

@@ -166,7 +166,8 @@ struct PafRec { uint32_t read, ctg, q_start, q_end, t_start, t_end, n_hits, stra
 #define MAP_GROUP 8  /* consecutive reads a wavefront looks at per step (small: a batch of 50 k reads must still fill the device) */
 
 struct MapArgs {
-    const MxRecord *mx;
+    const MxRecord *mx;     /* NULL for a sketch without records: positions in rpos, strands in the candidates (EmitArgs::rpos) */
+    const uint32_t *rpos;
     const uint32_t *mx_off; /* [nreads+1] */
     const Cand *cand;
     const uint32_t *read_len, *ctg_len;
@@ -338,16 +339,19 @@ __device__ __forceinline__ void map_read(const MapArgs &A, const uint32_t r, Hit
         const uint32_t i = c + lane;
         Cand cd;
         cd.cpos = 0; cd.meta = 0;
-        MxRecord mr;
-        mr.pos = 0; mr.meta = 0; mr.hash = 0;
-        if (i < nmx) { cd = A.cand[m0 + i]; mr = A.mx[m0 + i]; }
+        uint32_t rp = 0, rs = 0; /* the minimizer's position in the read, its strand */
+        if (i < nmx) {
+            cd = A.cand[m0 + i];
+            if (A.rpos) { rp = A.rpos[m0 + i]; rs = cd.meta >> 31; cd.meta &= 0x7FFFFFFFu; }
+            else { rp = A.mx[m0 + i].pos; rs = A.mx[m0 + i].meta & 1u; }
+        }
         bool v = (cd.meta & 1u) != 0;
         if (v && !P.repeat_filter) v = (int64_t)A.ctg_len[cd.meta >> 2] >= (int64_t)P.z;
         const unsigned long long bal = __ballot(v);
         if (v) {
             const uint32_t o = n + ntl_mbcnt(bal);
-            H.cf[o] = ((cd.meta >> 2) << HF_CTG_SHIFT) | ((cd.meta >> 1) & 1u) | ((mr.meta & 1u) << 1);
-            H.cpos[o] = cd.cpos; H.rpos[o] = mr.pos;
+            H.cf[o] = ((cd.meta >> 2) << HF_CTG_SHIFT) | ((cd.meta >> 1) & 1u) | (rs << 1);
+            H.cpos[o] = cd.cpos; H.rpos[o] = rp;
         }
         n += (uint32_t)__popcll(bal);
     }

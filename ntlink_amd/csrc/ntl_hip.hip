@@ -88,6 +88,8 @@ struct ntl_ctx {
     std::string err;
     std::string async_err;         /* first failure of work whose handle was already gone: reported by ntl_ctx_sync */
     std::string devname;
+    int skw_budget = 0;            /* two streams: chunks of strips a window wavefront takes before it ends (0: resident wavefronts), and */
+    int emit_wgs_per_cu = 0;       /* ... resident workgroups per CU of the emit kernel (0: one workgroup per tile) */
     int n_cu = 1;                  /* compute units of the device: the grid of a kernel whose wavefronts stay resident */
     std::map<const void *, int> occ; /* kernel -> workgroups one CU holds (hipOccupancyMaxActiveBlocksPerMultiprocessor, asked once) */
     bool prof = false;
@@ -1071,6 +1073,8 @@ struct ntl_sketch {
     /* ntl_sketch_run_indexed: the minimizers were looked up in index cand_gen while they were emitted */
     uint64_t cand_gen = 0;
     mutable DevBuf cand;    /* Cand[cap] */
+    bool no_records = false; /* ntl_sketch_run_for_map: `records` stays empty; positions in rpos, strands in the candidates */
+    mutable DevBuf rpos;    /* u32[cap] */
     mutable DevBuf rlen;    /* u32[nseq]: lengths of the sketched sequences (sketches made from a batch) */
     mutable DevBuf sums;    /* SketchSums on the device: total (read by the map kernels: a sketch that overflowed its arrays is left alone) */
     /* lazy completion */
@@ -1286,7 +1290,19 @@ static void launch_fast_r0(ntl_ctx *c, const Sketch2Args &B, unsigned strips)
                     unsigned wgs = (unsigned)std::max(1, use) * (unsigned)std::max(1, c->n_cu);
                     wgs = std::min(wgs, (strips + threads / 64u - 1u) / (threads / 64u));
                     wgs = (wgs + 7u) & ~7u;
-                    hipLaunchKernelGGL(kern, dim3(wgs), dim3(threads), 0, c->wstream, B);
+                    /* Two streams, NTL_SKW_BUDGET chunks per wavefront: short-lived workgroups, as many as it takes, that fill what
+                       the other stream's kernels leave free (those have the higher stream priority and a bounded number of
+                       resident workgroups: sketch_enqueue, emit) -- and the whole CU while that stream has nothing to run. */
+                    Sketch2Args Bq = B;
+                    int budget = c->pipelined ? c->skw_budget : 0;
+                    if (const char *e = getenv("NTL_SKW_BUDGET")) budget = atoi(e);
+                    if (budget >= 2) {
+                        const unsigned per_xcd_chunks = (((strips + 7u) >> 3) + SKW_CHUNK - 1u) / SKW_CHUNK;
+                        const unsigned per_wg = (threads / 64u) * (unsigned)budget;
+                        wgs = 8u * ((per_xcd_chunks + per_wg - 1u) / per_wg);
+                        Bq.chunk_budget = (uint32_t)budget;
+                    }
+                    hipLaunchKernelGGL(kern, dim3(wgs), dim3(threads), 0, c->wstream, Bq);
                 };
                 if (per_strip <= 175.0) { /* w >= 235 at ten candidates per window */
                     if (wave == 4) go(sketch_wave_kernel<4, 11, 4>, 256u);
@@ -1482,6 +1498,7 @@ static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const nt
             B.redo_count = redo.as<uint32_t>(); B.redo_list = redo.as<uint32_t>() + 2;
             B.fb_count = redo.as<uint32_t>() + 1; B.fb_list = redo.as<uint32_t>() + 2 + ub_strips + 1;
             B.chunk_next = redo.as<uint32_t>() + redo_words;
+            B.chunk_budget = 0;
             B.max_word = b->nwords_packed - 1;
             B.q16 = k / 16; B.r16 = k % 16;
             B.rev_a = (uint32_t)(k - 1) % 33u; B.rev_b = (uint32_t)(k - 1) % 31u;
@@ -1555,16 +1572,16 @@ static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const nt
     {
         ProfSpan sp(c, "sketch_emit");
         const uint64_t tiles = (nmask + EMIT_TILE - 1) / EMIT_TILE;
-        DevBuf tile_seq;
-        if ((rc = tile.alloc(c, tiles * 4)) || (rc = tile_seq.alloc(c, (tiles + 2) * 4))) return rc;
+        DevBuf tile_seq, tile_next;
+        if ((rc = tile.alloc(c, tiles * 4)) || (rc = tile_seq.alloc(c, (tiles + 2) * 4)) || (rc = tile_next.alloc(c, 8 * 16 * 4))) return rc;
         if (nseq)
             hipLaunchKernelGGL(tile_seq_kernel, dim3((unsigned)((nseq + 255) / 256)), dim3(256), 0, ms, (const uint64_t *)T.seq_base, (uint32_t)nseq,
                                tiles, tile_seq.as<uint32_t>());
         hipLaunchKernelGGL(mask_count_kernel, dim3((unsigned)tiles), dim3(EMIT_NT), 0, ms,
-                           (const uint32_t *)mask.p, nmask, tile.as<uint32_t>());
+                           (const uint32_t *)mask.p, nmask, tile.as<uint32_t>(), tile_next.as<uint32_t>());
         hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(SCAN_NT), 0, ms, tile.as<uint32_t>(), tiles, &dsums->total_mx, (uint64_t)0, (uint32_t *)nullptr);
         HIPCHK(c, hipGetLastError());
-        if ((rc = s->records.alloc(c, cap * sizeof(MxRecord)))) return rc;
+        if (s->no_records ? (rc = s->rpos.alloc(c, cap * 4)) : (rc = s->records.alloc(c, cap * sizeof(MxRecord)))) return rc;
         s->cap = cap;
         const int probe = !ix ? 0 : (ix->hit_fraction->load(std::memory_order_relaxed) <= 0.5f ? 1 : 2); /* tags first unless the last batch on this index mostly hit */
         if (ix) {
@@ -1582,18 +1599,31 @@ static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const nt
         E.g4 = (const uint64_t (*)[2])c->g4;
         E.g8 = (const uint64_t (*)[2])c->g8;
         E.slots = nullptr; E.tags = nullptr; E.special = nullptr; E.ix_bits = 0; E.cand = nullptr; E.nfound = nullptr;
+        E.rpos = s->no_records ? s->rpos.as<uint32_t>() : nullptr;
         if (ix) {
             E.slots = ix->slots.as<IndexSlot>(); E.tags = ix->tags.as<uint8_t>(); E.special = ix->special.as<IndexSpecial>();
             E.ix_bits = ix->bits; E.cand = s->cand.as<Cand>(); E.nfound = &dsums->nfound;
         }
         /* the emit kernel is the last reader of the bitmask and clears the words it read: the mask goes back clean */
+        /* Beside the window stage (two streams) the emit kernel keeps to a bounded number of resident workgroups that take their
+           tiles from counters -- the window kernel's short-lived workgroups fill what is left of a CU, all of it while this stream
+           is idle; alone: one workgroup per tile, as many resident as fit. */
+        E.ntiles = (uint32_t)tiles; E.tile_next = nullptr;
+        unsigned egrid = (unsigned)tiles;
+        {
+            int per_cu = c->pipelined ? c->emit_wgs_per_cu : 0;
+            if (const char *e = getenv("NTL_EMIT_WGS_PER_CU")) per_cu = atoi(e);
+            const uint64_t cap = (uint64_t)per_cu * (uint64_t)c->n_cu;
+            if (per_cu > 0 && cap >= 8 && cap < tiles) { egrid = (unsigned)cap; E.tile_next = tile_next.as<uint32_t>(); }
+            else if (per_cu < 0) { egrid = (unsigned)(-per_cu < 8 ? 8 : -per_cu); E.tile_next = tile_next.as<uint32_t>(); } /* tests: that many workgroups whatever the size */
+        }
         const char *eu = getenv("NTL_EMIT_U"); /* minimizers in flight per thread; read per call: the tests switch it inside one process */
         const int emit_u = eu ? atoi(eu) : 1;
-        if (probe == 0) hipLaunchKernelGGL((emit_kernel<0, 1>), dim3((unsigned)tiles), dim3(EMIT_NT), 0, ms, E);
-        else if (probe == 1 && emit_u >= 2) hipLaunchKernelGGL((emit_kernel<1, 2>), dim3((unsigned)tiles), dim3(EMIT_NT), 0, ms, E);
-        else if (probe == 1) hipLaunchKernelGGL((emit_kernel<1, 1>), dim3((unsigned)tiles), dim3(EMIT_NT), 0, ms, E);
-        else if (emit_u >= 2) hipLaunchKernelGGL((emit_kernel<2, 2>), dim3((unsigned)tiles), dim3(EMIT_NT), 0, ms, E);
-        else hipLaunchKernelGGL((emit_kernel<2, 1>), dim3((unsigned)tiles), dim3(EMIT_NT), 0, ms, E);
+        if (probe == 0) hipLaunchKernelGGL((emit_kernel<0, 1>), dim3(egrid), dim3(EMIT_NT), 0, ms, E);
+        else if (probe == 1 && emit_u >= 2) hipLaunchKernelGGL((emit_kernel<1, 2>), dim3(egrid), dim3(EMIT_NT), 0, ms, E);
+        else if (probe == 1) hipLaunchKernelGGL((emit_kernel<1, 1>), dim3(egrid), dim3(EMIT_NT), 0, ms, E);
+        else if (emit_u >= 2) hipLaunchKernelGGL((emit_kernel<2, 2>), dim3(egrid), dim3(EMIT_NT), 0, ms, E);
+        else hipLaunchKernelGGL((emit_kernel<2, 1>), dim3(egrid), dim3(EMIT_NT), 0, ms, E);
         HIPCHK(c, hipGetLastError());
         mask.clean = sev_get(c);
         if (mask.clean) HIPCHK(c, hipEventRecord(mask.clean, ms));
@@ -1623,7 +1653,7 @@ static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const nt
     return NTL_OK;
 }
 
-static int sketch_run_impl(ntl_ctx *c, const ntl_batch *b, int k, int w, const ntl_index *ix, ntl_sketch **out)
+static int sketch_run_impl(ntl_ctx *c, const ntl_batch *b, int k, int w, const ntl_index *ix, ntl_sketch **out, bool no_records = false)
 {
     if (!c || !b || !out) return NTL_EINVAL;
     *out = nullptr;
@@ -1633,6 +1663,7 @@ static int sketch_run_impl(ntl_ctx *c, const ntl_batch *b, int k, int w, const n
     if ((rc = sketch_geometry(c, k, w, G, C, nt))) return rc;
     ntl_sketch *s = new ntl_sketch();
     s->c = c; s->nseq = b->nseq; s->k = k; s->w = w; s->src_ix = ix;
+    s->no_records = no_records && ix;
     if (ix) ix->refs++;
     s->done = sev_get(c);
     s->slot = slot_get(c);
@@ -1700,6 +1731,18 @@ extern "C" int ntl_sketch_run_indexed(ntl_ctx *c, const ntl_batch *b, int k, int
     return sketch_run_impl(c, b, k, w, ix, out);
 }
 
+/* ... and made ONLY for ntl_map_run(ix, this sketch): the 16-byte records are never written (a minimizer leaves its position in
+ * the read and its candidate: 12 bytes instead of 24 written here and read by the map kernels).  Everything that needs the records
+ * (download, index build, overlap filter, a map against another index) answers NTL_EINVAL. */
+extern "C" int ntl_sketch_run_for_map(ntl_ctx *c, const ntl_batch *b, int k, int w, const ntl_index *ix, ntl_sketch **out)
+{
+    if (!ix) return NTL_EINVAL;
+    if (ix->c->device != c->device) return fail(c, NTL_EINVAL, "the index lives on another device");
+    return sketch_run_impl(c, b, k, w, ix, out, true);
+}
+
+extern "C" int ntl_sketch_has_records(const ntl_sketch *s) { return s && !s->no_records; }
+
 extern "C" void ntl_sketch_destroy(ntl_sketch *s) { sketch_unref(s); }
 extern "C" int ntl_sketch_wait(const ntl_sketch *s) { return s ? sketch_finalize(s) : NTL_EINVAL; }
 extern "C" uint64_t ntl_sketch_nseq(const ntl_sketch *s) { return s ? s->nseq : 0; }
@@ -1715,15 +1758,17 @@ extern "C" int ntl_sketch_download(const ntl_sketch *s, uint64_t *mx_off, uint64
     (void)hipSetDevice(c->device);
     int rc = sketch_finalize(s);
     if (rc) return rc;
+    if (s->no_records && (hash || pos || strand)) return fail(c, NTL_EINVAL, "a sketch made by ntl_sketch_run_for_map holds no records");
     const size_t off_bytes = ((s->nseq + 1) * 4 + 63) & ~(size_t)63;
     void *tmp = nullptr;
-    if ((rc = host_tmp(c, off_bytes + s->count * sizeof(MxRecord), &tmp))) return rc;
+    if ((rc = host_tmp(c, off_bytes + (s->no_records ? 0 : s->count * sizeof(MxRecord)), &tmp))) return rc;
     const uint32_t *off = (const uint32_t *)tmp;
     const MxRecord *rec = (const MxRecord *)((const char *)tmp + off_bytes);
     HIPCHK(c, hipMemcpyAsync(tmp, s->mx_off.p, (s->nseq + 1) * 4, hipMemcpyDeviceToHost, c->stream));
-    if (s->count) HIPCHK(c, hipMemcpyAsync((void *)rec, s->records.p, s->count * sizeof(MxRecord), hipMemcpyDeviceToHost, c->stream));
+    if (s->count && !s->no_records) HIPCHK(c, hipMemcpyAsync((void *)rec, s->records.p, s->count * sizeof(MxRecord), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (mx_off) for (uint64_t i = 0; i <= s->nseq; i++) mx_off[i] = off[i];
+    if (s->no_records) return NTL_OK;
     /* records -> the caller's column arrays, split over threads */
     unsigned nthr = std::thread::hardware_concurrency();
     nthr = nthr == 0 ? 1 : std::min(nthr, 16u);
@@ -1809,6 +1854,7 @@ extern "C" int ntl_overlap_filter(ntl_ctx *c, const ntl_sketch *s, const uint64_
     if (!c || !s || !region_off || !out) return NTL_EINVAL;
     *out = nullptr;
     (void)hipSetDevice(c->device);
+    if (s->no_records) return fail(c, NTL_EINVAL, "a sketch made by ntl_sketch_run_for_map holds no records");
     if (int frc = sketch_finalize(s)) return frc;
     const uint64_t nseq = s->nseq, n = s->count;
     const uint64_t nreg = region_off[nseq];
@@ -1875,6 +1921,7 @@ extern "C" int ntl_index_build(ntl_ctx *c, const ntl_sketch *ctg, const uint32_t
     if (!c || !ctg || !out || (!ctg_len && n_ctg)) return NTL_EINVAL;
     *out = nullptr;
     if ((uint64_t)n_ctg != ctg->nseq) return fail(c, NTL_EINVAL, "n_ctg must equal the number of sketched contigs");
+    if (ctg->no_records) return fail(c, NTL_EINVAL, "a sketch made by ntl_sketch_run_for_map holds no records");
     if (n_ctg >= (1u << 29)) return fail(c, NTL_EINVAL, "too many contigs"); /* contig id << 3 | flags in one word (map_kernels.h) */
     (void)hipSetDevice(c->device);
     if (int frc = sketch_finalize(ctg)) return frc; /* the table is sized from the number of contig minimizers */
@@ -1968,6 +2015,7 @@ static int map_enqueue(ntl_ctx *c, const ntl_index *ix, const ntl_sketch *reads,
 {
     const uint64_t nreads = reads->nseq;
     const bool have_cand = reads->cand_gen == ix->gen && reads->cand.p != nullptr;
+    if (reads->no_records && !have_cand) return fail(c, NTL_EINVAL, "a sketch made by ntl_sketch_run_for_map maps against the index it was made for only");
     if (!have_cand) { /* the lookup pass runs over the records: their number sizes its grid */
         if (int frc = sketch_finalize(reads)) return frc;
     }
@@ -2008,7 +2056,8 @@ static int map_enqueue(ntl_ctx *c, const ntl_index *ix, const ntl_sketch *reads,
         HIPCHK(c, hipGetLastError());
     }
     MapArgs A;
-    A.mx = reads->records.as<MxRecord>(); A.mx_off = reads->mx_off.as<uint32_t>();
+    A.mx = reads->no_records ? nullptr : reads->records.as<MxRecord>(); A.mx_off = reads->mx_off.as<uint32_t>();
+    A.rpos = reads->no_records ? reads->rpos.as<uint32_t>() : nullptr;
     A.cand = have_cand ? reads->cand.as<Cand>() : cand.as<Cand>();
     A.read_len = d_rlen; A.ctg_len = ix->ctg_len.as<uint32_t>(); A.nreads = (uint32_t)nreads;
     A.P.k = params->k; A.P.z = params->z; A.P.x = params->x; A.P.sensitive = params->sensitive;
@@ -2027,9 +2076,14 @@ static int map_enqueue(ntl_ctx *c, const ntl_index *ix, const ntl_sketch *reads,
             /* reads by size class, each class with the LDS staging that fits it; resident-size grids (28 / 14 / 8 wavefronts
                per CU fit) looping over all reads, 64 at a time */
             const uint64_t groups = (nreads + MAP_GROUP - 1) / MAP_GROUP;
-            hipLaunchKernelGGL((map_kernel<256, 64, 0>), dim3((unsigned)std::min<uint64_t>(groups, 4 * 7168)), dim3(MAP_NT), 0, ms, A);
-            hipLaunchKernelGGL((map_kernel<512, 128, 1>), dim3((unsigned)std::min<uint64_t>(groups, 4 * 3584)), dim3(MAP_NT), 0, ms, A);
-            hipLaunchKernelGGL((map_kernel<1024, 128, 2>), dim3((unsigned)std::min<uint64_t>(groups, 4 * 2048)), dim3(MAP_NT), 0, ms, A);
+            uint64_t g0 = 4 * 7168, g1 = 4 * 3584, g2 = 4 * 2048;
+            if (const char *e = getenv("NTL_MAP_WAVES_PER_CU")) { /* tuning: a bounded number of resident wavefronts beside the window stage */
+                const uint64_t cap = (uint64_t)std::max(1, atoi(e)) * (uint64_t)std::max(1, c->n_cu);
+                g0 = std::min(g0, cap); g1 = std::min(g1, cap); g2 = std::min(g2, cap);
+            }
+            hipLaunchKernelGGL((map_kernel<256, 64, 0>), dim3((unsigned)std::min<uint64_t>(groups, g0)), dim3(MAP_NT), 0, ms, A);
+            hipLaunchKernelGGL((map_kernel<512, 128, 1>), dim3((unsigned)std::min<uint64_t>(groups, g1)), dim3(MAP_NT), 0, ms, A);
+            hipLaunchKernelGGL((map_kernel<1024, 128, 2>), dim3((unsigned)std::min<uint64_t>(groups, g2)), dim3(MAP_NT), 0, ms, A);
             /* reads with more hits / runs than the largest staging holds (rare): same code on global scratch */
             hipLaunchKernelGGL(map_overflow_kernel, dim3((unsigned)std::min<uint64_t>(nreads, 8192)), dim3(MAP_NT), 0, ms, A); /* no LDS: 32 wavefronts per CU resident */
             HIPCHK(c, hipGetLastError());

@@ -74,6 +74,7 @@ struct Sketch2Args {
     uint32_t *fb_list;     /* sketch_thresh_kernel: the strips it gives up, for sketch_fast_list_kernel */
     uint32_t *fb_count;
     uint32_t *chunk_next;  /* sketch_wave_kernel: [16 x] = the next chunk of strips of XCD x's share that nobody has taken yet (zeroed per launch) */
+    uint32_t chunk_budget; /* sketch_wave_kernel: 0 = resident wavefronts that take chunks until none is left; else chunks per wavefront (>= 2) */
 };
 
 __device__ __forceinline__ uint32_t sk2_bases16(const uint32_t *__restrict__ packed, uint64_t gp, uint64_t max_word)
@@ -1328,11 +1329,18 @@ __global__ __launch_bounds__(64 * WAVES, WAVES >= 8 ? 8 : 7) void sketch_wave_ke
     if (L == 0) ahead = atomicAdd(counter, 2u);
     uint32_t chunk = lo + SKW_CHUNK * ntl_readfirstlane(ahead), sub = 0;
     ahead = chunk + SKW_CHUNK; /* (the first take covered two chunks) */
+    /* chunk_budget != 0: a wavefront takes that many chunks (>= 2) and ends -- workgroups that live for a fraction of the launch, in a
+       grid of as many as it takes: beside the other stream's kernels (which have the higher priority and a bounded number of resident
+       workgroups of their own) they fill whatever a CU has free, all of it while that stream is idle (ntl_hip.hip, launch_fast_r0) */
+    uint32_t left = B.chunk_budget ? B.chunk_budget - 2u : 0xFFFFFFFFu;
     auto next_strip = [&]() -> uint32_t {
         if (sub == SKW_CHUNK) {
             chunk = ntl_readfirstlane(ahead);
             sub = 0;
-            if (L == 0) ahead = lo + SKW_CHUNK * atomicAdd(counter, 1u); /* asked for a whole chunk before it is needed */
+            if (left) {
+                left--;
+                if (L == 0) ahead = lo + SKW_CHUNK * atomicAdd(counter, 1u); /* asked for a whole chunk before it is needed */
+            } else ahead = 0xFFFFFFF0u; /* no strip */
         }
         const uint32_t s = chunk + sub;
         sub++;

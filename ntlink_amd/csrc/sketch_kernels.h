@@ -430,9 +430,10 @@ struct MxRecord {
 
 /* pass 1 of the rank scan: set bits per tile */
 __global__ __launch_bounds__(EMIT_NT) void mask_count_kernel(const uint32_t *mask, uint64_t nwords,
-                                                             uint32_t *tile_cnt)
+                                                             uint32_t *tile_cnt, uint32_t *tile_next)
 {
     __shared__ uint32_t s_tmp[EMIT_NT];
+    if (tile_next && blockIdx.x == 0 && threadIdx.x < 8) tile_next[16 * threadIdx.x] = 0u; /* the emit kernel's tile counters (EmitArgs) */
     const uint64_t w0 = (uint64_t)blockIdx.x * EMIT_TILE + (uint64_t)threadIdx.x * EMIT_WPT;
     uint32_t c = 0;
     if (w0 + EMIT_WPT <= nwords) { /* the thread's eight words as two 16-byte loads (the array is 16-byte aligned, w0 a multiple of 8) */
@@ -485,12 +486,32 @@ struct EmitArgs {
     int ix_bits;
     Cand *cand;
     unsigned long long *nfound;
+    /* not NULL (ntl_sketch_run_for_map): the sketch will only ever be mapped against this index -- no 16-byte records; the map
+       kernels need a minimizer's position in the read (here, 4 bytes) and its strand (bit 31 of the candidate's meta: contig ids
+       stay below 2^29) and nothing else: 12 bytes written and read per minimizer instead of 24 */
+    uint32_t *rpos;
+    /* The grid need not hold a workgroup per tile: a workgroup walks over tiles.  tile_next = NULL: tiles blockIdx.x, + gridDim.x, ...;
+       else eight counters 16 words apart (zeroed by mask_count_kernel): a workgroup of residue x = blockIdx.x % 8 takes tiles
+       8 t + x, t = 0, 1, ... from counter x -- beside the window stage's kernel the emit kernel runs with a bounded number of
+       resident workgroups, and where those land (and how fast each one is) is not known in advance */
+    uint32_t ntiles;
+    uint32_t *tile_next;
 };
 
 #define EMIT_SEQ_CAP 512 /* sequence starts of one tile cached in LDS */
 
 /* largest s in [lo, hi) with base[s] <= gp */
 __device__ __forceinline__ uint32_t seq_of(const uint64_t *base, uint32_t lo, uint32_t hi, uint64_t gp)
+{
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (base[mid] <= gp) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+/* the same on a table in LDS (dev_intrin.h, ntl_lds_cu64) */
+__device__ __forceinline__ uint32_t seq_of_lds(ntl_lds_cu64 *base, uint32_t lo, uint32_t hi, uint64_t gp)
 {
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
@@ -509,18 +530,28 @@ __global__ __launch_bounds__(EMIT_NT) void emit_kernel(EmitArgs A)
     __shared__ uint16_t s_wrank[EMIT_TILE]; /* set bits of the tile before each of its words */
     __shared__ uint64_t s_seed[4][2];
     __shared__ uint64_t s_base[EMIT_SEQ_CAP];
+    ntl_lds_cu64 *const base_lds = NTL_LDS_CU64(s_base); /* every read of s_base goes through it */
     __shared__ uint32_t s_range[2];
     __shared__ uint64_t s_g4[256][2]; /* four-base init table: LDS copy (EMIT_NT == 256 entries) */
+    __shared__ uint32_t s_tile;
     const int t = threadIdx.x;
     if (t < 4) { s_seed[t][0] = A.seed_tab[t][0]; s_seed[t][1] = A.seed_tab[t][1]; }
     s_g4[t][0] = A.g4[t][0];
     s_g4[t][1] = A.g4[t][1];
-    const uint64_t tile_w0 = (uint64_t)blockIdx.x * EMIT_TILE;
+    uint32_t tile = blockIdx.x;
+    for (bool first_tile = true;; first_tile = false) {
+    if (A.tile_next) {
+        if (t == 0) s_tile = 8u * atomicAdd(&A.tile_next[16u * (blockIdx.x & 7u)], 1u) + (blockIdx.x & 7u);
+        __syncthreads(); /* (its next write lies behind the barriers of the tile's work) */
+        tile = s_tile;
+    } else if (!first_tile) tile += gridDim.x;
+    if (tile >= A.ntiles) break;
+    const uint64_t tile_w0 = (uint64_t)tile * EMIT_TILE;
     /* Sequences that overlap this tile of 65536 base positions: from the one its first position lies in to the one the next
        tile's first position lies in (tile_seq_kernel); their starts are cached in LDS.  More than EMIT_SEQ_CAP of them (tiny
        sequences) falls back to binary searches in global memory. */
-    const uint32_t s_lo = A.nseq ? A.tile_seq[blockIdx.x] : 0u;
-    const uint32_t s_hi = A.nseq ? A.tile_seq[blockIdx.x + 1] + 1u : 0u; /* candidates [s_lo, s_hi) */
+    const uint32_t s_lo = A.nseq ? A.tile_seq[tile] : 0u;
+    const uint32_t s_hi = A.nseq ? A.tile_seq[tile + 1] + 1u : 0u; /* candidates [s_lo, s_hi) */
     const uint64_t gp_last = tile_w0 * 32 + (uint64_t)EMIT_TILE * 32 - 1;
     const bool cached = s_hi - s_lo <= EMIT_SEQ_CAP;
     const uint32_t ncache = cached ? s_hi - s_lo : EMIT_SEQ_CAP;
@@ -540,7 +571,7 @@ __global__ __launch_bounds__(EMIT_NT) void emit_kernel(EmitArgs A)
     for (int i = 0; i < EMIT_WPT; i++) c += (uint32_t)__popc(words[i]);
     uint32_t total;
     const uint32_t excl = block_excl_scan<EMIT_NT>(c, s_tmp, total);
-    const uint32_t tile_base = A.tile_off[blockIdx.x];
+    const uint32_t tile_base = A.tile_off[tile];
     NTL_PRIO_LATENCY_BOUND(); /* (behind the scan: in front of the shared arrays' first use it trips the compiler's address-space lowering) */
     {
         uint32_t r = excl;
@@ -556,7 +587,7 @@ __global__ __launch_bounds__(EMIT_NT) void emit_kernel(EmitArgs A)
     {
         const uint64_t gp0 = tile_w0 * 32;
         for (uint32_t s = s_lo + (uint32_t)t; s <= A.nseq; s += EMIT_NT) {
-            const uint64_t g = s - s_lo < ncache ? s_base[s - s_lo] : A.seq_base[s];
+            const uint64_t g = s - s_lo < ncache ? base_lds[s - s_lo] : A.seq_base[s];
             if (g > gp_last) break; /* starts are sorted: nothing further for this thread */
             if (g < gp0) continue;  /* s_lo itself may start before the tile */
             const uint32_t wl = (uint32_t)((g >> 5) - tile_w0), b = (uint32_t)g & 31u;
@@ -589,8 +620,8 @@ __global__ __launch_bounds__(EMIT_NT) void emit_kernel(EmitArgs A)
                 const uint32_t i = i0 + (uint32_t)u * EMIT_NT;
                 const uint32_t ic = i < n ? i : i0; /* past the end: the first one again, result dropped */
                 const uint64_t gp = tile_w0 * 32 + s_list[ic];
-                const uint32_t sq = cached ? s_lo + seq_of(s_base, 0, s_hi - s_lo, gp) : seq_of(A.seq_base, s_lo, s_hi, gp);
-                const uint64_t sb = cached ? s_base[sq - s_lo] : A.seq_base[sq];
+                const uint32_t sq = cached ? s_lo + seq_of_lds(base_lds, 0, s_hi - s_lo, gp) : seq_of(A.seq_base, s_lo, s_hi, gp);
+                const uint64_t sb = cached ? base_lds[sq - s_lo] : A.seq_base[sq];
                 uint64_t fwd, rev;
                 hash_init_g4(A.packed, gp, A.k, s_g4, s_seed, fwd, rev);
                 uint64_t h = (fwd + rev) * A.mult;
@@ -609,8 +640,12 @@ __global__ __launch_bounds__(EMIT_NT) void emit_kernel(EmitArgs A)
                 for (int u = 0; u < U; u++) {
                     if (!ok[u]) continue;
                     const uint32_t at = tile_base + r0 + i0 + (uint32_t)u * EMIT_NT;
-                    A.out[at] = R[u];
-                    const Cand cd = pr[u].finish(tt[u], A.slots, A.tags, A.special, ((uint64_t)1 << A.ix_bits) - 1);
+                    if (!A.rpos) A.out[at] = R[u];
+                    Cand cd = pr[u].finish(tt[u], A.slots, A.tags, A.special, ((uint64_t)1 << A.ix_bits) - 1);
+                    if (A.rpos) {
+                        A.rpos[at] = R[u].pos;
+                        cd.meta |= R[u].meta << 31;
+                    }
                     A.cand[at] = cd;
                     found += cd.meta & 1u;
                 }
@@ -636,6 +671,7 @@ __global__ __launch_bounds__(EMIT_NT) void emit_kernel(EmitArgs A)
                 if (words[i]) A.mask[w0 + i] = 0u;
         }
     }
+    } /* tiles */
     if (PROBE) { /* one atomic per workgroup */
         __syncthreads();
         if (t == 0) s_range[0] = 0;

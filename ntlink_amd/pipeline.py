@@ -407,7 +407,7 @@ def _map_batches(dev, ix, batches, drain, stats, t_mark, w, first=None, text=Non
                     t_up = time.perf_counter()
                     dev.pinned_release(rs_.pinned if rs_.packed is not None else rs_.buf)  # on the device: the reader may refill it
                     rs_.buf = rs_.packed = rs_.pinned = None
-                    with wdev.sketch(rb, map_kw["k"], w, index=ix) as rsk:
+                    with wdev.sketch(rb, map_kw["k"], w, index=ix, records=False) as rsk:  # made for this map only: no records
                         t_sk = time.perf_counter()
                         with wdev.map(ix, rsk, rl, **map_kw) as res:
                             t_mp = time.perf_counter()

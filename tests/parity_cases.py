@@ -5,6 +5,7 @@ import os
 import numpy as np
 
 import oracle
+from ntlink_amd import capi
 from helpers import REF, contig_ids, load_scenario, parse_indexlr
 
 
@@ -453,9 +454,28 @@ def check_probe_forms(dev, contigs, reads, k, w, **kw):
                     ioff, ih, ip, istr = isk.download()
                     assert ires.n_index_hits == res.n_index_hits
                 assert np.array_equal(ioff, roff) and np.array_equal(ih, rh) and np.array_equal(ip, rp) and np.array_equal(istr, rstr)
+                # ... and the one made for this map only (ntl_sketch_run_for_map: positions and strands without the records)
+                with dev.sketch(rb, k, w, index=ix, records=False) as lsk, dev.map(ix, lsk, rlen, k=k, **kw) as lres:
+                    got3 = lres.download()
+                    assert lres.n_index_hits == res.n_index_hits and lsk.count == rsk.count
+                    for bad in (lambda: lsk.download(), lambda: dev.index(lsk, rlen)):
+                        try:
+                            bad()
+                        except capi.NtlError as exc:
+                            assert exc.code == capi.NTL_EINVAL
+                        else:
+                            raise AssertionError("a sketch without records handed out records")
+                    with dev.index(csk, ctg_len) as other:  # another index, even of the same contigs: not the one it was made for
+                        try:
+                            dev.map(other, lsk, rlen, k=k, **kw)
+                        except capi.NtlError as exc:
+                            assert exc.code == capi.NTL_EINVAL
+                        else:
+                            raise AssertionError("a sketch without records was mapped against another index")
             exp = oracle.map_reads(oix, ctg_len, roff, rlen, rh, rp, rstr, threads=0, k=k, **kw)
             assert_same_records(got, exp)
             assert_same_records(got2, exp)
+            assert_same_records(got3, exp)
     return fractions
 
 

@@ -97,6 +97,8 @@ inline void ntl_wave_sync() { pthread_barrier_wait(&sim::cur->wbar[sim::tid >> 6
 inline uint32_t ntl_readfirstlane(uint32_t v) { return __shfl(v, 0); }
 inline uint4 ntl_load4_a4(const uint32_t *p) { return make_uint4(p[0], p[1], p[2], p[3]); }
 inline uint2 ntl_lds_load2_ordered(const uint2 *p) { return *p; }
+typedef const uint64_t ntl_lds_cu64;
+#define NTL_LDS_CU64(p) ((ntl_lds_cu64 *)(p))
 #define NTL_OPAQUE(v) ((void)(v))
 template <int T> inline void ntl_lds_push_tagged(uint32_t *&p, uint32_t mask, uint32_t v) { *p++ = (v & ~mask) | (uint32_t)T; }
 inline uint32_t ntl_min3(uint32_t a, uint32_t b, uint32_t c) { const uint32_t m = a < b ? a : b; return m < c ? m : c; }

@@ -5,6 +5,7 @@ durations of both runs side by side.  usage: tools/e2e_first.py [--bases 16e9]""
 import argparse
 import json
 import os
+import resource
 import shutil
 import sys
 import tempfile
@@ -12,7 +13,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("NTL_PIPE_TRACE", "/tmp/ntl_pipe_trace.tsv")
+os.environ["NTL_PIPE_TRACE"] = os.path.abspath(os.environ.get("NTL_PIPE_TRACE", "/tmp/ntl_pipe_trace.tsv"))  # (run_pair is called from the data directory)
 import bench  # noqa: E402
 from ntlink_amd import capi, pipeline, synth  # noqa: E402
 
@@ -43,9 +44,14 @@ try:
             if f.startswith("asm.fa."):
                 os.remove(os.path.join(d, f))
         pipeline._TRACE.clear()
+        ru0 = resource.getrusage(resource.RUSAGE_SELF)
         t0 = time.perf_counter()
         st = pipeline.run_pair(dev, "asm.fa", " ".join(files), k=W["k"], w=W["w"], paf=True, pairs_tsv=True, sensitive=W["sensitive"])
         dt = time.perf_counter() - t0
+        ru1 = resource.getrusage(resource.RUSAGE_SELF)
+        rusage = {"user_s": round(ru1.ru_utime - ru0.ru_utime, 3), "sys_s": round(ru1.ru_stime - ru0.ru_stime, 3),
+                  "minor_faults": ru1.ru_minflt - ru0.ru_minflt, "voluntary_switches": ru1.ru_nvcsw - ru0.ru_nvcsw,
+                  "involuntary_switches": ru1.ru_nivcsw - ru0.ru_nivcsw}
         ev = {}
         for ln in open(os.environ["NTL_PIPE_TRACE"]):
             if ln.startswith("#"):
@@ -55,7 +61,7 @@ try:
         starts = {s: t for t, _, s in ev.get("dev_start", [])}
         dones = {s: t for t, _, s in ev.get("dev_done", [])}
         per_batch = [round(dones[s] - starts[s], 3) for s in sorted(starts) if s in dones]
-        out.append({"run": run, "seconds": round(dt, 3), "first_dev_start": round(min(starts.values()), 3) if starts else None,
+        out.append({"run": run, "seconds": round(dt, 3), "rusage": rusage, "first_dev_start": round(min(starts.values()), 3) if starts else None,
                     "last_dev_done": round(max(dones.values()), 3) if dones else None, "device_stage_s_per_batch": per_batch,
                     "t_contigs": st["t_contigs"], "t_contigs_parts": st.get("t_contigs_parts"), "t_device_parts": st.get("t_device_parts"),
                     "t_ingest": round(st["t_ingest"], 3), "t_write": round(st.get("t_write", 0), 3), "reader": st.get("reader"),
