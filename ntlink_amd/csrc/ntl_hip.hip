@@ -88,8 +88,7 @@ struct ntl_ctx {
     std::string err;
     std::string async_err;         /* first failure of work whose handle was already gone: reported by ntl_ctx_sync */
     std::string devname;
-    int skw_budget = 0;            /* two streams: chunks of strips a window wavefront takes before it ends (0: resident wavefronts), and */
-    int emit_wgs_per_cu = 0;       /* ... resident workgroups per CU of the emit kernel (0: one workgroup per tile) */
+    int skw_budget = 0;            /* two streams: chunks of strips a window wavefront takes before it ends (0: resident wavefronts; tuning) */
     int n_cu = 1;                  /* compute units of the device: the grid of a kernel whose wavefronts stay resident */
     std::map<const void *, int> occ; /* kernel -> workgroups one CU holds (hipOccupancyMaxActiveBlocksPerMultiprocessor, asked once) */
     bool prof = false;
@@ -1605,13 +1604,16 @@ static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const nt
             E.ix_bits = ix->bits; E.cand = s->cand.as<Cand>(); E.nfound = &dsums->nfound;
         }
         /* the emit kernel is the last reader of the bitmask and clears the words it read: the mask goes back clean */
-        /* Beside the window stage (two streams) the emit kernel keeps to a bounded number of resident workgroups that take their
-           tiles from counters -- the window kernel's short-lived workgroups fill what is left of a CU, all of it while this stream
-           is idle; alone: one workgroup per tile, as many resident as fit. */
+        /* Beside the window stage (two streams) the emit kernel may keep to a bounded number of resident workgroups that take
+           their tiles from counters; alone: one workgroup per tile, as many resident as fit. */
         E.ntiles = (uint32_t)tiles; E.tile_next = nullptr;
         unsigned egrid = (unsigned)tiles;
         {
-            int per_cu = c->pipelined ? c->emit_wgs_per_cu : 0;
+            /* the direct-slot form (most lookups hit: one random 64-byte line from HBM per minimizer) is bound by the rate of those
+               transactions and gains nothing beyond 12 wavefronts per CU, while the slots it holds are missed by the map kernels
+               and the window stage: C5 296-300 -> 269-271 ms per step at 3 workgroups per CU, 275 at 5, 280 at 4 with other window
+               grids (profiles/r04_share_sweep_C5.jsonl); the tag form (C3) is as fast uncapped (74.4-75.0 against 74.9-75.9) */
+            int per_cu = c->pipelined && probe == 2 ? 3 : 0;
             if (const char *e = getenv("NTL_EMIT_WGS_PER_CU")) per_cu = atoi(e);
             const uint64_t cap = (uint64_t)per_cu * (uint64_t)c->n_cu;
             if (per_cu > 0 && cap >= 8 && cap < tiles) { egrid = (unsigned)cap; E.tile_next = tile_next.as<uint32_t>(); }
