@@ -121,13 +121,67 @@ struct ntl_ctx {
 };
 #define NTL_NSLOTS 512u
 
+/* Page-locked host memory.  Large blocks are an anonymous mapping on 2-MB boundaries that asks for transparent huge pages and is then
+ * registered with the runtime: 6.5 ms per 146-MB staging buffer against 33-38 ms for hipHostMalloc, same DMA rate (54 GB/s) --
+ * tools/pin_bench.py, profiles/r04_pin_bench.txt; a process's first pass page-locks 1.4 GB of them.  Small blocks, and whatever the
+ * mapping or the registration refuses: hipHostMalloc. */
+#ifndef NTL_SIM
+#include <sys/mman.h>
+static std::mutex g_pin_mu;
+static std::map<void *, std::pair<void *, size_t>> g_pin_maps; /* registered pointer -> (mapping, its length) */
+#endif
+
+static hipError_t pin_alloc(void **out, size_t bytes)
+{
+#ifndef NTL_SIM
+    static const bool off = getenv("NTL_PIN_HOSTMALLOC") != nullptr; /* A/B */
+    if (bytes >= ((size_t)4 << 20) && !off) {
+        const size_t huge = (size_t)2 << 20, len = ((bytes + huge - 1) & ~(huge - 1)) + huge;
+        void *base = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (base != MAP_FAILED) {
+            void *p = (void *)(((uintptr_t)base + huge - 1) & ~(uintptr_t)(huge - 1));
+            (void)madvise(p, len - huge, MADV_HUGEPAGE);
+            if (hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess) {
+                std::lock_guard<std::mutex> g(g_pin_mu);
+                g_pin_maps[p] = {base, len};
+                *out = p;
+                return hipSuccess;
+            }
+            (void)hipGetLastError();
+            munmap(base, len);
+        }
+    }
+#endif
+    return hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault);
+}
+
+static void pin_free(void *p)
+{
+    if (!p) return;
+#ifndef NTL_SIM
+    {
+        std::unique_lock<std::mutex> g(g_pin_mu);
+        auto it = g_pin_maps.find(p);
+        if (it != g_pin_maps.end()) {
+            const std::pair<void *, size_t> m = it->second;
+            g_pin_maps.erase(it);
+            g.unlock();
+            (void)hipHostUnregister(p);
+            munmap(m.first, m.second);
+            return;
+        }
+    }
+#endif
+    (void)hipHostFree(p);
+}
+
 static int host_tmp(ntl_ctx *c, size_t bytes, void **out)
 {
     if (c->host_tmp_cap < bytes) {
-        if (c->host_tmp) (void)hipHostFree(c->host_tmp);
+        if (c->host_tmp) pin_free(c->host_tmp);
         c->host_tmp = nullptr; c->host_tmp_cap = 0;
         const size_t cap = bytes + bytes / 4 + 4096;
-        if (hipHostMalloc(&c->host_tmp, cap, hipHostMallocDefault) != hipSuccess) {
+        if (pin_alloc(&c->host_tmp, cap) != hipSuccess) {
             c->host_tmp = nullptr;
             c->err = "hipHostMalloc failed";
             return NTL_ENOMEM;
@@ -529,7 +583,7 @@ extern "C" void ntl_ctx_destroy(ntl_ctx *c)
     for (auto &kv : c->g8k) (void)hipFree(kv.second);
     for (auto &sl : c->slabs) (void)hipFree(sl.first);
     c->slabs.clear();
-    if (c->host_tmp) (void)hipHostFree(c->host_tmp);
+    if (c->host_tmp) pin_free(c->host_tmp);
     if (c->slots) (void)hipHostFree(c->slots);
     for (auto &kv : c->profs)
         for (auto &sp : kv.second.spans) { (void)hipEventDestroy(sp.first); (void)hipEventDestroy(sp.second); }
@@ -893,7 +947,7 @@ extern "C" int ntl_host_alloc(ntl_ctx *c, uint64_t bytes, void **out)
     if (!c || !out) return NTL_EINVAL;
     *out = nullptr;
     (void)hipSetDevice(c->device);
-    HIPCHK(c, hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    HIPCHK(c, pin_alloc(out, bytes));
     return NTL_OK;
 }
 
@@ -901,7 +955,7 @@ extern "C" void ntl_host_free(ntl_ctx *c, void *p)
 {
     if (!c || !p) return;
     (void)hipSetDevice(c->device);
-    (void)hipHostFree(p);
+    pin_free(p);
 }
 extern "C" uint64_t ntl_batch_nseq(const ntl_batch *b) { return b ? b->nseq : 0; }
 extern "C" uint64_t ntl_batch_bases(const ntl_batch *b) { return b ? b->bases : 0; }

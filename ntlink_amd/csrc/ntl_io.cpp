@@ -780,6 +780,7 @@ extern "C" int ntl_fastx_open(const char *path, ntl_fastx **out)
                read on their own (ntl_fastx_open_range) */
             size_t bs = 0, is = 0;
             void *m = (hn >= 28 && (head[3] & 4)) ? mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0) : MAP_FAILED;
+            if (m != MAP_FAILED) (void)madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
             if (m != MAP_FAILED && bgzf_member((const unsigned char *)m, (size_t)st.st_size, 0, &bs, &is) && !getenv("NTL_IO_NO_BGZF")) {
                 r->bgzf = true;
                 r->zmm = (const unsigned char *)m; r->zmm_len = (size_t)st.st_size;
@@ -910,8 +911,11 @@ extern "C" void ntl_fastx_close(ntl_fastx *r)
     if (!r) return;
     if (r->z_init) inflateEnd(&r->zs);
     if (r->map) buf_cache().give((char *)r->map, r->map_cap);
-    if (r->mm) munmap((void *)r->mm, r->mm_len);
-    if (r->zmm) munmap((void *)r->zmm, r->zmm_len);
+    /* The page-table entries of a multi-GB mapping are dropped under the mapping lock held for READING first (MADV_DONTNEED; the page
+       cache keeps its pages): munmap, which holds it for writing -- every page fault of the process waits, the other reader's
+       among them -- then finds nothing to drop. */
+    if (r->mm) { (void)madvise((void *)r->mm, r->mm_len, MADV_DONTNEED); munmap((void *)r->mm, r->mm_len); }
+    if (r->zmm) { (void)madvise((void *)r->zmm, r->zmm_len, MADV_DONTNEED); munmap((void *)r->zmm, r->zmm_len); }
     if (r->fd >= 0) close(r->fd);
     if (r->stage) buf_cache().give(r->stage, r->stage_cap);
     delete r;
@@ -1097,7 +1101,13 @@ static const char *view(ntl_fastx *r, size_t need, size_t *avail, bool *at_eof)
                 struct stat st;
                 const size_t len = fstat(r->fd, &st) == 0 ? (size_t)st.st_size : r->file_size;
                 void *m = mmap(nullptr, len, PROT_READ, MAP_PRIVATE, r->fd, 0);
-                if (m != MAP_FAILED) { r->mm = (const char *)m; r->mm_len = len; }
+                if (m != MAP_FAILED) {
+                    r->mm = (const char *)m; r->mm_len = len;
+                    /* read once, front to back.  Also: pages of a mapping that is NOT marked so are marked accessed when it is
+                       unmapped, which for pages a process has just written (a freshly copied input in tmpfs) means 8.6 M moves to the
+                       active list for 35 GB, under the LRU lock and inside munmap (profiles/r04_first_pass.txt: pgactivate) */
+                    (void)madvise(m, len, MADV_SEQUENTIAL);
+                }
             }
         }
         if (r->mm) {

@@ -17,6 +17,23 @@ os.environ["NTL_PIPE_TRACE"] = os.path.abspath(os.environ.get("NTL_PIPE_TRACE", 
 import bench  # noqa: E402
 from ntlink_amd import capi, pipeline, synth  # noqa: E402
 
+VM_KEYS = ("pgfault", "pgmajfault", "pgalloc_normal", "pgfree", "thp_fault_alloc", "thp_fault_fallback", "thp_collapse_alloc", "compact_stall",
+           "allocstall_normal", "pgscan_direct", "pgsteal_direct", "pgscan_kswapd", "numa_hit", "numa_miss", "numa_local", "numa_other",
+           "pgmigrate_success", "numa_pages_migrated", "numa_hint_faults", "thp_split_page", "pglazyfree", "pgactivate", "pgdeactivate")
+
+
+def vmstat():
+    out = {}
+    try:
+        for ln in open("/proc/vmstat"):
+            k, v = ln.split()
+            if k in VM_KEYS:
+                out[k] = int(v)
+    except OSError:
+        pass
+    return out
+
+
 ap = argparse.ArgumentParser()
 ap.add_argument("--bases", type=float, default=16e9)
 ap.add_argument("--workload", default="C3")
@@ -44,14 +61,18 @@ try:
             if f.startswith("asm.fa."):
                 os.remove(os.path.join(d, f))
         pipeline._TRACE.clear()
+        vm0 = vmstat()
         ru0 = resource.getrusage(resource.RUSAGE_SELF)
         t0 = time.perf_counter()
         st = pipeline.run_pair(dev, "asm.fa", " ".join(files), k=W["k"], w=W["w"], paf=True, pairs_tsv=True, sensitive=W["sensitive"])
         dt = time.perf_counter() - t0
         ru1 = resource.getrusage(resource.RUSAGE_SELF)
+        vm1 = vmstat()
         rusage = {"user_s": round(ru1.ru_utime - ru0.ru_utime, 3), "sys_s": round(ru1.ru_stime - ru0.ru_stime, 3),
                   "minor_faults": ru1.ru_minflt - ru0.ru_minflt, "voluntary_switches": ru1.ru_nvcsw - ru0.ru_nvcsw,
-                  "involuntary_switches": ru1.ru_nivcsw - ru0.ru_nivcsw}
+                  "involuntary_switches": ru1.ru_nivcsw - ru0.ru_nivcsw,
+                  "vmstat_host_wide": {k: vm1[k] - vm0[k] for k in vm1 if vm1[k] != vm0.get(k, 0)}}
+        shutil.copyfile(os.environ["NTL_PIPE_TRACE"], os.environ["NTL_PIPE_TRACE"] + f".run{run}")
         ev = {}
         for ln in open(os.environ["NTL_PIPE_TRACE"]):
             if ln.startswith("#"):
