@@ -513,7 +513,8 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
     import threading
     make_workers = threading.Thread(target=dev.workers, args=(max(1, int(os.environ.get("NTL_DEVICE_STREAMS", "2"))),), daemon=True)
     make_workers.start()
-    ctg = seqio.load_all([target], packed=packed)  # used once: page-locking a buffer for it would cost more than the staged copy
+    # into a page-locked buffer: registering one costs 45 us per MB (csrc/ntl_hip.hip, pin_alloc), the staged copy of a pageable one 130
+    ctg = seqio.load_all([target], alloc=dev.pinned_empty if packed else None, packed=packed)
     ctg_len = ctg.lengths
     make_workers.join()
     t_ctg_parsed = time.perf_counter()
@@ -538,6 +539,7 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
     stats = dict(read_bases=0, reads=0, read_minimizers=0, index_hits=0, t_contigs=0.0, t_ingest=0.0, t_device=0.0, t_handover=0.0, t_device_parts={})
     try:
         with (dev.batch_packed(ctg) if ctg.packed is not None else dev.batch(ctg.buf, ctg.offsets)) as cb:
+            dev.pinned_release(ctg.pinned)
             ctg.buf = ctg.packed = ctg.pinned = None
             t_ctg_up = time.perf_counter()
             with dev.sketch(cb, k, w) as csk:
