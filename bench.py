@@ -247,7 +247,7 @@ def run_workload(dev, comm, name, args, steps, warmup, rank, world, serial_steps
         for rb, rl in items:
             t_a = time.perf_counter()
             # as pipeline.run_pair makes it: looked up in the index while emitted (no separate probe pass), and for this map only (no records)
-            rsk = d.sketch(rb, k, w, index=ix, records=os.environ.get("NTL_BENCH_RECORDS", "0") != "1")
+            rsk = d.sketch(rb, k, w, index=ix, records=os.environ.get("NTL_BENCH_RECORDS", "0") == "1")
             t_b = time.perf_counter()
             res = d.map(ix, rsk, rl, **params)  # queued behind it; nothing waits
             if trace:

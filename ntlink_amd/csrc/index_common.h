@@ -29,8 +29,8 @@ __device__ __forceinline__ uint8_t index_tag(uint64_t key) { return (uint8_t)(((
 /* what a lookup leaves for the map kernel */
 struct Cand {
     uint32_t cpos;
-    uint32_t meta; /* bit 0: found and unique, bit 1: contig strand, bits 2..30: contig; bit 31: the READ minimizer's strand in a
-                      sketch without records (EmitArgs::rpos), else 0 */
+    uint32_t meta; /* bit 0: found and unique, bit 1: contig strand, bits 2..30: contig; bit 31: the READ minimizer's strand, put there
+                      by the kernel that made the lookup (emit_kernel, probe_kernel) for the map kernels; IndexProbe leaves it 0 */
 };
 
 /* One lookup, split so that a thread can start several before it finishes the first: start() issues the first random load

@@ -112,13 +112,13 @@ __global__ void index_insert_kernel(const MxRecord *mx, uint64_t n, IndexSlot *s
  * random cache line per lookup for nothing.  The host picks by the hit fraction of the previous batch on the same index. */
 template <bool TAGS>
 __global__ void probe_kernel(const MxRecord *mx, uint64_t n, const IndexSlot *slots, int bits,
-                             const IndexSpecial *special, Cand *cand, unsigned long long *nfound, const uint8_t *tags)
+                             const IndexSpecial *special, Cand *cand, uint32_t *rpos, unsigned long long *nfound, const uint8_t *tags)
 {
     unsigned long long found = 0;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x * PROBE_U;
     const uint64_t mask = ((uint64_t)1 << bits) - 1;
     for (uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x * PROBE_U + threadIdx.x; i0 < n; i0 += stride) {
-        uint64_t key[PROBE_U];
+        uint64_t key[PROBE_U], pm[PROBE_U]; /* pm: the record's position (low word) and strand | sequence << 1 (high word) */
         IndexProbe<TAGS> pr[PROBE_U];
         bool live[PROBE_U];
 #pragma unroll
@@ -126,6 +126,7 @@ __global__ void probe_kernel(const MxRecord *mx, uint64_t n, const IndexSlot *sl
             const uint64_t i = i0 + (uint64_t)u * blockDim.x;
             live[u] = i < n;
             key[u] = live[u] ? ntl_stream_load(&mx[i].hash) : 0; /* streamed once: keep L2 for the tags */
+            pm[u] = live[u] ? ntl_stream_load((const uint64_t *)&mx[i].pos) : 0;
         }
 #pragma unroll
         for (int u = 0; u < PROBE_U; u++)
@@ -134,7 +135,10 @@ __global__ void probe_kernel(const MxRecord *mx, uint64_t n, const IndexSlot *sl
         for (int u = 0; u < PROBE_U; u++) {
             if (!live[u]) continue;
             const Cand c = pr[u].finish(key[u], slots, tags, special, mask);
-            ntl_stream_store((uint64_t *)&cand[i0 + (uint64_t)u * blockDim.x], (uint64_t)c.cpos | ((uint64_t)c.meta << 32));
+            /* position in the read beside the candidate, the read strand in its bit 31: all the map kernels read (EmitArgs::rpos) */
+            const uint32_t meta = c.meta | ((uint32_t)(pm[u] >> 32) << 31);
+            ntl_stream_store((uint64_t *)&cand[i0 + (uint64_t)u * blockDim.x], (uint64_t)c.cpos | ((uint64_t)meta << 32));
+            rpos[i0 + (uint64_t)u * blockDim.x] = (uint32_t)pm[u];
             found += c.meta & 1u;
         }
     }
@@ -166,8 +170,7 @@ struct PafRec { uint32_t read, ctg, q_start, q_end, t_start, t_end, n_hits, stra
 #define MAP_GROUP 8  /* consecutive reads a wavefront looks at per step (small: a batch of 50 k reads must still fill the device) */
 
 struct MapArgs {
-    const MxRecord *mx;     /* NULL for a sketch without records: positions in rpos, strands in the candidates (EmitArgs::rpos) */
-    const uint32_t *rpos;
+    const uint32_t *rpos;   /* [minimizers] position in the read; the strand is bit 31 of the candidate's meta (EmitArgs::rpos) */
     const uint32_t *mx_off; /* [nreads+1] */
     const Cand *cand;
     const uint32_t *read_len, *ctg_len;
@@ -342,8 +345,9 @@ __device__ __forceinline__ void map_read(const MapArgs &A, const uint32_t r, Hit
         uint32_t rp = 0, rs = 0; /* the minimizer's position in the read, its strand */
         if (i < nmx) {
             cd = A.cand[m0 + i];
-            if (A.rpos) { rp = A.rpos[m0 + i]; rs = cd.meta >> 31; cd.meta &= 0x7FFFFFFFu; }
-            else { rp = A.mx[m0 + i].pos; rs = A.mx[m0 + i].meta & 1u; }
+            rp = A.rpos[m0 + i];
+            rs = cd.meta >> 31;
+            cd.meta &= 0x7FFFFFFFu;
         }
         bool v = (cd.meta & 1u) != 0;
         if (v && !P.repeat_filter) v = (int64_t)A.ctg_len[cd.meta >> 2] >= (int64_t)P.z;

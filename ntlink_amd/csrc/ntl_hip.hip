@@ -1126,8 +1126,8 @@ struct ntl_sketch {
     /* ntl_sketch_run_indexed: the minimizers were looked up in index cand_gen while they were emitted */
     uint64_t cand_gen = 0;
     mutable DevBuf cand;    /* Cand[cap] */
-    bool no_records = false; /* ntl_sketch_run_for_map: `records` stays empty; positions in rpos, strands in the candidates */
-    mutable DevBuf rpos;    /* u32[cap] */
+    bool no_records = false; /* ntl_sketch_run_for_map: `records` stays empty */
+    mutable DevBuf rpos;    /* u32[cap] beside cand: the minimizers' positions in their reads (their strands: bit 31 of Cand::meta) */
     mutable DevBuf rlen;    /* u32[nseq]: lengths of the sketched sequences (sketches made from a batch) */
     mutable DevBuf sums;    /* SketchSums on the device: total (read by the map kernels: a sketch that overflowed its arrays is left alone) */
     /* lazy completion */
@@ -1634,7 +1634,8 @@ static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const nt
                            (const uint32_t *)mask.p, nmask, tile.as<uint32_t>(), tile_next.as<uint32_t>());
         hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(SCAN_NT), 0, ms, tile.as<uint32_t>(), tiles, &dsums->total_mx, (uint64_t)0, (uint32_t *)nullptr);
         HIPCHK(c, hipGetLastError());
-        if (s->no_records ? (rc = s->rpos.alloc(c, cap * 4)) : (rc = s->records.alloc(c, cap * sizeof(MxRecord)))) return rc;
+        if (!s->no_records && (rc = s->records.alloc(c, cap * sizeof(MxRecord)))) return rc;
+        if (ix && (rc = s->rpos.alloc(c, cap * 4))) return rc;
         s->cap = cap;
         const int probe = !ix ? 0 : (ix->hit_fraction->load(std::memory_order_relaxed) <= 0.5f ? 1 : 2); /* tags first unless the last batch on this index mostly hit */
         if (ix) {
@@ -1645,14 +1646,14 @@ static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const nt
         EmitArgs E;
         E.packed = T.packed; E.seq_base = T.seq_base; E.nseq = (uint32_t)nseq; E.mask = (uint32_t *)mask.p;
         E.nwords = nmask; E.tile_off = tile.as<uint32_t>(); E.tile_seq = tile_seq.as<uint32_t>(); E.mx_off = s->mx_off.as<uint32_t>();
-        E.out = s->records.as<MxRecord>(); E.out_cap = (uint32_t)cap;
+        E.out = s->no_records ? nullptr : s->records.as<MxRecord>(); E.out_cap = (uint32_t)cap;
         E.k = k; E.mult = 1ull ^ ((uint64_t)k * 0x90b45d39fb6da1faull);
         uint64_t roll[16][2];
         make_tables(k, roll, E.seed_tab);
         E.g4 = (const uint64_t (*)[2])c->g4;
         E.g8 = (const uint64_t (*)[2])c->g8;
         E.slots = nullptr; E.tags = nullptr; E.special = nullptr; E.ix_bits = 0; E.cand = nullptr; E.nfound = nullptr;
-        E.rpos = s->no_records ? s->rpos.as<uint32_t>() : nullptr;
+        E.rpos = ix ? s->rpos.as<uint32_t>() : nullptr;
         if (ix) {
             E.slots = ix->slots.as<IndexSlot>(); E.tags = ix->tags.as<uint8_t>(); E.special = ix->special.as<IndexSpecial>();
             E.ix_bits = ix->bits; E.cand = s->cand.as<Cand>(); E.nfound = &dsums->nfound;
@@ -2079,10 +2080,10 @@ static int map_enqueue(ntl_ctx *c, const ntl_index *ix, const ntl_sketch *reads,
     const ntl_map_params *params = &R->params;
     int rc;
     hipStream_t ms = c->stream;
-    DevBuf cand, smaps, spafs, n3, off3, scr, sums, over;
+    DevBuf cand, rpos, smaps, spafs, n3, off3, scr, sums, over;
     R->dense_made = R->doff_made = false;
     const uint64_t cap = nmx ? nmx : 1;
-    if ((!have_cand && (rc = cand.alloc(c, cap * sizeof(Cand)))) ||
+    if ((!have_cand && ((rc = cand.alloc(c, cap * sizeof(Cand))) || (rc = rpos.alloc(c, cap * 4)))) ||
         (rc = smaps.alloc(c, cap * sizeof(MapRec))) ||
         (rc = spafs.alloc(c, cap * sizeof(PafRec))) || (rc = n3.alloc(c, 3 * (nreads + 1) * 4)) ||
         (rc = off3.alloc(c, 3 * (nreads + 1) * 4)) || (rc = scr.alloc(c, (uint64_t)(MAP_NHA + MAP_NRA) * cap * 4)) ||
@@ -2101,19 +2102,19 @@ static int map_enqueue(ntl_ctx *c, const ntl_index *ix, const ntl_sketch *reads,
             if (ix->hit_fraction->load(std::memory_order_relaxed) <= 0.5f)
                 hipLaunchKernelGGL(probe_kernel<true>, grid, dim3(256), 0, ms,
                                    (const MxRecord *)reads->records.as<MxRecord>(), nmx, (const IndexSlot *)ix->slots.as<IndexSlot>(),
-                                   ix->bits, (const IndexSpecial *)ix->special.as<IndexSpecial>(), cand.as<Cand>(),
+                                   ix->bits, (const IndexSpecial *)ix->special.as<IndexSpecial>(), cand.as<Cand>(), rpos.as<uint32_t>(),
                                    &dsums->nfound, (const uint8_t *)ix->tags.as<uint8_t>());
             else
                 hipLaunchKernelGGL(probe_kernel<false>, grid, dim3(256), 0, ms,
                                    (const MxRecord *)reads->records.as<MxRecord>(), nmx, (const IndexSlot *)ix->slots.as<IndexSlot>(),
-                                   ix->bits, (const IndexSpecial *)ix->special.as<IndexSpecial>(), cand.as<Cand>(),
+                                   ix->bits, (const IndexSpecial *)ix->special.as<IndexSpecial>(), cand.as<Cand>(), rpos.as<uint32_t>(),
                                    &dsums->nfound, (const uint8_t *)ix->tags.as<uint8_t>());
         }
         HIPCHK(c, hipGetLastError());
     }
     MapArgs A;
-    A.mx = reads->no_records ? nullptr : reads->records.as<MxRecord>(); A.mx_off = reads->mx_off.as<uint32_t>();
-    A.rpos = reads->no_records ? reads->rpos.as<uint32_t>() : nullptr;
+    A.mx_off = reads->mx_off.as<uint32_t>();
+    A.rpos = have_cand ? reads->rpos.as<uint32_t>() : rpos.as<uint32_t>();
     A.cand = have_cand ? reads->cand.as<Cand>() : cand.as<Cand>();
     A.read_len = d_rlen; A.ctg_len = ix->ctg_len.as<uint32_t>(); A.nreads = (uint32_t)nreads;
     A.P.k = params->k; A.P.z = params->z; A.P.x = params->x; A.P.sensitive = params->sensitive;

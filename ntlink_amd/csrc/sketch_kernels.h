@@ -486,9 +486,9 @@ struct EmitArgs {
     int ix_bits;
     Cand *cand;
     unsigned long long *nfound;
-    /* not NULL (ntl_sketch_run_for_map): the sketch will only ever be mapped against this index -- no 16-byte records; the map
-       kernels need a minimizer's position in the read (here, 4 bytes) and its strand (bit 31 of the candidate's meta: contig ids
-       stay below 2^29) and nothing else: 12 bytes written and read per minimizer instead of 24 */
+    /* PROBE != 0: what the map kernels need of a minimizer besides its candidate -- its position in the read (here, 4 bytes) and its
+       strand (bit 31 of the candidate's meta: contig ids stay below 2^29): they read 12 bytes per minimizer and never the 16-byte
+       records, which a sketch made only to be mapped (ntl_sketch_run_for_map: out = NULL) does not write at all */
     uint32_t *rpos;
     /* The grid need not hold a workgroup per tile: a workgroup walks over tiles.  tile_next = NULL: tiles blockIdx.x, + gridDim.x, ...;
        else eight counters 16 words apart (zeroed by mask_count_kernel): a workgroup of residue x = blockIdx.x % 8 takes tiles
@@ -640,12 +640,10 @@ __global__ __launch_bounds__(EMIT_NT) void emit_kernel(EmitArgs A)
                 for (int u = 0; u < U; u++) {
                     if (!ok[u]) continue;
                     const uint32_t at = tile_base + r0 + i0 + (uint32_t)u * EMIT_NT;
-                    if (!A.rpos) A.out[at] = R[u];
+                    if (A.out) A.out[at] = R[u];
                     Cand cd = pr[u].finish(tt[u], A.slots, A.tags, A.special, ((uint64_t)1 << A.ix_bits) - 1);
-                    if (A.rpos) {
-                        A.rpos[at] = R[u].pos;
-                        cd.meta |= R[u].meta << 31;
-                    }
+                    A.rpos[at] = R[u].pos;
+                    cd.meta |= R[u].meta << 31;
                     A.cand[at] = cd;
                     found += cd.meta & 1u;
                 }
