@@ -185,8 +185,7 @@ int ntl_sketch_run(ntl_ctx *ctx, const ntl_batch *b, int k, int w, ntl_sketch **
 int ntl_sketch_run_indexed(ntl_ctx *ctx, const ntl_batch *b, int k, int w, const ntl_index *ix, ntl_sketch **out);
 /* ... and made ONLY to be mapped against `ix` (what the pair stage does with a read batch, whose minimizers the reference
  * never keeps either: bin/ntlink_pair.py:352-367 reads indexlr's lines off a pipe): the 16-byte records are not written.  A
- * minimizer leaves its position in the read and its candidate, 12 bytes instead of 24 written by the emitter and read by the map
- * kernels.  ntl_sketch_count / _wait / _nseq and ntl_map_run(ix, this sketch) work; ntl_sketch_download with a record column,
+ * minimizer leaves its candidate and its position in the read, the 12 bytes the map kernels read of it (28 with the records).  ntl_sketch_count / _wait / _nseq and ntl_map_run(ix, this sketch) work; ntl_sketch_download with a record column,
  * ntl_index_build, ntl_overlap_filter and a map against another index answer NTL_EINVAL.  Mappings are those of the other forms. */
 int ntl_sketch_run_for_map(ntl_ctx *ctx, const ntl_batch *b, int k, int w, const ntl_index *ix, ntl_sketch **out);
 /* 0 for a sketch made by ntl_sketch_run_for_map. */

@@ -199,6 +199,48 @@ __device__ __forceinline__ void hash_init_g4(const uint32_t *__restrict__ packed
     rev = srot_u(u, (uint32_t)(k - 1) % 33u, (uint32_t)(k - 1) % 31u);
 }
 
+/* The same with TWO four-base groups per rotation: with g4r[b] = {srot^4(g4[b].f), sror^4(g4[b].u)} beside g4,
+ *   f' = srot^4(srot^4(f) ^ g4[b0].f) ^ g4[b1].f = srot^8(f) ^ g4r[b0].f ^ g4[b1].f      (the rotations are linear over XOR)
+ * -- half the split rotations (7 VALU instructions each) of hash_init_g4; a group that is left over (k % 8 >= 4) takes the single step. */
+__device__ __forceinline__ void hash_init_g4p(const uint32_t *__restrict__ packed, uint64_t gp, int k,
+                                              const uint64_t (*g4)[2], const uint64_t (*g4r)[2], const uint64_t (*seed_tab)[2],
+                                              uint64_t &fwd, uint64_t &rev)
+{
+    if (k > 64) { hash_init_loop(packed, gp, k, g4, seed_tab, fwd, rev); return; }
+    const uint64_t wi = gp >> 4;
+    const uint32_t a2 = 2u * ((uint32_t)gp & 15u);
+    uint32_t raw[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) raw[i] = (16 * i < k + 16) ? packed[wi + i] : 0u;
+    uint32_t s[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) s[i] = ntl_alignbit(raw[i + 1], raw[i], a2);
+    const int ng = k >> 2, np = ng >> 1;
+    uint64_t f = 0, u = 0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        if (q < np) { /* uniform */
+            const uint32_t w16 = s[q >> 1] >> (16 * (q & 1));
+            const uint32_t b0 = w16 & 255u, b1 = (w16 >> 8) & 255u;
+            f = srot_h(f, 8, 8) ^ g4r[b0][0] ^ g4[b1][0];
+            u = srot_h(u, 25, 23) ^ g4r[b0][1] ^ g4[b1][1];
+        }
+    }
+    if (ng & 1) {
+        const int g = ng - 1;
+        const uint32_t byte = (s[(g >> 2) & 3] >> (8 * (g & 3))) & 255u;
+        f = srot_h(f, 4, 4) ^ g4[byte][0];
+        u = srot_h(u, 29, 27) ^ g4[byte][1];
+    }
+    for (int j = ng * 4; j < k; j++) {
+        const uint32_t c = load_base(packed, gp + (uint64_t)j);
+        f = srol1(f) ^ seed_tab[c][0];
+        u = sror1(u) ^ seed_tab[c][1];
+    }
+    fwd = f;
+    rev = srot_u(u, (uint32_t)(k - 1) % 33u, (uint32_t)(k - 1) % 31u);
+}
+
 /* Exclusive scan of one value per thread over a workgroup of NT threads; returns the prefix and
  * the workgroup total.  s_tmp must hold NT entries. */
 template <int NT>

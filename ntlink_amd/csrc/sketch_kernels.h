@@ -533,11 +533,15 @@ __global__ __launch_bounds__(EMIT_NT) void emit_kernel(EmitArgs A)
     ntl_lds_cu64 *const base_lds = NTL_LDS_CU64(s_base); /* every read of s_base goes through it */
     __shared__ uint32_t s_range[2];
     __shared__ uint64_t s_g4[256][2]; /* four-base init table: LDS copy (EMIT_NT == 256 entries) */
+    __shared__ uint64_t s_g4r[256][2]; /* ... and the same rotated by four bases: two groups per rotation (hash_init_g4p) */
     __shared__ uint32_t s_tile;
     const int t = threadIdx.x;
     if (t < 4) { s_seed[t][0] = A.seed_tab[t][0]; s_seed[t][1] = A.seed_tab[t][1]; }
-    s_g4[t][0] = A.g4[t][0];
-    s_g4[t][1] = A.g4[t][1];
+    {
+        const uint64_t gf = A.g4[t][0], gu = A.g4[t][1];
+        s_g4[t][0] = gf; s_g4[t][1] = gu;
+        s_g4r[t][0] = srot_h(gf, 4, 4); s_g4r[t][1] = srot_h(gu, 29, 27);
+    }
     uint32_t tile = blockIdx.x;
     for (bool first_tile = true;; first_tile = false) {
     if (A.tile_next) {
@@ -545,6 +549,7 @@ __global__ __launch_bounds__(EMIT_NT) void emit_kernel(EmitArgs A)
         __syncthreads(); /* (its next write lies behind the barriers of the tile's work) */
         tile = s_tile;
     } else if (!first_tile) tile += gridDim.x;
+    tile = ntl_readfirstlane(tile); /* uniform, and known to be: everything derived from it stays in scalar registers */
     if (tile >= A.ntiles) break;
     const uint64_t tile_w0 = (uint64_t)tile * EMIT_TILE;
     /* Sequences that overlap this tile of 65536 base positions: from the one its first position lies in to the one the next
@@ -623,7 +628,7 @@ __global__ __launch_bounds__(EMIT_NT) void emit_kernel(EmitArgs A)
                 const uint32_t sq = cached ? s_lo + seq_of_lds(base_lds, 0, s_hi - s_lo, gp) : seq_of(A.seq_base, s_lo, s_hi, gp);
                 const uint64_t sb = cached ? base_lds[sq - s_lo] : A.seq_base[sq];
                 uint64_t fwd, rev;
-                hash_init_g4(A.packed, gp, A.k, s_g4, s_seed, fwd, rev);
+                hash_init_g4p(A.packed, gp, A.k, s_g4, s_g4r, s_seed, fwd, rev);
                 uint64_t h = (fwd + rev) * A.mult;
                 h ^= h >> 27;
                 tt[u] = h;
