@@ -45,7 +45,11 @@
  * the next user of the bitmask it read and cleared).  No call of the hot path waits on the host: sizes stay on the device,
  * result handles are completed lazily (sketch_finalize / mapres_finalize) when a count or a record is asked for.
  */
-enum { SID_MAIN = 0, SID_W = 1 };
+/* SID_P (round 4, an experiment behind NTL_PREP_STREAM=1): a third stream that only runs a sketch's PREPARATION -- the per-sequence
+ * tables, the scan of the strip counts, the strip table: small dependent kernels that need nothing but the batch and sit on the window
+ * stream's critical path (C3: 2.5 of 71 ms per step).  On a stream of their own they run while the previous window kernel still does
+ * -- and the step gets LONGER (ntl_ctx_create); by default SID_P is the window stream. */
+enum { SID_MAIN = 0, SID_W = 1, SID_P = 2, NTL_NSID = 3 };
 
 struct ProfEntry {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> spans;
@@ -56,7 +60,7 @@ struct ProfEntry {
 /* a cached device block that was used on both streams: whoever takes it waits for the events of the streams it is not on */
 struct XBlock {
     void *p = nullptr;
-    hipEvent_t ev[2] = {nullptr, nullptr};
+    hipEvent_t ev[NTL_NSID] = {nullptr, nullptr, nullptr}; /* nullptr: not used on that stream */
 };
 
 /* a zero-filled minimizer bitmask whose last reader (emit_kernel) cleared what the window stage had set */
@@ -84,6 +88,7 @@ struct ntl_ctx {
     hipStream_t stream = nullptr;  /* MAIN */
     hipStream_t wstream = nullptr; /* window stage; == stream when the pipeline is off */
     hipStream_t wstream_own = nullptr; /* the second stream itself (ntl_ctx_set_pipeline switches wstream between it and MAIN) */
+    hipStream_t pstream = nullptr, pstream_own = nullptr; /* a sketch's preparation (SID_P); == stream when the pipeline is off */
     bool pipelined = false;
     std::string err;
     std::string async_err;         /* first failure of work whose handle was already gone: reported by ntl_ctx_sync */
@@ -98,7 +103,7 @@ struct ntl_ctx {
     void *g4 = nullptr;                 /* device copy of the four-base init table */
     void *g8 = nullptr;                 /* device copy of the eight-base init table (1 MB) */
     std::map<int, void *> g8k;          /* k -> the two k-dependent ring forms of g8 the fast window pass reads (1 MB per k, sketch2_kernels.h) */
-    std::multimap<size_t, void *> pool[2]; /* cached device blocks by size, per stream they were last used on */
+    std::multimap<size_t, void *> pool[NTL_NSID]; /* cached device blocks by size, per stream they were last used on */
     std::multimap<size_t, XBlock> xpool;   /* ... and those that were used on both */
     size_t pool_bytes = 0;
     size_t pool_cap = (size_t)32 << 30; /* upper bound of pool_bytes */
@@ -116,8 +121,13 @@ struct ntl_ctx {
     std::deque<Zombie> zombies;
     hipEvent_t throttle[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     uint64_t n_enqueued = 0;            /* sketches queued so far: the host runs at most 8 of them ahead of the device */
-    hipStream_t s(int sid) const { return sid == SID_W ? wstream : stream; }
-    int sid(int want) const { return pipelined ? want : SID_MAIN; }
+    hipStream_t s(int sid) const { return sid == SID_W ? wstream : (sid == SID_P ? pstream : stream); }
+    int sid(int want) const
+    {
+        if (!pipelined) return SID_MAIN;
+        if (want == SID_P && pstream == wstream) return SID_W; /* no stream of its own: the preparation is window-stage work */
+        return want;
+    }
 };
 #define NTL_NSLOTS 512u
 
@@ -309,13 +319,13 @@ static void dev_free(ntl_ctx *c, void *p)
 
 static void pool_drop_all(ntl_ctx *c)
 {
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < NTL_NSID; i++) {
         for (auto &kv : c->pool[i]) dev_free(c, kv.second);
         c->pool[i].clear();
     }
     for (auto &kv : c->xpool) {
         dev_free(c, kv.second.p);
-        sev_put(c, kv.second.ev[0]); sev_put(c, kv.second.ev[1]);
+        for (int o = 0; o < NTL_NSID; o++) sev_put(c, kv.second.ev[o]);
     }
     c->xpool.clear();
     c->pool_bytes = 0;
@@ -407,32 +417,47 @@ struct DevBuf {
             c->pool[sid].erase(it);
             return NTL_OK;
         }
-        auto xt = c->xpool.lower_bound(want);
-        if (xt != c->xpool.end() && xt->first <= most) {
-            XBlock &x = xt->second;
-            for (int o = 0; o < 2; o++) {
-                if (o != sid && x.ev[o]) (void)hipStreamWaitEvent(c->s(sid), x.ev[o], 0);
-                sev_put(c, x.ev[o]);
-            }
-            p = x.p; bytes = xt->first;
-            c->pool_bytes -= xt->first;
-            c->xpool.erase(xt);
-            return NTL_OK;
+        /* A block that was used on several streams: one whose work on the OTHER streams has run by now is taken as it is; else a
+           new block is made rather than this stream made to wait (the preparation of sub-batch i+1 would wait for the window
+           kernel of sub-batch i, which is what the third stream is there to avoid; two or three blocks per size then go round);
+           only when no memory is to be had does the taker wait. */
+        auto first = c->xpool.lower_bound(want), pick = c->xpool.end();
+        for (auto xt = first; xt != c->xpool.end() && xt->first <= most; ++xt) {
+            bool ready = true;
+            for (int o = 0; o < NTL_NSID; o++)
+                if (o != sid && xt->second.ev[o] && hipEventQuery(xt->second.ev[o]) != hipSuccess) { ready = false; break; }
+            if (ready) { pick = xt; break; }
         }
-        int rc = dev_alloc(c, want, &p);
-        if (rc) { p = nullptr; return rc; }
-        bytes = want;
+        (void)hipGetLastError(); /* (hipErrorNotReady is not an error) */
+        int rc = NTL_OK;
+        if (pick == c->xpool.end()) {
+            rc = dev_alloc(c, want, &p);
+            if (rc == NTL_OK) { bytes = want; return NTL_OK; }
+            p = nullptr;
+            if (first == c->xpool.end() || first->first > most) return rc;
+            pick = first; /* out of memory: the oldest candidate, and a wait */
+            c->err.clear();
+        }
+        XBlock &x = pick->second;
+        for (int o = 0; o < NTL_NSID; o++) {
+            if (o != sid && x.ev[o]) (void)hipStreamWaitEvent(c->s(sid), x.ev[o], 0);
+            sev_put(c, x.ev[o]);
+        }
+        p = x.p; bytes = pick->first;
+        c->pool_bytes -= pick->first;
+        c->xpool.erase(pick);
         return NTL_OK;
     }
     void touch(int sid) const { if (c) used |= (uint8_t)(1u << c->sid(sid)); }
     void release()
     {
         if (p && c) {
-            if (used == 1u || used == 2u) c->pool[used >> 1].insert({bytes, p});
+            if (used == 1u || used == 2u || used == 4u) c->pool[used >> 1].insert({bytes, p});
             else {
                 XBlock x;
                 x.p = p;
-                for (int o = 0; o < 2; o++) {
+                for (int o = 0; o < NTL_NSID; o++) {
+                    if (!(used & (1u << o))) continue;
                     x.ev[o] = sev_get(c);
                     if (x.ev[o]) (void)hipEventRecord(x.ev[o], c->s(o));
                     else (void)hipStreamSynchronize(c->s(o)); /* no event to be had: the slow, safe way */
@@ -445,7 +470,7 @@ struct DevBuf {
                largest blocks go first, they are the least likely to be asked for again at exactly their size */
             while (c->pool_bytes > c->pool_cap) {
                 std::multimap<size_t, void *> *big = nullptr;
-                for (int i = 0; i < 2; i++)
+                for (int i = 0; i < NTL_NSID; i++)
                     if (!c->pool[i].empty() && (!big || std::prev(c->pool[i].end())->first > std::prev(big->end())->first)) big = &c->pool[i];
                 if (big && (c->xpool.empty() || std::prev(big->end())->first >= std::prev(c->xpool.end())->first)) {
                     auto it = std::prev(big->end());
@@ -456,7 +481,7 @@ struct DevBuf {
                 } else if (!c->xpool.empty()) {
                     auto it = std::prev(c->xpool.end());
                     dev_free(c, it->second.p);
-                    sev_put(c, it->second.ev[0]); sev_put(c, it->second.ev[1]);
+                    for (int o = 0; o < NTL_NSID; o++) sev_put(c, it->second.ev[o]);
                     c->pool_bytes -= it->first;
                     c->xpool.erase(it);
                 } else break;
@@ -526,6 +551,17 @@ extern "C" int ntl_ctx_create(int device, ntl_ctx **out)
         if (e2 != hipSuccess) { c->wstream = c->stream; c->pipelined = false; }
         else c->wstream_own = c->wstream;
     }
+    c->pstream = c->stream;
+    /* NTL_PREP_STREAM=1 only: measured and NOT kept as the default (profiles/r04_prep_stream.jsonl: C3 75.5-76.0 ms per step against
+       72.6-73.1, C5 278-283 against 259-266) -- with the window kernels back to back the lookup kernel of the other stream never
+       gets the whole device for the 0.1 ms the preparation takes, and loses more (42 -> 57 ms per step) than the window stage gains */
+    if (c->pipelined && getenv("NTL_PREP_STREAM") && atoi(getenv("NTL_PREP_STREAM")) != 0) {
+        /* the preparation's few small kernels are wanted early: the highest priority */
+        hipError_t e3 = prio ? hipStreamCreateWithPriority(&c->pstream_own, hipStreamNonBlocking, greatest)
+                             : hipStreamCreateWithFlags(&c->pstream_own, hipStreamNonBlocking);
+        if (e3 != hipSuccess) c->pstream_own = nullptr;
+    }
+    c->pstream = c->pipelined ? (c->pstream_own ? c->pstream_own : c->wstream) : c->stream;
     {
         uint64_t g4[256][2];
         make_g4(g4);
@@ -567,6 +603,7 @@ static hipError_t sync_both(ntl_ctx *c)
 {
     hipError_t e = hipStreamSynchronize(c->stream);
     if (c->wstream != c->stream) { const hipError_t e2 = hipStreamSynchronize(c->wstream); if (e == hipSuccess) e = e2; }
+    if (c->pstream != c->stream && c->pstream != c->wstream) { const hipError_t e3 = hipStreamSynchronize(c->pstream); if (e == hipSuccess) e = e3; }
     return e;
 }
 
@@ -591,6 +628,7 @@ extern "C" void ntl_ctx_destroy(ntl_ctx *c)
     for (auto &e : c->throttle) sev_put(c, e);
     for (auto e : c->sev_free) (void)hipEventDestroy(e);
     if (c->wstream_own) (void)hipStreamDestroy(c->wstream_own);
+    if (c->pstream_own) (void)hipStreamDestroy(c->pstream_own);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -610,15 +648,18 @@ extern "C" int ntl_ctx_set_pipeline(ntl_ctx *c, int on)
     if (on && !c->wstream_own) return fail(c, NTL_EINVAL, "this context was created without a window stream (NTL_PIPELINE=0)");
     c->pipelined = on != 0;
     c->wstream = on ? c->wstream_own : c->stream;
+    c->pstream = on ? (c->pstream_own ? c->pstream_own : c->wstream) : c->stream;
     /* Everything queued has run (both streams were drained above), so every cached block is free on either stream: they all
        move to MAIN's cache.  Switching off, sid() maps every request to MAIN and the window-stage blocks would otherwise lie
        stranded in pool[SID_W] (counted, never handed out: the next step allocated its temporaries anew); switching on, the
        window stage's first requests miss its own cache once and are served from then on. */
-    for (auto &kv : c->pool[SID_W]) c->pool[SID_MAIN].insert(kv);
-    c->pool[SID_W].clear();
+    for (int i = 1; i < NTL_NSID; i++) {
+        for (auto &kv : c->pool[i]) c->pool[SID_MAIN].insert(kv);
+        c->pool[i].clear();
+    }
     for (auto &kv : c->xpool) {
         c->pool[SID_MAIN].insert({kv.first, kv.second.p});
-        sev_put(c, kv.second.ev[0]); sev_put(c, kv.second.ev[1]);
+        for (int o = 0; o < NTL_NSID; o++) sev_put(c, kv.second.ev[o]);
     }
     c->xpool.clear();
     return NTL_OK;
@@ -718,7 +759,7 @@ struct ntl_batch {
     /* a batch whose creating call returned without waiting (the synthetic ones): recorded on MAIN behind its last kernel;
        the window stream waits for it once */
     hipEvent_t ready = nullptr;
-    mutable bool w_waited = false;
+    mutable bool w_waited = false, p_waited = false;
 };
 
 static void batch_unref(const ntl_batch *cb)
@@ -737,6 +778,10 @@ static void batch_on_wstream(ntl_ctx *c, const ntl_batch *b)
     if (!c->pipelined) return;
     if (b->ready && !b->w_waited) { (void)hipStreamWaitEvent(c->wstream, b->ready, 0); b->w_waited = true; }
     b->packed.touch(SID_W); b->seq_base.touch(SID_W); b->seq_run_first.touch(SID_W); b->run_start.touch(SID_W); b->run_len.touch(SID_W);
+    if (c->pstream != c->wstream) { /* the preparation reads the sequence and run tables on its own stream */
+        if (b->ready && !b->p_waited) { (void)hipStreamWaitEvent(c->pstream, b->ready, 0); b->p_waited = true; }
+        b->seq_base.touch(SID_P); b->seq_run_first.touch(SID_P); b->run_start.touch(SID_P); b->run_len.touch(SID_P);
+    }
 }
 
 /* Host arrays in, device layout out: the bases travel as they are (one byte each) and are packed and
@@ -1468,8 +1513,8 @@ static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const nt
     int C, nt, rc;
     if ((rc = sketch_geometry(c, k, w, G, C, nt))) return rc;
     const uint64_t nseq = b->nseq;
-    const int wsid = c->sid(SID_W);
-    hipStream_t ws = c->s(wsid), ms = c->stream;
+    const int wsid = c->sid(SID_W), psid = c->sid(SID_P);
+    hipStream_t ws = c->s(wsid), ms = c->stream, ps = c->s(psid);
     /* the host runs at most 8 sketches ahead of the device */
     {
         hipEvent_t &t = c->throttle[c->n_enqueued & 7u];
@@ -1480,9 +1525,10 @@ static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const nt
     bool fast = false;
     /* nstrips / strip_first hold nseq+1 entries: the scan leaves the total behind the last one */
     const uint64_t nmask = (b->total_gpos + 31) / 32 + 1;
-    if ((rc = run_n.alloc(c, (b->nruns + 1) * 4, wsid)) || (rc = run_ord.alloc(c, (b->nruns + 1) * 4, wsid)) ||
-        (rc = seq_M.alloc(c, (nseq + 1) * 4, wsid)) || (rc = nstrips.alloc(c, (nseq + 1) * 4, wsid)) ||
-        (rc = strip_first.alloc(c, (nseq + 2) * 4, wsid)) || (rc = s->mx_off.alloc(c, (nseq + 1) * 4)) ||
+    /* the preparation's arrays: made on its stream (psid), and those the window stage reads marked as used there too */
+    if ((rc = run_n.alloc(c, (b->nruns + 1) * 4, psid)) || (rc = run_ord.alloc(c, (b->nruns + 1) * 4, psid)) ||
+        (rc = seq_M.alloc(c, (nseq + 1) * 4, psid)) || (rc = nstrips.alloc(c, (nseq + 1) * 4, psid)) ||
+        (rc = strip_first.alloc(c, (nseq + 2) * 4, psid)) || (rc = s->mx_off.alloc(c, (nseq + 1) * 4)) ||
         (rc = s->sums.alloc(c, sizeof(SketchSums)))) {
         return rc;
     }
@@ -1505,26 +1551,34 @@ static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const nt
         if (len + 2 > (uint64_t)k + (uint64_t)w) ub_strips += (len - k - w + 2 + (uint64_t)G.NWO - 1) / (uint64_t)G.NWO;
     }
     if (ub_strips >= 0x7FFFFFFFull) return fail(c, NTL_EINVAL, "batch too large: too many strips");
-    if ((rc = strip_tab.alloc(c, (ub_strips + 1) * sizeof(StripInfo), wsid))) return rc;
+    if ((rc = strip_tab.alloc(c, (ub_strips + 1) * sizeof(StripInfo), psid))) return rc;
     DevBuf strip_lite;
-    if ((rc = strip_lite.alloc(c, (ub_strips + 1) * sizeof(StripLite), wsid))) return rc;
+    if ((rc = strip_lite.alloc(c, (ub_strips + 1) * sizeof(StripLite), psid))) return rc;
+    run_n.touch(SID_W); run_ord.touch(SID_W); seq_M.touch(SID_W); strip_tab.touch(SID_W); strip_lite.touch(SID_W);
     SketchSums *dsums = s->sums.as<SketchSums>();
     HIPCHK(c, hipMemsetAsync(dsums, 0, sizeof(SketchSums), ms));
     {
-        ProfSpan sp(c, "sketch_meta", wsid);
+        ProfSpan sp(c, "sketch_meta", psid);
         if (nseq) {
             KTables K;
             K.run_n = run_n.as<uint32_t>(); K.run_ord = run_ord.as<uint32_t>();
             K.seq_M = seq_M.as<uint32_t>(); K.seq_nstrips = nstrips.as<uint32_t>();
-            hipLaunchKernelGGL(seq_meta_kernel, dim3((unsigned)((nseq + 255) / 256)), dim3(256), 0, ws, T, K, k, w, G.NWO);
+            hipLaunchKernelGGL(seq_meta_kernel, dim3((unsigned)((nseq + 255) / 256)), dim3(256), 0, ps, T, K, k, w, G.NWO);
             HIPCHK(c, hipGetLastError());
-            if ((rc = device_scan(c, nstrips.as<uint32_t>(), strip_first.as<uint32_t>(), nseq, nullptr, 1, nullptr, wsid))) return rc;
-            hipLaunchKernelGGL(strip_table_kernel, dim3((unsigned)((ub_strips + 255) / 256 + 1)), dim3(256), 0, ws, T,
+            if ((rc = device_scan(c, nstrips.as<uint32_t>(), strip_first.as<uint32_t>(), nseq, nullptr, 1, nullptr, psid))) return rc;
+            hipLaunchKernelGGL(strip_table_kernel, dim3((unsigned)((ub_strips + 255) / 256 + 1)), dim3(256), 0, ps, T,
                                (const uint32_t *)run_n.as<uint32_t>(), (const uint32_t *)run_ord.as<uint32_t>(),
                                (const uint32_t *)seq_M.as<uint32_t>(), (const uint32_t *)strip_first.as<uint32_t>(), G.NWO,
                                C * nt, strip_tab.as<StripInfo>(), (uint32_t)ub_strips + 1u, strip_lite.as<StripLite>());
             HIPCHK(c, hipGetLastError());
         }
+    }
+    if (ps != ws && nseq) { /* preparation -> window stage */
+        hipEvent_t e = sev_get(c);
+        if (!e) return fail(c, NTL_EDEVICE, "hipEventCreate failed");
+        HIPCHK(c, hipEventRecord(e, ps));
+        HIPCHK(c, hipStreamWaitEvent(ws, e, 0));
+        sev_put(c, e); /* the wait holds what it needs; the handle may be recorded again */
     }
     if (ub_strips) {
         SketchArgs A;

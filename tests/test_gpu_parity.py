@@ -409,6 +409,25 @@ def test_async_order_and_unseen_results(dev, monkeypatch):
     dev.sync()
 
 
+def test_preparation_on_a_stream_of_its_own(monkeypatch):
+    """NTL_PREP_STREAM=1 (an experiment that is not the default): a sketch's per-sequence tables and strip table
+    are made on a third stream while the previous window kernel still runs; their arrays go round in the cross-stream block cache
+    (a block whose other streams are still busy is not waited for, another one is made).  Same records, same mappings."""
+    monkeypatch.setenv("NTL_PREP_STREAM", "1")
+    chroms, cbuf, coff, names, _ = synth.make_assembly(3, 1, 10, 200_000)
+    rbuf, roff, _ = synth.make_reads(4, chroms, 5_000_000, 12_000, 0.02, 0.015, 0.015, lognormal_sigma=0.4)
+    contigs = [cbuf[int(coff[i]):int(coff[i + 1])].tobytes() for i in range(len(coff) - 1)]
+    reads = [rbuf[int(roff[i]):int(roff[i + 1])].tobytes() for i in range(len(roff) - 1)]
+    d = capi.Device(0)
+    try:
+        assert d.pipelined
+        assert pc.check_async_order(d, contigs, reads, 32, 250, z=1000) > 100
+        pc.check_full_pipeline(d, contigs, reads[:60], 24, 100, z=1000, sensitive=True)
+        d.sync()
+    finally:
+        d.close()
+
+
 def test_handles_outlive_their_inputs(dev, monkeypatch):
     """ADVICE r3 on the device: the index, the contig sketch and both batches are destroyed before the result of a read sketch
     that overflowed its record array is asked for (sketch and mapping are then made again from that index), and 700 completed

@@ -361,6 +361,20 @@ def test_sim_handles_outlive_their_inputs(monkeypatch):
         d.close()
 
 
+def test_sim_preparation_on_a_stream_of_its_own(monkeypatch):
+    """NTL_PREP_STREAM=1 under the mock: the third stream's code path (three block caches, blocks used on several streams going
+    round) -- the mock runs streams in order, so this checks the bookkeeping, the GPU test the concurrency."""
+    contigs = pc.fixture_seqs("scaffolds_4.fa")
+    reads = pc.fixture_seqs("long_reads_4_top5.fa")
+    monkeypatch.setenv("NTL_PREP_STREAM", "1")
+    d = simlib.device()
+    try:
+        assert pc.check_async_order(d, contigs, reads, 40, 100, z=1000) > 0
+        d.sync()
+    finally:
+        d.close()
+
+
 def test_sim_text_made_on_the_device(dev):
     """ntl_mapres_format under the mock: the verbose and PAF lines of test 7's five reads == the host emitters' == the oracle's;
     and a batch without any mapping gives two empty texts."""
