@@ -206,6 +206,10 @@ uint64_t ntl_sketch_redo_strips(const ntl_sketch *s);
 /* ... and how many strips the threshold pass (71 <= w <= 255: only k-mers with a small key are looked at) handed to the
  * block-minima pass because one of their windows had no such k-mer (about 0.7 % on random sequence). */
 uint64_t ntl_sketch_fallback_strips(const ntl_sketch *s);
+/* ... and whether the window passes wrote per-strip minimizer LISTS (1: the windows ntLink runs with, 94 <= w <= 255, k <= 64) or
+ * the bitmask of one bit per base (0: every other window; NTL_SKETCH_LISTS=0; a sketch whose lists ran out of room -- low-complexity
+ * sequence throughout -- and was made again).  The result is the same either way. */
+int ntl_sketch_from_lists(const ntl_sketch *s);
 /* mx_off[nseq+1]: minimizers of sequence i are [mx_off[i], mx_off[i+1]); hash/pos/strand hold
  * ntl_sketch_count() entries (the three fields `indexlr` prints as H:pos:strand). */
 int ntl_sketch_download(const ntl_sketch *s, uint64_t *mx_off, uint64_t *hash, uint32_t *pos,

@@ -22,7 +22,7 @@ SYMBOLS = [
     "ntl_batch_create", "ntl_batch_create_packed", "ntl_batch_create_packed_at", "ntl_packed_words", "ntl_batch_destroy", "ntl_batch_nseq", "ntl_batch_bases", "ntl_host_alloc", "ntl_host_free",
     "ntl_synth_genome", "ntl_synth_slices", "ntl_batch_download",
     "ntl_sketch_run", "ntl_sketch_run_indexed", "ntl_sketch_run_for_map", "ntl_sketch_has_records", "ntl_sketch_destroy", "ntl_sketch_nseq", "ntl_sketch_count", "ntl_sketch_download",
-    "ntl_sketch_strips", "ntl_sketch_redo_strips", "ntl_sketch_fallback_strips", "ntl_sketch_wait", "ntl_mapres_wait",
+    "ntl_sketch_strips", "ntl_sketch_redo_strips", "ntl_sketch_fallback_strips", "ntl_sketch_from_lists", "ntl_sketch_wait", "ntl_mapres_wait",
     "ntl_sketch_from_host", "ntl_overlap_filter",
     "ntl_index_build", "ntl_index_destroy", "ntl_index_size",
     "ntl_map_run", "ntl_mapres_destroy", "ntl_mapres_n_mappings", "ntl_mapres_n_hits", "ntl_mapres_n_pafs",
@@ -114,6 +114,7 @@ def load(path=None):
     for nm in ("ntl_sketch_strips", "ntl_sketch_redo_strips", "ntl_sketch_fallback_strips"):
         getattr(L, nm).argtypes = [vp]
         getattr(L, nm).restype = C.c_uint64
+    L.ntl_sketch_from_lists.argtypes = [vp]
     L.ntl_sketch_download.argtypes = [vp, u64p, u64p, u32p, u8p]
     L.ntl_sketch_from_host.argtypes = [vp, C.c_uint64, u64p, u64p, u32p, u8p, C.POINTER(vp)]
     L.ntl_overlap_filter.argtypes = [vp, vp, u64p, u32p, u32p, C.POINTER(vp)]
@@ -271,6 +272,12 @@ class Sketch(_Handle):
     def fallback_strips(self):
         self.wait()
         return int(self.dev.L.ntl_sketch_fallback_strips(self.ptr))
+
+    @property
+    def from_lists(self):
+        """True: the window passes wrote per-strip minimizer lists; False: the bitmask (diagnostics; same result)."""
+        self.wait()
+        return bool(self.dev.L.ntl_sketch_from_lists(self.ptr))
 
     def download(self):
         """(mx_off u64[nseq+1], hash u64, pos u32, strand u8 [1 = '+'])."""

@@ -81,6 +81,16 @@ __device__ __forceinline__ uint32_t ntl_quad_sum(uint32_t v)
     return v;
 }
 
+/* minimum over the 64 lanes of a wavefront, in every lane (uniform): the rows' minima, then four v_readlane and three s_min */
+__device__ __forceinline__ uint32_t ntl_wave_min(uint32_t v)
+{
+    v = ntl_row_min16(v);
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    const uint32_t ab = a < b ? a : b, cd = c < d ? c : d;
+    return ab < cd ? ab : cd;
+}
+
 __device__ __forceinline__ uint32_t ntl_row_max16(uint32_t v)
 {
     uint32_t t;

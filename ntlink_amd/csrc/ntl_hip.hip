@@ -274,7 +274,7 @@ static void reap(ntl_ctx *c, bool block)
         }
         if (q != hipSuccess && c->async_err.empty()) c->async_err = std::string("device work failed: ") + hipGetErrorString(q);
         if (q == hipSuccess && z.slot && c->async_err.empty()) {
-            if (z.kind == 1 && (uint32_t)z.slot->w[0] > z.cap)
+            if (z.kind == 1 && ((uint32_t)z.slot->w[0] > z.cap || (uint32_t)(z.slot->w[1] >> 32)))
                 c->async_err = "a sketch held more minimizers than its record array and was destroyed before anybody asked for its count";
             if (z.kind == 2 && (uint32_t)z.slot->w[1])
                 c->async_err = "an accepted contig appeared twice in one read (bin/ntlink_utils.py:262-266)";
@@ -1155,7 +1155,8 @@ struct ntl_index {
 };
 
 /* what emit_kernel leaves in the sketch's page-locked slot */
-struct SketchSums { uint32_t total_mx, redo_n, fb_n, pad_; unsigned long long nfound; }; /* redo_n, fb_n: one 8-byte copy */
+struct SketchSums { uint32_t total_mx, redo_n, fb_n, list_fail; unsigned long long nfound; }; /* redo_n, fb_n: one 8-byte copy; list_fail: the
+                                                                                                      strips' lists ran out of pool (StripLists) */
 
 struct ntl_sketch {
     ntl_ctx *c;
@@ -1172,6 +1173,8 @@ struct ntl_sketch {
     uint64_t cand_gen = 0;
     mutable DevBuf cand;    /* Cand[cap] */
     bool no_records = false; /* ntl_sketch_run_for_map: `records` stays empty */
+    mutable bool from_lists = false; /* diagnostics: the last round of sketch_enqueue wrote lists */
+    mutable bool no_lists = false; /* the window stage writes the bitmask whatever the window: the second round of a sketch whose lists ran out of pool */
     mutable DevBuf rpos;    /* u32[cap] beside cand: the minimizers' positions in their reads (their strands: bit 31 of Cand::meta) */
     mutable DevBuf rlen;    /* u32[nseq]: lengths of the sketched sequences (sketches made from a batch) */
     mutable DevBuf sums;    /* SketchSums on the device: total (read by the map kernels: a sketch that overflowed its arrays is left alone) */
@@ -1353,6 +1356,18 @@ static void ctx_prime(ntl_ctx *c)
 #endif
 }
 
+/* does the window pass of this sketch run as sketch_wave_kernel (one wavefront per strip)?  Where a lane's first k-mer lies in its own
+   64 bases and a strip's candidates fit its list; NTL_SKETCH_WAVE=0: the workgroup-per-strip form (A/B, tests).  Read per call: the
+   tests switch it inside one process. */
+static int wave_form(const Sketch2Args &B, int nt)
+{
+    const char *we = getenv("NTL_SKETCH_WAVE");
+    const int wave = we ? atoi(we) : 1;
+    const double per_strip = 4096.0 * (double)B.thresh / 4294967296.0; /* candidates a strip is expected to hold */
+    if (nt == 256 && B.thresh && B.A.G.a + 2 <= 16 && (B.dbg & ~24) == 0 && wave && B.A.G.k <= 64 && per_strip <= 440.0) return wave;
+    return 0;
+}
+
 /* fast 32-bit pass over the single-run strips (sketch2_kernels.h) */
 template <int NT, int R0>
 static void launch_fast_r0(ntl_ctx *c, const Sketch2Args &B, unsigned strips)
@@ -1369,10 +1384,9 @@ static void launch_fast_r0(ntl_ctx *c, const Sketch2Args &B, unsigned strips)
         if (NT == 256 && B.thresh && B.A.G.a + 2 <= 16 && (B.dbg & ~24) == 0) { /* (ablation bits 8 and 16 exist in this kernel too) */
             /* one wavefront per strip, 64 k-mers per lane (sketch_wave_kernel, round 4) where a lane's first k-mer lies in its own
                64 bases and a strip's candidates fit its list; NTL_SKETCH_WAVE=0: the workgroup-per-strip form (A/B, tests) */
-            const char *we = getenv("NTL_SKETCH_WAVE");
-            const int wave = we ? atoi(we) : 1;
+            const int wave = wave_form(B, NT);
             const double per_strip = 4096.0 * (double)B.thresh / 4294967296.0; /* candidates a strip is expected to hold */
-            if (wave && B.A.G.k <= 64 && per_strip <= 440.0) {
+            if (wave) {
                 /* resident wavefronts that walk over their strips: as many workgroups as the device holds at once (a multiple of 8:
                    one share of the strips per XCD).  <wavefronts per workgroup, staging slots per lane, scan rounds>: the slots hold a
                    lane's 64 p candidates + 4.5 sigma, the list (64 per round) a strip's 4096 p + 4 sigma; what does not fit is given up */
@@ -1522,7 +1536,6 @@ static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const nt
         reap(c, false);
     }
     DevBuf run_n, run_ord, seq_M, nstrips, strip_first, tile, redo, strip_tab;
-    bool fast = false;
     /* nstrips / strip_first hold nseq+1 entries: the scan leaves the total behind the last one */
     const uint64_t nmask = (b->total_gpos + 31) / 32 + 1;
     /* the preparation's arrays: made on its stream (psid), and those the window stage reads marked as used there too */
@@ -1532,12 +1545,6 @@ static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const nt
         (rc = s->sums.alloc(c, sizeof(SketchSums)))) {
         return rc;
     }
-    CleanMask mask;
-    if ((rc = mask_take(c, nmask * 4, wsid, &mask))) return rc;
-    struct MaskGuard { /* error paths: the mask is not known to be clean any more */
-        ntl_ctx *c; CleanMask *m;
-        ~MaskGuard() { if (m->p) { dev_free(c, m->p); m->p = nullptr; } }
-    } mask_guard{c, &mask};
     batch_on_wstream(c, b);
     SeqTables T;
     T.packed = b->packed.as<uint32_t>(); T.seq_base = b->seq_base.as<uint64_t>();
@@ -1551,6 +1558,60 @@ static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const nt
         if (len + 2 > (uint64_t)k + (uint64_t)w) ub_strips += (len - k - w + 2 + (uint64_t)G.NWO - 1) / (uint64_t)G.NWO;
     }
     if (ub_strips >= 0x7FFFFFFFull) return fail(c, NTL_EINVAL, "batch too large: too many strips");
+    /* Which window pass, and what it writes.  32-bit fast pass + exact pass over what it flags; the exact pass alone for small windows
+       / huge k.  Where the fast pass is sketch_wave_kernel (94 <= w <= 255, k <= 64: every window ntLink is run with) the passes write
+       per-strip LISTS of minimizers (sketch_kernels.h, StripLists) and emit_list_kernel reads those; everywhere else, a bitmask of one
+       bit per base and emit_kernel.  NTL_SKETCH_LISTS=0: the bitmask everywhere (A/B, tests). */
+    bool fast = C == 16 && k <= 16 * SK2_QMAX && G.a + 2 <= SK2_PAD;
+    if (const char *e = getenv("NTL_SKETCH_FAST")) fast = fast && atoi(e) != 0; /* 0: exact pass only (A/B, tests) */
+    Sketch2Args B;
+    memset(&B, 0, sizeof B);
+    B.A.G = G;
+    if (fast) {   /* sketch_thresh_kernel (threshold-sparsified windows) where a strip's candidate list fits: keys below
+                     T = 2^32 * cpw / w are candidates, cpw = 10 of them per window -- fewer and more strips have a window without
+                     one (they take the exact pass: 0.7 % at 10, 2 % at 9), more and the list work grows (profiles/r03p_*).
+                     NTL_SKETCH_THRESH=0: sketch_fast_kernel everywhere; = x: x candidates per window.  Read per call: the tests
+                     switch it inside one process. */
+        const char *e = getenv("NTL_SKETCH_THRESH");
+        double cpw = e ? atof(e) : 10.0;
+        if (cpw == 1.0) cpw = 10.0;
+        /* a strip's expected 4096 cpw / w candidates must fit the list with room for their spread: 402 entries beside
+           the staged keys (w >= 121 at 10 per window), 680 without them (sketch_thresh_kernel<.., DIRECT>: w >= 71) */
+        if (cpw > 0 && nt != 128 && w <= 255 && 4096.0 * cpw / w <= 580.0)
+            B.thresh = (uint32_t)std::min(4294967295.0, 4294967296.0 * cpw / w);
+        if (const char *e2 = getenv("NTL_SKETCH_ABLATE")) B.dbg = atoi(e2); /* tools/sketch_bench.py only: results are wrong */
+        if (const char *e2 = getenv("NTL_SKETCH_FORCE_REDO")) B.force_redo = atoi(e2); /* tests: every strip takes both passes */
+    }
+    StripLists Ls;
+    memset(&Ls, 0, sizeof Ls);
+    DevBuf lcnt, lent, loff;
+    bool lists = fast && nseq && ub_strips && !s->no_lists && wave_form(B, nt) != 0;
+    if (const char *e = getenv("NTL_SKETCH_LISTS")) lists = lists && atoi(e) != 0;
+    if (lists) {
+        /* a slot holds the expected 2 NWO / (w + 1) minimizers of a strip with room for their spread (what does not fit -- low-complexity
+           sequence -- lives in the pool behind the slots); the pool: 32 entries per strip, at least a million */
+        const double mean = 2.0 * (double)G.NWO / (double)(w + 1);
+        uint64_t slot = ((uint64_t)(mean * 1.25 + 24.0) + 15u) & ~(uint64_t)15u;
+        if (const char *e = getenv("NTL_LIST_SLOT")) slot = std::max<uint64_t>(1, (uint64_t)atoll(e)); /* tests: force strips into the pool */
+        uint64_t pool = std::max<uint64_t>((uint64_t)1 << 20, 32 * ub_strips);
+        if (const char *e = getenv("NTL_LIST_POOL")) pool = (uint64_t)atoll(e);                      /* tests: make the pool run out */
+        if ((ub_strips + 1) * slot + pool >= 0xFFFFFFF0ull) lists = false; /* (entries are addressed with 32 bits) */
+        else {
+            Ls.slot = (uint32_t)slot; Ls.ovf_base = (uint32_t)((ub_strips + 1) * slot); Ls.ovf_cap = (uint32_t)pool;
+            /* cnt[ub_strips + 1] (+ the two control words behind it), zeroed: a strip nobody lists has none */
+            if ((rc = lcnt.alloc(c, (ub_strips + 4) * 4, wsid)) || (rc = lent.alloc(c, ((ub_strips + 1) * slot + pool) * 4, wsid)) ||
+                (rc = loff.alloc(c, (ub_strips + 2) * 4))) return rc;
+            lcnt.touch(SID_MAIN); lent.touch(SID_MAIN);
+            Ls.cnt = lcnt.as<uint32_t>(); Ls.ent = lent.as<uint32_t>(); Ls.ctl = Ls.cnt + ub_strips + 2;
+            HIPCHK(c, hipMemsetAsync(lcnt.p, 0, (ub_strips + 4) * 4, ws));
+        }
+    }
+    CleanMask mask;
+    if (!lists && (rc = mask_take(c, nmask * 4, wsid, &mask))) return rc;
+    struct MaskGuard { /* error paths: the mask is not known to be clean any more */
+        ntl_ctx *c; CleanMask *m;
+        ~MaskGuard() { if (m->p) { dev_free(c, m->p); m->p = nullptr; } }
+    } mask_guard{c, &mask};
     if ((rc = strip_tab.alloc(c, (ub_strips + 1) * sizeof(StripInfo), psid))) return rc;
     DevBuf strip_lite;
     if ((rc = strip_lite.alloc(c, (ub_strips + 1) * sizeof(StripLite), psid))) return rc;
@@ -1590,9 +1651,7 @@ static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const nt
         A.g4 = (const uint64_t (*)[2])c->g4;
         A.g8 = (const uint64_t (*)[2])c->g8;
         A.redo_list = nullptr; A.redo_count = nullptr;
-        /* 32-bit fast pass + exact pass over what it flags; the exact pass alone for small windows / huge k */
-        fast = C == 16 && k <= 16 * SK2_QMAX && G.a + 2 <= SK2_PAD;
-        if (const char *e = getenv("NTL_SKETCH_FAST")) fast = fast && atoi(e) != 0; /* 0: exact pass only (A/B, tests) */
+        A.Ls = Ls;
         if (fast) {
             /* [0] strips for the exact pass, [1] strips the threshold pass gave up, then the two lists */
             /* ... and behind them the eight chunk counters of sketch_wave_kernel (one per XCD's share of the strips), 64 bytes apart */
@@ -1600,7 +1659,6 @@ static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const nt
             if ((rc = redo.alloc(c, (redo_words + 8 * 16) * 4, wsid))) return rc;
             HIPCHK(c, hipMemsetAsync(redo.p, 0, 8, ws));
             HIPCHK(c, hipMemsetAsync(redo.as<uint32_t>() + redo_words, 0, 8 * 16 * 4, ws));
-            Sketch2Args B;
             B.A = A;
             B.redo_count = redo.as<uint32_t>(); B.redo_list = redo.as<uint32_t>() + 2;
             B.fb_count = redo.as<uint32_t>() + 1; B.fb_list = redo.as<uint32_t>() + 2 + ub_strips + 1;
@@ -1629,24 +1687,6 @@ static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const nt
                 B.g8k = (const uint2 *)it->second;
                 B.g4k = B.g8k + 2 * 65536;
             }
-            B.force_redo = 0;
-            B.dbg = 0;
-            B.thresh = 0;
-            {   /* sketch_thresh_kernel (threshold-sparsified windows) where a strip's candidate list fits: keys below
-                   T = 2^32 * cpw / w are candidates, cpw = 10 of them per window -- fewer and more strips have a window without
-                   one (they take the exact pass: 0.7 % at 10, 2 % at 9), more and the list work grows (profiles/r03p_*).
-                   NTL_SKETCH_THRESH=0: sketch_fast_kernel everywhere; = x: x candidates per window.  Read per call: the tests
-                   switch it inside one process. */
-                const char *e = getenv("NTL_SKETCH_THRESH");
-                double cpw = e ? atof(e) : 10.0;
-                if (cpw == 1.0) cpw = 10.0;
-                /* a strip's expected 4096 cpw / w candidates must fit the list with room for their spread: 402 entries beside
-                   the staged keys (w >= 121 at 10 per window), 680 without them (sketch_thresh_kernel<.., DIRECT>: w >= 71) */
-                if (cpw > 0 && nt != 128 && w <= 255 && 4096.0 * cpw / w <= 580.0)
-                    B.thresh = (uint32_t)std::min(4294967295.0, 4294967296.0 * cpw / w);
-            }
-            if (const char *e = getenv("NTL_SKETCH_ABLATE")) B.dbg = atoi(e); /* tools/sketch_bench.py only: results are wrong */
-            if (const char *e = getenv("NTL_SKETCH_FORCE_REDO")) B.force_redo = atoi(e); /* tests: every strip takes both passes */
             {
                 ProfSpan sp(c, "sketch_mask", wsid);
                 if (nt == 128) launch_fast_r0<128, 0>(c, B, (unsigned)ub_strips);
@@ -1678,15 +1718,26 @@ static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const nt
     }
     {
         ProfSpan sp(c, "sketch_emit");
-        const uint64_t tiles = (nmask + EMIT_TILE - 1) / EMIT_TILE;
+        const uint64_t tiles = lists ? (ub_strips + EL_STRIPS - 1) / EL_STRIPS : (nmask + EMIT_TILE - 1) / EMIT_TILE;
         DevBuf tile_seq, tile_next;
-        if ((rc = tile.alloc(c, tiles * 4)) || (rc = tile_seq.alloc(c, (tiles + 2) * 4)) || (rc = tile_next.alloc(c, 8 * 16 * 4))) return rc;
-        if (nseq)
-            hipLaunchKernelGGL(tile_seq_kernel, dim3((unsigned)((nseq + 255) / 256)), dim3(256), 0, ms, (const uint64_t *)T.seq_base, (uint32_t)nseq,
-                               tiles, tile_seq.as<uint32_t>());
-        hipLaunchKernelGGL(mask_count_kernel, dim3((unsigned)tiles), dim3(EMIT_NT), 0, ms,
-                           (const uint32_t *)mask.p, nmask, tile.as<uint32_t>(), tile_next.as<uint32_t>());
-        hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(SCAN_NT), 0, ms, tile.as<uint32_t>(), tiles, &dsums->total_mx, (uint64_t)0, (uint32_t *)nullptr);
+        if ((rc = tile_next.alloc(c, 8 * 16 * 4))) return rc;
+        if (lists) {
+            /* ranks: a scan over one count per strip; the total (or, if the lists ran out of pool, a total no array holds: the map
+               kernels leave such a sketch alone and sketch_finalize makes it again through the bitmask) */
+            strip_first.touch(SID_MAIN); strip_tab.touch(SID_MAIN);
+            if ((rc = device_scan(c, Ls.cnt, loff.as<uint32_t>(), ub_strips, nullptr, 1, &dsums->total_mx))) return rc;
+            hipLaunchKernelGGL(list_fail_kernel, dim3(1), dim3(64), 0, ms, (const uint32_t *)Ls.ctl, &dsums->total_mx, &dsums->list_fail, tile_next.as<uint32_t>());
+            hipLaunchKernelGGL(mx_off_from_strips_kernel, dim3((unsigned)((nseq + 256) / 256)), dim3(256), 0, ms, (const uint32_t *)strip_first.as<uint32_t>(),
+                               (const uint32_t *)loff.as<uint32_t>(), (uint32_t)nseq, s->mx_off.as<uint32_t>());
+        } else {
+            if ((rc = tile.alloc(c, tiles * 4)) || (rc = tile_seq.alloc(c, (tiles + 2) * 4))) return rc;
+            if (nseq)
+                hipLaunchKernelGGL(tile_seq_kernel, dim3((unsigned)((nseq + 255) / 256)), dim3(256), 0, ms, (const uint64_t *)T.seq_base, (uint32_t)nseq,
+                                   tiles, tile_seq.as<uint32_t>());
+            hipLaunchKernelGGL(mask_count_kernel, dim3((unsigned)tiles), dim3(EMIT_NT), 0, ms,
+                               (const uint32_t *)mask.p, nmask, tile.as<uint32_t>(), tile_next.as<uint32_t>());
+            hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(SCAN_NT), 0, ms, tile.as<uint32_t>(), tiles, &dsums->total_mx, (uint64_t)0, (uint32_t *)nullptr);
+        }
         HIPCHK(c, hipGetLastError());
         if (!s->no_records && (rc = s->records.alloc(c, cap * sizeof(MxRecord)))) return rc;
         if (ix && (rc = s->rpos.alloc(c, cap * 4))) return rc;
@@ -1730,23 +1781,36 @@ static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const nt
         }
         const char *eu = getenv("NTL_EMIT_U"); /* minimizers in flight per thread; read per call: the tests switch it inside one process */
         const int emit_u = eu ? atoi(eu) : 1;
+        if (lists) {
+            EmitListArgs Q;
+            Q.Ls = Ls; Q.strip_tab = strip_tab.as<StripInfo>(); Q.strip_off = loff.as<uint32_t>(); Q.nstrips = (uint32_t)ub_strips;
+            if (probe == 0) hipLaunchKernelGGL((emit_list_kernel<0>), dim3(egrid), dim3(EL_NT), 0, ms, E, Q);
+            else if (probe == 1) hipLaunchKernelGGL((emit_list_kernel<1>), dim3(egrid), dim3(EL_NT), 0, ms, E, Q);
+            else hipLaunchKernelGGL((emit_list_kernel<2>), dim3(egrid), dim3(EL_NT), 0, ms, E, Q);
+        } else
         if (probe == 0) hipLaunchKernelGGL((emit_kernel<0, 1>), dim3(egrid), dim3(EMIT_NT), 0, ms, E);
         else if (probe == 1 && emit_u >= 2) hipLaunchKernelGGL((emit_kernel<1, 2>), dim3(egrid), dim3(EMIT_NT), 0, ms, E);
         else if (probe == 1) hipLaunchKernelGGL((emit_kernel<1, 1>), dim3(egrid), dim3(EMIT_NT), 0, ms, E);
         else if (emit_u >= 2) hipLaunchKernelGGL((emit_kernel<2, 2>), dim3(egrid), dim3(EMIT_NT), 0, ms, E);
         else hipLaunchKernelGGL((emit_kernel<2, 1>), dim3(egrid), dim3(EMIT_NT), 0, ms, E);
         HIPCHK(c, hipGetLastError());
-        mask.clean = sev_get(c);
-        if (mask.clean) HIPCHK(c, hipEventRecord(mask.clean, ms));
-        else HIPCHK(c, hipStreamSynchronize(ms));
-        c->masks.push_back(mask);
-        mask.p = nullptr; /* handed over */
+        if (mask.p) {
+            mask.clean = sev_get(c);
+            if (mask.clean) HIPCHK(c, hipEventRecord(mask.clean, ms));
+            else HIPCHK(c, hipStreamSynchronize(ms));
+            c->masks.push_back(mask);
+            mask.p = nullptr; /* handed over */
+        }
         /* lengths of the sketched sequences for the map kernels (the batch may be gone by then) */
-        if (b->d_seq_len && nseq) {
+        if (b->d_seq_len && nseq && !s->rlen.p) { /* (a second round keeps the array of the first: ntl_map_run may hold its address already) */
             if ((rc = s->rlen.alloc(c, nseq * 4))) return rc;
             HIPCHK(c, hipMemcpyAsync(s->rlen.p, b->d_seq_len, nseq * 4, hipMemcpyDeviceToDevice, ms));
         }
         SketchSums *hs = (SketchSums *)s->slot;
+        if (lists) { /* the true total (the device's copy says "too many" when the lists ran out), and whether they did */
+            HIPCHK(c, hipMemcpyAsync(&hs->total_mx, loff.as<uint32_t>() + ub_strips, 4, hipMemcpyDeviceToHost, ms));
+            HIPCHK(c, hipMemcpyAsync(&hs->list_fail, &dsums->list_fail, 4, hipMemcpyDeviceToHost, ms));
+        } else
         HIPCHK(c, hipMemcpyAsync(&hs->total_mx, &dsums->total_mx, 4, hipMemcpyDeviceToHost, ms));
         if (ix) HIPCHK(c, hipMemcpyAsync(&hs->nfound, &dsums->nfound, 8, hipMemcpyDeviceToHost, ms));
     }
@@ -1758,6 +1822,7 @@ static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const nt
         c->n_enqueued++;
     }
     s->strips = ub_strips;
+    s->from_lists = lists;
     s->pending = true;
     /* temporaries return to the context's cache here; every later user of those blocks is queued behind the kernels above
        on the stream they were used on, so no wait is needed */
@@ -1812,8 +1877,9 @@ static int sketch_finalize(const ntl_sketch *cs)
         if (e != hipSuccess) { s->failed = fail(c, NTL_EDEVICE, std::string("sketch: ") + hipGetErrorString(e)); break; }
         const SketchSums hs = *(const SketchSums *)s->slot;
         s->count = hs.total_mx; s->redo_strips = hs.redo_n; s->fallback_strips = hs.fb_n; s->nfound = hs.nfound;
-        if (s->count <= s->cap) break;
+        if (s->count <= s->cap && !hs.list_fail) break;
         if (round || !s->src) { s->failed = fail(c, NTL_EINTERNAL, "sketch: the exact-size round overflowed again"); break; }
+        if (hs.list_fail) s->no_lists = true; /* the strips' lists ran out of pool (the counts are right): once more, through the bitmask */
         s->gen++;
         memset(s->slot, 0, sizeof(PinSlot));
         const int rc = sketch_enqueue(c, s->src, s->k, s->w, s->src_ix, s, s->count);
@@ -1860,6 +1926,7 @@ extern "C" uint64_t ntl_sketch_nseq(const ntl_sketch *s) { return s ? s->nseq : 
 extern "C" uint64_t ntl_sketch_count(const ntl_sketch *s) { return s && sketch_finalize(s) == NTL_OK ? s->count : 0; }
 extern "C" uint64_t ntl_sketch_strips(const ntl_sketch *s) { return s ? s->strips : 0; }
 extern "C" uint64_t ntl_sketch_redo_strips(const ntl_sketch *s) { return s && sketch_finalize(s) == NTL_OK ? s->redo_strips : 0; }
+extern "C" int ntl_sketch_from_lists(const ntl_sketch *s) { return s && sketch_finalize(s) == NTL_OK && s->from_lists ? 1 : 0; }
 extern "C" uint64_t ntl_sketch_fallback_strips(const ntl_sketch *s) { return s && sketch_finalize(s) == NTL_OK ? s->fallback_strips : 0; }
 
 extern "C" int ntl_sketch_download(const ntl_sketch *s, uint64_t *mx_off, uint64_t *hash, uint32_t *pos, uint8_t *strand)

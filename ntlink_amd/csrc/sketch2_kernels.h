@@ -175,7 +175,7 @@ __device__ __forceinline__ void sk2_fast_strip(const Sketch2Args &B, const uint3
     __shared__ uint32_t s_bm[NT + PAD];         /* block minima; INF behind NT */
     __shared__ uint32_t s_pre0[NT + 4];         /* minimum of the first R0 elements of each block */
     __shared__ uint32_t s_bits[NBW];
-    __shared__ uint32_t s_njobs, s_flag;
+    __shared__ uint32_t s_njobs, s_flag, s_q0;
     __shared__ uint32_t s_roll[64];             /* [2 * (in<<2|out)] = the 31-bit-ring parts {fwd seed >> 33, rev seed >> 32} of roll_tab */
     __shared__ uint32_t s_t0[NT + PAD];         /* range-minimum levels */
     __shared__ uint32_t s_t1[BIG ? NT + PAD : 1];
@@ -196,7 +196,8 @@ __device__ __forceinline__ void sk2_fast_strip(const Sketch2Args &B, const uint3
     if (L < NBW) s_bits[L] = 0;
     if (L < PAD) s_bm[NT + L] = SK2_INF;
     if (L < 4) s_pre0[NT + L] = SK2_INF;
-    if (L == 0) { s_njobs = 0; s_flag = B.force_redo ? 1u : 0u; }
+    if (L == 0) { s_njobs = 0; s_flag = B.force_redo ? 1u : 0u; s_q0 = NTL_NONE; }
+    const bool lists = A.Ls.cnt != nullptr;
 
     const int64_t e_lane = (int64_t)I.E0 + (int64_t)L * C; /* ordinal of this lane's element t = 0 */
     const uint64_t gp = (uint64_t)((int64_t)I.base + I.P0 + (int64_t)L * C);
@@ -383,7 +384,13 @@ __device__ __forceinline__ void sk2_fast_strip(const Sketch2Args &B, const uint3
     if (own) {
         /* window (0,0) belongs to the previous strip, so the strip's first owned window (0,1) is always searched;
            window (LW-1,16) is the next strip's */
-        if (L == 0) { if (e_lane + 1 + G.w <= (int64_t)I.M) chg |= 2u; le &= ~2u; }
+        if (L == 0) {
+            if (e_lane + 1 + G.w <= (int64_t)I.M) chg |= 2u;
+            le &= ~2u;
+            /* Lists: window 0 is searched as well (bit 0 is nobody's: job 0) -- its minimum is the previous strip's to list, not
+               this one's, whether window 1 has the same or not (StripLists); the bitmask takes the same bit twice. */
+            if (lists && e_lane >= 0) chg |= 1u;
+        }
         if (L == G.LW - 1) { chg &= 0xFFFFu; le &= 0xFFFFu; }
         /* entering element < previous minimum (and not near it): the minimum dropped, and only the entering element can be
            below the old minimum: it is the new minimum, alone within SK2_NEAR, no search needed */
@@ -473,7 +480,8 @@ __device__ __forceinline__ void sk2_fast_strip(const Sketch2Args &B, const uint3
             const bool ok = n == 1 && (!blk || n2 == 1);
             const uint32_t pos = blk ? p2 : code;
             if (act && q == 0) {
-                if (ok) atomicOr(&s_bits[pos >> 5], 1u << (pos & 31u));
+                if (ok && g == 0u) s_q0 = pos; /* (lists: the minimum of window 0) */
+                else if (ok) atomicOr(&s_bits[pos >> 5], 1u << (pos & 31u));
                 else {
                     s_flag = 8u;
 #ifdef NTL_SIM
@@ -487,7 +495,10 @@ __device__ __forceinline__ void sk2_fast_strip(const Sketch2Args &B, const uint3
 
     /* ---- phase 7: proven minimizers to the global bitmask; flagged strips to the exact pass ---- */
     const uint32_t flagged = s_flag; /* written before the barrier above */
-    if (L < NBW && !flagged) {
+    if (lists) {
+        if (!flagged)
+            strip_bits_to_list<NT, NBW>(A.Ls, strip, s_bits, s_t0, [&](uint32_t i) -> uint32_t { return (uint32_t)(I.P0 + (int64_t)i); }, s_q0);
+    } else if (L < NBW && !flagged) {
         const uint32_t word = s_bits[L];
         if (word) {
             const uint64_t g0 = (uint64_t)((int64_t)I.base + I.P0 + 32 * (int64_t)L);
@@ -1365,8 +1376,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES >= 8 ? 8 : 7) void sketch_wave_ke
         const uint32_t strip = s0;
         I = I1; I1 = I2; W = W1;
         s0 = s1; s1 = s2;
-        const uint32_t hi = ntl_readfirstlane(Ic.z);
+        const uint32_t hi_raw = ntl_readfirstlane(Ic.z);
+        const uint32_t hi = hi_raw & 0xFFFFu;
         if (hi == 0u) continue; /* past the last strip, or a strip that crosses non-ACGT runs: sketch_mask_kernel<.., MULTI = true> */
+        const bool has_w0 = (hi_raw & STRIP_FIRST) == 0u; /* element 0 is a k-mer of the sequence, window 0 the previous strip's last */
 
         /* ---- the lane's bases: 64 that leave (so) and the 64 that enter (si), k bases further on ---- */
         uint32_t so[4], si[4];
@@ -1454,8 +1467,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES >= 8 ? 8 : 7) void sketch_wave_ke
         uint32_t mine[S];
 #pragma unroll
         for (int j = 0; j < S; j++) mine[j] = (uint32_t)j < cnt ? slots[j] : SK2_INF;
-        uint32_t first = 0;
-        if (L == 0 && cnt && (mine[0] & 63u) == 0u) { first = 1; cnt--; } /* element 0 belongs to the windows of the previous strip only */
+        uint32_t first = 0, k0 = SK2_INF;
+        if (L == 0 && cnt && (mine[0] & 63u) == 0u) { first = 1; cnt--; k0 = mine[0]; } /* element 0 belongs to the windows of the previous strip only */
+        k0 = ntl_readfirstlane(k0);
         if (hi < (uint32_t)(64 * C)) { /* the sequence ends inside the strip: positions >= hi are not elements */
             uint32_t keep = 0;
 #pragma unroll
@@ -1488,7 +1502,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES >= 8 ? 8 : 7) void sketch_wave_ke
            pays for the slowest lane either way, and without diverging lanes there are no execution masks to juggle); a lane
            without a candidate in the last round works on the last candidate again and drops the answer. ---- */
         uint32_t found = 0; /* bit r: this lane's candidate of round r is a minimizer */
+        uint32_t q0bit = 0; /* bit 0: this lane's candidate of round 0 is the minimum of window 0 */
         if (L == 0) bad |= pos[4] - 1u >= w; /* elements 1 .. w without a candidate */
+        /* The strip's own windows start at elements 1 .. NWO (the next strip's at its element 1 = NWO + 1 of this one), so the
+           last element of an own window is V - 1: no window reaches V, as if a blocker stood there, and a candidate at or behind
+           V is nobody's minimum here.  (The bitmask did not mind a bit set by two strips; the lists do: StripLists.) */
+        const uint32_t V = (uint32_t)A.G.NWO + w;
         for (uint32_t r = 0; r * 64u < n; r++) {
             const uint32_t i0 = (uint32_t)L + 64u * r;
             const bool real = i0 < n;
@@ -1496,8 +1515,20 @@ __global__ __launch_bounds__(64 * WAVES, WAVES >= 8 ? 8 : 7) void sketch_wave_ke
             const uint32_t mk = keys[i + 4u], mp = pos[i + 4u];
             const uint32_t lim = mk + SKW_NEAR;
             bool b = lim >= B.thresh;
-            uint32_t Rp = mp + w;
+            uint32_t Rp = mp + w < V ? mp + w : V;
             b |= pos[i + 5u] - mp - 1u >= w; /* a window between two candidates */
+            if (r == 0u && has_w0) {
+                /* Window 0 = elements 0 .. w - 1 is the previous strip's last one, and its minimum is that strip's to list, not
+                   this one's -- whichever of this strip's windows it is the minimum of as well.  The candidates in it are the
+                   first entries of the list (and element 0, k0, if it is one): the least key, alone within the tolerance. */
+                const bool inw0 = real && mp < w;
+                uint32_t kmin = ntl_wave_min(inw0 ? mk : SK2_INF);
+                kmin = kmin < k0 ? kmin : k0;
+                const bool near0 = inw0 && mk <= kmin + SKW_NEAR;
+                const uint32_t nn = (uint32_t)__popcll(__ballot(near0)) + (k0 != SK2_INF && k0 <= kmin + SKW_NEAR ? 1u : 0u);
+                b |= nn != 1u || kmin == SK2_INF || (n > 64u && pos[67] < w); /* a near tie, no candidate, or more than this round sees */
+                q0bit = near0 ? 1u : 0u;
+            }
             uint32_t q0, q1, q2, q3;
             {   /* to the right: the first blocker nearer than w; ends at the right sentinel (key 0) at the latest */
                 const uint32_t *kp = keys + i + 5u;
@@ -1531,14 +1562,31 @@ __global__ __launch_bounds__(64 * WAVES, WAVES >= 8 ? 8 : 7) void sketch_wave_ke
             }
             if (real) {
                 bad |= b;
-                if (!blocked) found |= 1u << r;
+                if (!blocked && mp < V) found |= 1u << r;
             }
         }
+        found &= ~q0bit;
 
         /* ---- proven minimizers to the global bitmask; a strip that was given up writes none and goes to the block-minima pass ---- */
         const bool flagged = B.force_redo || over || __ballot(bad) != 0ull;
         if (flagged) {
             if (L == 0) B.fb_list[atomicAdd(B.fb_count, 1u)] = strip;
+        } else if (A.Ls.cnt) {
+            /* the strip's list: its minimizers' positions in the sequence, in order (candidate i = L + 64 r: by rounds, then by lanes) */
+            uint32_t total = 0;
+            for (uint32_t r = 0; r * 64u < n; r++) total += (uint32_t)__popcll(__ballot((found >> r) & 1u));
+            uint32_t at = 0;
+            if (L == 0) at = strip_list_place(A.Ls, strip, total);
+            at = ntl_readfirstlane(at);
+            if (at != NTL_NONE) {
+                const uint32_t p0 = ntl_readfirstlane(Ic.w);
+                for (uint32_t r = 0; r * 64u < n; r++) {
+                    const bool mine_r = (found >> r) & 1u;
+                    const unsigned long long bal = __ballot(mine_r);
+                    if (mine_r) A.Ls.ent[at + ntl_mbcnt(bal)] = p0 + pos[(uint32_t)L + 64u * r + 4u];
+                    at += (uint32_t)__popcll(bal);
+                }
+            }
         } else {
             const uint64_t g0 = ((uint64_t)Ic.y << 32) | Ic.x;
             while (found) {

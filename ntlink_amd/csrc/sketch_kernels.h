@@ -87,8 +87,68 @@ struct StripInfo {
    lie in the sequence (0: not a strip of its kind -- past the last strip, or across non-ACGT runs) */
 struct __attribute__((aligned(16))) StripLite {
     uint64_t g0;
-    uint32_t hi, pad_;
+    uint32_t hi;  /* bits 0..15: the elements; bit 16 (STRIP_FIRST): the first strip of its sequence -- element 0 is virtual, there is no window 0 */
+    uint32_t p0;  /* position in the sequence of element 0 (2^32 - 1 for a first strip that starts at the sequence's first base) */
 };
+#define STRIP_FIRST 0x10000u
+
+/*
+ * Per-strip minimizer LISTS (round 5) -- what the window passes of the large windows write instead of bits in a bitmask of one
+ * bit per base (which had to be written with atomics, counted, read again, expanded and cleared: 2.3 GB of traffic per 3.9-Gbases
+ * launch for 0.5 GB of bits, and most of the emit kernel's instructions).  Every strip owns the windows that START at its elements
+ * 1 .. NWO, and a minimizer belongs to the strip that owns the FIRST window it is the minimum of (the windows a k-mer is the
+ * minimum of are consecutive, and their minima move monotonically), i.e. a strip lists
+ *       { argmin of window s : 1 <= s <= NWO }  \  { argmin of window 0 }
+ * in position order -- every minimizer of the sequence exactly once over its strips, in order over the strips.  A list's entries
+ * are positions in the sequence (u32).  Strip s's list lives in its slot ent[s * slot ..] when it fits (cnt[s] <= slot), else in a
+ * pool behind the slots, at ent[ovf_base + ent[s * slot] ..]: low-complexity sequence has up to one minimizer per base.  A pool that
+ * runs out sets ctl[1]; the counts are still right, and the sketch is made again through the bitmask (sketch_finalize).
+ */
+struct StripLists {
+    uint32_t *cnt;     /* [nstrips + 1] minimizers per strip, zeroed per sketch; NULL: the passes write the bitmask */
+    uint32_t *ent;
+    uint32_t slot;     /* entries per slot */
+    uint32_t ovf_base; /* first entry of the pool */
+    uint32_t ovf_cap;  /* its entries */
+    uint32_t *ctl;     /* [0] next free pool entry, [1] != 0: the pool ran out */
+};
+
+/* where a strip's `total` entries go: an index into ent (total > slot: a piece of the pool; NTL_NONE when the pool has run out).
+   One lane calls it.  (All of ent is addressed with 32 bits: the host takes the bitmask path for anything larger.) */
+__device__ __forceinline__ uint32_t strip_list_place(const StripLists &Ls, uint32_t strip, uint32_t total)
+{
+    Ls.cnt[strip] = total;
+    if (total <= Ls.slot) return strip * Ls.slot;
+    const uint32_t off = atomicAdd(&Ls.ctl[0], total);
+    if (off > Ls.ovf_cap || total > Ls.ovf_cap - off) { Ls.ctl[1] = 1u; return NTL_NONE; }
+    Ls.ent[(uint64_t)strip * Ls.slot] = off;
+    return Ls.ovf_base + off;
+}
+
+/* A workgroup's strip-local emission bitmask (bit i: element i of the strip is listed) as the strip's list; pos_of(i) = the position
+   in the sequence of element i.  All NT threads call it; s_tmp holds NT words. */
+template <int NT, int NBW, typename F>
+__device__ __forceinline__ void strip_bits_to_list(const StripLists &Ls, uint32_t strip, const uint32_t *s_bits, uint32_t *s_tmp, F pos_of,
+                                                   uint32_t drop = NTL_NONE)
+{
+    const int L = threadIdx.x;
+    uint32_t m = L < NBW ? s_bits[L] : 0u;
+    if ((drop >> 5) == (uint32_t)L) m &= ~(1u << (drop & 31u)); /* an element that is not this strip's to list */
+    uint32_t total;
+    uint32_t at = block_excl_scan<NT>((uint32_t)__popc(m), s_tmp, total);
+    if (L == 0) s_tmp[0] = strip_list_place(Ls, strip, total);
+    __syncthreads();
+    const uint32_t first = s_tmp[0];
+    if (first != NTL_NONE) {
+        uint32_t *const dst = Ls.ent + first;
+        while (m) {
+            const uint32_t b = (uint32_t)__ffs(m) - 1u;
+            m &= m - 1u;
+            dst[at++] = pos_of(32u * (uint32_t)L + b);
+        }
+    }
+    __syncthreads(); /* s_tmp may be written again */
+}
 
 __global__ void strip_table_kernel(SeqTables T, const uint32_t *run_n, const uint32_t *run_ord, const uint32_t *seq_M,
                                    const uint32_t *strip_first, int NWO, int strip_elems, StripInfo *tab, uint32_t cap, StripLite *lite)
@@ -97,7 +157,7 @@ __global__ void strip_table_kernel(SeqTables T, const uint32_t *run_n, const uin
     if (i >= cap) return;
     if (i >= strip_first[T.nseq]) { /* the grid of the sketch kernel is an upper bound */
         tab[i].seq = NTL_NONE;
-        if (lite) { lite[i].g0 = 0; lite[i].hi = 0; lite[i].pad_ = 0; }
+        if (lite) { lite[i].g0 = 0; lite[i].hi = 0; lite[i].p0 = 0; }
         return;
     }
     uint32_t lo = 0, hi = T.nseq; /* largest s with strip_first[s] <= i */
@@ -130,8 +190,8 @@ __global__ void strip_table_kernel(SeqTables T, const uint32_t *run_n, const uin
     if (lite) {
         const int64_t left = (int64_t)I.M - (int64_t)I.E0;
         lite[i].g0 = (uint64_t)((int64_t)I.base + I.P0);
-        lite[i].hi = I.multi ? 0u : (uint32_t)(left < (int64_t)strip_elems ? left : (int64_t)strip_elems);
-        lite[i].pad_ = 0;
+        lite[i].hi = I.multi ? 0u : ((uint32_t)(left < (int64_t)strip_elems ? left : (int64_t)strip_elems) | (I.E0 < 0 ? STRIP_FIRST : 0u));
+        lite[i].p0 = (uint32_t)I.P0;
     }
 }
 
@@ -149,6 +209,7 @@ struct SketchArgs {
     const struct StripLite *strip_lite; /* [nstrips + 1] the same for sketch_wave_kernel */
     const uint32_t *redo_list;   /* not NULL: process exactly these strips (flagged by sketch_fast_kernel), looping */
     const uint32_t *redo_count;
+    StripLists Ls;               /* Ls.cnt != NULL: the strips' minimizers go to their lists, not to the bitmask */
 };
 
 /* 16-bit strip-local index back to 32 bits (0xFFFF -> NTL_NONE) */
@@ -313,8 +374,9 @@ __device__ __forceinline__ void sketch_mask_strip(const SketchArgs &A, const uin
     bool A0_fin = false;
     /* emitted minimizers: single-run strips set bits in the strip-local LDS bitmask without a branch
        (OR of 0 when nothing is emitted); multi-run strips go straight to the global bitmask */
+    const bool lists = A.Ls.cnt != nullptr;
     auto emit = [&](uint32_t idx, bool flag) {
-        if (!MULTI) {
+        if (!MULTI || lists) { /* (a multi-run strip's list is made from the strip-local bits too) */
             /* lanes with nothing to emit set a bit in a private dummy word behind the bitmask (harmless, never
                read): no branch, no same-address serialisation; a flag implies a real index */
             const uint32_t ii = flag ? idx : (uint32_t)((NBW + (L & 63)) * 32);
@@ -383,7 +445,14 @@ __device__ __forceinline__ void sketch_mask_strip(const SketchArgs &A, const uin
         if (!MULTI) emit(A0_i, f0);
         else if (f0) emit(A0_i, true);
     }
-    if (!MULTI) {
+    if (lists) {
+        /* the windows above are the strip's OWN windows 1 .. NWO, and an element is emitted where the minimum moves to it: each
+           minimizer by the strip that owns the first of its windows (StripLists) */
+        __syncthreads();
+        strip_bits_to_list<NT, NBW>(A.Ls, strip, s_bits, (uint32_t *)s_bm_h, [&](uint32_t i) -> uint32_t {
+            return MULTI ? s_pos[(i % C) * NT + (i / C)] : (uint32_t)(I.P0 + (int64_t)i);
+        });
+    } else if (!MULTI) {
         __syncthreads();
         /* flush the strip-local bitmask: strip element 32*L.. starts at global bit g0 */
         if (L < NBW) {
@@ -682,5 +751,141 @@ __global__ __launch_bounds__(EMIT_NT) void emit_kernel(EmitArgs A)
         if (found) atomicAdd(&s_range[0], (uint32_t)found);
         __syncthreads();
         if (t == 0 && s_range[0]) atomicAdd(A.nfound, (unsigned long long)s_range[0]);
+    }
+}
+
+/* ---------------------------------------------------------------------------- emit from the strips' lists -------- */
+
+#define EL_NT 256
+#define EL_STRIPS 128 /* strips per tile: a thread (of the first EL_STRIPS) per strip sets the tile up */
+#define EL_CAP 2048   /* minimizers per round */
+
+struct EmitListArgs {
+    StripLists Ls;
+    const StripInfo *strip_tab;
+    const uint32_t *strip_off; /* [nstrips + 1] exclusive scan of Ls.cnt: the rank of a strip's first minimizer */
+    uint32_t nstrips;
+};
+
+/* behind the scan of the strips' counts: a sketch whose lists ran out of pool carries a total that no array holds (the map kernels
+   leave it alone, map_sketch_overflowed) and the flag that tells sketch_finalize why; also zeroes the emit kernel's tile counters */
+__global__ void list_fail_kernel(const uint32_t *__restrict__ ctl, uint32_t *__restrict__ total, uint32_t *__restrict__ flag, uint32_t *__restrict__ tile_next)
+{
+    if (threadIdx.x < 8) tile_next[16 * threadIdx.x] = 0u;
+    if (threadIdx.x == 0) {
+        const uint32_t f = ctl[1];
+        *flag = f;
+        if (f) *total = 0xFFFFFFFFu;
+    }
+}
+
+/* offsets of the per-sequence lists: the rank of the first minimizer of a sequence's first strip (a sequence without strips: of the
+   next strip; mx_off[nseq] = the total) */
+__global__ void mx_off_from_strips_kernel(const uint32_t *__restrict__ strip_first, const uint32_t *__restrict__ strip_off, uint32_t nseq,
+                                          uint32_t *__restrict__ mx_off)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s <= nseq) mx_off[s] = strip_off[strip_first[s]];
+}
+
+/*
+ * emit_list_kernel: what emit_kernel does, from the per-strip lists instead of the bitmask (round 5).  No bits to expand and to
+ * rank, no sequence to search: a minimizer's rank is its strip's offset (a scan over one count per strip, not over the bitmask)
+ * plus its place in the list, its sequence is the strip's.  A workgroup takes a tile of EL_STRIPS consecutive strips; the strips'
+ * threads spread their strip's number over the tile's ranks (one byte per minimizer in LDS), then a lane per minimizer: list entry
+ * (lanes of one strip: consecutive words), the k-mer's hash from its bases, the record, the index lookup.
+ */
+template <int PROBE>
+__global__ __launch_bounds__(EL_NT) void emit_list_kernel(EmitArgs A, EmitListArgs Q)
+{
+    unsigned long long found = 0;
+    __shared__ uint8_t s_sid[EL_CAP];
+    __shared__ uint32_t s_seq[EL_STRIPS], s_first[EL_STRIPS], s_loc[EL_STRIPS];
+    __shared__ uint64_t s_sbase[EL_STRIPS];
+    __shared__ uint64_t s_seed[4][2];
+    __shared__ uint64_t s_g4[256][2];  /* four-base init table: LDS copy (EL_NT == 256 entries) */
+    __shared__ uint64_t s_g4r[256][2]; /* ... and the same rotated by four bases: two groups per rotation (hash_init_g4p) */
+    __shared__ uint32_t s_tile, s_found;
+    static_assert(EL_NT == 256 && EL_STRIPS <= 256, "one table entry per thread; strip numbers are bytes");
+    const int t = threadIdx.x;
+    if (t < 4) { s_seed[t][0] = A.seed_tab[t][0]; s_seed[t][1] = A.seed_tab[t][1]; }
+    if (t == 0) s_found = 0;
+    {
+        const uint64_t gf = A.g4[t][0], gu = A.g4[t][1];
+        s_g4[t][0] = gf; s_g4[t][1] = gu;
+        s_g4r[t][0] = srot_h(gf, 4, 4); s_g4r[t][1] = srot_h(gu, 29, 27);
+    }
+    if (Q.Ls.ctl[1]) return; /* the lists ran out of pool: nothing here is complete (list_fail_kernel) */
+    uint32_t tile = blockIdx.x;
+    for (bool first_tile = true;; first_tile = false) {
+        if (A.tile_next) { /* a bounded number of resident workgroups that take their tiles from counters (EmitArgs) */
+            __syncthreads();
+            if (t == 0) s_tile = 8u * atomicAdd(&A.tile_next[16u * (blockIdx.x & 7u)], 1u) + (blockIdx.x & 7u);
+            __syncthreads();
+            tile = s_tile;
+        } else if (!first_tile) tile += gridDim.x;
+        tile = ntl_readfirstlane(tile);
+        if (tile >= A.ntiles) break;
+        const uint32_t strip0 = tile * EL_STRIPS;
+        const uint32_t strip1 = strip0 + EL_STRIPS < Q.nstrips ? strip0 + EL_STRIPS : Q.nstrips;
+        const uint32_t tile_base = Q.strip_off[strip0], total = Q.strip_off[strip1] - tile_base;
+        if (!first_tile && !A.tile_next) __syncthreads(); /* the previous tile's last readers of the strip tables */
+        uint32_t my_cnt = 0, my_loc = 0;
+        if ((uint32_t)t < strip1 - strip0) {
+            const uint32_t strip = strip0 + (uint32_t)t;
+            my_cnt = Q.Ls.cnt[strip];
+            my_loc = Q.strip_off[strip] - tile_base;
+            s_loc[t] = my_loc;
+            if (my_cnt) {
+                s_seq[t] = Q.strip_tab[strip].seq;
+                s_sbase[t] = Q.strip_tab[strip].base;
+                s_first[t] = my_cnt <= Q.Ls.slot ? strip * Q.Ls.slot : Q.Ls.ovf_base + Q.Ls.ent[(uint64_t)strip * Q.Ls.slot];
+            }
+        }
+        NTL_PRIO_LATENCY_BOUND();
+        for (uint32_t r0 = 0; r0 < total; r0 += EL_CAP) {
+            {   /* the strip of every rank of this round */
+                const uint32_t lo = my_loc > r0 ? my_loc : r0;
+                const uint32_t hi = my_loc + my_cnt < r0 + EL_CAP ? my_loc + my_cnt : r0 + EL_CAP;
+                for (uint32_t j = lo; j < hi; j++) s_sid[j - r0] = (uint8_t)t;
+            }
+            __syncthreads();
+            const uint32_t n = total - r0 < EL_CAP ? total - r0 : EL_CAP;
+            for (uint32_t i = t; i < n; i += EL_NT) {
+                const uint32_t sid = s_sid[i];
+                const uint32_t p = Q.Ls.ent[s_first[sid] + (r0 + i - s_loc[sid])];
+                const uint32_t sq = s_seq[sid];
+                const uint64_t gp = s_sbase[sid] + p;
+                uint64_t fwd, rev;
+                hash_init_g4p(A.packed, gp, A.k, s_g4, s_g4r, s_seed, fwd, rev);
+                uint64_t h = (fwd + rev) * A.mult;
+                h ^= h >> 27;
+                MxRecord R;
+                R.hash = h;
+                R.pos = p;
+                R.meta = (sq << 1) | (fwd <= rev ? 1u : 0u);
+                const uint32_t at = tile_base + r0 + i;
+                if (at >= A.out_cap) continue;
+                if (PROBE) {
+                    IndexProbe<PROBE == 1> pr;
+                    pr.start(h, A.slots, A.tags, A.ix_bits);
+                    if (A.out) A.out[at] = R;
+                    Cand cd = pr.finish(h, A.slots, A.tags, A.special, ((uint64_t)1 << A.ix_bits) - 1);
+                    A.rpos[at] = p;
+                    cd.meta |= R.meta << 31;
+                    A.cand[at] = cd;
+                    found += cd.meta & 1u;
+                } else {
+                    A.out[at] = R;
+                }
+            }
+            __syncthreads();
+        }
+    } /* tiles */
+    if (PROBE) { /* one atomic per workgroup */
+        __syncthreads();
+        if (found) atomicAdd(&s_found, (uint32_t)found);
+        __syncthreads();
+        if (t == 0 && s_found) atomicAdd(A.nfound, (unsigned long long)s_found);
     }
 }

@@ -20,7 +20,7 @@ def check_sketch(dev, seqs, k, w, threads=0, info=None):
     with dev.batch(seqs) as b, dev.sketch(b, k, w) as sk:
         off, h, p, s = sk.download()
         if info is not None:
-            info.update(strips=sk.strips, redo_strips=sk.redo_strips, fallback_strips=sk.fallback_strips)
+            info.update(strips=sk.strips, redo_strips=sk.redo_strips, fallback_strips=sk.fallback_strips, from_lists=sk.from_lists)
     ooff, oh, op, os_ = oracle.sketch_batch(b"".join(seqs), offsets_of(seqs), k, w, threads=threads)
     assert np.array_equal(off, ooff), "per-sequence minimizer counts differ"
     assert np.array_equal(p, op), "positions differ"
@@ -515,3 +515,42 @@ def check_async_order(dev, contigs, reads, k, w, **kw):
     dev.sync()                                         # nothing failed behind our back
     ix.close(); csk.close()
     return n_maps
+
+
+def check_strip_lists(dev, monkeypatch, scale=1):
+    """Round 5: for the windows ntLink runs with the window passes write per-strip minimizer LISTS (every minimizer by the strip that
+    owns the first window it is the minimum of) instead of a bitmask.  Same records as the oracle whichever pass lists a strip --
+    sketch_wave_kernel, the block-minima pass for what it gives up, the exact pass (forced: every strip through all three), the
+    multi-run pass (N in the sequences) -- with strips across several strips' seams (sequences of many strips), with lists that
+    live in the pool (slot of one entry), on low-complexity sequence (a minimizer per base), and when the pool runs out (the sketch
+    is made again through the bitmask)."""
+    import fuzz_cases
+    rng = np.random.default_rng(15)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    seqs = [bytes(acgt[rng.integers(0, 4, n)]) for n in tuple(n * scale for n in (30000, 12000, 4127, 300, 8000, 281, 3871, 0, 31, 9000))]
+    withn = [s[:2000] + b"N" * 7 + s[2000:5000] + b"NN" + s[5000:] for s in seqs[:2]] + seqs[2:5]
+    lowc = [b"A" * 6000 + seqs[1][:3000] + b"ACACACAC" * 700 + seqs[4], b"T" * 300, seqs[0][:9000]]
+    for k, w in ((32, 250), (24, 100), (40, 137)):
+        info = {}
+        assert check_sketch(dev, seqs, k, w, info=info) > 0
+        assert info["from_lists"], (k, w, info)
+        assert check_sketch(dev, withn, k, w, info=info) > 0 and info["from_lists"]
+        assert check_sketch(dev, lowc, k, w, info=info) > 0 and info["from_lists"] and info["redo_strips"] > 0
+    assert check_sketch(dev, fuzz_cases.fuzz_sequences(2)[:12], 32, 250, info=info) > 0 and info["from_lists"]
+    with monkeypatch.context() as m:
+        m.setenv("NTL_LIST_SLOT", "1")  # every list of more than one entry lives in the pool
+        assert check_sketch(dev, seqs + lowc, 32, 250, info=info) > 0 and info["from_lists"]
+        m.setenv("NTL_LIST_POOL", "500")  # ... which runs out
+        assert check_sketch(dev, seqs + lowc, 32, 250, info=info) > 0 and not info["from_lists"]
+        check_full_pipeline(dev, fixture_seqs("scaffolds_4.fa"), fixture_seqs("long_reads_4_top5.fa"), 40, 100, z=1000)
+    with monkeypatch.context() as m:
+        m.setenv("NTL_SKETCH_FORCE_REDO", "1")
+        assert check_sketch(dev, seqs + withn, 32, 250, info=info) > 0 and info["from_lists"]
+        assert info["fallback_strips"] == info["redo_strips"] > 0
+    with monkeypatch.context() as m:
+        m.setenv("NTL_SKETCH_THRESH", "4")  # most strips come back from the block-minima pass
+        assert check_sketch(dev, seqs, 32, 250, info=info) > 0 and info["from_lists"] and info["fallback_strips"] > 3
+    with monkeypatch.context() as m:
+        m.setenv("NTL_SKETCH_LISTS", "0")
+        assert check_sketch(dev, seqs, 32, 250, info=info) > 0 and not info["from_lists"]
+    assert check_sketch(dev, seqs, 32, 64, info=info) > 0 and not info["from_lists"]  # (a window of the bitmask passes)

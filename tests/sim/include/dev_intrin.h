@@ -31,6 +31,16 @@ inline uint32_t ntl_row_min16(uint32_t v)
     return v;
 }
 
+inline uint32_t ntl_wave_min(uint32_t v)
+{
+    const int l = (int)(sim::tid & 63u);
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t t = __shfl(v, (l + d) & 63);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+
 inline uint32_t ntl_shl1_or_eq(uint32_t acc, uint32_t a, uint32_t b) { return (acc << 1) | (a == b ? 1u : 0u); }
 
 inline uint32_t ntl_quad_min(uint32_t v)

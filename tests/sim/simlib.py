@@ -7,8 +7,10 @@ from ntlink_amd import capi
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 SIM_LIB = os.path.join(HERE, "build", "libntlink_sim.so")
-SRC = [os.path.join(ROOT, "ntlink_amd", "csrc", f) for f in
-       ("ntl_hip.hip", "ntl_io.cpp", "ntl_pairs.cpp", "ntl_liftover.cpp", "overlap_kernels.h", "dev_common.h", "scan_kernels.h", "sketch_kernels.h", "sketch2_kernels.h", "map_kernels.h", "pack_kernels.h", "synth_kernels.h")] + \
+CSRC = os.path.join(ROOT, "ntlink_amd", "csrc")
+UNITS = [os.path.join(CSRC, f) for f in ("ntl_hip.hip", "ntl_io.cpp", "ntl_pairs.cpp", "ntl_liftover.cpp")]
+# every header of the product's kernels is a dependency (dev_intrin.h is replaced by the mock's own file of that name)
+SRC = UNITS + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + \
       [os.path.join(HERE, "sim_runtime.cpp"), os.path.join(HERE, "include", "hip", "hip_runtime.h"),
        os.path.join(HERE, "include", "dev_intrin.h")]
 
@@ -30,7 +32,7 @@ def _build_locked(sanitize):
     cmd = ["g++", "-O1", "-g1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-ffp-contract=off", "-Wall",
            "-Wno-unused-function", "-Wno-unknown-pragmas", "-x", "c++",
            "-I", os.path.join(HERE, "include"), "-I", os.path.join(ROOT, "ntlink_amd", "csrc"),
-           SRC[0], SRC[1], SRC[2], SRC[3], os.path.join(HERE, "sim_runtime.cpp"), "-lz", "-ldl", "-o", out]
+           *UNITS, os.path.join(HERE, "sim_runtime.cpp"), "-lz", "-ldl", "-o", out]
     if sanitize:
         cmd[1:1] = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer"]
     subprocess.check_call(cmd)

@@ -289,7 +289,8 @@ def test_fast_window_pass_flags_keys_it_cannot_order(dev):
 
 
 @pytest.mark.parametrize("env", [{"NTL_SKETCH_FORCE_REDO": "1"}, {"NTL_SKETCH_FAST": "0"}, {"NTL_SKETCH_NT": "128"}, {"NTL_SKETCH_NT": "256"},
-                                 {"NTL_SKETCH_NT": "128", "NTL_SKETCH_FAST": "0"}, {"NTL_SKETCH_C": "4"}, {"NTL_SKETCH_CAP_GUESS": "1000"}],
+                                 {"NTL_SKETCH_NT": "128", "NTL_SKETCH_FAST": "0"}, {"NTL_SKETCH_C": "4"}, {"NTL_SKETCH_CAP_GUESS": "1000"},
+                                 {"NTL_SKETCH_LISTS": "0"}, {"NTL_LIST_SLOT": "8"}, {"NTL_LIST_SLOT": "8", "NTL_LIST_POOL": "2000"}],
                          ids=lambda e: ",".join(f"{k[11:]}={v}" for k, v in e.items()))
 def test_sketch_variants_on_the_gpu(dev, monkeypatch, env):
     """Every tuning variant of the window pass and the second emit pass (record array denser than guessed) on the GPU,
@@ -300,6 +301,12 @@ def test_sketch_variants_on_the_gpu(dev, monkeypatch, env):
     for seed, k, w in ((1, 32, 100), (2, 32, 250), (3, 24, 100), (7, 40, 16)):
         pc.check_sketch(dev, fuzz_cases.fuzz_sequences(seed), k, w)
     pc.check_sketch(dev, pc.edge_sequences(), 32, 100)
+
+
+def test_strip_lists(dev, monkeypatch):
+    """Round 5: per-strip minimizer lists instead of the bitmask, every pass that writes them, lists in the pool, a pool that runs
+    out (parity_cases.check_strip_lists), on sequences of up to 300 strips."""
+    pc.check_strip_lists(dev, monkeypatch, scale=40)
 
 
 @pytest.mark.parametrize("name,n_reads", [("C3", 100_000), ("C5", 100_000)])

@@ -497,3 +497,8 @@ def test_sim_one_pass_reader(dev, tmp_path, monkeypatch, form):
     assert got_names == [n for n, _ in want] and got_lens == [len(s) for _, s in want]
     if form in ("fasta", "fasta_wrapped", "fastq"):
         assert n_one >= 3 and st.get("one_pass_batches", 0) == n_one  # several batches, all read in one pass
+
+
+def test_sim_strip_lists(dev, monkeypatch):
+    """Round 5: per-strip minimizer lists instead of the bitmask (parity_cases.check_strip_lists)."""
+    pc.check_strip_lists(dev, monkeypatch)
