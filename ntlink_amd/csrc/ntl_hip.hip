@@ -1417,9 +1417,13 @@ static void launch_fast_r0(ntl_ctx *c, const Sketch2Args &B, unsigned strips)
                     hipLaunchKernelGGL(kern, dim3(wgs), dim3(threads), 0, c->wstream, Bq);
                 };
                 if (per_strip <= 175.0) { /* w >= 235 at ten candidates per window */
-                    if (wave == 4) go(sketch_wave_kernel<4, 11, 4>, 256u);
+                    /* (lists, round 5: the other stream's emit_list_kernel keeps to two resident workgroups per CU -- sketch_enqueue --
+                       and the window stage takes 24 of the 32 wavefront slots: C3 70.7 ms per step against 75.9 at 16 and 82.5 at
+                       32, profiles/r05_share_sweep_C3.jsonl) */
+                    const unsigned beside = B.A.Ls.cnt ? 24u : 16u;
+                    if (wave == 4) go(sketch_wave_kernel<4, 11, 4>, 256u, beside);
                     else if (wave == 16) go(sketch_wave_kernel<16, 11, 4>, 1024u);
-                    else go(sketch_wave_kernel<8, 11, 4>, 512u);
+                    else go(sketch_wave_kernel<8, 11, 4>, 512u, beside);
                 } else if (per_strip <= 300.0) { /* w >= 137 */
                     go(sketch_wave_kernel<8, 15, 6>, 512u);
                 } else {                         /* w >= 94 */
@@ -1773,7 +1777,9 @@ static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const nt
                transactions and gains nothing beyond 12 wavefronts per CU, while the slots it holds are missed by the map kernels
                and the window stage: C5 296-300 -> 269-271 ms per step at 3 workgroups per CU, 275 at 5, 280 at 4 with other window
                grids (profiles/r04_share_sweep_C5.jsonl); the tag form (C3) is as fast uncapped (74.4-75.0 against 74.9-75.9) */
-            int per_cu = c->pipelined && probe == 2 ? 3 : 0;
+            /* emit_list_kernel (44 registers, 13 KB of LDS) would fill all 32 wavefront slots of a CU, and the window stage's resident
+               workgroups of the next sub-batch then wait for them to drain (C3: 91 ms per step uncapped, 75.9 at two per CU) */
+            int per_cu = !c->pipelined ? 0 : (probe == 2 ? 3 : (lists ? 2 : 0));
             if (const char *e = getenv("NTL_EMIT_WGS_PER_CU")) per_cu = atoi(e);
             const uint64_t cap = (uint64_t)per_cu * (uint64_t)c->n_cu;
             if (per_cu > 0 && cap >= 8 && cap < tiles) { egrid = (unsigned)cap; E.tile_next = tile_next.as<uint32_t>(); }

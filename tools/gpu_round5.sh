@@ -1,24 +1,28 @@
 #!/bin/bash
-# One GPU-box visit (round 4 form): build, all gpu tests, smoke, the default bench line (C3 pipelined + serial pass + C2/C5 +
+# One GPU-box visit (round 4 form, kept for round 5): build, all gpu tests, smoke, the default bench line (C3 pipelined + serial pass + C2/C5 +
 # cpu baseline + end to end), a single-rank torch.distributed.run line, then -- with NTL_PIPELINE=0, so that per-kernel
 # figures are those of kernels running alone -- rocprofv3 kernel trace + three PMC passes per workload, each in its own run.
-# usage: tools/gpu_round4.sh <tag> [workloads to profile, default "C3 C5 C2"]
+# usage: tools/gpu_round5.sh <tag> [workloads to profile, default "C3 C5 C2"]   (SKIP_TESTS / SKIP_TORCHRUN / SKIP_PROF / SKIP_BENCH=1)
 set -x
-TAG=${1:-r04z}; shift
+TAG=${1:-r05z}; shift
 WL=${*:-C3 C5 C2}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+[ -f "$R/bench.py" ] || { echo "no bench.py under $R"; exit 1; }
+cd "$R"
 O=gpurun_out/$TAG; mkdir -p $O
 python __graft_entry__.py > $O/build.log 2>&1 || { tail -20 $O/build.log; exit 1; }
 if [ -z "$SKIP_TESTS" ]; then
 timeout 1800 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $O/pytest_gpu.log
 timeout 300 python __graft_entry__.py smoke 2>&1 | tail -2 | tee $O/smoke.log
 fi
+if [ -z "$SKIP_BENCH" ]; then
 timeout 1500 python bench.py $BENCH_ARGS > $O/bench.json 2> $O/bench.err
 head -c 1500 $O/bench.json; echo; tail -5 $O/bench.err
+fi
 if [ -z "$SKIP_TORCHRUN" ]; then
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-others > $O/bench_torchrun1.json 2> $O/bench_torchrun1.err; tail -c 300 $O/bench_torchrun1.json; tail -3 $O/bench_torchrun1.err
 fi
 if [ -z "$SKIP_PROF" ]; then
-R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 export NTL_PIPELINE=0
 for W in $WL; do
