@@ -109,8 +109,12 @@ struct ntl_ctx {
     size_t pool_cap = (size_t)32 << 30; /* upper bound of pool_bytes */
     /* Blocks up to NTL_SLAB_MAX_REQ are cut from slabs of NTL_SLAB_BYTES (a bump pointer; the cache above recycles them): a
        hipMalloc costs 4-9 ms of host time whatever its size, and a context's first read batch asked for seventy of them -- 0.6 s
-       per context of a process's first pass (profiles/r04_first_pass.txt).  A slab block that the cache drops is not reused. */
-    std::vector<std::pair<char *, size_t>> slabs;
+       per context of a process's first pass (profiles/r04_first_pass.txt).  A slab block that the cache drops goes onto the slabs'
+       free list (by size) and is handed out again; a slab without a live block goes back to the driver when memory runs out
+       (dev_alloc), so the bound of the cache bounds the slabs too (round 5). */
+    struct Slab { char *base; size_t size; size_t live; };
+    std::vector<Slab> slabs;
+    std::multimap<size_t, void *> slab_free;   /* dropped slab blocks by size */
     char *slab_cur = nullptr, *slab_end = nullptr;
     std::mutex slab_mu; /* (dev_free may be asked about another context's block: index_unref) */
     std::deque<CleanMask> masks;
@@ -303,28 +307,58 @@ static PinSlot *slot_get(ntl_ctx *c)
 #define NTL_SLAB_BYTES ((size_t)1 << 30)
 #define NTL_SLAB_MAX_REQ ((size_t)192 << 20)
 
-static bool in_slab(ntl_ctx *c, const void *p)
+static hipError_t sync_both(ntl_ctx *c);
+
+/* the slab a block lies in (slab_mu held), or NULL */
+static ntl_ctx::Slab *slab_of(ntl_ctx *c, const void *p)
 {
-    std::lock_guard<std::mutex> g(c->slab_mu);
     for (auto &sl : c->slabs)
-        if ((const char *)p >= sl.first && (const char *)p < sl.first + sl.second) return true;
-    return false;
+        if ((const char *)p >= sl.base && (const char *)p < sl.base + sl.size) return &sl;
+    return nullptr;
 }
 
-/* gives a block of dev_alloc back to the driver (a slab block: nothing to do, its slab goes with the context) */
-static void dev_free(ntl_ctx *c, void *p)
+/* Gives a block of dev_alloc (of `bytes`, as asked for there) back.  A single block: hipFree, which waits for the device.  A slab
+   block: the same wait -- whatever is still queued on the block has run -- and then onto the slabs' free list. */
+static void dev_free(ntl_ctx *c, void *p, size_t bytes)
 {
-    if (p && !in_slab(c, p)) (void)hipFree(p);
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> g(c->slab_mu);
+        if (!slab_of(c, p)) { (void)hipFree(p); return; }
+    }
+    (void)sync_both(c);
+    std::lock_guard<std::mutex> g(c->slab_mu);
+    ntl_ctx::Slab *sl = slab_of(c, p);
+    if (sl && sl->live) sl->live--;
+    c->slab_free.insert({(bytes + 255) & ~(size_t)255, p});
+}
+
+/* slabs without a live block go back to the driver (out of memory: dev_alloc); returns the bytes freed */
+static size_t slabs_trim(ntl_ctx *c)
+{
+    std::lock_guard<std::mutex> g(c->slab_mu);
+    size_t freed = 0;
+    for (size_t i = 0; i < c->slabs.size();) {
+        ntl_ctx::Slab sl = c->slabs[i];
+        if (sl.live) { i++; continue; }
+        for (auto it = c->slab_free.begin(); it != c->slab_free.end();)
+            it = ((char *)it->second >= sl.base && (char *)it->second < sl.base + sl.size) ? c->slab_free.erase(it) : std::next(it);
+        if (c->slab_cur >= sl.base && c->slab_cur <= sl.base + sl.size) c->slab_cur = c->slab_end = nullptr;
+        (void)hipFree(sl.base);
+        freed += sl.size;
+        c->slabs.erase(c->slabs.begin() + (long)i);
+    }
+    return freed;
 }
 
 static void pool_drop_all(ntl_ctx *c)
 {
     for (int i = 0; i < NTL_NSID; i++) {
-        for (auto &kv : c->pool[i]) dev_free(c, kv.second);
+        for (auto &kv : c->pool[i]) dev_free(c, kv.second, kv.first);
         c->pool[i].clear();
     }
     for (auto &kv : c->xpool) {
-        dev_free(c, kv.second.p);
+        dev_free(c, kv.second.p, kv.first);
         for (int o = 0; o < NTL_NSID; o++) sev_put(c, kv.second.ev[o]);
     }
     c->xpool.clear();
@@ -342,6 +376,16 @@ static int dev_alloc(ntl_ctx *c, size_t bytes, void **out)
 #endif
     if (use_slabs && bytes <= NTL_SLAB_MAX_REQ) {
         const size_t need = (bytes + 255) & ~(size_t)255;
+        {   /* a dropped slab block of this size (dev_free has waited for whatever was queued on it) */
+            std::lock_guard<std::mutex> g(c->slab_mu);
+            auto it = c->slab_free.lower_bound(need);
+            if (it != c->slab_free.end() && it->first <= need + need / 4) {
+                *out = it->second;
+                if (ntl_ctx::Slab *sl = slab_of(c, it->second)) sl->live++;
+                c->slab_free.erase(it);
+                return NTL_OK;
+            }
+        }
         if (!c->slab_cur || (size_t)(c->slab_end - c->slab_cur) < need) {
             void *sl = nullptr;
             const auto ts = std::chrono::steady_clock::now();
@@ -350,12 +394,16 @@ static int dev_alloc(ntl_ctx *c, size_t bytes, void **out)
                 pe.done_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts).count();
                 pe.launches++;
                 std::lock_guard<std::mutex> g(c->slab_mu);
-                c->slabs.push_back({(char *)sl, NTL_SLAB_BYTES});
+                /* what is left of the slab before it, as a free block (else it would be lost while one of its blocks lives) */
+                if (c->slab_cur && c->slab_end - c->slab_cur >= 256) c->slab_free.insert({(size_t)(c->slab_end - c->slab_cur) & ~(size_t)255, c->slab_cur});
+                c->slabs.push_back({(char *)sl, NTL_SLAB_BYTES, 0});
                 c->slab_cur = (char *)sl; c->slab_end = (char *)sl + NTL_SLAB_BYTES;
             } else (void)hipGetLastError(); /* no room for a slab: single blocks as before */
         }
         if (c->slab_cur && (size_t)(c->slab_end - c->slab_cur) >= need) {
+            std::lock_guard<std::mutex> g(c->slab_mu);
             *out = c->slab_cur;
+            if (ntl_ctx::Slab *sl = slab_of(c, c->slab_cur)) sl->live++;
             c->slab_cur += need;
             return NTL_OK;
         }
@@ -371,8 +419,10 @@ static int dev_alloc(ntl_ctx *c, size_t bytes, void **out)
         fprintf(stderr, "ntl pool: hipMalloc %.1f MB -> %s in %.3f ms (cached %.1f MB of %.1f)\n", bytes / 1e6, e == hipSuccess ? "ok" : "FAILED",
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), c->pool_bytes / 1e6, c->pool_cap / 1e6);
     if (e != hipSuccess) {
-        /* drop the cache and retry once */
+        /* drop the cache -- single blocks go back to the driver, slab blocks to their free list and the slabs that hold nothing
+           else to the driver -- and retry once */
         pool_drop_all(c);
+        (void)slabs_trim(c);
         e = hipMalloc(out, bytes);
         if (e != hipSuccess) return fail(c, NTL_ENOMEM, "hipMalloc failed");
     }
@@ -475,12 +525,12 @@ struct DevBuf {
                 if (big && (c->xpool.empty() || std::prev(big->end())->first >= std::prev(c->xpool.end())->first)) {
                     auto it = std::prev(big->end());
                     if (g_pool_trace) fprintf(stderr, "ntl pool: over the bound, hipFree %.1f MB\n", it->first / 1e6);
-                    dev_free(c, it->second); /* waits for the device: safe whatever is still queued */
+                    dev_free(c, it->second, it->first); /* waits for the device: safe whatever is still queued */
                     c->pool_bytes -= it->first;
                     big->erase(it);
                 } else if (!c->xpool.empty()) {
                     auto it = std::prev(c->xpool.end());
-                    dev_free(c, it->second.p);
+                    dev_free(c, it->second.p, it->first);
                     for (int o = 0; o < NTL_NSID; o++) sev_put(c, it->second.ev[o]);
                     c->pool_bytes -= it->first;
                     c->xpool.erase(it);
@@ -614,11 +664,11 @@ extern "C" void ntl_ctx_destroy(ntl_ctx *c)
     (void)sync_both(c);
     reap(c, true);
     pool_drop_all(c);
-    for (auto &m : c->masks) { dev_free(c, m.p); sev_put(c, m.clean); }
+    for (auto &m : c->masks) { dev_free(c, m.p, m.bytes); sev_put(c, m.clean); }
     (void)hipFree(c->g4);
     (void)hipFree(c->g8);
     for (auto &kv : c->g8k) (void)hipFree(kv.second);
-    for (auto &sl : c->slabs) (void)hipFree(sl.first);
+    for (auto &sl : c->slabs) (void)hipFree(sl.base);
     c->slabs.clear();
     if (c->host_tmp) pin_free(c->host_tmp);
     if (c->slots) (void)hipHostFree(c->slots);
@@ -1201,7 +1251,7 @@ static void index_unref(const ntl_index *cix, ntl_ctx *by)
     (void)hipSetDevice(ix->c->device);
     if (by != ix->c) {
         for (DevBuf *b : {&ix->slots, &ix->special, &ix->ctg_len, &ix->cnt, &ix->tags}) {
-            if (b->p) dev_free(ix->c, b->p);
+            if (b->p) dev_free(ix->c, b->p, b->bytes);
             b->p = nullptr; b->bytes = 0;
         }
         if (ix->built) (void)hipEventDestroy(ix->built);
@@ -1472,7 +1522,7 @@ static int mask_take(ntl_ctx *c, size_t bytes, int sid, CleanMask *out)
         }
     }
     while (c->masks.size() > 4) { /* other batch sizes came and went */
-        dev_free(c, c->masks.front().p);
+        dev_free(c, c->masks.front().p, c->masks.front().bytes);
         sev_put(c, c->masks.front().clean);
         c->masks.pop_front();
     }
@@ -1614,7 +1664,7 @@ static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const nt
     if (!lists && (rc = mask_take(c, nmask * 4, wsid, &mask))) return rc;
     struct MaskGuard { /* error paths: the mask is not known to be clean any more */
         ntl_ctx *c; CleanMask *m;
-        ~MaskGuard() { if (m->p) { dev_free(c, m->p); m->p = nullptr; } }
+        ~MaskGuard() { if (m->p) { dev_free(c, m->p, m->bytes); m->p = nullptr; } }
     } mask_guard{c, &mask};
     if ((rc = strip_tab.alloc(c, (ub_strips + 1) * sizeof(StripInfo), psid))) return rc;
     DevBuf strip_lite;

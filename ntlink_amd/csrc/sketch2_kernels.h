@@ -1301,8 +1301,13 @@ __device__ __forceinline__ void skw_steps(std::integer_sequence<int, J...>, uint
     (skw_step<T0 + J>(fx, ry, fd, sd[J], tm1, low6, dst), ...);
 }
 
+/* wavefronts per SIMD a shape is compiled for = what its LDS lets a CU hold (the register budget follows from it): the shapes of the
+   large windows 32 wavefronts per CU; <8,15,6> three workgroups of 40 KB, <8,19,8> three of 48 KB: 24; <4,19,8> five of 28 KB: 20 */
+template <int WAVES, int S>
+constexpr int skw_waves_per_simd() { return S >= 15 ? (WAVES >= 8 ? 6 : 5) : (WAVES >= 8 ? 8 : 7); }
+
 template <int WAVES, int S, int ROUNDS>
-__global__ __launch_bounds__(64 * WAVES, WAVES >= 8 ? 8 : 7) void sketch_wave_kernel(Sketch2Args B)
+__global__ __launch_bounds__(64 * WAVES, (skw_waves_per_simd<WAVES, S>())) void sketch_wave_kernel(Sketch2Args B)
 {
     constexpr int C = 64;
     constexpr uint32_t SLOTS = 64u * (uint32_t)S;      /* words of a wavefront's key array: staging slots, then the list's keys in place */

@@ -497,3 +497,24 @@ def test_kernel_variants_full_pipeline(dev, monkeypatch, env):
         pc.check_full_pipeline(dev, contigs, reads, k, w, z=1000, sensitive=sens)
     for seed, k, w in ((1, 32, 100), (2, 32, 250), (3, 24, 64), (5, 40, 255)):
         pc.check_sketch(dev, fuzz_cases.fuzz_sequences(seed), k, w)
+
+
+def test_slab_blocks_are_reused_when_the_cache_drops_them(monkeypatch):
+    """blocks of 192 MB or less are cut from 1-GB slabs, and a slab block that the block cache evicted used to be lost
+    (the cache's bound no longer bounded device memory).  With a cache bound of zero every released block is evicted at once: the
+    slabs' free list hands them out again, so sixty sketches of varying size make no more allocations than the first few did --
+    and stay bit-exact."""
+    monkeypatch.setenv("NTL_POOL_MAX_BYTES", "0")
+    d = capi.Device(0)
+    try:
+        rng = np.random.default_rng(3)
+        acgt = np.frombuffer(b"ACGT", np.uint8)
+        counts = []
+        for i in range(60):
+            n = int(rng.integers(20_000, 400_000))
+            seqs = [bytes(acgt[rng.integers(0, 4, n)]), bytes(acgt[rng.integers(0, 4, n // 3)])]
+            assert pc.check_sketch(d, seqs, 32, 250 if i % 2 else 100) > 0
+            counts.append(d.prof_get("hipMalloc")[1])
+        assert counts[-1] <= counts[9] + 1, counts  # (single blocks above 192 MB would count too: none here)
+    finally:
+        d.close()

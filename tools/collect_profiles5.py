@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Copies the summaries of one GPU visit (gpurun_out/<tag>/, written by tools/gpu_round4.sh) into profiles/ and refreshes
+"""Copies the summaries of one GPU visit (gpurun_out/<tag>/, written by tools/gpu_round5.sh) into profiles/ and refreshes
 profiles/traffic.json[workload] for every workload that was profiled: HBM bytes, VALU instructions and the SIMD cycles
 per VALU instruction of a READ-batch launch of the dominant window kernel, and the same counters for the other big kernels of a step
 (emit with the index lookup, the map kernels), from the PMC passes (NTL_PIPELINE=0: kernels alone) of the bench command,
 together with the kernel-source signature and the bases per launch the passes were taken on (bench.py quotes them only
-while both still match).   usage: tools/collect_profiles4.py <tag>"""
+while both still match).   usage: tools/collect_profiles5.py <tag>"""
 import collections
 import csv
 import json
@@ -82,6 +82,8 @@ for workload in ("C3", "C5", "C2"):
         continue
     json.dump(summary, open(os.path.join(out, f"{tag}_pmc_summary_{workload}.json"), "w"), indent=1)
     for a, b in ((f"trace_{workload}/kt_kernel_stats.csv", f"bench_{workload}_serial_kernel_stats.csv"),
+                 (f"trace_{workload}_pipe/kt_kernel_stats.csv", f"bench_{workload}_pipelined_kernel_stats.csv"),
+                 (f"bench_trace_{workload}_pipe.json", f"bench_{workload}_pipelined_profiled_run.json"),
                  (f"bench_trace_{workload}.json", f"bench_{workload}_profiled_run.json")):
         if os.path.exists(os.path.join(src, a)) and os.path.getsize(os.path.join(src, a)):
             shutil.copy(os.path.join(src, a), os.path.join(out, f"{tag}_{b}"))
@@ -117,13 +119,13 @@ for workload in ("C3", "C5", "C2"):
                    salu_per_valu=round(avg("pmc_sq", "SQ_INSTS_SALU") / vi, 3), lds_per_valu=round(avg("pmc_sq", "SQ_INSTS_LDS") / vi, 3),
                    clock_ghz=round(cyc / dur, 3), profiled_launch_ms=round(dur / 1e6, 4),
                    wait_inst_any_over_wave_cycles=round(avg("pmc_sq", "SQ_WAIT_INST_ANY") / max(avg("pmc_sq", "SQ_WAVE_CYCLES"), 1), 3),
-                   isa_mix="profiles/r04_isa_mix.json",
+                   isa_mix="profiles/r05_isa_mix.json",
                    valu_source=f"profiles/{tag}_pmc_summary_{workload}.json (pmc_sq pass): SQ_INSTS_VALU and GRBM_GUI_ACTIVE (/ 8 XCDs x 1024 SIMDs = SIMD cycles), "
                                f"average over the {n} read-batch launches (SQ_ACTIVE_INST_VALU equals SQ_INSTS_VALU in these files: it is not a busy-cycle count and is not used)")
     # the other big kernels of a step: bytes, VALU share, duration per launch
     others = {}
     for k in set(summary.get("pmc_sq", {})) | set(summary.get("pmc_fetch", {})):
-        if not any(x in k for x in ("emit_kernel", "map_kernel", "map_overflow", "map_gather", "mask_count", "probe_kernel")):
+        if not any(x in k for x in ("emit_kernel", "emit_list_kernel", "map_kernel", "map_overflow", "map_gather", "mask_count", "probe_kernel", "sketch_fast_list")):
             continue
         e = {}
         sq = summary.get("pmc_sq", {}).get(k)

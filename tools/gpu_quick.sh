@@ -16,7 +16,7 @@ for W in $WL; do
   python - <<PY
 import json
 d=json.load(open("$O/bench_$W.json")); c=d["config"]; r=d["roofline"]
-print("$W", d["value"], "Gbases/s", d["ms_per_step"], "ms/step; window alone", r["avg_launch_ms"], "ms; in pipe", r["in_timed_region"]["avg_launch_ms"])
+print("$W", d["value"], "Gbases/s", d["ms_per_step"], "ms/step; window in pipe", r["avg_launch_ms"], "ms; alone", r["kernels_alone"]["avg_launch_ms"])
 print("  in pipe", c["stage_ms_per_step"]); print("  alone  ", c["serial_pass"]["ms_per_step"], c["serial_pass"]["stage_ms_per_step"])
 PY
 done

@@ -24,6 +24,11 @@ timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --mast
 fi
 if [ -z "$SKIP_PROF" ]; then
 cd /tmp && export TMPDIR=/tmp
+# the default (two-stream) command under the kernel trace: the window kernel's average duration INSIDE the timed region (roofline.avg_launch_ms)
+for W in $WL; do
+B="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-others --serial-steps 0 --workload $W"
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/trace_${W}_pipe -o kt -- $B > $R/$O/bench_trace_${W}_pipe.json 2> $R/$O/trace_${W}_pipe.err
+done
 export NTL_PIPELINE=0
 for W in $WL; do
 B="python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-e2e --no-others --serial-steps 0 --workload $W"
