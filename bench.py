@@ -372,8 +372,7 @@ def summarize(R, args, world, dev_name):
            "index_size": R["index_size"], "mappings_hits_pafs_per_step": list(stats["counts"]), "window_strips_per_step": stats.get("strips"),
            # k-mers of the reads / lane positions of their strips (a strip = one wavefront x 4096 positions): what the window kernel's lanes
            # roll that is a k-mer of a read -- the rest is the overlap of consecutive strips (w - 1 + 16 of 4096) and the empty end of a read's last strip
-           "window_lane_utilisation": (round((read_bases - (k - 1) * sum(len(x) for x in wl.read_lens)) / (stats["strips"] * 4096.0), 4)
-                                       if stats.get("strips") else None),
+           "window_lane_utilisation": window_lane_utilisation(wl.read_lens, k, w),
            "device": dev_name, "gen_s": round(R["gen_s"], 2),
            "contig_stage_ms": round(R["contig_stage_ms"], 2),
            "contig_stage_kernels_ms": {nm: round(v[0], 3) for nm, v in R["contig_prof"].items() if v[1]},
@@ -524,6 +523,29 @@ def pmc_summary(workload, scale, bases_per_launch):
 
 
 VALU_FLOOR_PER_KMER = 9.0
+
+
+def window_lane_utilisation(read_lens, k, w):
+    """k-mers of the reads / lane-steps the window kernel rolls for them.  The strip geometry of sketch_wave_kernel (ntl_hip.hip
+    sketch_geometry, sketch2_kernels.h skw_per_lane): a read of M k-mers is cut into strips of 4096 elements that start NWO apart;
+    a wavefront rolls 64 lanes x 64 steps over a strip, 64 x (16, 32 or 48) over a read's short last strip.  What is not a read's k-mer:
+    the w - 1 + 16 elements consecutive strips share, and the unused end of the last strip's last sixteen-step block."""
+    import numpy as np
+    if not (94 <= w <= 255 and k <= 64):
+        return None
+    nwo = (256 - ((w - 16) // 16 + 2)) * 16 - 1
+    M = np.concatenate([np.asarray(x, np.int64) for x in read_lens]) - (k - 1)
+    M = M[M >= w]
+    n = (M - w + nwo) // nwo  # strips of each read
+    steps, i = 0, 0
+    while True:
+        m = M[n > i]
+        if not len(m):
+            break
+        hi = np.minimum(4096, m - i * nwo + 1)
+        steps += int(np.where(hi > 3072, 64, 16 * ((hi + 1023) // 1024)).sum()) * 64
+        i += 1
+    return round(float(M.sum()) / steps, 4) if steps else None
 
 
 def valu_roofline(pm, avg_launch_ms, bases_per_launch):

@@ -1261,10 +1261,20 @@ __device__ __forceinline__ uint4 skw_strip_load(const StripLite *tab, uint32_t s
     return v;
 }
 
+/* k-mers per lane of a strip of `hi` elements: 64, or -- a sequence's last strip -- the multiple of 16 that still covers it: the
+   wavefront rolls 16, 32 or 48 steps instead of 64, all lanes at work (round 5; a tail strip used to roll 64 steps with the lanes
+   behind the sequence's end idle: 15 % of all lane-steps at C3; blocks of eight steps instead of sixteen: no shorter, 2.114 against
+   2.102 ms per C3 launch) */
+__device__ __forceinline__ uint32_t skw_per_lane(uint32_t hi_raw)
+{
+    const uint32_t hi = hi_raw & 0xFFFFu;
+    return hi > 3072u ? 64u : ((hi + 1023u) >> 10) << 4;
+}
+
 __device__ __forceinline__ SkwWords skw_words_load(const uint32_t *__restrict__ packed, const uint4 I, int L, int k, uint32_t wmax)
 {
     SkwWords W;
-    const uint64_t gp = (((uint64_t)I.y << 32) | I.x) + (uint64_t)(L * 64);
+    const uint64_t gp = (((uint64_t)I.y << 32) | I.x) + (uint64_t)((uint32_t)L * skw_per_lane(I.z));
     const uint64_t gq = gp + (uint64_t)k;
     uint32_t wi = (uint32_t)(gp >> 4), wq = (uint32_t)(gq >> 4);
     wi = wi < wmax ? wi : wmax; /* over-reads behind the last sequence: values never used */
@@ -1391,7 +1401,8 @@ __global__ __launch_bounds__(64 * WAVES, (skw_waves_per_simd<WAVES, S>())) void 
         so[0] = ntl_alignbit(Wc.o0.y, Wc.o0.x, Wc.ao); so[1] = ntl_alignbit(Wc.o0.z, Wc.o0.y, Wc.ao); so[2] = ntl_alignbit(Wc.o0.w, Wc.o0.z, Wc.ao); so[3] = ntl_alignbit(Wc.o4, Wc.o0.w, Wc.ao);
         si[0] = ntl_alignbit(Wc.i0.y, Wc.i0.x, Wc.ai); si[1] = ntl_alignbit(Wc.i0.z, Wc.i0.y, Wc.ai); si[2] = ntl_alignbit(Wc.i0.w, Wc.i0.z, Wc.ai); si[3] = ntl_alignbit(Wc.i4, Wc.i0.w, Wc.ai);
 
-        const uint32_t lane_pos = (uint32_t)(L * C);
+        const uint32_t Cs = ntl_readfirstlane(skw_per_lane(hi_raw)); /* k-mers per lane of this strip */
+        const uint32_t lane_pos = (uint32_t)L * Cs;
         const uint32_t tm1 = lane_pos < hi ? B.thresh - 1u : 0u; /* lanes behind the sequence's last k-mer roll over whatever follows it: nothing of theirs is a candidate */
         uint32_t low6 = 63u;
         NTL_OPAQUE(low6); /* a register, not a literal per step; and not loop-invariant for the optimiser */
@@ -1436,6 +1447,8 @@ __global__ __launch_bounds__(64 * WAVES, (skw_waves_per_simd<WAVES, S>())) void 
             if (fd + ry <= tm1) ntl_lds_push_tagged<0>(dst, low6, fd + ry);
 #pragma unroll
             for (int m = 0; m < 4; m++) {
+                if ((uint32_t)(16 * m) >= Cs) break; /* (a short last strip: its lanes hold 16, 32 or 48 k-mers; the step that a block of
+                                                        sixteen makes beyond them is the next lane's first k-mer, dropped below) */
                 uint32_t wz[4];
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
@@ -1475,11 +1488,11 @@ __global__ __launch_bounds__(64 * WAVES, (skw_waves_per_simd<WAVES, S>())) void 
         uint32_t first = 0, k0 = SK2_INF;
         if (L == 0 && cnt && (mine[0] & 63u) == 0u) { first = 1; cnt--; k0 = mine[0]; } /* element 0 belongs to the windows of the previous strip only */
         k0 = ntl_readfirstlane(k0);
-        if (hi < (uint32_t)(64 * C)) { /* the sequence ends inside the strip: positions >= hi are not elements */
+        if (hi < (uint32_t)(64 * C)) { /* the sequence ends inside the strip: positions >= hi are not elements (nor is a lane's step Cs) */
             uint32_t keep = 0;
 #pragma unroll
             for (int j = 0; j < S; j++)
-                if ((uint32_t)j >= first && (uint32_t)j < first + cnt && lane_pos + (mine[j] & 63u) < hi) keep++;
+                if ((uint32_t)j >= first && (uint32_t)j < first + cnt && (mine[j] & 63u) < Cs && lane_pos + (mine[j] & 63u) < hi) keep++;
             cnt = keep;
         }
         const uint32_t incl = ntl_wave_incl_scan(cnt);
