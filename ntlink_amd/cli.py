@@ -170,7 +170,7 @@ def write_time_file(kv, command, wall_s, stats):
              "\tExit status: 0"]
     for key in sorted(stats or {}):
         if key.startswith("t_") or key in ("read_bases", "reads", "read_minimizers", "index_hits", "index_size", "parsed_bytes",
-                                           "parsed_bytes_per_rank", "pin_per_rank"):
+                                           "parsed_bytes_per_rank", "pin_per_rank", "contigs_parsed_by_per_rank"):
             lines.append(f"\tntlink_amd {key}: {stats[key]:.3f}" if isinstance(stats[key], float) else f"\tntlink_amd {key}: {stats[key]}")
     with open(f"{prefix}.n{kv['n']}.scaffold.dot.time", "w") as fh:
         fh.write("\n".join(lines) + "\n")

@@ -323,6 +323,79 @@ class LocalComm:
         pass
 
 
+def _node_leader(comm):
+    """(lowest rank on this rank's host, ranks on this host): the ranks of one node share what only one of them has to make."""
+    import socket
+    hosts = comm.allgather(os.environ.get("NTL_FAKE_HOSTNAME") or socket.gethostname())
+    mine = [r for r, h in enumerate(hosts) if h == hosts[comm.rank]]
+    return mine[0], mine
+
+
+_SHARED_FIELDS = ("names_blob", "names_off", "offsets", "packed", "seq_run_first", "run_start", "run_len")
+
+
+def shared_contigs(comm, target, alloc, packed, stats=None):
+    """The target FASTA parsed and packed ONCE PER NODE (round 5; BASELINE configs[3]: eight ranks on one host each parsed the same 3-GB
+    file -- eight times 0.2 s of all parser threads, on a CPU quota that eight ranks share).  The lowest rank of a host parses as a
+    single process would (seqio.load_all), writes the arrays of the packed set -- names, offsets, 2-bit words, ACGT-run table -- into one
+    file under /dev/shm and tells the others its name; they map it read-only and upload from the mapping.  The file is unlinked as
+    soon as every rank of the host has it open.  Every GPU still sketches and indexes the contigs itself (6 ms of kernels: a peer
+    copy of the finished table would save less than its synchronisation costs).  NTL_SHARE_CONTIGS=0, one rank per host, or an
+    unpacked load: every rank parses."""
+    import json
+    import mmap
+    import numpy as np
+    share = comm.world > 1 and packed and os.environ.get("NTL_SHARE_CONTIGS", "1") != "0"
+    leader, peers = _node_leader(comm) if share else (comm.rank, [comm.rank])
+    if not share or len(peers) == 1:
+        if stats is not None:
+            stats["contigs_parsed_by"] = comm.rank
+        if share:  # the collectives below are the whole world's: keep in step with the hosts that do share
+            comm.allgather(None)
+            comm.allgather(None)
+        return seqio.load_all([target], alloc=alloc if packed else None, packed=packed), None
+    path, ss = None, None
+    if comm.rank == leader:
+        ss = seqio.load_all([target], alloc=alloc, packed=True)
+        arrays = dict(names_blob=ss.names.blob, names_off=ss.names.off, offsets=np.ascontiguousarray(ss.offsets, np.uint64),
+                      packed=ss.packed, seq_run_first=ss.seq_run_first, run_start=ss.run_start, run_len=ss.run_len)
+        shm = "/dev/shm" if os.path.isdir("/dev/shm") else (os.environ.get("TMPDIR") or "/tmp")
+        path = os.path.join(shm, f"ntlink_amd.ctg.{os.getuid()}.{os.getpid()}.{int(time.time() * 1e6) & 0xFFFFFF:06x}")
+        head, at = {}, 4096
+        for key in _SHARED_FIELDS:
+            a = np.ascontiguousarray(arrays[key])
+            head[key] = (str(a.dtype), int(a.size), at)
+            at += (a.nbytes + 63) & ~63
+        hb = json.dumps(head).encode()
+        assert len(hb) + 8 <= 4096
+        with open(path, "wb") as fh:
+            fh.write(len(hb).to_bytes(8, "little") + hb)
+            for key in _SHARED_FIELDS:
+                fh.seek(head[key][2])
+                np.ascontiguousarray(arrays[key]).tofile(fh)
+            fh.truncate(max(at, 4096))
+    paths = comm.allgather(path)  # (also: the file is complete)
+    mapping = None
+    if comm.rank != leader:
+        with open(paths[leader], "rb") as fh:
+            mapping = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
+        n = int.from_bytes(mapping[:8], "little")
+        head = json.loads(bytes(mapping[8:8 + n]))
+        arr = {key: np.frombuffer(mapping, dtype=np.dtype(dt), count=cnt, offset=off) for key, (dt, cnt, off) in head.items()}
+        arr = {key: (a if key == "packed" else np.array(a)) for key, a in arr.items()}  # only the 2-bit words stay a view of the mapping
+        ss = seqio.SeqSet(seqio.Names(arr["names_blob"], arr["names_off"]), None, arr["offsets"], packed=arr["packed"],
+                          runs=(arr["seq_run_first"], arr["run_start"], arr["run_len"]))
+    comm.allgather(None)  # every rank of every host has its leader's file open
+    if comm.rank == leader:
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
+    if stats is not None:
+        stats["contigs_parsed_by"] = leader
+    return ss, mapping
+
+
 def shard_range(offsets, rank, world):
     """Contiguous read range [lo, hi) of this rank, balanced by bases; concatenating the ranks' ranges
     in rank order restores the input order.  (Sharding of in-memory batches: the bench and callers that
@@ -514,7 +587,8 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
     make_workers = threading.Thread(target=dev.workers, args=(max(1, int(os.environ.get("NTL_DEVICE_STREAMS", "2"))),), daemon=True)
     make_workers.start()
     # into a page-locked buffer: registering one costs 45 us per MB (csrc/ntl_hip.hip, pin_alloc), the staged copy of a pageable one 130
-    ctg = seqio.load_all([target], alloc=dev.pinned_empty if packed else None, packed=packed)
+    ctg_share = {}
+    ctg, ctg_mapping = shared_contigs(comm, target, dev.pinned_empty, packed, ctg_share)  # (several ranks on a host: one of them parses)
     ctg_len = ctg.lengths
     make_workers.join()
     t_ctg_parsed = time.perf_counter()
@@ -541,6 +615,12 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
         with (dev.batch_packed(ctg) if ctg.packed is not None else dev.batch(ctg.buf, ctg.offsets)) as cb:
             dev.pinned_release(ctg.pinned)
             ctg.buf = ctg.packed = ctg.pinned = None
+            if ctg_mapping is not None:  # the node's shared copy of the packed contigs: uploaded, not needed any more
+                try:
+                    ctg_mapping.close()
+                except BufferError:  # (a view still alive somewhere: the mapping goes with it)
+                    pass
+                ctg_mapping = None
             t_ctg_up = time.perf_counter()
             with dev.sketch(cb, k, w) as csk:
                 t_ctg_sk = time.perf_counter()
@@ -586,10 +666,13 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
             if root:
                 for e in exts:
                     os.replace(prefix + e + ".assembling", prefix + e)
-            mine = (out.tally.export(), {key: stats[key] for key in ("read_bases", "reads", "read_minimizers", "index_hits", "parsed_bytes")})
+            mine = (out.tally.export(), {key: stats[key] for key in ("read_bases", "reads", "read_minimizers", "index_hits", "parsed_bytes")},
+                    ctg_share.get("contigs_parsed_by"))
             parts = comm.gather(mine)  # pair-tally deltas and five counters per rank
             if root:
                 stats["parsed_bytes_per_rank"] = [p[1]["parsed_bytes"] for p in parts]
+                stats["contigs_parsed_by_per_rank"] = [p[2] for p in parts]  # (one parser per host: shared_contigs)
+                parts = [p[:2] for p in parts]
                 for exported, st in parts[1:]:
                     out.tally.merge(exported)
                     for key in ("read_bases", "reads", "read_minimizers", "index_hits", "parsed_bytes"):

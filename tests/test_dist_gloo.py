@@ -120,6 +120,9 @@ def test_ranks_equal_single_process(tmp_path, world, port):
     assert sum(per) == total == int(rep["ntlink_amd parsed_bytes"]) and len(per) == world
     longest = max(len(s) for _, s in __import__("oracle").read_fastx(str(tmp_path / "long_reads_4_top5.fa"))) + 200
     assert all(abs(b - total / world) <= longest for b in per)
+    # one rank of the host parsed the target FASTA, the others mapped its packed copy (pipeline.shared_contigs)
+    assert json.loads(rep["ntlink_amd contigs_parsed_by_per_rank"]) == [0] * world
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith(f"ntlink_amd.ctg.{os.getuid()}.")]
 
 
 def test_three_ranks_many_reads_and_files(tmp_path):
@@ -141,6 +144,24 @@ def test_three_ranks_many_reads_and_files(tmp_path):
     for ext in (".verbose_mapping.tsv", ".paf", ".pairs.tsv"):
         assert read_text(pre + ext) == read_text(d + ext), ext
     assert read_text(pre + ".pairs.tsv") == read_text(os.path.join(REF, "expected_outputs", "scaffolds_1.fa.k32.w250.z1000.pairs.tsv"))
+
+
+@pytest.mark.parametrize("env,want,port", [({"NTL_TEST_FAKE_HOSTS": "2"}, [0, 1, 0], 29577), ({"NTL_SHARE_CONTIGS": "0"}, [0, 1, 2], 29578)],
+                         ids=["two_hosts", "no_sharing"])
+def test_contigs_are_parsed_once_per_host(tmp_path, env, want, port):
+    """pipeline.shared_contigs: with the three ranks dealt out over two (pretended) hosts the lowest rank of each host parses the target
+    and the third rank maps its host's copy; NTL_SHARE_CONTIGS=0: every rank parses, as before round 5.  Same files either way."""
+    for n in ("scaffolds_4.fa", "long_reads_4_top5.fa"):
+        shutil.copy(os.path.join(REF, n), tmp_path / n)
+    _run_ranks(tmp_path, 3, port, ["target=scaffolds_4.fa", "reads=long_reads_4_top5.fa", "k=40", "w=100", "paf=True", "ntlink_pairs_tsv=True", "v=1"],
+               extra_env=env)
+    pre = str(tmp_path / "scaffolds_4.fa.k40.w100.z1000")
+    d = os.path.join(GEN, "fixtures", "t7_top5_k40_w100")
+    for ext in (".verbose_mapping.tsv", ".paf", ".pairs.tsv"):
+        assert read_text(pre + ext) == read_text(d + ext), ext
+    rep = dict(line.strip().split(": ", 1) for line in open(pre + ".n1.scaffold.dot.time") if ": " in line)
+    assert json.loads(rep["ntlink_amd contigs_parsed_by_per_rank"]) == want
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith(f"ntlink_amd.ctg.{os.getuid()}.")]
 
 
 def _fake_host(root, gpus_per_node=(4, 4), cpus_per_node=64, cpu_max="1600000 100000"):
