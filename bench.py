@@ -495,6 +495,30 @@ def main():
                 Ro["ix"].close(); Ro["csk"].close(); Ro["wl"].close()
             except Exception as exc:  # the headline line must not be lost to a failure behind it: said, not hidden
                 others[name] = {"error": f"{type(exc).__name__}: {exc}"}
+        # BASELINE configs[3] seen from ONE rank of eight: this GPU takes the eighth of C3's reads (and the sub-batch size) that a rank of
+        # `--gpus 8` takes -- what a rank does when its seven neighbours do not get in its way (they share the host, not the GPU).  The
+        # driver's 1/2/4/8 curve is the measurement; this line is the per-rank rate to read it against.
+        if args.workload == "C3":
+            try:
+                import copy
+                a8 = copy.copy(args)
+                a8.emulate_world, a8.strong = 8, True
+                Re = run_workload(dev, comm, "C3", a8, 40, 3, 0, 1, 0)
+                v, ms, cfg_e, _roof_e = summarize(Re, a8, 1, dev.name)
+                others["C3_one_rank_of_8"] = {"value": round(v, 3), "unit": "Gbases/s per rank", "ms_per_step": round(ms, 3), "steps": 40,
+                                              "read_bases_per_step": int(Re["total_bases"]), "sub_batches": len(Re["wl"].read_batches),
+                                              "times_8": round(8 * v, 1),
+                                              "note": "--emulate-world 8 on this one GPU; times_8 = eight such ranks if nothing but the host is shared"}
+                Re["ix"].close(); Re["csk"].close(); Re["wl"].close()
+            except Exception as exc:
+                others["C3_one_rank_of_8"] = {"error": f"{type(exc).__name__}: {exc}"}
+        # the dense sketches of the stages around `pair` (ntLink:243-251 k15 w5 on contig ends;
+        # bin/ntlink_patch_gaps.py:417-441 k20 w10 on read pieces) on today's kernels, with the same two rooflines
+        for name, (kk, ww) in (("f3_k15_w5", (15, 5)), ("f4_k20_w10", (20, 10))):
+            try:
+                others[name] = dense_sketch_line(dev, kk, ww)
+            except Exception as exc:
+                others[name] = {"error": f"{type(exc).__name__}: {exc}"}
         out["other_workloads"] = others
     if rank == 0:
         print(json.dumps(out), flush=True)
@@ -520,6 +544,43 @@ def pmc_summary(workload, scale, bases_per_launch):
             "measured_cycles_per_wave_instr": t.get("measured_cycles_per_wave_instr"),
             "profiled_launch_ms": t.get("profiled_launch_ms"),
             "clock_ghz": t.get("clock_ghz"), "isa_mix": t.get("isa_mix")}
+
+
+def dense_sketch_line(dev, k, w, bases=200_000_000, reps=5):
+    """Sketch rate at the window sizes of the stages around `pair`: a minimizer every (w + 1) / 2 bases, so the records (16 B each) are most of
+    the bytes and the windows are too small for the threshold-sparsified pass (every k-mer would be a candidate): the exact 64-bit
+    window pass (sketch_mask_kernel, 4 k-mers per lane) + emit_kernel.  These stages sketch contig ends and read pieces -- megabases, not
+    the read set -- so the line is here for the record, not as a target."""
+    import numpy as np
+    b = dev.synth_genome(77, np.full(bases // 2_000_000, 2_000_000, np.uint32))
+    try:
+        with dev.sketch(b, k, w) as sk:
+            n = sk.count
+            from_lists = sk.from_lists
+        dev.sync()
+        dev.prof_enable(True)
+        dev.prof_reset()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            with dev.sketch(b, k, w) as sk:
+                sk.wait()
+        dev.sync()
+        dt = (time.perf_counter() - t0) / reps
+        prof = {nm: round(dev.prof_get(nm)[0] / reps, 4) for nm in ("sketch_meta", "sketch_mask", "sketch_redo", "sketch_emit")}
+    finally:
+        b.close()
+    d = n / bases
+    bpb = 0.25 + 16.0 * d
+    win_ms = prof["sketch_mask"] + prof["sketch_redo"]
+    return {"workload": f"{bases} bp of random sequence in 2-Mbp pieces, k={k} w={w}, one sketch call (records, no lookup)", "minimizers": int(n),
+            "density": round(d, 4), "value": round(bases / dt / 1e9, 1), "unit": "Gbases/s", "ms_per_sketch": round(dt * 1e3, 3),
+            "records_G_per_s": round(n / dt / 1e9, 2), "stage_ms": prof, "window_pass": "per-strip lists" if from_lists else "bitmask (sketch_mask_kernel, exact 64-bit pass)",
+            "roofline": {"bound": "hbm", "bytes_per_base": round(bpb, 3), "formula": "0.25 + 16 d (packed bases in, 16-byte records out)",
+                         "achieved": round(bpb * bases / (dt * 1e-0) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(bpb * bases / dt / 1e9 / HBM_PEAK_GBS, 4),
+                         "window_kernel": {"ms": round(win_ms, 4), "Gbases_per_s": round(bases / (win_ms * 1e-3) / 1e9, 1) if win_ms > 0 else None},
+                         "emit_kernel": {"ms": prof["sketch_emit"],
+                                         "GB_per_s_of_records": round(16.0 * n / (prof["sketch_emit"] * 1e-3) / 1e9, 1) if prof["sketch_emit"] > 0 else None}}}
 
 
 VALU_FLOOR_PER_KMER = 9.0

@@ -387,13 +387,6 @@ void ntl_text_destroy(ntl_text *t);
 /* n bytes at the end of fd (O_APPEND or not: the position is taken once), written by the I/O worker pool in parallel pieces. */
 int ntl_write_blob(int fd, const char *p, uint64_t n);
 
-/* ---- inflate on the device (an experiment's entry point; nothing in the product path calls it) ----
- * `gzip -cd FILES |` of the read files (ntLink:113-117,222) for BGZF (bgzip) files: n independent DEFLATE streams -- the caller has
- * walked the members' gzip headers -- each inflated by one lane.  Stream i is comp[in_off[i] ..) (bounded by in_off[i+1]), its text
- * goes to out[out_off[i] .. out_off[i+1]).  *kernel_ms: the kernel alone; *n_failed: members that did not inflate to their size. */
-int ntl_bgzf_inflate(ntl_ctx *ctx, const uint8_t *comp, uint64_t comp_bytes, const uint64_t *in_off, const uint64_t *out_off,
-                     uint64_t n, uint8_t *out, double *kernel_ms, uint64_t *n_failed);
-
 /* ---- host-side pair tally (no GPU involved) ------------------------------------------------- */
 
 /* The contig-pair bookkeeping of bin/ntlink_pair.py (tally_pairs_from_mappings :416-435, add_pair

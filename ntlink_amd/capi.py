@@ -33,7 +33,7 @@ SYMBOLS = [
     "ntl_tally_create", "ntl_tally_destroy", "ntl_tally_add", "ntl_tally_npairs", "ntl_tally_ngaps", "ntl_tally_export", "ntl_tally_merge",
     "ntl_liftover",
     "ntl_names_create", "ntl_names_destroy", "ntl_mapres_format", "ntl_text_sizes", "ntl_text_download", "ntl_text_destroy", "ntl_write_blob",
-    "ntl_tally_add_ends", "ntl_bgzf_inflate",
+    "ntl_tally_add_ends",
 ]
 
 MAPPING_DT = np.dtype([("read", "<u4"), ("ctg", "<u4"), ("n_hits", "<u4"), ("pad", "<u4"), ("hit_off", "<u8")])
@@ -179,7 +179,6 @@ def load(path=None):
     L.ntl_text_destroy.argtypes = [vp]
     L.ntl_text_destroy.restype = None
     L.ntl_write_blob.argtypes = [C.c_int, vp, C.c_uint64]
-    L.ntl_bgzf_inflate.argtypes = [vp, vp, C.c_uint64, u64p, u64p, C.c_uint64, vp, C.POINTER(C.c_double), u64p]
     for nm in ("npairs", "ngaps"):
         f = getattr(L, "ntl_tally_" + nm)
         f.argtypes = [vp]
@@ -594,38 +593,6 @@ class Device:
         self._chk(self.L.ntl_names_create(self.ptr, blob.ctypes.data if len(blob) else None, _ptr(off, C.c_uint64),
                                           _ptr(ln, C.c_uint32) if len(ln) else None, len(nm), C.byref(p)))
         return NameTable(self, p)
-
-    def bgzf_inflate(self, data):
-        """(text as uint8 array, kernel milliseconds, members, members that failed): every member of the BGZF file in `data` (bytes)
-        inflated by one lane of the device (ntl_bgzf_inflate: an experiment, not the product's reader)."""
-        import struct
-        buf = np.frombuffer(data, np.uint8)
-        ins, outs, at, o = [], [0], 0, 0
-        while at + 18 <= len(data):
-            if data[at:at + 4] != b"\x1f\x8b\x08\x04":
-                raise ValueError("not a BGZF member")
-            xlen = struct.unpack_from("<H", data, at + 10)[0]
-            x, bsize = at + 12, None
-            while x < at + 12 + xlen:
-                si1, si2, slen = data[x], data[x + 1], struct.unpack_from("<H", data, x + 2)[0]
-                if si1 == 66 and si2 == 67:
-                    bsize = struct.unpack_from("<H", data, x + 4)[0] + 1
-                x += 4 + slen
-            if bsize is None:
-                raise ValueError("gzip member without a BC field")
-            isize = struct.unpack_from("<I", data, at + bsize - 4)[0]
-            if isize:
-                ins.append(at + 12 + xlen)
-                o += isize
-                outs.append(o)
-            at += bsize
-        ins.append(len(data))
-        in_off, out_off = np.array(ins, np.uint64), np.array(outs, np.uint64)
-        out = np.empty(max(o, 1), np.uint8)
-        ms, bad = C.c_double(), C.c_uint64()
-        self._chk(self.L.ntl_bgzf_inflate(self.ptr, buf.ctypes.data, len(buf), _ptr(in_off, C.c_uint64), _ptr(out_off, C.c_uint64), len(ins) - 1,
-                                          out.ctypes.data, C.byref(ms), C.byref(bad)))
-        return out[:o], ms.value, len(ins) - 1, int(bad.value)
 
     def index(self, contig_sketch, ctg_len):
         cl = np.ascontiguousarray(ctg_len, np.uint32)

@@ -29,7 +29,6 @@
 #include "synth_kernels.h"
 #include "overlap_kernels.h"
 #include "format_kernels.h"
-#include "inflate_kernels.h"
 
 #define NTL_END_PAD 4096u /* bases of padding behind the last sequence (rolling over-reads) */
 #define SK_NT 256
@@ -2493,50 +2492,6 @@ extern "C" int ntl_mapres_download(const ntl_mapres *r, ntl_mapping *maps, ntl_h
     }
     if (pafs && r->n_pafs) HIPCHK(c, hipMemcpyAsync(pafs, r->pafs.p, r->n_pafs * sizeof(PafRec), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, main_wait(c));
-    return NTL_OK;
-}
-
-/* ------------------------------------------------------------------ inflate on the device (experiment) ---- */
-
-/* Inflates n independent DEFLATE streams (the members of a BGZF file; the caller has walked the gzip headers): stream i is
- * comp[in_off[i] .. in_off[i+1]) at most, its text goes to out[out_off[i] .. out_off[i+1]).  Host arrays in, host array out;
- * *kernel_ms = the kernel alone (HIP events).  An experiment's entry point: nothing in the product calls it. */
-extern "C" int ntl_bgzf_inflate(ntl_ctx *c, const uint8_t *comp, uint64_t comp_bytes, const uint64_t *in_off, const uint64_t *out_off,
-                                uint64_t n, uint8_t *out, double *kernel_ms, uint64_t *n_failed)
-{
-    if (!c || !comp || !in_off || !out_off || !out || n == 0 || n >= 0xFFFFFFFFull) return NTL_EINVAL;
-    (void)hipSetDevice(c->device);
-    const uint64_t out_bytes = out_off[n];
-    DevBuf d_comp, d_in, d_outoff, d_out, d_status, d_scr;
-    int rc;
-    if ((rc = d_comp.alloc(c, comp_bytes + 64)) || (rc = d_in.alloc(c, (n + 1) * 8)) || (rc = d_outoff.alloc(c, (n + 1) * 8)) ||
-        (rc = d_out.alloc(c, out_bytes + 64)) || (rc = d_status.alloc(c, n * 4)) || (rc = d_scr.alloc(c, n * (INF_LSYM + INF_DSYM))))
-        return rc;
-    HIPCHK(c, hipMemsetAsync((char *)d_comp.p + comp_bytes, 0, 64, c->stream));
-    HIPCHK(c, hipMemcpyAsync(d_comp.p, comp, comp_bytes, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(d_in.p, in_off, (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(d_outoff.p, out_off, (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    InflateArgs A;
-    A.comp = d_comp.as<uint8_t>(); A.in_off = d_in.as<uint64_t>(); A.out_off = d_outoff.as<uint64_t>(); A.out = d_out.as<uint8_t>();
-    A.n = (uint32_t)n; A.status = d_status.as<uint32_t>(); A.scratch = d_scr.as<uint8_t>();
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    HIPCHK(c, hipEventCreate(&e0));
-    HIPCHK(c, hipEventCreate(&e1));
-    HIPCHK(c, hipEventRecord(e0, c->stream));
-    hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((unsigned)((n + INF_NT - 1) / INF_NT)), dim3(INF_NT), 0, c->stream, A);
-    HIPCHK(c, hipEventRecord(e1, c->stream));
-    HIPCHK(c, hipGetLastError());
-    std::vector<uint32_t> st(n);
-    HIPCHK(c, hipMemcpyAsync(out, d_out.p, out_bytes, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(st.data(), d_status.p, n * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, main_wait(c));
-    float ms = 0;
-    (void)hipEventElapsedTime(&ms, e0, e1);
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    if (kernel_ms) *kernel_ms = ms;
-    uint64_t bad = 0;
-    for (uint32_t v : st) bad += v != 0;
-    if (n_failed) *n_failed = bad;
     return NTL_OK;
 }
 

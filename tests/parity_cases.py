@@ -228,56 +228,6 @@ def check_device_text(dev, contigs, reads, k, w, read_names=None, ctg_names=None
     return len(m), len(got_v), len(got_p)
 
 
-def bgzf_bytes(data, block=0xFF00, level=6):
-    """`bgzip` of `data` in memory (helpers.write_bgzf's layout: members with the BC field, the empty EOF member)"""
-    import struct
-    import zlib
-    out = []
-    for ch in [data[i:i + block] for i in range(0, len(data), block)] + [b""]:
-        co = zlib.compressobj(level, zlib.DEFLATED, -15)
-        body = co.compress(ch) + co.flush()
-        out.append(b"\x1f\x8b\x08\x04" + b"\x00" * 4 + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(body) + 8 - 1)
-                   + body + struct.pack("<II", zlib.crc32(ch) & 0xFFFFFFFF, len(ch)))
-    return b"".join(out)
-
-
-def fastq_text(seed, n_reads, read_len):
-    rng = np.random.default_rng(seed)
-    acgt = np.frombuffer(b"ACGT", np.uint8)
-    out = []
-    for i in range(n_reads):
-        ln = int(rng.integers(read_len // 2, read_len * 2))
-        seq = bytes(acgt[rng.integers(0, 4, ln)])
-        qual = bytes((rng.integers(0, 12, ln) + 53).astype(np.uint8))
-        out.append(b"@read_%d runid=abcdef0123 ch=%d\n" % (i, i % 512) + seq + b"\n+\n" + qual + b"\n")
-    return b"".join(out)
-
-
-def check_device_inflate(dev, scale=1):
-    """ntl_bgzf_inflate == the text that was compressed, for every block type DEFLATE has: dynamic codes (FASTQ-like text at zlib
-    levels 1, 6 and 9), stored blocks (level 0; incompressible bytes), fixed codes (tiny members), long overlapping matches (runs of
-    one byte, a repeated phrase), members of 1 byte and of the maximum size."""
-    rng = np.random.default_rng(3)
-    cases = []
-    fq = fastq_text(5, 40 * scale, 3000)
-    for level in (1, 6, 9, 0):
-        cases.append((f"fastq level {level}", bgzf_bytes(fq, level=level), fq))
-    rnd = bytes(rng.integers(0, 256, 150_000 * scale, dtype=np.uint8))
-    cases.append(("random bytes", bgzf_bytes(rnd), rnd))
-    runs = b"A" * 70_000 + b"ACGT" * 20_000 + b"the same phrase again and again, " * 3000
-    cases.append(("runs", bgzf_bytes(runs), runs))
-    tiny = b"ACGTNACGT\n" * 7
-    cases.append(("tiny members", bgzf_bytes(tiny, block=11), tiny))
-    cases.append(("one byte", bgzf_bytes(b"x"), b"x"))
-    total = 0
-    for name, comp, text in cases:
-        got, ms, n, bad = dev.bgzf_inflate(comp)
-        assert bad == 0, (name, bad, n)
-        assert bytes(got) == text, (name, len(got), len(text))
-        total += len(text)
-    return total
-
-
 def fixture_seqs(fname):
     return [s for _, s in oracle.read_fastx(os.path.join(REF, fname))]
 

@@ -461,11 +461,6 @@ def test_text_made_on_the_device(dev, k, w, rl, sens, err):
     assert pc.check_device_text(dev, contigs[:2], [b"ACGT" * 500, b""], k, w, z=1000) == (0, 0, 0)
 
 
-def test_device_inflate(dev):
-    """bgzf_inflate_kernel on the GPU: dynamic, fixed and stored blocks, long overlapping matches, tiny and full members."""
-    assert pc.check_device_inflate(dev, scale=20) > 5_000_000
-
-
 def test_one_stream_and_back(dev):
     contigs = pc.fixture_seqs("scaffolds_1.fa")
     reads = pc.fixture_seqs("long_reads_4_top5.fa")

@@ -385,11 +385,6 @@ def test_sim_text_made_on_the_device(dev):
     assert pc.check_device_text(dev, contigs[:3], [b"ACGT" * 200, b"", b"N" * 300], 40, 100, z=1000) == (0, 0, 0)
 
 
-def test_sim_device_inflate(dev):
-    """bgzf_inflate_kernel (one lane per BGZF member; an experiment) under the mock: every block type against the text"""
-    assert pc.check_device_inflate(dev) > 400_000
-
-
 def test_sim_one_stream_and_back(dev):
     """ntl_ctx_set_pipeline: the window stage back on the one stream at a quiet point, and out again: same records."""
     contigs = pc.fixture_seqs("scaffolds_4.fa")
