@@ -2500,6 +2500,7 @@ extern "C" int ntl_mapres_download(const ntl_mapres *r, ntl_mapping *maps, ntl_h
 struct ntl_names {
     ntl_ctx *c;
     uint64_t n = 0;
+    uint64_t max_len = 0; /* the longest name: bounds the bytes of a header / PAF line (ntl_mapres_format) */
     DevBuf blob, off, len; /* bytes, u64[n + 1], u32[n] (or none) */
 };
 
@@ -2512,6 +2513,7 @@ extern "C" int ntl_names_create(ntl_ctx *c, const char *blob, const uint64_t *of
     t->c = c; t->n = n;
     const uint64_t zero = 0;
     const uint64_t bytes = n ? off[n] : 0;
+    for (uint64_t i = 0; i < n; i++) t->max_len = std::max<uint64_t>(t->max_len, off[i + 1] - off[i]);
     int rc;
     if ((rc = t->blob.alloc(c, bytes + 16)) || (rc = t->off.alloc(c, (n + 1) * 8)) || (len && (rc = t->len.alloc(c, (n + 1) * 4)))) return rc;
     if (bytes) HIPCHK(c, hipMemcpyAsync(t->blob.p, blob, bytes, hipMemcpyHostToDevice, c->stream));
@@ -2546,9 +2548,17 @@ extern "C" int ntl_mapres_format(const ntl_mapres *r, const ntl_names *reads, co
     if (int frc = mapres_finalize(r)) return frc;
     if (!reads->len.p || !contigs->len.p) return fail(c, NTL_EINVAL, "ntl_mapres_format: both name tables need their lengths");
     if (r->n_hits >= 0xFFFFFF00ull || r->n_maps >= 0xFFFFFF00ull) return fail(c, NTL_ERANGE, "ntl_mapres_format: too many records for one text");
-    /* 32-bit offsets: a token is at most 27 bytes, a name at most what the tables hold */
-    const uint64_t bound = r->n_hits * 27 + (r->n_maps + r->n_pafs) * 64 + (r->n_maps + r->n_pafs) * 2 * 4096;
-    if (bound >= 0xFFFFFFFFull && r->n_hits * 27 >= 0xF0000000ull) return fail(c, NTL_ERANGE, "ntl_mapres_format: more than 4 GB of text in one batch");
+    /* 32-bit offsets, every one of the three scans (tokens, headers, PAF lines) bounded on its own: a token is at most 27 bytes, a header
+       two names + a count + three separators, a PAF line two names + ten numbers + strand and tabs (the header and PAF
+       sums could wrap unseen and the fill kernel then wrote at wrapped offsets) */
+    {
+        const uint64_t names2 = reads->max_len + contigs->max_len;
+        const uint64_t tok_b = r->n_hits * 27, hdr_b = r->n_maps * (names2 + 16), paf_b = r->n_pafs * (names2 + 10 * 11 + 16);
+        uint64_t most = 0xFFFFFF00ull;
+        if (const char *e = getenv("NTL_FORMAT_MAX_TEXT")) most = (uint64_t)atoll(e); /* tests: the caller's fallback without 4 GB of text */
+        if (tok_b + hdr_b >= most || paf_b >= most)
+            return fail(c, NTL_ERANGE, "ntl_mapres_format: the text of this batch may exceed 4 GB (32-bit offsets): format it on the host, or map smaller batches");
+    }
     std::unique_ptr<ntl_text> t(new ntl_text());
     t->c = c; t->n_maps = r->n_maps;
     const uint32_t nm = (uint32_t)r->n_maps, nh = want_verbose ? (uint32_t)r->n_hits : 0u, np = want_paf ? (uint32_t)r->n_pafs : 0u;

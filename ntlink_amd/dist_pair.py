@@ -95,16 +95,21 @@ def pin_rank(local_rank, local_world):
     mine, how = cpus[local_rank * per:(local_rank + 1) * per] or cpus, "contiguous slice"
     numa = gpu_numa_nodes()
     if len(numa) >= local_world and all(n is not None for n in numa[:local_world]):
-        node = numa[local_rank]
-        try:
-            node_cpus = [c for c in _cpulist(open(_sys(f"/sys/devices/system/node/node{node}/cpulist")).read()) if c in set(cpus)]
-        except (OSError, ValueError):
-            node_cpus = []
-        peers = [r for r in range(local_world) if numa[r] == node]  # ranks whose GPUs share the node, in rank order
-        share = len(node_cpus) // len(peers)
-        if share >= 1:
-            at = peers.index(local_rank) * share
-            mine, how = node_cpus[at:at + share], f"NUMA node {node} of GPU {local_rank}"
+        # One policy for ALL ranks of the host (every rank computes the same answer): NUMA placement only if every rank gets at least
+        # one core of its GPU's node -- a cpuset that leaves some node without cores would otherwise put those ranks on contiguous
+        # slices that overlap the cores of the NUMA-placed ones.
+        node_cpus, shares = {}, {}
+        for node in set(numa[:local_world]):
+            try:
+                node_cpus[node] = [c for c in _cpulist(open(_sys(f"/sys/devices/system/node/node{node}/cpulist")).read()) if c in set(cpus)]
+            except (OSError, ValueError):
+                node_cpus[node] = []
+            shares[node] = len(node_cpus[node]) // sum(1 for r in range(local_world) if numa[r] == node)
+        if all(sh >= 1 for sh in shares.values()):
+            node = numa[local_rank]
+            peers = [r for r in range(local_world) if numa[r] == node]  # ranks whose GPUs share the node, in rank order
+            at = peers.index(local_rank) * shares[node]
+            mine, how = node_cpus[node][at:at + shares[node]], f"NUMA node {node} of GPU {local_rank}"
     if "NTL_SYSFS_ROOT" not in os.environ:
         try:
             os.sched_setaffinity(0, mine)

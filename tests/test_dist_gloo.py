@@ -311,3 +311,12 @@ def test_pin_rank_choices_on_made_up_hosts(tmp_path, monkeypatch):
     assert all(p["how"] == "contiguous slice" and p["cores"] == 8 for p in pins) and [p["first_core"] for p in pins] == list(range(0, 64, 8))
     assert all(p["io_threads"] == 6 and p["io_readers"] is None for p in pins)  # 32 granted cores / 8 ranks = 4 each: both pairs kept
     assert dist_pair.pin_rank(0, 1) is None and dist_pair.LAST_PIN == {}
+    # a cpuset that holds node 0's cores only, GPUs 4-7 on node 1 -- no rank of node 1 can be NUMA-placed, so NO rank is:
+    # eight disjoint slices instead of four NUMA shares overlapped by four fallback slices
+    c = str(tmp_path / "c")
+    _fake_host(c, gpus_per_node=(4, 4), cpus_per_node=16, cpu_max="1600000 100000")
+    with open(c + "/sys/devices/system/cpu/online", "w") as fh:
+        fh.write("0-15\n")
+    pins = [pin(c, r, 8) for r in range(8)]
+    assert all(p["how"] == "contiguous slice" and p["cores"] == 2 for p in pins)
+    assert [p["first_core"] for p in pins] == list(range(0, 16, 2))

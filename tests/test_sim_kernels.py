@@ -79,12 +79,29 @@ def test_sim_pair_driver_files(dev, tmp_path):
         finally:
             del os.environ["NTL_DEVICE_STREAMS"]
         assert st["reads"] == 5
+        # a batch whose text may pass the 32-bit offsets of the device's formatter (here: pretended, 1000 bytes) is refused with
+        # NTL_ERANGE -- headers, tokens and PAF lines each bounded -- and the host's emitters write the same bytes
+        os.environ["NTL_FORMAT_MAX_TEXT"] = "1000"
+        try:
+            from ntlink_amd import capi
+            ctgs, rds = pc.fixture_seqs("scaffolds_4.fa"), pc.fixture_seqs("long_reads_4_top5.fa")
+            cl, rl = np.array([len(x) for x in ctgs], np.uint32), np.array([len(x) for x in rds], np.uint32)
+            with dev.batch(ctgs) as cb, dev.sketch(cb, 40, 100) as csk, dev.index(csk, cl) as ix, dev.batch(rds) as rb, \
+                    dev.sketch(rb, 40, 100, index=ix) as rsk, dev.map(ix, rsk, rl, k=40, z=1000) as res, \
+                    dev.names(["r%d" % i for i in range(len(rds))], rl) as rn, dev.names(["c%d" % i for i in range(len(ctgs))], cl) as cn:
+                with pytest.raises(capi.NtlError) as ei:
+                    res.format(rn, cn, True, True)
+                assert ei.value.code == capi.NTL_ERANGE
+            pipeline.run_pair(dev, "scaffolds_4.fa", "long_reads_4_top5.fa", k=40, w=100, paf=True, pairs_tsv=True, prefix="hostfmt", write_contig_tsv=False)
+        finally:
+            del os.environ["NTL_FORMAT_MAX_TEXT"]
     finally:
         os.chdir(cwd)
     pre = str(tmp_path / "scaffolds_4.fa.k40.w100.z1000")
     d = os.path.join(GEN, "fixtures", "t7_top5_k40_w100")
     for ext in (".verbose_mapping.tsv", ".paf", ".pairs.tsv"):
         assert read_text(str(tmp_path / "streams3") + ext) == read_text(d + ext), ext
+        assert read_text(str(tmp_path / "hostfmt") + ext) == read_text(d + ext), ext
     assert read_text(pre + ".verbose_mapping.tsv") == read_text(d + ".verbose_mapping.tsv")
     assert set(read_text(pre + ".paf").splitlines()) == TEST7_PAF
     assert read_text(pre + ".pairs.tsv") == read_text(d + ".pairs.tsv")
