@@ -101,6 +101,14 @@ __device__ __forceinline__ uint32_t ntl_row_max16(uint32_t v)
     return v;
 }
 
+/* x + x, kept an addition (the compiler turns it into the slower v_lshlrev_b32 x, 1) */
+__device__ __forceinline__ uint32_t ntl_double(uint32_t x)
+{
+    uint32_t r;
+    asm("v_add_u32 %0, %1, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
 /* bit reversal of a 32-bit word: v_bfrev_b32 */
 __device__ __forceinline__ uint32_t ntl_brev(uint32_t x) { return __builtin_bitreverse32(x); }
 

@@ -1299,7 +1299,7 @@ __device__ __forceinline__ void skw_step(uint32_t &fx, uint32_t &ry, uint32_t &f
     fx = ntl_alignbit(fx, fd, 31) ^ sd.x; /* srol1 on the ring: (fx << 1) | ring bit 30, which is the top bit of fd = fx << 1 */
     const uint32_t a = ry ^ sd.y;
     ry = ntl_alignbit(a >> 1, a, 1);      /* sror1: ring bit 0 (bit 1 of a) -> bit 31 */
-    fd = fx << 1;
+    fd = ntl_double(fx); /* fx << 1 as fx + fx: v_add_u32 issues in 2.4 cycles, v_lshlrev_b32 in 4.4 (profiles/valu_cycles.json) */
     const uint32_t key = fd + ry;
     if (key <= tm1) ntl_lds_push_tagged<T>(dst, low6, key);
 }

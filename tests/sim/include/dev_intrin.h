@@ -70,6 +70,8 @@ inline uint32_t ntl_row_max16(uint32_t v)
     return v;
 }
 
+inline uint32_t ntl_double(uint32_t x) { return x + x; }
+
 inline uint32_t ntl_brev(uint32_t x)
 {
     x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
