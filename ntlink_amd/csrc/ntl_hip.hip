@@ -1839,9 +1839,13 @@ static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const nt
         if (lists) {
             EmitListArgs Q;
             Q.Ls = Ls; Q.strip_tab = strip_tab.as<StripInfo>(); Q.strip_off = loff.as<uint32_t>(); Q.nstrips = (uint32_t)ub_strips;
-            if (probe == 0) hipLaunchKernelGGL((emit_list_kernel<0>), dim3(egrid), dim3(EL_NT), 0, ms, E, Q);
-            else if (probe == 1) hipLaunchKernelGGL((emit_list_kernel<1>), dim3(egrid), dim3(EL_NT), 0, ms, E, Q);
-            else hipLaunchKernelGGL((emit_list_kernel<2>), dim3(egrid), dim3(EL_NT), 0, ms, E, Q);
+            if (probe == 0) hipLaunchKernelGGL((emit_list_kernel<0, 1>), dim3(egrid), dim3(EL_NT), 0, ms, E, Q);
+            else if (probe == 1 && emit_u >= 4) hipLaunchKernelGGL((emit_list_kernel<1, 4>), dim3(egrid), dim3(EL_NT), 0, ms, E, Q);
+            else if (probe == 1 && emit_u >= 2) hipLaunchKernelGGL((emit_list_kernel<1, 2>), dim3(egrid), dim3(EL_NT), 0, ms, E, Q);
+            else if (probe == 1) hipLaunchKernelGGL((emit_list_kernel<1, 1>), dim3(egrid), dim3(EL_NT), 0, ms, E, Q);
+            else if (emit_u >= 4) hipLaunchKernelGGL((emit_list_kernel<2, 4>), dim3(egrid), dim3(EL_NT), 0, ms, E, Q);
+            else if (emit_u >= 2) hipLaunchKernelGGL((emit_list_kernel<2, 2>), dim3(egrid), dim3(EL_NT), 0, ms, E, Q);
+            else hipLaunchKernelGGL((emit_list_kernel<2, 1>), dim3(egrid), dim3(EL_NT), 0, ms, E, Q);
         } else
         if (probe == 0) hipLaunchKernelGGL((emit_kernel<0, 1>), dim3(egrid), dim3(EMIT_NT), 0, ms, E);
         else if (probe == 1 && emit_u >= 2) hipLaunchKernelGGL((emit_kernel<1, 2>), dim3(egrid), dim3(EMIT_NT), 0, ms, E);

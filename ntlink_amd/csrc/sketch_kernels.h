@@ -795,7 +795,7 @@ __global__ void mx_off_from_strips_kernel(const uint32_t *__restrict__ strip_fir
  * threads spread their strip's number over the tile's ranks (one byte per minimizer in LDS), then a lane per minimizer: list entry
  * (lanes of one strip: consecutive words), the k-mer's hash from its bases, the record, the index lookup.
  */
-template <int PROBE>
+template <int PROBE, int U = 1>
 __global__ __launch_bounds__(EL_NT) void emit_list_kernel(EmitArgs A, EmitListArgs Q)
 {
     unsigned long long found = 0;
@@ -851,32 +851,54 @@ __global__ __launch_bounds__(EL_NT) void emit_list_kernel(EmitArgs A, EmitListAr
             }
             __syncthreads();
             const uint32_t n = total - r0 < EL_CAP ? total - r0 : EL_CAP;
-            for (uint32_t i = t; i < n; i += EL_NT) {
-                const uint32_t sid = s_sid[i];
-                const uint32_t p = Q.Ls.ent[s_first[sid] + (r0 + i - s_loc[sid])];
-                const uint32_t sq = s_seq[sid];
-                const uint64_t gp = s_sbase[sid] + p;
-                uint64_t fwd, rev;
-                hash_init_g4p(A.packed, gp, A.k, s_g4, s_g4r, s_seed, fwd, rev);
-                uint64_t h = (fwd + rev) * A.mult;
-                h ^= h >> 27;
-                MxRecord R;
-                R.hash = h;
-                R.pos = p;
-                R.meta = (sq << 1) | (fwd <= rev ? 1u : 0u);
-                const uint32_t at = tile_base + r0 + i;
-                if (at >= A.out_cap) continue;
+            /* U minimizers per thread and step, in straight-line code: their list entries, then their base words, then their first index
+               loads are in flight together -- the kernel's time is the latency of these dependent random accesses, and beside the
+               window stage it keeps to two workgroups per CU: what it cannot have in wavefronts it has in loads per wavefront */
+            for (uint32_t i0 = t; i0 < n; i0 += U * EL_NT) {
+                uint32_t p[U], sq[U], sidv[U];
+                bool ok[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const uint32_t i = i0 + (uint32_t)u * EL_NT;
+                    const uint32_t ic = i < n ? i : i0; /* past the end: the first one again, result dropped */
+                    sidv[u] = s_sid[ic];
+                    p[u] = Q.Ls.ent[s_first[sidv[u]] + (r0 + ic - s_loc[sidv[u]])];
+                    ok[u] = i < n && tile_base + r0 + i < A.out_cap;
+                }
+                uint64_t h[U];
+                MxRecord R[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    sq[u] = s_seq[sidv[u]];
+                    const uint64_t gp = s_sbase[sidv[u]] + p[u];
+                    uint64_t fwd, rev;
+                    hash_init_g4p(A.packed, gp, A.k, s_g4, s_g4r, s_seed, fwd, rev);
+                    uint64_t hh = (fwd + rev) * A.mult;
+                    hh ^= hh >> 27;
+                    h[u] = hh;
+                    R[u].hash = hh;
+                    R[u].pos = p[u];
+                    R[u].meta = (sq[u] << 1) | (fwd <= rev ? 1u : 0u);
+                }
                 if (PROBE) {
-                    IndexProbe<PROBE == 1> pr;
-                    pr.start(h, A.slots, A.tags, A.ix_bits);
-                    if (A.out) A.out[at] = R;
-                    Cand cd = pr.finish(h, A.slots, A.tags, A.special, ((uint64_t)1 << A.ix_bits) - 1);
-                    A.rpos[at] = p;
-                    cd.meta |= R.meta << 31;
-                    A.cand[at] = cd;
-                    found += cd.meta & 1u;
+                    IndexProbe<PROBE == 1> pr[U];
+#pragma unroll
+                    for (int u = 0; u < U; u++) pr[u].start(h[u], A.slots, A.tags, A.ix_bits);
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        if (!ok[u]) continue;
+                        const uint32_t at = tile_base + r0 + i0 + (uint32_t)u * EL_NT;
+                        if (A.out) A.out[at] = R[u];
+                        Cand cd = pr[u].finish(h[u], A.slots, A.tags, A.special, ((uint64_t)1 << A.ix_bits) - 1);
+                        A.rpos[at] = p[u];
+                        cd.meta |= R[u].meta << 31;
+                        A.cand[at] = cd;
+                        found += cd.meta & 1u;
+                    }
                 } else {
-                    A.out[at] = R;
+#pragma unroll
+                    for (int u = 0; u < U; u++)
+                        if (ok[u]) A.out[tile_base + r0 + i0 + (uint32_t)u * EL_NT] = R[u];
                 }
             }
             __syncthreads();

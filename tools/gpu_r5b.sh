@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 5: settings sweeps of how the two streams share the device (tools/share_sweep.py), C3 and C5.
+# Round 5: settings sweeps of how the two streams share the device (tools/share_sweep.py).  usage: tools/gpu_r5b.sh <tag>
 set -x
 TAG=${1:-r05b}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -7,6 +7,5 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$R"
 O=gpurun_out/$TAG; mkdir -p $O
 python __graft_entry__.py > $O/build.log 2>&1 || { tail -20 $O/build.log; exit 1; }
-timeout 900 python tools/share_sweep.py --workload C3 --steps 3 '' 'NTL_PREP_STREAM=1' 'NTL_PIPELINE=0' 'NTL_PIPELINE=0 NTL_SKW_WGS_PER_CU=3' 'NTL_PIPELINE=0 NTL_SKW_WGS_PER_CU=2' 'NTL_EMIT_WGS_PER_CU=2 NTL_SKW_WGS_PER_CU=3' 2>$O/sweep_C3.err | tee $O/sweep_C3.jsonl
-NTL_PREP_STREAM=1 timeout 900 python tools/share_sweep.py --workload C3 --steps 3 '' 'NTL_EMIT_WGS_PER_CU=1' 'NTL_EMIT_WGS_PER_CU=3'  2>$O/sweep_C3p.err | tee $O/sweep_C3p.jsonl
-tail -n 3 $O/sweep_C3.err $O/sweep_C3p.err
+timeout 1200 python tools/share_sweep.py --workload C3 --steps 3 '' 'NTL_SKETCH_WAVE=4 NTL_SKW_WGS_PER_CU=6' 'NTL_SKETCH_WAVE=4 NTL_SKW_WGS_PER_CU=5' 'NTL_SKETCH_WAVE=4 NTL_SKW_WGS_PER_CU=7' 'NTL_SKETCH_WAVE=4 NTL_SKW_WGS_PER_CU=6 NTL_EMIT_WGS_PER_CU=3' 'NTL_SKETCH_WAVE=4 NTL_SKW_WGS_PER_CU=6 NTL_EMIT_U=2' 'NTL_SKETCH_WAVE=4 NTL_SKW_WGS_PER_CU=6 NTL_EMIT_U=2 NTL_EMIT_WGS_PER_CU=3' 'NTL_SKETCH_WAVE=4 NTL_SKW_WGS_PER_CU=6 NTL_EMIT_WGS_PER_CU=1' 'NTL_SKETCH_WAVE=4 NTL_SKW_WGS_PER_CU=5 NTL_EMIT_WGS_PER_CU=3' 'NTL_SKETCH_WAVE=4 NTL_SKW_WGS_PER_CU=6 NTL_EMIT_WGS_PER_CU=4' 2>$O/sweep_C3.err | tee $O/sweep_C3.jsonl
+tail -n 3 $O/sweep_C3.err 
