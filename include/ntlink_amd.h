@@ -414,6 +414,12 @@ int ntl_tally_export(const ntl_tally *t, uint32_t *src, uint8_t *src_ori, uint32
 int ntl_tally_merge(ntl_tally *t, uint64_t npairs, const uint32_t *src, const uint8_t *src_ori, const uint32_t *tgt,
                     const uint8_t *tgt_ori, const uint32_t *anchor, const uint64_t *gap_off, const int64_t *gaps);
 
+/* The two small files behind the tally: <prefix>.pairs.tsv (write_pairs, bin/ntlink_pair.py:490-496; pairs_path may be NULL) and
+ * <prefix>.n<n>.scaffold.dot (build_scaffold_graph :263-305, filter_graph_global :498-506 with min_n = n, print_directed_graph
+ * :133-155; dot_path may be NULL) from the pairs that pass filter_pairs_distances (:247-255) and filter_weak_anchor_pairs
+ * (:241-244, anchor >= a).  *n_kept (may be NULL): the pairs that passed. */
+int ntl_tally_write(const ntl_tally *t, int a, int min_n, const char *pairs_path, const char *dot_path, uint64_t *n_kept);
+
 /* ---- liftover of the verbose mappings (no GPU involved) -------------------------------------- */
 
 /* <prefix>.verbose_mapping.tsv moved to the coordinates of the scaffolds an AGP describes, file to file: the work of

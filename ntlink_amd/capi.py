@@ -33,7 +33,7 @@ SYMBOLS = [
     "ntl_tally_create", "ntl_tally_destroy", "ntl_tally_add", "ntl_tally_npairs", "ntl_tally_ngaps", "ntl_tally_export", "ntl_tally_merge",
     "ntl_liftover",
     "ntl_names_create", "ntl_names_destroy", "ntl_mapres_format", "ntl_text_sizes", "ntl_text_download", "ntl_text_destroy", "ntl_write_blob",
-    "ntl_tally_add_ends",
+    "ntl_tally_add_ends", "ntl_tally_write",
 ]
 
 MAPPING_DT = np.dtype([("read", "<u4"), ("ctg", "<u4"), ("n_hits", "<u4"), ("pad", "<u4"), ("hit_off", "<u8")])
@@ -184,6 +184,7 @@ def load(path=None):
         f.argtypes = [vp]
         f.restype = C.c_uint64
     L.ntl_tally_export.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    L.ntl_tally_write.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, C.c_char_p, u64p]
     L.ntl_tally_merge.argtypes = [vp, C.c_uint64, vp, vp, vp, vp, vp, vp, vp]
     L.ntl_liftover.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_uint64, vp, u64p, vp, u64p, vp, vp, vp, vp, u64p, u64p]
     _libs[path] = L

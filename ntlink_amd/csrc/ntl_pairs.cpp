@@ -9,6 +9,7 @@
  * thread -- a few tens of nanoseconds per pair against microseconds in the Python loop.
  */
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
@@ -34,6 +35,8 @@ struct ntl_tally {
     std::unordered_map<uint64_t, uint32_t> slot;
     std::vector<PairEntry> pairs; /* first-insertion order */
     uint64_t ngaps = 0;
+    std::string names;               /* the contig ids, for the writers (ntl_tally_write) */
+    std::vector<uint64_t> name_off;
 };
 
 extern "C" int ntl_tally_create(const char *ctg_names, const uint64_t *ctg_name_off, const uint32_t *ctg_len, uint64_t n_ctg,
@@ -43,6 +46,7 @@ extern "C" int ntl_tally_create(const char *ctg_names, const uint64_t *ctg_name_
     ntl_tally *t = new ntl_tally();
     t->k = k; t->f = f;
     t->ctg_len.assign(ctg_len, ctg_len + n_ctg);
+    if (n_ctg) { t->names.assign(ctg_names, ctg_names + ctg_name_off[n_ctg]); t->name_off.assign(ctg_name_off, ctg_name_off + n_ctg + 1); }
     std::vector<uint32_t> order(n_ctg);
     std::iota(order.begin(), order.end(), 0u);
     auto cmp3 = [&](uint32_t a, uint32_t b) { /* str.__lt__ on ids = byte order, shorter first on a tie */
@@ -205,6 +209,134 @@ extern "C" int ntl_tally_merge(ntl_tally *t, uint64_t npairs, const uint32_t *sr
         t->pairs[e].gaps.insert(t->pairs[e].gaps.end(), gaps + gap_off[i], gaps + gap_off[i + 1]);
         t->ngaps += ng;
         t->pairs[e].anchor += anchor[i];
+    }
+    return NTL_OK;
+}
+
+/* ---- the two small files behind the tally, written natively (round 5: the Python loops over the pairs were 15 % of a 32-Gbases
+ * file-to-file run) ----
+ * <prefix>.pairs.tsv (write_pairs, bin/ntlink_pair.py:490-496) and <prefix>.n<n>.scaffold.dot (build_scaffold_graph :263-305,
+ * filter_graph_global :498-506, print_directed_graph :133-155) from the pairs that pass filter_pairs_distances (:247-255: the gap
+ * estimate must be larger than minus either contig's length) and filter_weak_anchor_pairs (:241-244: anchor >= a).
+ * gap estimate = int(numpy.median(gaps)): the middle element, or the mean of the two middle ones, truncated toward zero (:70-74).
+ * The dot file keeps what the Python dicts keep: sources and vertices in order of first appearance, an edge named twice keeps its
+ * place and takes the later value; "scaf_num" = the largest N of a contig called ntLink_N, else None. */
+namespace {
+struct Buf {
+    FILE *f;
+    std::string s;
+    explicit Buf(FILE *fh) : f(fh) { s.reserve(1 << 20); }
+    void flush() { if (!s.empty()) { fwrite(s.data(), 1, s.size(), f); s.clear(); } }
+    void put(const char *p, size_t n) { s.append(p, n); if (s.size() > (1u << 20) - 4096) flush(); }
+    void put(const std::string &x) { put(x.data(), x.size()); }
+    void put(const char *z) { put(z, strlen(z)); }
+    void num(long long v) { char b[24]; int n = snprintf(b, sizeof b, "%lld", v); put(b, (size_t)n); }
+};
+
+long long gap_estimate(const std::vector<int64_t> &gaps, std::vector<int64_t> &tmp)
+{
+    tmp = gaps;
+    const size_t n = tmp.size(), m = n / 2;
+    std::nth_element(tmp.begin(), tmp.begin() + (long)m, tmp.end());
+    if (n & 1) return (long long)tmp[m];
+    const int64_t hi = tmp[m], lo = *std::max_element(tmp.begin(), tmp.begin() + (long)m);
+    const double med = ((double)lo + (double)hi) / 2.0; /* numpy: mean of the two middle values, in float64 */
+    return (long long)med;                              /* int(): toward zero */
+}
+} // namespace
+
+extern "C" int ntl_tally_write(const ntl_tally *t, int a, int min_n, const char *pairs_path, const char *dot_path, uint64_t *n_kept)
+{
+    if (!t) return NTL_EINVAL;
+    const size_t nc = t->ctg_len.size();
+    auto name = [&](uint32_t c) { return std::string(t->names.data() + t->name_off[c], (size_t)(t->name_off[c + 1] - t->name_off[c])); };
+    /* name -> length as dict(zip(names, lengths)) has it: the last contig of a name wins */
+    std::unordered_map<std::string, uint32_t> len_of;
+    len_of.reserve(nc * 2);
+    for (size_t c = 0; c < nc; c++) len_of[name((uint32_t)c)] = t->ctg_len[c];
+    struct Kept { uint32_t e; long long d; };
+    std::vector<Kept> kept;
+    std::vector<int64_t> tmp;
+    for (size_t i = 0; i < t->pairs.size(); i++) {
+        const PairEntry &e = t->pairs[i];
+        if (e.gaps.empty()) continue; /* (a pair is only ever made with a gap) */
+        const long long g = gap_estimate(e.gaps, tmp);
+        if (g <= -(long long)len_of[name(e.src)] || g <= -(long long)len_of[name(e.tgt)]) continue;
+        if ((long long)e.anchor < (long long)a) continue;
+        kept.push_back({(uint32_t)i, g});
+    }
+    if (n_kept) *n_kept = kept.size();
+    auto ori = [](const PairEntry &e, bool src) { return ((src ? (e.key >> 32) : e.key) & 1u) ? '+' : '-'; };
+    if (pairs_path) {
+        FILE *fh = fopen(pairs_path, "w");
+        if (!fh) return NTL_EINVAL;
+        Buf o(fh);
+        for (const Kept &kp : kept) {
+            const PairEntry &e = t->pairs[kp.e];
+            o.put(name(e.src)); o.put(ori(e, true) == '+' ? "+" : "-"); o.put("\t");
+            o.put(name(e.tgt)); o.put(ori(e, false) == '+' ? "+" : "-"); o.put("\tn=");
+            o.num((long long)e.gaps.size()); o.put(", gap_estimates=[");
+            for (size_t j = 0; j < e.gaps.size(); j++) { if (j) o.put(", "); o.num((long long)e.gaps[j]); }
+            o.put("], anchor="); o.num((long long)e.anchor); o.put("\n");
+        }
+        o.flush();
+        if (fclose(fh) != 0) return NTL_EINVAL;
+    }
+    if (dot_path) {
+        std::vector<std::string> vertices;            /* insertion order */
+        std::unordered_map<std::string, uint32_t> vid;
+        struct Edge { uint32_t to; long long d; uint64_t n; };
+        std::vector<std::pair<uint32_t, std::vector<Edge>>> adj; /* sources in insertion order, their targets in insertion order */
+        std::unordered_map<uint32_t, uint32_t> src_at;
+        auto vertex = [&](const std::string &v) {
+            auto it = vid.find(v);
+            if (it != vid.end()) return it->second;
+            const uint32_t id = (uint32_t)vertices.size();
+            vid.emplace(v, id); vertices.push_back(v);
+            return id;
+        };
+        auto edge = [&](uint32_t from, uint32_t to, long long d, uint64_t n) {
+            auto it = src_at.find(from);
+            if (it == src_at.end()) { it = src_at.emplace(from, (uint32_t)adj.size()).first; adj.push_back({from, {}}); }
+            for (Edge &x : adj[it->second].second)
+                if (x.to == to) { x.d = d; x.n = n; return; }
+            adj[it->second].second.push_back({to, d, n});
+        };
+        for (const Kept &kp : kept) {
+            const PairEntry &e = t->pairs[kp.e];
+            const std::string s = name(e.src), g = name(e.tgt);
+            const char so = ori(e, true), to = ori(e, false);
+            const uint32_t f0 = vertex(s + so), f1 = vertex(g + to), r0 = vertex(g + (to == '+' ? '-' : '+')), r1 = vertex(s + (so == '+' ? '-' : '+'));
+            edge(f0, f1, kp.d, e.gaps.size());
+            edge(r0, r1, kp.d, e.gaps.size());
+        }
+        bool have = false;
+        unsigned long long largest = 0;
+        for (size_t c = 0; c < nc; c++) { /* ^ntLink_(\d+)$ */
+            const std::string nm = name((uint32_t)c);
+            if (nm.size() > 7 && nm.compare(0, 7, "ntLink_") == 0 && std::all_of(nm.begin() + 7, nm.end(), [](char ch) { return ch >= '0' && ch <= '9'; })) {
+                const unsigned long long v = strtoull(nm.c_str() + 7, nullptr, 10);
+                if (!have || v > largest) { largest = v; have = true; }
+            }
+        }
+        FILE *fh = fopen(dot_path, "w");
+        if (!fh) return NTL_EINVAL;
+        Buf o(fh);
+        o.put("digraph G {\ngraph [scaf_num=");
+        if (have) o.num((long long)largest); else o.put("None");
+        o.put("]\n");
+        for (const std::string &v : vertices) {
+            o.put("\""); o.put(v); o.put("\" [l="); o.num((long long)len_of[v.substr(0, v.size() - 1)]); o.put("]\n");
+        }
+        for (auto &sa : adj)
+            for (const Edge &x : sa.second)
+                if (x.n >= (uint64_t)std::max(min_n, 0)) {
+                    o.put("\""); o.put(vertices[sa.first]); o.put("\" -> \""); o.put(vertices[x.to]); o.put("\" [d="); o.num(x.d);
+                    o.put(" e=100 n="); o.num((long long)x.n); o.put("]\n");
+                }
+        o.put("}\n");
+        o.flush();
+        if (fclose(fh) != 0) return NTL_EINVAL;
     }
     return NTL_OK;
 }

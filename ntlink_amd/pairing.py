@@ -125,6 +125,17 @@ class PairTally:
             hits["ctg_pos"], hits["ctg_strand"], hits["read_pos"], hits["read_strand"] = cols[:, 0], cols[:, 1], cols[:, 2], cols[:, 3]
         self.add_batch({"maps": maps, "hits": hits}, [rmax])
 
+    def write(self, a, min_n, pairs_path, dot_path):
+        """<prefix>.pairs.tsv (pairs_path may be None) and <prefix>.n<n>.scaffold.dot from the pairs that pass the two filters, written
+        by the native tally (ntl_tally_write); the Python forms below (filtered / write_pairs / write_dot) give the same bytes and
+        stay for callers that want the dict.  -> pairs kept."""
+        kept = C.c_uint64()
+        rc = self._L.ntl_tally_write(self._h, int(a), int(min_n), pairs_path.encode() if pairs_path else None,
+                                     dot_path.encode() if dot_path else None, C.byref(kept))
+        if rc != 0:
+            raise OSError(f"ntl_tally_write failed with {rc} ({pairs_path}, {dot_path})")
+        return int(kept.value)
+
     # ---- filters and writers -------------------------------------------------------------
 
     @staticmethod

@@ -115,15 +115,20 @@ class PairOutputs:
 
 
 def finish_pairs(tally, prefix, n, a, write_pairs_tsv):
+    """filter_pairs_distances, filter_weak_anchor_pairs, write_pairs, the scaffold graph (bin/ntlink_pair.py:594-606): the native
+    tally writes both files (NTL_NATIVE_PAIRS=0: the Python forms in pairing.py, same bytes)."""
+    dot = f"{prefix}.n{n}.scaffold.dot"
+    if os.environ.get("NTL_NATIVE_PAIRS", "1") != "0":
+        _log("Printing graph", dot)
+        return tally.write(a, int(n), prefix + ".pairs.tsv" if write_pairs_tsv else None, dot)
     pairs = tally.filtered(a)
     if write_pairs_tsv:
         with open(prefix + ".pairs.tsv", "w") as fh:
             pairing.write_pairs(fh, pairs)
-    dot = f"{prefix}.n{n}.scaffold.dot"
     _log("Printing graph", dot)
     with open(dot, "w") as fh:
         pairing.write_dot(fh, pairs, tally.names, tally.ctg_len, int(n))
-    return pairs
+    return len(pairs)
 
 
 def run_indexlr(dev, paths, k, w, out, with_len, batch_bases=DEFAULT_BATCH_BASES, with_strand=True):

@@ -149,6 +149,16 @@ def test_writers_and_tally_on_fixtures(tag, target, reads, k, w, gold, tmp_path)
         assert got[:2] == exp[:2] and got[-1] == exp[-1] == "}"
         assert sorted(l for l in got if "->" not in l) == sorted(l for l in exp if "->" not in l)
         assert [l for l in got if "->" in l] == [l for l in exp if "->" in l]
+    # the native writers (ntl_tally_write, what the drivers use) leave the bytes of the Python forms, for every filter setting
+    for a, min_n in ((1, 1), (2, 1), (1, 2), (3, 3)):
+        kept = t.write(a, min_n, str(tmp_path / "n.pairs.tsv"), str(tmp_path / "n.dot"))
+        fp = t.filtered(a)
+        assert kept == len(fp)
+        pb, db = io.StringIO(), io.StringIO()
+        pairing.write_pairs(pb, fp)
+        pairing.write_dot(db, fp, cs_.names, cs_.lengths, min_n)
+        assert read_text(str(tmp_path / "n.pairs.tsv")) == pb.getvalue(), (a, min_n)
+        assert read_text(str(tmp_path / "n.dot")) == db.getvalue(), (a, min_n)
 
 
 @pytest.mark.parametrize("name", SCENARIOS)
@@ -588,3 +598,34 @@ def test_parallel_readers_keep_the_input_order(tmp_path):
     for readers in (2, 3):
         assert _records(list(seqio.load_parallel(mixed, readers=readers, chunk_bytes=100_000, max_bases=30_000))) == want
     assert _records(list(seqio.load_parallel(gz, readers=2, max_bases=30_000))) == _records(list(seqio.load(gz, max_bases=30_000)))
+
+
+def test_native_pair_writers_on_made_up_tallies(tmp_path):
+    """ntl_tally_write against the Python writers on pairs the fixtures do not have: even and odd gap lists with negative medians
+    (int() truncates toward zero), estimates at and beyond minus a contig's length (dropped), contigs called ntLink_N (scaf_num),
+    a pair whose reverse complement is another pair's edge (the dict keeps the first place and the later value)."""
+    rng = np.random.default_rng(9)
+    names = [f"ntLink_{i}" if i % 3 == 0 else f"c{i}" for i in range(40)]
+    lens = rng.integers(50, 400, len(names)).astype(np.uint32)
+    t = pairing.PairTally(names, lens, 32, 10)
+    n = 300
+    src, tgt = rng.integers(0, len(names), n).astype(np.uint32), rng.integers(0, len(names), n).astype(np.uint32)
+    keep = src != tgt
+    src, tgt = src[keep], tgt[keep]
+    so, to = rng.integers(0, 2, len(src)).astype(np.uint8), rng.integers(0, 2, len(src)).astype(np.uint8)
+    anchor = rng.integers(1, 5, len(src)).astype(np.uint32)
+    ng = rng.integers(1, 6, len(src))
+    goff = np.zeros(len(src) + 1, np.uint64)
+    goff[1:] = np.cumsum(ng)
+    gaps = rng.integers(-500, 500, int(goff[-1])).astype(np.int64)
+    t.merge((src, so, tgt, to, anchor, goff, gaps))
+    for a, min_n in ((1, 1), (2, 2), (4, 1)):
+        kept = t.write(a, min_n, str(tmp_path / "p.tsv"), str(tmp_path / "g.dot"))
+        fp = t.filtered(a)
+        assert 0 < kept == len(fp) < len(t.pairs)
+        pb, db = io.StringIO(), io.StringIO()
+        pairing.write_pairs(pb, fp)
+        pairing.write_dot(db, fp, names, lens, min_n)
+        assert read_text(str(tmp_path / "p.tsv")) == pb.getvalue()
+        assert read_text(str(tmp_path / "g.dot")) == db.getvalue()
+    assert "scaf_num=39" in read_text(str(tmp_path / "g.dot"))
