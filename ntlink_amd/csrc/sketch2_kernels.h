@@ -1372,9 +1372,15 @@ __global__ __launch_bounds__(64 * WAVES, (skw_waves_per_simd<WAVES, S>())) void 
         sub++;
         return s < end ? s : 0xFFFFFFFFu;
     };
+    /* a strip's table entry is the same in every lane: it is loaded as a vector (see above) and kept as four SCALARS from the iteration
+       after the one that asked for it -- one entry in flight in vector registers instead of three held there (round 5: the kernel's
+       registers are what the other stream's kernels do not get) */
+    auto uniform4 = [](const uint4 v) {
+        return make_uint4(ntl_readfirstlane(v.x), ntl_readfirstlane(v.y), ntl_readfirstlane(v.z), ntl_readfirstlane(v.w));
+    };
     uint32_t s0 = next_strip(), s1 = next_strip();
-    uint4 I = skw_strip_load(A.strip_lite, s0, end);
-    uint4 I1 = skw_strip_load(A.strip_lite, s1, end);
+    uint4 I = uniform4(skw_strip_load(A.strip_lite, s0, end));
+    uint4 I1v = skw_strip_load(A.strip_lite, s1, end);
     SkwWords W = skw_words_load(A.T.packed, I, L, k, wmax);
     __syncthreads(); /* the tables are in LDS; the only workgroup barrier of the kernel */
 
@@ -1384,16 +1390,18 @@ __global__ __launch_bounds__(64 * WAVES, (skw_waves_per_simd<WAVES, S>())) void 
     while (s0 != 0xFFFFFFFFu) {
         /* two strips ahead: the table entry; one strip ahead: the base words */
         const uint32_t s2 = next_strip();
-        const uint4 I2 = skw_strip_load(A.strip_lite, s2, end);
-        const SkwWords W1 = skw_words_load(A.T.packed, I1, L, k, wmax);
+        const uint4 I2v = skw_strip_load(A.strip_lite, s2, end);
         const uint4 Ic = I;
         const SkwWords Wc = W;
         const uint32_t strip = s0;
-        I = I1; I1 = I2; W = W1;
+        I = uniform4(I1v); I1v = I2v; /* (I: the next strip's entry, asked for a whole strip ago; its base words are asked for behind the rolling loop, below) */
         s0 = s1; s1 = s2;
-        const uint32_t hi_raw = ntl_readfirstlane(Ic.z);
+        const uint32_t hi_raw = Ic.z;
         const uint32_t hi = hi_raw & 0xFFFFu;
-        if (hi == 0u) continue; /* past the last strip, or a strip that crosses non-ACGT runs: sketch_mask_kernel<.., MULTI = true> */
+        if (hi == 0u) { /* past the last strip, or a strip that crosses non-ACGT runs: sketch_mask_kernel<.., MULTI = true> */
+            W = skw_words_load(A.T.packed, I, L, k, wmax);
+            continue;
+        }
         const bool has_w0 = (hi_raw & STRIP_FIRST) == 0u; /* element 0 is a k-mer of the sequence, window 0 the previous strip's last */
 
         /* ---- the lane's bases: 64 that leave (so) and the 64 that enter (si), k bases further on ---- */
@@ -1477,6 +1485,10 @@ __global__ __launch_bounds__(64 * WAVES, (skw_waves_per_simd<WAVES, S>())) void 
                 }
             }
         }
+        /* the next strip's base words: asked for HERE, behind the rolling loop (where the registers are scarcest: twelve of them held
+           across it made the compiler spill into scratch memory, five stores and six loads per strip) and in front of the list and the
+           scans, which take long enough to cover the loads */
+        W = skw_words_load(A.T.packed, I, L, k, wmax);
         uint32_t cnt = (uint32_t)(dst - slots);
         bool bad = cnt > (uint32_t)S; /* (what it wrote beyond its slots lies in the next lane's, or behind the array: the strip is given up) */
 
@@ -1597,7 +1609,7 @@ __global__ __launch_bounds__(64 * WAVES, (skw_waves_per_simd<WAVES, S>())) void 
             if (L == 0) at = strip_list_place(A.Ls, strip, total);
             at = ntl_readfirstlane(at);
             if (at != NTL_NONE) {
-                const uint32_t p0 = ntl_readfirstlane(Ic.w);
+                const uint32_t p0 = Ic.w;
                 for (uint32_t r = 0; r * 64u < n; r++) {
                     const bool mine_r = (found >> r) & 1u;
                     const unsigned long long bal = __ballot(mine_r);
