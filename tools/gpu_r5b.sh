@@ -7,7 +7,5 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$R"
 O=gpurun_out/$TAG; mkdir -p $O
 python __graft_entry__.py > $O/build.log 2>&1 || { tail -20 $O/build.log; exit 1; }
-for P in 2 0; do
-NTL_PIPELINE_PRIO=$P timeout 1200 python tools/share_sweep.py --workload C3 --steps 3 '' 'NTL_EMIT_WGS_PER_CU=4' 'NTL_EMIT_WGS_PER_CU=6' 'NTL_EMIT_WGS_PER_CU=8' 'NTL_EMIT_WGS_PER_CU=0' 'NTL_EMIT_WGS_PER_CU=4 NTL_SKW_WGS_PER_CU=2' 'NTL_EMIT_WGS_PER_CU=0 NTL_SKW_WGS_PER_CU=2' 2>$O/sweep_C3.err | sed "s/^{/{\"prio\": $P, /" | tee -a $O/sweep_C3.jsonl
-done
+timeout 1200 python tools/share_sweep.py --workload C3 --steps 3 '' 'NTL_EMIT_WGS_PER_CU=3' 'NTL_EMIT_WGS_PER_CU=4' 'NTL_EMIT_WGS_PER_CU=1' 'NTL_SKW_WGS_PER_CU=4' 'NTL_SKW_WGS_PER_CU=4 NTL_EMIT_WGS_PER_CU=1' 'NTL_SKETCH_WAVE=4 NTL_SKW_WGS_PER_CU=6' 'NTL_SKETCH_WAVE=4 NTL_SKW_WGS_PER_CU=7' 'NTL_SKETCH_WAVE=4 NTL_SKW_WGS_PER_CU=7 NTL_EMIT_WGS_PER_CU=1' 'NTL_SKETCH_WAVE=4 NTL_SKW_WGS_PER_CU=5' 2>$O/sweep_C3.err | tee $O/sweep_C3.jsonl
 tail -n 3 $O/sweep_C3.err 
