@@ -241,6 +241,82 @@ __device__ __forceinline__ void hash_init_g4p(const uint32_t *__restrict__ packe
     rev = srot_u(u, (uint32_t)(k - 1) % 33u, (uint32_t)(k - 1) % 31u);
 }
 
+/* hash_init_g4p for U k-mers at once (round 5).  hash_init_g4p's loads sit behind uniform branches on k (which words a k-mer needs),
+ * so two calls in a row are compiled as two chains, one behind the other: nothing of the second k-mer is asked for before the first
+ * is hashed.  Here the base words of every k-mer are loaded in front of everything else (`packed` carries 4096 bases of padding behind its
+ * last sequence: no bounds to check), and each uniform branch holds the step of ALL U k-mers: U memory round trips in
+ * flight instead of one. */
+template <int U>
+__device__ __forceinline__ void hash_init_g4p_multi(const uint32_t *__restrict__ packed, const uint64_t (&gp)[U], int k,
+                                                    const uint64_t (*g4)[2], const uint64_t (*g4r)[2], const uint64_t (*seed_tab)[2],
+                                                    uint64_t (&fwd)[U], uint64_t (&rev)[U])
+{
+    if (k > 64) {
+#pragma unroll
+        for (int x = 0; x < U; x++) hash_init_loop(packed, gp[x], k, g4, seed_tab, fwd[x], rev[x]);
+        return;
+    }
+    /* four words in ONE load per k-mer (a k-mer of up to 49 bases lies in them wherever it starts), the fifth only for longer k: every
+       lane's k-mer sits in another cache line, so a load instruction is 64 line lookups in the CU's vector cache whatever its width --
+       and those lookups, not the latency, are what the lookup kernel's time is made of (five one-word loads: 22.4 ms per C3 step
+       alone; three or four as before: 20.7; one: see DESIGN 4.2) */
+    uint32_t raw[U][5];
+#pragma unroll
+    for (int x = 0; x < U; x++) {
+        const uint4 v = ntl_load4_a4(packed + (gp[x] >> 4));
+        raw[x][0] = v.x; raw[x][1] = v.y; raw[x][2] = v.z; raw[x][3] = v.w; raw[x][4] = 0u;
+    }
+    if (k > 49) {
+#pragma unroll
+        for (int x = 0; x < U; x++) raw[x][4] = packed[(gp[x] >> 4) + 4];
+    }
+    uint32_t s[U][4];
+#pragma unroll
+    for (int x = 0; x < U; x++) {
+        const uint32_t a2 = 2u * ((uint32_t)gp[x] & 15u);
+#pragma unroll
+        for (int i = 0; i < 4; i++) s[x][i] = ntl_alignbit(raw[x][i + 1], raw[x][i], a2);
+    }
+    const int ng = k >> 2, np = ng >> 1;
+    uint64_t f[U], u[U];
+#pragma unroll
+    for (int x = 0; x < U; x++) { f[x] = 0; u[x] = 0; }
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        if (q < np) { /* uniform */
+#pragma unroll
+            for (int x = 0; x < U; x++) {
+                const uint32_t w16 = s[x][q >> 1] >> (16 * (q & 1));
+                const uint32_t b0 = w16 & 255u, b1 = (w16 >> 8) & 255u;
+                f[x] = srot_h(f[x], 8, 8) ^ g4r[b0][0] ^ g4[b1][0];
+                u[x] = srot_h(u[x], 25, 23) ^ g4r[b0][1] ^ g4[b1][1];
+            }
+        }
+    }
+    if (ng & 1) {
+        const int g = ng - 1;
+#pragma unroll
+        for (int x = 0; x < U; x++) {
+            const uint32_t byte = (g < 4 ? s[x][0] : (g < 8 ? s[x][1] : (g < 12 ? s[x][2] : s[x][3]))) >> (8 * (g & 3)) & 255u;
+            f[x] = srot_h(f[x], 4, 4) ^ g4[byte][0];
+            u[x] = srot_h(u[x], 29, 27) ^ g4[byte][1];
+        }
+    }
+    for (int j = ng * 4; j < k; j++) {
+#pragma unroll
+        for (int x = 0; x < U; x++) {
+            const uint32_t c = load_base(packed, gp[x] + (uint64_t)j);
+            f[x] = srol1(f[x]) ^ seed_tab[c][0];
+            u[x] = sror1(u[x]) ^ seed_tab[c][1];
+        }
+    }
+#pragma unroll
+    for (int x = 0; x < U; x++) {
+        fwd[x] = f[x];
+        rev[x] = srot_u(u[x], (uint32_t)(k - 1) % 33u, (uint32_t)(k - 1) % 31u);
+    }
+}
+
 /* Exclusive scan of one value per thread over a workgroup of NT threads; returns the prefix and
  * the workgroup total.  s_tmp must hold NT entries. */
 template <int NT>

@@ -782,9 +782,14 @@ static int device_scan(ntl_ctx *c, const uint32_t *in, uint32_t *out, uint64_t n
     hipStream_t st = c->s(sid);
     if ((rc = tile.alloc(c, tiles * 4 * batch, sid))) return rc;
     hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)tiles, batch), dim3(SCAN_NT), 0, st, in, n, tile.as<uint32_t>(), n + 1, tiles);
-    hipLaunchKernelGGL(scan_tiles_kernel, dim3(1, batch), dim3(SCAN_NT), 0, st, tile.as<uint32_t>(), tiles, out + n, n + 1, sums_dev);
-    hipLaunchKernelGGL(scan_down_kernel, dim3((unsigned)tiles, batch), dim3(SCAN_NT), 0, st, in, out, n,
-                       (const uint32_t *)tile.as<uint32_t>(), n + 1, tiles);
+    if (tiles <= 4096) { /* two launches: every workgroup of the second sums the tiles in front of its own */
+        hipLaunchKernelGGL(scan_down_self_kernel, dim3((unsigned)tiles, batch), dim3(SCAN_NT), 0, st, in, out, n,
+                           (const uint32_t *)tile.as<uint32_t>(), n + 1, tiles, sums_dev);
+    } else {
+        hipLaunchKernelGGL(scan_tiles_kernel, dim3(1, batch), dim3(SCAN_NT), 0, st, tile.as<uint32_t>(), tiles, out + n, n + 1, sums_dev);
+        hipLaunchKernelGGL(scan_down_kernel, dim3((unsigned)tiles, batch), dim3(SCAN_NT), 0, st, in, out, n,
+                           (const uint32_t *)tile.as<uint32_t>(), n + 1, tiles);
+    }
     HIPCHK(c, hipGetLastError());
     if (total_host) {
         for (unsigned y = 0; y < batch; y++)
@@ -1656,8 +1661,20 @@ static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const nt
                 (rc = loff.alloc(c, (ub_strips + 2) * 4))) return rc;
             lcnt.touch(SID_MAIN); lent.touch(SID_MAIN);
             Ls.cnt = lcnt.as<uint32_t>(); Ls.ent = lent.as<uint32_t>(); Ls.ctl = Ls.cnt + ub_strips + 2;
-            HIPCHK(c, hipMemsetAsync(lcnt.p, 0, (ub_strips + 4) * 4, ws));
+            lcnt.touch(SID_P); /* (zeroed by strip_table_kernel, on the preparation's stream) */
         }
+    }
+    /* the fast pass's counters and lists: [0] strips for the exact pass, [1] strips the threshold pass gave up, then the eight chunk
+       counters of sketch_wave_kernel (one per XCD's share of the strips, 64 bytes apart), then the two lists.  Zeroed -- with the
+       strips' counts -- by strip_table_kernel: one launch instead of three fills on the window stream's critical path (round 5) */
+    StripZero Z;
+    memset(&Z, 0, sizeof Z);
+    const uint64_t redo_head = 16 + 8 * 16; /* words in front of the lists */
+    if (fast && ub_strips) {
+        if ((rc = redo.alloc(c, (redo_head + 2 * ub_strips + 4) * 4, wsid))) return rc;
+        redo.touch(SID_P);
+        Z.head = redo.as<uint32_t>(); Z.nhead = (uint32_t)redo_head;
+        Z.cnt = Ls.cnt; Z.ncnt = Ls.cnt ? (uint32_t)(ub_strips + 4) : 0u;
     }
     CleanMask mask;
     if (!lists && (rc = mask_take(c, nmask * 4, wsid, &mask))) return rc;
@@ -1683,7 +1700,7 @@ static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const nt
             hipLaunchKernelGGL(strip_table_kernel, dim3((unsigned)((ub_strips + 255) / 256 + 1)), dim3(256), 0, ps, T,
                                (const uint32_t *)run_n.as<uint32_t>(), (const uint32_t *)run_ord.as<uint32_t>(),
                                (const uint32_t *)seq_M.as<uint32_t>(), (const uint32_t *)strip_first.as<uint32_t>(), G.NWO,
-                               C * nt, strip_tab.as<StripInfo>(), (uint32_t)ub_strips + 1u, strip_lite.as<StripLite>());
+                               C * nt, strip_tab.as<StripInfo>(), (uint32_t)ub_strips + 1u, strip_lite.as<StripLite>(), Z);
             HIPCHK(c, hipGetLastError());
         }
     }
@@ -1706,16 +1723,10 @@ static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const nt
         A.redo_list = nullptr; A.redo_count = nullptr;
         A.Ls = Ls;
         if (fast) {
-            /* [0] strips for the exact pass, [1] strips the threshold pass gave up, then the two lists */
-            /* ... and behind them the eight chunk counters of sketch_wave_kernel (one per XCD's share of the strips), 64 bytes apart */
-            const uint64_t redo_words = 2 * ub_strips + 4;
-            if ((rc = redo.alloc(c, (redo_words + 8 * 16) * 4, wsid))) return rc;
-            HIPCHK(c, hipMemsetAsync(redo.p, 0, 8, ws));
-            HIPCHK(c, hipMemsetAsync(redo.as<uint32_t>() + redo_words, 0, 8 * 16 * 4, ws));
             B.A = A;
-            B.redo_count = redo.as<uint32_t>(); B.redo_list = redo.as<uint32_t>() + 2;
-            B.fb_count = redo.as<uint32_t>() + 1; B.fb_list = redo.as<uint32_t>() + 2 + ub_strips + 1;
-            B.chunk_next = redo.as<uint32_t>() + redo_words;
+            B.redo_count = redo.as<uint32_t>(); B.fb_count = redo.as<uint32_t>() + 1;
+            B.chunk_next = redo.as<uint32_t>() + 16;
+            B.redo_list = redo.as<uint32_t>() + redo_head; B.fb_list = B.redo_list + ub_strips + 2;
             B.chunk_budget = 0;
             B.max_word = b->nwords_packed - 1;
             B.q16 = k / 16; B.r16 = k % 16;

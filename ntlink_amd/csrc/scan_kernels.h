@@ -87,3 +87,38 @@ __global__ __launch_bounds__(SCAN_NT) void scan_down_kernel(const uint32_t *in, 
         r += v[i];
     }
 }
+
+/* scan_tiles_kernel + scan_down_kernel in one launch (round 5: one dependent launch less on the streams' critical paths): every
+ * workgroup sums the counts of the tiles in front of its own itself -- tiles^2 / 2 words in all, nothing for the few hundred tiles
+ * of a strip or sequence table -- and the last one writes the total.  tile_cnt holds scan_reduce_kernel's sums, untouched. */
+__global__ __launch_bounds__(SCAN_NT) void scan_down_self_kernel(const uint32_t *in, uint32_t *out, uint64_t n, const uint32_t *tile_cnt,
+                                                                 uint64_t stride, uint64_t tiles, uint32_t *extra)
+{
+    __shared__ uint32_t s_tmp[SCAN_NT];
+    in += (uint64_t)blockIdx.y * stride;
+    out += (uint64_t)blockIdx.y * stride;
+    tile_cnt += (uint64_t)blockIdx.y * tiles;
+    uint32_t part = 0;
+    for (uint64_t j = threadIdx.x; j < blockIdx.x; j += SCAN_NT) part += tile_cnt[j];
+    uint32_t before;
+    block_excl_scan<SCAN_NT>(part, s_tmp, before);
+    const uint64_t i0 = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_IPT;
+    uint32_t v[SCAN_IPT];
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_IPT; i++) {
+        v[i] = i0 + i < n ? in[i0 + i] : 0u;
+        c += v[i];
+    }
+    uint32_t total;
+    uint32_t r = before + block_excl_scan<SCAN_NT>(c, s_tmp, total);
+#pragma unroll
+    for (int i = 0; i < SCAN_IPT; i++) {
+        if (i0 + i < n) out[i0 + i] = r;
+        r += v[i];
+    }
+    if (blockIdx.x + 1 == gridDim.x && threadIdx.x == 0) {
+        out[n] = before + total;
+        if (extra) extra[blockIdx.y] = before + total;
+    }
+}

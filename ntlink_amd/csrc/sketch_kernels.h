@@ -150,10 +150,21 @@ __device__ __forceinline__ void strip_bits_to_list(const StripLists &Ls, uint32_
     __syncthreads(); /* s_tmp may be written again */
 }
 
+/* what the window passes count into, zeroed here (one thread per word) instead of by fills of their own: the strips' minimizer counts
+   with the lists' two control words behind them, and the head of the fast pass's buffer (its two counters and sketch_wave_kernel's
+   chunk counters) */
+struct StripZero {
+    uint32_t *cnt; uint32_t ncnt;
+    uint32_t *head; uint32_t nhead;
+};
+
 __global__ void strip_table_kernel(SeqTables T, const uint32_t *run_n, const uint32_t *run_ord, const uint32_t *seq_M,
-                                   const uint32_t *strip_first, int NWO, int strip_elems, StripInfo *tab, uint32_t cap, StripLite *lite)
+                                   const uint32_t *strip_first, int NWO, int strip_elems, StripInfo *tab, uint32_t cap, StripLite *lite,
+                                   StripZero Z)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; /* one thread per strip */
+    for (uint32_t j = i; j < Z.ncnt; j += gridDim.x * blockDim.x) Z.cnt[j] = 0u;
+    if (i < Z.nhead) Z.head[i] = 0u;
     if (i >= cap) return;
     if (i >= strip_first[T.nseq]) { /* the grid of the sketch kernel is an upper bound */
         tab[i].seq = NTL_NONE;
@@ -865,20 +876,22 @@ __global__ __launch_bounds__(EL_NT) void emit_list_kernel(EmitArgs A, EmitListAr
                     p[u] = Q.Ls.ent[s_first[sidv[u]] + (r0 + ic - s_loc[sidv[u]])];
                     ok[u] = i < n && tile_base + r0 + i < A.out_cap;
                 }
-                uint64_t h[U];
+                uint64_t h[U], gpv[U], fwd[U], rev[U];
                 MxRecord R[U];
 #pragma unroll
                 for (int u = 0; u < U; u++) {
                     sq[u] = s_seq[sidv[u]];
-                    const uint64_t gp = s_sbase[sidv[u]] + p[u];
-                    uint64_t fwd, rev;
-                    hash_init_g4p(A.packed, gp, A.k, s_g4, s_g4r, s_seed, fwd, rev);
-                    uint64_t hh = (fwd + rev) * A.mult;
+                    gpv[u] = s_sbase[sidv[u]] + p[u];
+                }
+                hash_init_g4p_multi<U>(A.packed, gpv, A.k, s_g4, s_g4r, s_seed, fwd, rev);
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    uint64_t hh = (fwd[u] + rev[u]) * A.mult;
                     hh ^= hh >> 27;
                     h[u] = hh;
                     R[u].hash = hh;
                     R[u].pos = p[u];
-                    R[u].meta = (sq[u] << 1) | (fwd <= rev ? 1u : 0u);
+                    R[u].meta = (sq[u] << 1) | (fwd[u] <= rev[u] ? 1u : 0u);
                 }
                 if (PROBE) {
                     IndexProbe<PROBE == 1> pr[U];
