@@ -7,7 +7,6 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$R"
 O=gpurun_out/$TAG; mkdir -p $O
 python __graft_entry__.py > $O/build.log 2>&1 || { tail -20 $O/build.log; exit 1; }
-timeout 1200 python tools/share_sweep.py --workload C3 --steps 3 '' 'NTL_EMIT_U=2' 'NTL_EMIT_U=4' 'NTL_EMIT_U=2 NTL_EMIT_WGS_PER_CU=1' 'NTL_EMIT_U=4 NTL_EMIT_WGS_PER_CU=1' 'NTL_EMIT_U=2 NTL_EMIT_WGS_PER_CU=3' 'NTL_EMIT_U=2 NTL_MAP_WAVES_PER_CU=48' 'NTL_EMIT_U=4 NTL_EMIT_WGS_PER_CU=1 NTL_MAP_WAVES_PER_CU=48' 2>$O/sweep_C3.err | tee $O/sweep_C3.jsonl
-timeout 900 python tools/share_sweep.py --workload C5 --steps 2 '' 'NTL_EMIT_U=2' 'NTL_EMIT_U=4' 'NTL_EMIT_U=2 NTL_EMIT_WGS_PER_CU=2' 2>>$O/sweep_C3.err | tee $O/sweep_C5.jsonl
-NTL_PIPELINE=0 timeout 600 python tools/share_sweep.py --workload C3 --steps 2 '' 'NTL_EMIT_U=2' 'NTL_EMIT_U=4' 2>>$O/sweep_C3.err | tee $O/sweep_C3_alone.jsonl
+timeout 1200 python tools/share_sweep.py --workload C3 --steps 3 '' 'NTL_SKW_RETRY=0' '' 'NTL_SKW_RETRY=0' 'NTL_EMIT_WGS_PER_CU=3' 'NTL_EMIT_WGS_PER_CU=4' 'NTL_EMIT_WGS_PER_CU=3 NTL_SKW_RETRY=0' 2>$O/sweep_C3.err | tee $O/sweep_C3.jsonl
+timeout 900 python tools/share_sweep.py --workload C5 --steps 2 '' 'NTL_SKW_RETRY=0' '' 'NTL_SKW_RETRY=0' 2>>$O/sweep_C3.err | tee $O/sweep_C5.jsonl
 tail -n 3 $O/sweep_C3.err 
