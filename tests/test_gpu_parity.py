@@ -513,3 +513,32 @@ def test_slab_blocks_are_reused_when_the_cache_drops_them(monkeypatch):
         assert counts[-1] <= counts[9] + 1, counts  # (single blocks above 192 MB would count too: none here)
     finally:
         d.close()
+
+
+@pytest.mark.parametrize("name", ["C3", "C5"])
+def test_full_sub_batch_lists_equal_bitmask(name, monkeypatch):
+    """A size-independent check at the bench's own sub-batch size (3.9 Gbases of device-generated reads against the full 3-Gbp
+    assembly): the window -> emit stage exists twice -- per-strip lists + emit_list_kernel, and the bitmask + mask_count / emit_kernel
+    (NTL_SKETCH_LISTS=0) -- with different ownership rules, ranks and kernels; every minimizer record of the contigs and of the
+    reads, the index size and every mapping / hit / PAF record of the batch must agree between the two."""
+    d = capi.Device(0)
+    try:
+        wl = synth.DeviceWorkload(d, name, with_reads=False)
+        k, w = wl.W["k"], wl.W["w"]
+        rb, rlen = wl.make_reads(3_900_000_000, seed=(77, 1))
+        got = []
+        for lists in ("1", "0"):
+            monkeypatch.setenv("NTL_SKETCH_LISTS", lists)
+            with d.sketch(wl.contigs, k, w) as csk, d.index(csk, wl.ctg_len) as ix, d.sketch(rb, k, w, index=ix) as rsk, \
+                    d.map(ix, rsk, rlen, k=k, z=1000, x=0.0, sensitive=wl.W["sensitive"], repeat_filter=False) as res:
+                assert csk.from_lists == rsk.from_lists == (lists == "1")
+                r = res.download()
+                got.append((csk.download(), len(ix), rsk.download(), r["maps"], r["hits"], r["pafs"]))
+        (c1, n1, s1, m1, h1, p1), (c0, n0, s0, m0, h0, p0) = got
+        assert n1 == n0 and len(s1[1]) == len(s0[1]) > 20_000_000
+        for a, b in zip(c1 + s1, c0 + s0):
+            assert np.array_equal(a, b)
+        assert np.array_equal(m1, m0) and np.array_equal(h1, h0) and np.array_equal(p1, p0) and len(m1) > 100_000
+        rb.close(); wl.close()
+    finally:
+        d.close()
