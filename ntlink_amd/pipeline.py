@@ -359,27 +359,41 @@ def shared_contigs(comm, target, alloc, packed, stats=None):
             comm.allgather(None)
             comm.allgather(None)
         return seqio.load_all([target], alloc=alloc if packed else None, packed=packed), None
-    path, ss = None, None
+    path, ss, failure = None, None, None
     if comm.rank == leader:
-        ss = seqio.load_all([target], alloc=alloc, packed=True)
-        arrays = dict(names_blob=ss.names.blob, names_off=ss.names.off, offsets=np.ascontiguousarray(ss.offsets, np.uint64),
-                      packed=ss.packed, seq_run_first=ss.seq_run_first, run_start=ss.run_start, run_len=ss.run_len)
-        shm = "/dev/shm" if os.path.isdir("/dev/shm") else (os.environ.get("TMPDIR") or "/tmp")
-        path = os.path.join(shm, f"ntlink_amd.ctg.{os.getuid()}.{os.getpid()}.{int(time.time() * 1e6) & 0xFFFFFF:06x}")
-        head, at = {}, 4096
-        for key in _SHARED_FIELDS:
-            a = np.ascontiguousarray(arrays[key])
-            head[key] = (str(a.dtype), int(a.size), at)
-            at += (a.nbytes + 63) & ~63
-        hb = json.dumps(head).encode()
-        assert len(hb) + 8 <= 4096
-        with open(path, "wb") as fh:
-            fh.write(len(hb).to_bytes(8, "little") + hb)
+        try:
+            ss = seqio.load_all([target], alloc=alloc, packed=True)
+            arrays = dict(names_blob=ss.names.blob, names_off=ss.names.off, offsets=np.ascontiguousarray(ss.offsets, np.uint64),
+                          packed=ss.packed, seq_run_first=ss.seq_run_first, run_start=ss.run_start, run_len=ss.run_len)
+            shm = os.environ.get("NTL_SHM_DIR") or ("/dev/shm" if os.path.isdir("/dev/shm") else (os.environ.get("TMPDIR") or "/tmp"))
+            path = os.path.join(shm, f"ntlink_amd.ctg.{os.getuid()}.{os.getpid()}.{int(time.time() * 1e6) & 0xFFFFFF:06x}")
+            head, at = {}, 4096
             for key in _SHARED_FIELDS:
-                fh.seek(head[key][2])
-                np.ascontiguousarray(arrays[key]).tofile(fh)
-            fh.truncate(max(at, 4096))
+                a = np.ascontiguousarray(arrays[key])
+                head[key] = (str(a.dtype), int(a.size), at)
+                at += (a.nbytes + 63) & ~63
+            hb = json.dumps(head).encode()
+            assert len(hb) + 8 <= 4096
+            with open(path, "wb") as fh:
+                fh.write(len(hb).to_bytes(8, "little") + hb)
+                for key in _SHARED_FIELDS:
+                    fh.seek(head[key][2])
+                    np.ascontiguousarray(arrays[key]).tofile(fh)
+                fh.truncate(max(at, 4096))
+        except BaseException as exc:
+            # the others wait in the collective below: they must hear of it, not hang (a target that does not parse fails on every rank,
+            # as it did when every rank parsed)
+            if isinstance(path, str):
+                try:
+                    os.unlink(path)
+                except OSError:
+                    pass
+            failure, path = exc, ("failed", f"{type(exc).__name__}: {exc}")
     paths = comm.allgather(path)  # (also: the file is complete)
+    if failure is not None:
+        raise failure
+    if isinstance(paths[leader], tuple):
+        raise OSError(f"{target}: the rank that parses it for this host (rank {leader}) failed: {paths[leader][1]}")
     mapping = None
     if comm.rank != leader:
         with open(paths[leader], "rb") as fh:

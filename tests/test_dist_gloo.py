@@ -85,7 +85,8 @@ def test_byte_range_readers_see_every_record_once(tmp_path, fastq, wrap):
 
 
 def _run_ranks(tmp_path, world, port, args, extra_env=None):
-    env = dict(os.environ, OMP_NUM_THREADS="1", NTLINK_AMD_LIB=simlib.build(), NTL_IO_THREADS="2")
+    os.makedirs(tmp_path / "shm", exist_ok=True)  # where a host's shared copy of the packed contigs lives for a moment (pipeline.shared_contigs)
+    env = dict(os.environ, OMP_NUM_THREADS="1", NTLINK_AMD_LIB=simlib.build(), NTL_IO_THREADS="2", NTL_SHM_DIR=str(tmp_path / "shm"))
     for key, val in (extra_env or {}).items():
         if val is None:
             env.pop(key, None)
@@ -122,7 +123,7 @@ def test_ranks_equal_single_process(tmp_path, world, port):
     assert all(abs(b - total / world) <= longest for b in per)
     # one rank of the host parsed the target FASTA, the others mapped its packed copy (pipeline.shared_contigs)
     assert json.loads(rep["ntlink_amd contigs_parsed_by_per_rank"]) == [0] * world
-    assert not [f for f in os.listdir("/dev/shm") if f.startswith(f"ntlink_amd.ctg.{os.getuid()}.")]
+    assert os.listdir(tmp_path / "shm") == []
 
 
 def test_three_ranks_many_reads_and_files(tmp_path):
@@ -161,7 +162,7 @@ def test_contigs_are_parsed_once_per_host(tmp_path, env, want, port):
         assert read_text(pre + ext) == read_text(d + ext), ext
     rep = dict(line.strip().split(": ", 1) for line in open(pre + ".n1.scaffold.dot.time") if ": " in line)
     assert json.loads(rep["ntlink_amd contigs_parsed_by_per_rank"]) == want
-    assert not [f for f in os.listdir("/dev/shm") if f.startswith(f"ntlink_amd.ctg.{os.getuid()}.")]
+    assert os.listdir(tmp_path / "shm") == []
 
 
 def _fake_host(root, gpus_per_node=(4, 4), cpus_per_node=64, cpu_max="1600000 100000"):
@@ -320,3 +321,17 @@ def test_pin_rank_choices_on_made_up_hosts(tmp_path, monkeypatch):
     pins = [pin(c, r, 8) for r in range(8)]
     assert all(p["how"] == "contiguous slice" and p["cores"] == 2 for p in pins)
     assert [p["first_core"] for p in pins] == list(range(0, 16, 2))
+
+
+def test_a_target_that_does_not_parse_fails_every_rank(tmp_path):
+    """pipeline.shared_contigs: only one rank of a host parses the target; when it fails, the ranks that wait for its copy must fail
+    with it -- not hang in the collective -- and nothing stays under /dev/shm."""
+    shutil.copy(os.path.join(REF, "long_reads_4_top5.fa"), tmp_path / "long_reads_4_top5.fa")
+    os.makedirs(tmp_path / "shm")
+    env = dict(os.environ, OMP_NUM_THREADS="1", NTLINK_AMD_LIB=simlib.build(), NTL_IO_THREADS="2", NTL_SHM_DIR=str(tmp_path / "shm"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3", "--master-addr", "127.0.0.1",
+           "--master-port", "29579", os.path.join(ROOT, "tests", "dist_worker.py"), "pair", "target=missing.fa", "reads=long_reads_4_top5.fa",
+           "k=40", "w=100"]
+    assert subprocess.call(cmd, cwd=tmp_path, env=env, timeout=300, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) != 0
+    assert os.listdir(tmp_path / "shm") == []
+    assert not [f for f in os.listdir(tmp_path) if "verbose_mapping" in f or f.endswith(".paf")]
