@@ -274,6 +274,11 @@ class Sketch(_Handle):
         return int(self.dev.L.ntl_sketch_fallback_strips(self.ptr))
 
     @property
+    def has_records(self):
+        """False for a sketch made only to be mapped (Device.sketch(..., index=ix, records=False)): nothing to download."""
+        return bool(self.dev.L.ntl_sketch_has_records(self.ptr))
+
+    @property
     def from_lists(self):
         """True: the window passes wrote per-strip minimizer lists; False: the bitmask (diagnostics; same result)."""
         self.wait()

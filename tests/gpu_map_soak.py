@@ -5,7 +5,9 @@ driver and the bench do it -- sketch and map of batch i+1 are queued BEFORE the 
 streams of a context really overlap -- and every mapping, hit and PAF record is compared with the oracle's (its own sketch of
 the downloaded bases, its own index of the whole assembly, its own map loop).  C5 (HiFi, --sensitive, h = 0.92: all three LDS
 size classes of the map kernels and the global-scratch path) is the default.
-Usage: tests/gpu_map_soak.py [workload=C5] [batches=10] [bases per batch=1e9] [seed0=300]"""
+records=0: the read sketches are made with Device.sketch(..., index=ix, records=False) -- ntl_sketch_run_for_map, the call form of
+the pair driver and of bench.py: no minimizer records exist on the device, the mappings alone are compared.
+Usage: tests/gpu_map_soak.py [workload=C5] [batches=10] [bases per batch=1e9] [seed0=300] [records=1]"""
 import os
 import sys
 import time
@@ -23,6 +25,7 @@ name = sys.argv[1] if len(sys.argv) > 1 else "C5"
 batches = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 bases = int(float(sys.argv[3])) if len(sys.argv) > 3 else 1_000_000_000
 seed0 = int(sys.argv[4]) if len(sys.argv) > 4 else 300
+records = bool(int(sys.argv[5])) if len(sys.argv) > 5 else True
 cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
 dev = capi.Device(0)
 wl = synth.DeviceWorkload(dev, name, with_reads=False)
@@ -50,10 +53,12 @@ def check(item):
     global tot, nmaps, nhits, npafs
     b, rbuf, roff, rlen, rsk, res = item
     got = res.download()
-    off, h, p, s = rsk.download()
+    assert rsk.has_records == records
+    if records:
+        off, h, p, s = rsk.download()
     res.close(); rsk.close()
     qoff, qh, qp, qs = oracle.sketch_batch(rbuf, roff, k, w, threads=cores)
-    if not (np.array_equal(off, qoff) and np.array_equal(h, qh) and np.array_equal(p, qp) and np.array_equal(s, qs)):
+    if records and not (np.array_equal(off, qoff) and np.array_equal(h, qh) and np.array_equal(p, qp) and np.array_equal(s, qs)):
         print(f"SKETCH MISMATCH workload {name} seed ({seed0}, {b})")
         sys.exit(1)
     exp = oracle.map_reads(oix, wl.ctg_len, qoff, rlen, qh, qp, qs, threads=cores, **kw)
@@ -70,7 +75,7 @@ def check(item):
 
 for b in range(batches):
     rb, rlen = wl.make_reads(bases, seed=(seed0, b))
-    rsk = dev.sketch(rb, k, w, index=ix)       # queued
+    rsk = dev.sketch(rb, k, w, index=ix, records=records)  # queued
     res = dev.map(ix, rsk, rlen, **kw)         # queued behind it: nothing has waited yet
     rbuf, roff = rb.download()
     rb.close()
@@ -79,5 +84,5 @@ for b in range(batches):
     prev = (b, rbuf, roff, rlen, rsk, res)
 check(prev)
 dev.sync()
-print(f"map soak clean: {name} k{k} w{w} sensitive={W['sensitive']}, {tot} bases, {nmaps} mappings, {nhits} hits, {npafs} PAF records; "
+print(f"map soak clean: {name} k{k} w{w} sensitive={W['sensitive']} records={records}, {tot} bases, {nmaps} mappings, {nhits} hits, {npafs} PAF records; "
       f"reads by minimizer count <=256 / <=512 / <=1024 / more: {classes.tolist()}; {time.time() - t0:.0f} s")

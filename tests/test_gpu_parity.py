@@ -336,11 +336,17 @@ def test_full_size_assembly_parity(dev, name, n_reads):
         with dev.sketch(rb, k, w) as rsk, dev.map(ix, rsk, rlen, **params) as res:
             got = res.download()
             r_off, rh, rp, rs = rsk.download()
+        # the call form of the pair driver and of bench.py (round 6): a read sketch made only to be mapped
+        # (ntl_sketch_run_for_map: no records, the lookups inside emit_list_kernel on the tagged full-size index), against the ORACLE
+        with dev.sketch(rb, k, w, index=ix, records=False) as fsk, dev.map(ix, fsk, rlen, **params) as fres:
+            assert not fsk.has_records
+            got_for_map = fres.download()
         rb.close()
     q_off, qh, qp, qs = oracle.sketch_batch(rbuf, roff, k, w)
     assert np.array_equal(r_off, q_off) and np.array_equal(rh, qh) and np.array_equal(rp, qp) and np.array_equal(rs, qs)
     exp = oracle.map_reads(oix, wl.ctg_len, q_off, rlen, qh, qp, qs, threads=0, **params)
     pc.assert_same_records(got, exp)
+    pc.assert_same_records(got_for_map, exp)
     assert len(got["maps"]) > 0.9 * len(rlen) and len(rlen) >= n_reads * 0.99
     wl.close()
 

@@ -29,8 +29,10 @@ def test_sketch_volume_soak(args):
     assert "volume soak clean" in out, out[-2000:]
 
 
-def test_mapping_volume_soak():
-    """4 Gbases of C5 reads (HiFi, --sensitive, h = 0.92) mapped with both streams overlapping: every mapping, hit and PAF record
-    equal to the oracle's."""
-    out = _run("gpu_map_soak.py", "C5", 4, 1e9, 500)
+@pytest.mark.parametrize("args", [("C5", 4, 1e9, 500), ("C3", 4, 1e9, 510, 0)], ids=["C5_records", "C3_for_map_no_records"])
+def test_mapping_volume_soak(args):
+    """4 Gbases of C5 reads (HiFi, --sensitive, h = 0.92) mapped with both streams overlapping, and (round 6) 4 Gbases of C3 reads
+    (ONT, tags) through the record-less call form of the pair driver and the bench (`records=False`: ntl_sketch_run_for_map):
+    every mapping, hit and PAF record equal to the oracle's."""
+    out = _run("gpu_map_soak.py", *args)
     assert "soak clean" in out, out[-2000:]
