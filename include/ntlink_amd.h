@@ -68,6 +68,7 @@ extern "C" {
 #define NTL_ENOMEM (-3)
 #define NTL_EINTERNAL (-4) /* an internal invariant failed (reported, never silently ignored) */
 #define NTL_ERANGE (-5)    /* ntl_tally_add: an overhang came out negative (the reference asserts) */
+#define NTL_EIO (-6)       /* a file could not be created or written completely; ntl_io_errno() has the errno */
 
 typedef struct ntl_ctx ntl_ctx;
 typedef struct ntl_batch ntl_batch;
@@ -417,8 +418,12 @@ int ntl_tally_merge(ntl_tally *t, uint64_t npairs, const uint32_t *src, const ui
 /* The two small files behind the tally: <prefix>.pairs.tsv (write_pairs, bin/ntlink_pair.py:490-496; pairs_path may be NULL) and
  * <prefix>.n<n>.scaffold.dot (build_scaffold_graph :263-305, filter_graph_global :498-506 with min_n = n, print_directed_graph
  * :133-155; dot_path may be NULL) from the pairs that pass filter_pairs_distances (:247-255) and filter_weak_anchor_pairs
- * (:241-244, anchor >= a).  *n_kept (may be NULL): the pairs that passed. */
+ * (:241-244, anchor >= a).  *n_kept (may be NULL): the pairs that passed.  Each file is written beside its place and renamed when it
+ * is complete (the reference leaves no partial output behind, bin/ntlink_pair.py:608-613); NTL_EIO when a file cannot be created,
+ * written or closed, with the errno in ntl_io_errno(). */
 int ntl_tally_write(const ntl_tally *t, int a, int min_n, const char *pairs_path, const char *dot_path, uint64_t *n_kept);
+/* errno of the calling thread's last call that returned NTL_EIO (0: none). */
+int ntl_io_errno(void);
 
 /* ---- liftover of the verbose mappings (no GPU involved) -------------------------------------- */
 

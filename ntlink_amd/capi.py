@@ -33,7 +33,7 @@ SYMBOLS = [
     "ntl_tally_create", "ntl_tally_destroy", "ntl_tally_add", "ntl_tally_npairs", "ntl_tally_ngaps", "ntl_tally_export", "ntl_tally_merge",
     "ntl_liftover",
     "ntl_names_create", "ntl_names_destroy", "ntl_mapres_format", "ntl_text_sizes", "ntl_text_download", "ntl_text_destroy", "ntl_write_blob",
-    "ntl_tally_add_ends", "ntl_tally_write",
+    "ntl_tally_add_ends", "ntl_tally_write", "ntl_io_errno",
 ]
 
 MAPPING_DT = np.dtype([("read", "<u4"), ("ctg", "<u4"), ("n_hits", "<u4"), ("pad", "<u4"), ("hit_off", "<u8")])
@@ -66,6 +66,11 @@ def load(path=None):
         return _libs[path]
     if not os.path.exists(path):
         raise NtlError(f"HIP extension not built: {path} is missing (run __graft_entry__.build())")
+    if path == DEFAULT_LIB and not os.environ.get("NTL_ALLOW_STALE_LIB"):
+        # what runs is what the sources beside it say (build.py: content signatures; objects and library travel to the GPU box)
+        from . import build
+        if not build.library_is_current():
+            raise NtlError(f"{path} was not built from the sources beside it (signature mismatch): run __graft_entry__.build()")
     L = C.CDLL(path)
     vp, u64p, u32p, u8p = C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)
     L.ntl_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
@@ -185,6 +190,7 @@ def load(path=None):
         f.restype = C.c_uint64
     L.ntl_tally_export.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     L.ntl_tally_write.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, C.c_char_p, u64p]
+    L.ntl_io_errno.argtypes = []
     L.ntl_tally_merge.argtypes = [vp, C.c_uint64, vp, vp, vp, vp, vp, vp, vp]
     L.ntl_liftover.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_uint64, vp, u64p, vp, u64p, vp, vp, vp, vp, u64p, u64p]
     _libs[path] = L

@@ -193,6 +193,9 @@ __device__ __forceinline__ void ntl_lds_push_tagged(uint32_t *&p, uint32_t mask,
     p = (uint32_t *)q;
 }
 
+/* a - b, 0 where it would wrap: v_sub_u32 with the clamp bit */
+__device__ __forceinline__ uint32_t ntl_sub_sat(uint32_t a, uint32_t b) { return __builtin_elementwise_sub_sat(a, b); }
+
 /* minimum of three: v_min3_u32 */
 __device__ __forceinline__ uint32_t ntl_min3(uint32_t a, uint32_t b, uint32_t c)
 {

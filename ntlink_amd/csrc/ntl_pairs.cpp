@@ -8,10 +8,12 @@
  * lists keep the order of the reads, pairs the order of first appearance), so it runs on one
  * thread -- a few tens of nanoseconds per pair against microseconds in the Python loop.
  */
+#include <errno.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 #include <algorithm>
 #include <numeric>
 #include <string>
@@ -222,15 +224,46 @@ extern "C" int ntl_tally_merge(ntl_tally *t, uint64_t npairs, const uint32_t *sr
  * The dot file keeps what the Python dicts keep: sources and vertices in order of first appearance, an edge named twice keeps its
  * place and takes the later value; "scaf_num" = the largest N of a contig called ntLink_N, else None. */
 namespace {
+thread_local int t_io_errno = 0;
+
 struct Buf {
     FILE *f;
     std::string s;
+    bool bad = false; /* a short write: the stream's error flag alone is not enough (fclose may still return 0) */
     explicit Buf(FILE *fh) : f(fh) { s.reserve(1 << 20); }
-    void flush() { if (!s.empty()) { fwrite(s.data(), 1, s.size(), f); s.clear(); } }
+    void flush()
+    {
+        if (!s.empty()) {
+            if (!bad && fwrite(s.data(), 1, s.size(), f) != s.size()) { bad = true; t_io_errno = errno ? errno : EIO; }
+            s.clear();
+        }
+    }
     void put(const char *p, size_t n) { s.append(p, n); if (s.size() > (1u << 20) - 4096) flush(); }
     void put(const std::string &x) { put(x.data(), x.size()); }
     void put(const char *z) { put(z, strlen(z)); }
     void num(long long v) { char b[24]; int n = snprintf(b, sizeof b, "%lld", v); put(b, (size_t)n); }
+};
+
+/* a file written beside its place and renamed when complete: never a partial .pairs.tsv / .dot */
+struct TmpFile {
+    std::string path, tmp;
+    FILE *fh = nullptr;
+    explicit TmpFile(const char *p) : path(p), tmp(std::string(p) + ".tmp." + std::to_string((long long)getpid()))
+    {
+        fh = fopen(tmp.c_str(), "w");
+        if (!fh) t_io_errno = errno ? errno : EIO;
+    }
+    int finish(Buf &o)
+    {
+        o.flush();
+        bool ok = !o.bad && !ferror(fh);
+        if (fclose(fh) != 0 && ok) { ok = false; t_io_errno = errno ? errno : EIO; }
+        fh = nullptr;
+        if (ok && rename(tmp.c_str(), path.c_str()) != 0) { ok = false; t_io_errno = errno ? errno : EIO; }
+        if (!ok) { if (!t_io_errno) t_io_errno = EIO; (void)remove(tmp.c_str()); return NTL_EIO; }
+        return NTL_OK;
+    }
+    ~TmpFile() { if (fh) { fclose(fh); (void)remove(tmp.c_str()); } }
 };
 
 long long gap_estimate(const std::vector<int64_t> &gaps, std::vector<int64_t> &tmp)
@@ -267,10 +300,11 @@ extern "C" int ntl_tally_write(const ntl_tally *t, int a, int min_n, const char 
     }
     if (n_kept) *n_kept = kept.size();
     auto ori = [](const PairEntry &e, bool src) { return ((src ? (e.key >> 32) : e.key) & 1u) ? '+' : '-'; };
+    t_io_errno = 0;
     if (pairs_path) {
-        FILE *fh = fopen(pairs_path, "w");
-        if (!fh) return NTL_EINVAL;
-        Buf o(fh);
+        TmpFile tf(pairs_path);
+        if (!tf.fh) return NTL_EIO;
+        Buf o(tf.fh);
         for (const Kept &kp : kept) {
             const PairEntry &e = t->pairs[kp.e];
             o.put(name(e.src)); o.put(ori(e, true) == '+' ? "+" : "-"); o.put("\t");
@@ -279,8 +313,7 @@ extern "C" int ntl_tally_write(const ntl_tally *t, int a, int min_n, const char 
             for (size_t j = 0; j < e.gaps.size(); j++) { if (j) o.put(", "); o.num((long long)e.gaps[j]); }
             o.put("], anchor="); o.num((long long)e.anchor); o.put("\n");
         }
-        o.flush();
-        if (fclose(fh) != 0) return NTL_EINVAL;
+        if (int rc = tf.finish(o)) return rc;
     }
     if (dot_path) {
         std::vector<std::string> vertices;            /* insertion order */
@@ -319,9 +352,9 @@ extern "C" int ntl_tally_write(const ntl_tally *t, int a, int min_n, const char 
                 if (!have || v > largest) { largest = v; have = true; }
             }
         }
-        FILE *fh = fopen(dot_path, "w");
-        if (!fh) return NTL_EINVAL;
-        Buf o(fh);
+        TmpFile tf(dot_path);
+        if (!tf.fh) return NTL_EIO;
+        Buf o(tf.fh);
         o.put("digraph G {\ngraph [scaf_num=");
         if (have) o.num((long long)largest); else o.put("None");
         o.put("]\n");
@@ -335,8 +368,9 @@ extern "C" int ntl_tally_write(const ntl_tally *t, int a, int min_n, const char 
                     o.put(" e=100 n="); o.num((long long)x.n); o.put("]\n");
                 }
         o.put("}\n");
-        o.flush();
-        if (fclose(fh) != 0) return NTL_EINVAL;
+        if (int rc = tf.finish(o)) return rc;
     }
     return NTL_OK;
 }
+
+extern "C" int ntl_io_errno(void) { return t_io_errno; }

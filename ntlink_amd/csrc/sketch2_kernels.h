@@ -1330,7 +1330,8 @@ __global__ __launch_bounds__(64 * WAVES, (skw_waves_per_simd<WAVES, S>())) void 
     /* the list's positions are words at a constant distance KP from their keys (one address register serves both), in the upper part
        of the same array: once the staged keys are in registers only the list lives there */
     constexpr uint32_t KP = NLIST;
-    constexpr uint32_t NWORDS = SLOTS + (uint32_t)(C - S) > 2u * NLIST ? SLOTS + (uint32_t)(C - S) : 2u * NLIST; /* the slots + what lane 63 may write beyond them */
+    constexpr uint32_t NSCAN = 2u * NLIST + (CAP + 1u) / 2u; /* the list, and the scanners' indices (16 bits each) behind it */
+    constexpr uint32_t NWORDS = SLOTS + (uint32_t)(C - S) > NSCAN ? SLOTS + (uint32_t)(C - S) : NSCAN; /* the slots + what lane 63 may write beyond them */
     __shared__ __attribute__((aligned(16))) uint32_t s_keys[WAVES][NWORDS];
 
     const SketchArgs &A = B.A;
@@ -1527,26 +1528,28 @@ __global__ __launch_bounds__(64 * WAVES, (skw_waves_per_simd<WAVES, S>())) void 
         }
         ntl_wave_sync();
 
-        /* ---- one lane per candidate (sketch_thresh_kernel, phase 4), four list entries per step.  Every branch is uniform over the
-           wavefront: a lane whose scan has ended reads its last four entries again until the slowest lane's has (the wavefront
-           pays for the slowest lane either way, and without diverging lanes there are no execution masks to juggle); a lane
-           without a candidate in the last round works on the last candidate again and drops the answer. ---- */
-        uint32_t found = 0; /* bit r: this lane's candidate of round r is a minimizer */
-        uint32_t q0bit = 0; /* bit 0: this lane's candidate of round 0 is the minimum of window 0 */
+        /* ---- round 6: who has to scan at all.  Four candidates in five are nobody's minimum, and most of them show it at once: a
+           candidate with a CERTAINLY smaller key (more than SKW_NEAR below its own: the keys then order the hashes) among its four
+           list neighbours on either side, all eight of them less than a window apart, lies in no window without one of the two --
+           whatever else the strip holds, whatever the keys above the threshold are, however its ties fall.  One pass over the
+           list, a lane per candidate, a dozen LDS reads and no loop, takes those out (71 % of them: P(the least of five on one side)
+           = 1/5 each, 1/9 both); what is left -- 50 of a strip's 164 at w = 250 -- is scanned as before, in ONE round where there
+           were three (the rounds cost the same whoever sits in them: the wavefront waits for its slowest lane).  The candidates
+           that drop out stay in the list: they are still somebody's blockers.  The same pass makes the two checks that belong to the
+           list and not to a candidate's scan: a gap of a window between two candidates, and window 0 (whose minimum is the previous
+           strip's to list: it does not scan either). ---- */
+        uint16_t *const sidx = (uint16_t *)(keys + 2u * NLIST); /* the scanners' list indices, behind the list (the staging slots there are in registers) */
+        uint32_t ns = 0;
         if (L == 0) bad |= pos[4] - 1u >= w; /* elements 1 .. w without a candidate */
-        /* The strip's own windows start at elements 1 .. NWO (the next strip's at its element 1 = NWO + 1 of this one), so the
-           last element of an own window is V - 1: no window reaches V, as if a blocker stood there, and a candidate at or behind
-           V is nobody's minimum here.  (The bitmask did not mind a bit set by two strips; the lists do: StripLists.) */
-        const uint32_t V = (uint32_t)A.G.NWO + w;
         for (uint32_t r = 0; r * 64u < n; r++) {
             const uint32_t i0 = (uint32_t)L + 64u * r;
             const bool real = i0 < n;
             const uint32_t i = real ? i0 : n - 1u;
-            const uint32_t mk = keys[i + 4u], mp = pos[i + 4u];
-            const uint32_t lim = mk + SKW_NEAR;
-            bool b = lim >= B.thresh;
-            uint32_t Rp = mp + w < V ? mp + w : V;
-            b |= pos[i + 5u] - mp - 1u >= w; /* a window between two candidates */
+            const uint32_t *kp = keys + i;
+            const uint32_t l3 = kp[0], l2 = kp[1], l1 = kp[2], l0 = kp[3], mk = kp[4], r0 = kp[5], r1 = kp[6], r2 = kp[7], r3 = kp[8];
+            const uint32_t pl4 = kp[KP], pl2 = kp[KP + 2], mp = kp[KP + 4], pn = kp[KP + 5], pr2 = kp[KP + 6], pr4 = kp[KP + 8];
+            bool b = pn - mp - 1u >= w; /* a window between two candidates */
+            bool scan = real;
             if (r == 0u && has_w0) {
                 /* Window 0 = elements 0 .. w - 1 is the previous strip's last one, and its minimum is that strip's to list, not
                    this one's -- whichever of this strip's windows it is the minimum of as well.  The candidates in it are the
@@ -1557,8 +1560,39 @@ __global__ __launch_bounds__(64 * WAVES, (skw_waves_per_simd<WAVES, S>())) void 
                 const bool near0 = inw0 && mk <= kmin + SKW_NEAR;
                 const uint32_t nn = (uint32_t)__popcll(__ballot(near0)) + (k0 != SK2_INF && k0 <= kmin + SKW_NEAR ? 1u : 0u);
                 b |= nn != 1u || kmin == SK2_INF || (n > 64u && pos[67] < w); /* a near tie, no candidate, or more than this round sees */
-                q0bit = near0 ? 1u : 0u;
+                scan = scan && !near0;
             }
+            const uint32_t sure = ntl_sub_sat(mk, SKW_NEAR); /* keys below it are certainly smaller (none, for a key within the tolerance of the sentinels' 0) */
+            /* how far apart the two are: the second neighbour's position where one of the nearer two is smaller, else the fourth's (the nearer
+               smaller one's own position would be a read more and decide 2 candidates of 164 more; the fourth's alone, 22 fewer) */
+            const uint32_t ml2 = l0 < l1 ? l0 : l1, mr2 = r0 < r1 ? r0 : r1;
+            const uint32_t pl = ml2 < sure ? pl2 : pl4, pr = mr2 < sure ? pr2 : pr4;
+            const bool out = (ntl_min3(ml2, l2, l3) < sure) & (ntl_min3(mr2, r2, r3) < sure) & (pr - pl <= w);
+            scan = scan && !out;
+            const unsigned long long bal = __ballot(scan);
+            if (scan) sidx[ns + ntl_mbcnt(bal)] = (uint16_t)i;
+            ns += (uint32_t)__popcll(bal);
+            if (real) bad |= b;
+        }
+        ntl_wave_sync(); /* the scanners' indices are other lanes' to read */
+
+        /* ---- one lane per scanner (sketch_thresh_kernel, phase 4), four list entries per step.  Every branch is uniform over the
+           wavefront: a lane whose scan has ended reads its last four entries again until the slowest lane's has (the wavefront
+           pays for the slowest lane either way, and without diverging lanes there are no execution masks to juggle); a lane
+           without a scanner in the last round works on the last one again and drops the answer. ---- */
+        uint32_t found = 0; /* bit r: this lane's scanner of round r is a minimizer */
+        /* The strip's own windows start at elements 1 .. NWO (the next strip's at its element 1 = NWO + 1 of this one), so the
+           last element of an own window is V - 1: no window reaches V, as if a blocker stood there, and a candidate at or behind
+           V is nobody's minimum here.  (The bitmask did not mind a bit set by two strips; the lists do: StripLists.) */
+        const uint32_t V = (uint32_t)A.G.NWO + w;
+        for (uint32_t r = 0; r * 64u < ns; r++) {
+            const uint32_t j0 = (uint32_t)L + 64u * r;
+            const bool real = j0 < ns;
+            const uint32_t i = sidx[real ? j0 : ns - 1u];
+            const uint32_t mk = keys[i + 4u], mp = pos[i + 4u];
+            const uint32_t lim = mk + SKW_NEAR;
+            bool b = lim >= B.thresh;
+            uint32_t Rp = mp + w < V ? mp + w : V;
             uint32_t q0, q1, q2, q3;
             {   /* to the right: the first blocker nearer than w; ends at the right sentinel (key 0) at the latest */
                 const uint32_t *kp = keys + i + 5u;
@@ -1588,32 +1622,36 @@ __global__ __launch_bounds__(64 * WAVES, (skw_waves_per_simd<WAVES, S>())) void 
                     kp -= go ? 4 : 0;
                 }
                 const uint32_t fb = sk2t_first_le(q0, q1, q2, q3, lim);
-                blocked = fb != 4u && (int32_t)kp[KP + 3u - (fb != 4u ? fb : 3u)] >= need;
+                const uint32_t *ke = kp + 3u - (fb != 4u ? fb : 3u);
+                const uint32_t ek = ke[0];
+                blocked = fb != 4u && (int32_t)ke[KP] >= need;
+                /* ... and is it certainly smaller?  (Round 6.  While every candidate scanned, a near tie of two candidates was seen from
+                   its left one, whose scan to the right ends at the other; now the left one may have dropped out before the scans.) */
+                b |= blocked && ek + SKW_NEAR >= mk;
             }
             if (real) {
                 bad |= b;
                 if (!blocked && mp < V) found |= 1u << r;
             }
         }
-        found &= ~q0bit;
 
-        /* ---- proven minimizers to the global bitmask; a strip that was given up writes none and goes to the block-minima pass ---- */
+        /* ---- proven minimizers to the strip's list (or the global bitmask); a strip that was given up writes none and goes to the block-minima pass ---- */
         const bool flagged = B.force_redo || over || __ballot(bad) != 0ull;
         if (flagged) {
             if (L == 0) B.fb_list[atomicAdd(B.fb_count, 1u)] = strip;
         } else if (A.Ls.cnt) {
-            /* the strip's list: its minimizers' positions in the sequence, in order (candidate i = L + 64 r: by rounds, then by lanes) */
+            /* the strip's list: its minimizers' positions in the sequence, in order (scanner j = L + 64 r: by rounds, then by lanes) */
             uint32_t total = 0;
-            for (uint32_t r = 0; r * 64u < n; r++) total += (uint32_t)__popcll(__ballot((found >> r) & 1u));
+            for (uint32_t r = 0; r * 64u < ns; r++) total += (uint32_t)__popcll(__ballot((found >> r) & 1u));
             uint32_t at = 0;
             if (L == 0) at = strip_list_place(A.Ls, strip, total);
             at = ntl_readfirstlane(at);
             if (at != NTL_NONE) {
                 const uint32_t p0 = Ic.w;
-                for (uint32_t r = 0; r * 64u < n; r++) {
+                for (uint32_t r = 0; r * 64u < ns; r++) {
                     const bool mine_r = (found >> r) & 1u;
                     const unsigned long long bal = __ballot(mine_r);
-                    if (mine_r) A.Ls.ent[at + ntl_mbcnt(bal)] = p0 + pos[(uint32_t)L + 64u * r + 4u];
+                    if (mine_r) A.Ls.ent[at + ntl_mbcnt(bal)] = p0 + pos[(uint32_t)sidx[(uint32_t)L + 64u * r] + 4u];
                     at += (uint32_t)__popcll(bal);
                 }
             }
@@ -1622,7 +1660,7 @@ __global__ __launch_bounds__(64 * WAVES, (skw_waves_per_simd<WAVES, S>())) void 
             while (found) {
                 const uint32_t r = (uint32_t)__ffs(found) - 1u;
                 found &= found - 1u;
-                const uint64_t g = g0 + pos[(uint32_t)L + 64u * r + 4u];
+                const uint64_t g = g0 + pos[(uint32_t)sidx[(uint32_t)L + 64u * r] + 4u];
                 atomicOr(&A.mask[g >> 5], 1u << ((uint32_t)g & 31u));
             }
         }

@@ -10,6 +10,7 @@ The order-sensitive per-read tally itself is native (csrc/ntl_pairs.cpp); filter
 writers work on its export.
 """
 import ctypes as C
+import os
 import re
 
 import numpy as np
@@ -132,6 +133,9 @@ class PairTally:
         kept = C.c_uint64()
         rc = self._L.ntl_tally_write(self._h, int(a), int(min_n), pairs_path.encode() if pairs_path else None,
                                      dot_path.encode() if dot_path else None, C.byref(kept))
+        if rc == -6:  # NTL_EIO: with the errno, as the Python writers it replaces would raise
+            err = int(self._L.ntl_io_errno())
+            raise OSError(err, f"{os.strerror(err)}: writing {pairs_path} / {dot_path}")
         if rc != 0:
             raise OSError(f"ntl_tally_write failed with {rc} ({pairs_path}, {dot_path})")
         return int(kept.value)

@@ -328,12 +328,88 @@ class LocalComm:
         pass
 
 
-def _node_leader(comm):
-    """(lowest rank on this rank's host, ranks on this host): the ranks of one node share what only one of them has to make."""
+def _node_id():
+    """What two ranks must share to be on one node: the host name AND the kernel's boot id (containers on different machines may carry
+    the same host name) AND the device and inode of the directory the shared file would live in (two containers of one machine have
+    separate /dev/shm mounts)."""
     import socket
-    hosts = comm.allgather(os.environ.get("NTL_FAKE_HOSTNAME") or socket.gethostname())
+    name = os.environ.get("NTL_FAKE_HOSTNAME") or socket.gethostname()
+    if os.environ.get("NTL_FAKE_HOSTNAME"):
+        return name
+    try:
+        with open("/proc/sys/kernel/random/boot_id") as fh:
+            boot = fh.read().strip()
+    except OSError:
+        boot = ""
+    try:
+        st = os.stat(_shm_dir())
+        where = f"{st.st_dev}:{st.st_ino}"
+    except OSError:
+        where = ""
+    return f"{name}/{boot}/{where}"
+
+
+def _shm_dir():
+    return os.environ.get("NTL_SHM_DIR") or ("/dev/shm" if os.path.isdir("/dev/shm") else (os.environ.get("TMPDIR") or "/tmp"))
+
+
+def _node_leader(comm):
+    """(lowest rank on this rank's node, ranks on this node): the ranks of one node share what only one of them has to make."""
+    hosts = comm.allgather(_node_id())
     mine = [r for r, h in enumerate(hosts) if h == hosts[comm.rank]]
     return mine[0], mine
+
+
+_shared_files = set()  # published and not yet unlinked: removed at exit if this process dies between the two collectives
+
+
+def _cleanup_shared():
+    for path in list(_shared_files):
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
+        _shared_files.discard(path)
+
+
+def _publish(arrays):
+    """The packed contig set into one file of the node's shared-memory directory: a name nobody can guess, created exclusively, not
+    through a link, readable by this user only.  Raises OSError when there is no room (checked before a byte is written: a tmpfs
+    that fills up takes the machine's memory with it) or the directory cannot be written."""
+    import atexit
+    import json
+    import secrets
+    shm = _shm_dir()
+    head, at = {}, 4096
+    for key in _SHARED_FIELDS:
+        a = np.ascontiguousarray(arrays[key])
+        head[key] = (str(a.dtype), int(a.size), at)
+        at += (a.nbytes + 63) & ~63
+    hb = json.dumps(head).encode()
+    assert len(hb) + 8 <= 4096
+    vfs = os.statvfs(shm)
+    if vfs.f_bavail * vfs.f_frsize < at + (64 << 20):
+        raise OSError(f"{shm}: {vfs.f_bavail * vfs.f_frsize >> 20} MB free, the packed target takes {at >> 20} MB")
+    path = os.path.join(shm, f"ntlink_amd.ctg.{os.getuid()}.{secrets.token_hex(12)}")
+    fd = os.open(path, os.O_CREAT | os.O_EXCL | os.O_WRONLY | getattr(os, "O_NOFOLLOW", 0), 0o600)
+    if not _shared_files:
+        atexit.register(_cleanup_shared)
+    _shared_files.add(path)
+    try:
+        with os.fdopen(fd, "wb") as fh:
+            fh.write(len(hb).to_bytes(8, "little") + hb)
+            for key in _SHARED_FIELDS:
+                fh.seek(head[key][2])
+                np.ascontiguousarray(arrays[key]).tofile(fh)
+            fh.truncate(max(at, 4096))
+    except BaseException:
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
+        _shared_files.discard(path)
+        raise
+    return path
 
 
 _SHARED_FIELDS = ("names_blob", "names_off", "offsets", "packed", "seq_run_first", "run_start", "run_len")
@@ -361,57 +437,58 @@ def shared_contigs(comm, target, alloc, packed, stats=None):
         return seqio.load_all([target], alloc=alloc if packed else None, packed=packed), None
     path, ss, failure = None, None, None
     if comm.rank == leader:
+        # Parsing and publishing fail differently (round 6): a target that does not parse fails on every rank, as it did when
+        # every rank parsed; a copy that cannot be PUBLISHED (no room in /dev/shm -- Docker's default is 64 MB --, a read-only or
+        # quota'd tmpfs) only costs the sharing: the other ranks of the host are told to parse for themselves.
         try:
             ss = seqio.load_all([target], alloc=alloc, packed=True)
-            arrays = dict(names_blob=ss.names.blob, names_off=ss.names.off, offsets=np.ascontiguousarray(ss.offsets, np.uint64),
-                          packed=ss.packed, seq_run_first=ss.seq_run_first, run_start=ss.run_start, run_len=ss.run_len)
-            shm = os.environ.get("NTL_SHM_DIR") or ("/dev/shm" if os.path.isdir("/dev/shm") else (os.environ.get("TMPDIR") or "/tmp"))
-            path = os.path.join(shm, f"ntlink_amd.ctg.{os.getuid()}.{os.getpid()}.{int(time.time() * 1e6) & 0xFFFFFF:06x}")
-            head, at = {}, 4096
-            for key in _SHARED_FIELDS:
-                a = np.ascontiguousarray(arrays[key])
-                head[key] = (str(a.dtype), int(a.size), at)
-                at += (a.nbytes + 63) & ~63
-            hb = json.dumps(head).encode()
-            assert len(hb) + 8 <= 4096
-            with open(path, "wb") as fh:
-                fh.write(len(hb).to_bytes(8, "little") + hb)
-                for key in _SHARED_FIELDS:
-                    fh.seek(head[key][2])
-                    np.ascontiguousarray(arrays[key]).tofile(fh)
-                fh.truncate(max(at, 4096))
         except BaseException as exc:
-            # the others wait in the collective below: they must hear of it, not hang (a target that does not parse fails on every rank,
-            # as it did when every rank parsed)
-            if isinstance(path, str):
-                try:
-                    os.unlink(path)
-                except OSError:
-                    pass
+            # the others wait in the collective below: they must hear of it, not hang
             failure, path = exc, ("failed", f"{type(exc).__name__}: {exc}")
+        if failure is None:
+            try:
+                path = _publish(dict(names_blob=ss.names.blob, names_off=ss.names.off, offsets=np.ascontiguousarray(ss.offsets, np.uint64),
+                                     packed=ss.packed, seq_run_first=ss.seq_run_first, run_start=ss.run_start, run_len=ss.run_len))
+            except (OSError, AssertionError) as exc:
+                path = ("noshare", f"{type(exc).__name__}: {exc}")
     paths = comm.allgather(path)  # (also: the file is complete)
     if failure is not None:
         raise failure
-    if isinstance(paths[leader], tuple):
-        raise OSError(f"{target}: the rank that parses it for this host (rank {leader}) failed: {paths[leader][1]}")
-    mapping = None
+    mine = paths[leader]
+    if isinstance(mine, tuple) and mine[0] == "failed":
+        raise OSError(f"{target}: the rank that parses it for this host (rank {leader}) failed: {mine[1]}")
+    mapping, parsed_by = None, leader
     if comm.rank != leader:
-        with open(paths[leader], "rb") as fh:
-            mapping = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
-        n = int.from_bytes(mapping[:8], "little")
-        head = json.loads(bytes(mapping[8:8 + n]))
-        arr = {key: np.frombuffer(mapping, dtype=np.dtype(dt), count=cnt, offset=off) for key, (dt, cnt, off) in head.items()}
-        arr = {key: (a if key == "packed" else np.array(a)) for key, a in arr.items()}  # only the 2-bit words stay a view of the mapping
-        ss = seqio.SeqSet(seqio.Names(arr["names_blob"], arr["names_off"]), None, arr["offsets"], packed=arr["packed"],
-                          runs=(arr["seq_run_first"], arr["run_start"], arr["run_len"]))
-    comm.allgather(None)  # every rank of every host has its leader's file open
-    if comm.rank == leader:
+        if isinstance(mine, str):
+            try:
+                with open(mine, "rb") as fh:
+                    mapping = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
+                n = int.from_bytes(mapping[:8], "little")
+                head = json.loads(bytes(mapping[8:8 + n]))
+                arr = {key: np.frombuffer(mapping, dtype=np.dtype(dt), count=cnt, offset=off) for key, (dt, cnt, off) in head.items()}
+                arr = {key: (a if key == "packed" else np.array(a)) for key, a in arr.items()}  # only the 2-bit words stay a view of the mapping
+                ss = seqio.SeqSet(seqio.Names(arr["names_blob"], arr["names_off"]), None, arr["offsets"], packed=arr["packed"],
+                                  runs=(arr["seq_run_first"], arr["run_start"], arr["run_len"]))
+            except (OSError, ValueError, KeyError) as exc:  # a file this rank cannot see after all (another mount): parse here
+                mapping, ss = None, None
+                if stats is not None:
+                    stats["contigs_share_failed"] = f"{type(exc).__name__}: {exc}"
+        elif stats is not None:
+            stats["contigs_share_failed"] = mine[1]
+    elif isinstance(mine, tuple) and stats is not None:
+        stats["contigs_share_failed"] = mine[1]
+    comm.allgather(None)  # every rank of every host has its leader's file open (or has given it up)
+    if comm.rank == leader and isinstance(path, str):
         try:
             os.unlink(path)
         except OSError:
             pass
+        _shared_files.discard(path)
+    if ss is None:  # nothing was shared with this rank: parse as a single process would
+        ss = seqio.load_all([target], alloc=alloc, packed=True)
+        parsed_by = comm.rank
     if stats is not None:
-        stats["contigs_parsed_by"] = leader
+        stats["contigs_parsed_by"] = parsed_by
     return ss, mapping
 
 

@@ -37,6 +37,18 @@ for b in range(batches):
     ooff, oh, op, os_ = oracle.sketch_batch(rbuf, roff, k, w)
     if not (np.array_equal(off, ooff) and np.array_equal(h, oh) and np.array_equal(p, op) and np.array_equal(s, os_)):
         print(f"SKETCH MISMATCH workload {name} seed ({seed0}, {b}): {len(h)} records, oracle {len(oh)}")
+        # the reads whose lists differ, for a replay under the SIMT mock (NTL_SOAK_DUMP=<file>)
+        cnt, ocnt = np.diff(off.astype(np.int64)), np.diff(ooff.astype(np.int64))
+        badr = [r for r in range(len(cnt)) if cnt[r] != ocnt[r] or not np.array_equal(p[off[r]:off[r + 1]], op[ooff[r]:ooff[r + 1]])
+                or not np.array_equal(h[off[r]:off[r + 1]], oh[ooff[r]:ooff[r + 1]])]
+        print(f"{len(badr)} reads differ; first: {badr[:5]}")
+        for r in badr[:3]:
+            mine, theirs = p[off[r]:off[r + 1]].tolist(), op[ooff[r]:ooff[r + 1]].tolist()
+            print(f"read {r} len {int(roff[r + 1] - roff[r])}: device-only positions {sorted(set(mine) - set(theirs))}, oracle-only {sorted(set(theirs) - set(mine))}")
+        if os.environ.get("NTL_SOAK_DUMP"):
+            with open(os.environ["NTL_SOAK_DUMP"], "wb") as fh:
+                for r in badr[:8]:
+                    fh.write(b">r%d\n" % r + bytes(rbuf[roff[r]:roff[r + 1]]) + b"\n")
         sys.exit(1)
     tot += int(roff[-1]); mx += len(h)
     print(f"batch {b}: {int(roff[-1])} bases, {len(h)} minimizers equal, redo strips so far {redo}, {time.time() - t0:.0f} s", flush=True)

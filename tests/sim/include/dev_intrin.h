@@ -113,6 +113,7 @@ typedef const uint64_t ntl_lds_cu64;
 #define NTL_LDS_CU64(p) ((ntl_lds_cu64 *)(p))
 #define NTL_OPAQUE(v) ((void)(v))
 template <int T> inline void ntl_lds_push_tagged(uint32_t *&p, uint32_t mask, uint32_t v) { *p++ = (v & ~mask) | (uint32_t)T; }
+inline uint32_t ntl_sub_sat(uint32_t a, uint32_t b) { return a > b ? a - b : 0u; }
 inline uint32_t ntl_min3(uint32_t a, uint32_t b, uint32_t c) { const uint32_t m = a < b ? a : b; return m < c ? m : c; }
 inline uint32_t ntl_le4_mask(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, uint32_t lim)
 {

@@ -35,3 +35,21 @@ def test_no_cpu_fallback():
         pytest.skip("GPU present")
     with pytest.raises(capi.NtlError):
         capi.Device(0)
+
+
+def test_library_signature_is_checked(monkeypatch, tmp_path):
+    """Round 6: staleness by content.  The built library carries the sha256 of its sources and flags; `capi.load` refuses the default
+    library when that signature is not the sources' (objects and the .so travel to the GPU box: what runs must be what is committed),
+    and a second `build_hip` reuses everything."""
+    from ntlink_amd import build
+    build_hip()
+    assert build.library_is_current()
+    build_hip()
+    assert build.last_action == "reused"
+    sig = open(build.OUT + ".sig").read().strip()
+    assert sig == build.source_signature() and len(sig) == 64
+    assert build.source_signature(("-DNTL_SOMETHING",)) != sig  # the flags are part of it
+    monkeypatch.setattr(build, "library_is_current", lambda *a: False)
+    monkeypatch.setattr(capi, "_libs", {})
+    with pytest.raises(capi.NtlError, match="signature"):
+        capi.load()

@@ -323,6 +323,21 @@ def test_pin_rank_choices_on_made_up_hosts(tmp_path, monkeypatch):
     assert [p["first_core"] for p in pins] == list(range(0, 16, 2))
 
 
+def test_a_copy_that_cannot_be_published_costs_only_the_sharing(tmp_path):
+    """pipeline.shared_contigs: no room or no directory for the host's shared copy of the packed contigs is not a failure of
+    the run -- the ranks are told and parse the target themselves, as they did before round 5; same outputs."""
+    for n in ("scaffolds_4.fa", "long_reads_4_top5.fa"):
+        shutil.copy(os.path.join(REF, n), tmp_path / n)
+    _run_ranks(tmp_path, 2, 29581, ["target=scaffolds_4.fa", "reads=long_reads_4_top5.fa", "k=40", "w=100", "paf=True", "v=1"],
+               extra_env={"NTL_SHM_DIR": str(tmp_path / "no_such_directory")})
+    pre = str(tmp_path / "scaffolds_4.fa.k40.w100.z1000")
+    d = os.path.join(GEN, "fixtures", "t7_top5_k40_w100")
+    assert read_text(pre + ".verbose_mapping.tsv") == read_text(d + ".verbose_mapping.tsv")
+    assert read_text(pre + ".paf") == read_text(d + ".paf")
+    rep = dict(line.strip().split(": ", 1) for line in open(pre + ".n1.scaffold.dot.time") if ": " in line)
+    assert json.loads(rep["ntlink_amd contigs_parsed_by_per_rank"]) == [0, 1]
+
+
 def test_a_target_that_does_not_parse_fails_every_rank(tmp_path):
     """pipeline.shared_contigs: only one rank of a host parses the target; when it fails, the ranks that wait for its copy must fail
     with it -- not hang in the collective -- and nothing stays under /dev/shm."""

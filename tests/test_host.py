@@ -629,3 +629,23 @@ def test_native_pair_writers_on_made_up_tallies(tmp_path):
         assert read_text(str(tmp_path / "p.tsv")) == pb.getvalue()
         assert read_text(str(tmp_path / "g.dot")) == db.getvalue()
     assert "scaf_num=39" in read_text(str(tmp_path / "g.dot"))
+
+
+def test_native_pair_writers_report_io_errors(tmp_path):
+    """a file that cannot be created or written completely is an OSError that carries the errno (as the Python writers it
+    replaces would raise), and no partial .pairs.tsv / .dot is left behind (written beside its place, renamed when complete)."""
+    import errno
+    t = pairing.PairTally(["a", "b"], np.array([100, 100], np.uint32), 32, 10)
+    t.merge((np.array([0], np.uint32), np.array([1], np.uint8), np.array([1], np.uint32), np.array([1], np.uint8), np.array([2], np.uint32),
+             np.array([0, 2], np.uint64), np.array([5, 7], np.int64)))
+    with pytest.raises(OSError) as exc:
+        t.write(1, 1, str(tmp_path / "no_such_dir" / "p.tsv"), str(tmp_path / "g.dot"))
+    assert exc.value.errno == errno.ENOENT
+    assert os.listdir(tmp_path) == []
+    if os.path.exists("/dev/full"):  # every write fails with ENOSPC; the rename of the temporary never happens
+        os.symlink("/dev/full", tmp_path / f"g.dot.tmp.{os.getpid()}")
+        with pytest.raises(OSError) as exc:
+            t.write(1, 1, None, str(tmp_path / "g.dot"))
+        assert exc.value.errno == errno.ENOSPC and not os.path.exists(tmp_path / "g.dot")
+    assert t.write(1, 1, str(tmp_path / "p.tsv"), str(tmp_path / "g2.dot")) == 1
+    assert sorted(f for f in os.listdir(tmp_path) if not f.startswith("g.dot.tmp")) == ["g2.dot", "p.tsv"]

@@ -10,7 +10,7 @@ cd "$R"
 O=gpurun_out/$TAG; mkdir -p $O
 python __graft_entry__.py > $O/build.log 2>&1 || { tail -20 $O/build.log; exit 1; }
 if [ "$TESTS" = all ]; then timeout 1800 python -m pytest tests -m gpu -x -q 2>&1 | tail -5 | tee $O/pytest_gpu.log
-elif [ -n "$TESTS" ]; then timeout 1200 python -m pytest tests -m gpu -x -q $TESTS 2>&1 | tail -5 | tee $O/pytest_gpu.log; fi
+elif [ -n "$TESTS" ]; then timeout 1200 bash -c "python -m pytest tests -m gpu -x -q $TESTS" 2>&1 | tail -5 | tee $O/pytest_gpu.log; fi
 for W in $WL; do
   env $ENVS timeout 600 python bench.py --workload $W --steps 6 --warmup 2 --no-cpu-baseline --no-e2e --no-others > $O/bench_$W.json 2> $O/bench_$W.err
   python - <<PY

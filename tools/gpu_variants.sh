@@ -13,7 +13,7 @@ for V in default $VARIANTS; do
     export NTLINK_AMD_LIB=$R/ntlink_amd/build/var_$V/libntlink_hip.so
     [ -f "$NTLINK_AMD_LIB" ] || { echo "no $NTLINK_AMD_LIB"; continue; }
   fi
-  if [ -n "$TESTS" ]; then timeout 900 python -m pytest tests -m gpu -x -q $TESTS 2>&1 | tail -3; fi
+  if [ -n "$TESTS" ]; then timeout 900 bash -c "python -m pytest tests -m gpu -x -q $TESTS" 2>&1 | tail -3; fi
   for W in $WL; do
     timeout 600 python bench.py --workload $W --steps ${STEPS:-6} --warmup 2 --no-cpu-baseline --no-e2e --no-others > $O/bench_${W}_$V.json 2> $O/bench_${W}_$V.err
     python - <<PY
