@@ -1418,7 +1418,9 @@ static int wave_form(const Sketch2Args &B, int nt)
     const char *we = getenv("NTL_SKETCH_WAVE");
     const int wave = we ? atoi(we) : 1;
     const double per_strip = 4096.0 * (double)B.thresh / 4294967296.0; /* candidates a strip is expected to hold */
-    if (nt == 256 && B.thresh && B.A.G.a + 2 <= 16 && (B.dbg & ~24) == 0 && wave && B.A.G.k <= 64 && per_strip <= 440.0) return wave;
+    /* (a + 2 <= 16, w <= 255, is the workgroup-per-strip passes' limit, not this kernel's: a window only enters its scans as a distance.
+       Round 6: up to the block-minima pass's w <= 1135, which decides the strips it gives up) */
+    if (nt == 256 && B.thresh && B.A.G.a + 2 <= SK2_PAD && (B.dbg & ~24) == 0 && wave && B.A.G.k <= 64 && per_strip <= 440.0) return wave;
     return 0;
 }
 
@@ -1435,7 +1437,7 @@ static void launch_fast_r0(ntl_ctx *c, const Sketch2Args &B, unsigned strips)
         const char *le = getenv("NTL_SKETCH_LANES"); /* read per call: the tests switch it inside one process */
         const int lanes = le ? atoi(le) : 0;
         /* the window pass on threshold-sparsified windows where the geometry allows it (B.thresh != 0) */
-        if (NT == 256 && B.thresh && B.A.G.a + 2 <= 16 && (B.dbg & ~24) == 0) { /* (ablation bits 8 and 16 exist in this kernel too) */
+        if (NT == 256 && B.thresh && (B.A.G.a + 2 <= 16 || wave_form(B, NT)) && (B.dbg & ~24) == 0) { /* (ablation bits 8 and 16 exist in this kernel too) */
             /* one wavefront per strip, 64 k-mers per lane (sketch_wave_kernel, round 4) where a lane's first k-mer lies in its own
                64 bases and a strip's candidates fit its list; NTL_SKETCH_WAVE=0: the workgroup-per-strip form (A/B, tests) */
             const int wave = wave_form(B, NT);
@@ -1486,7 +1488,8 @@ static void launch_fast_r0(ntl_ctx *c, const Sketch2Args &B, unsigned strips)
                     if (wave == 4 || (c->pipelined && wave != 8)) go(sketch_wave_kernel<4, 19, 8>, 256u, 12u);
                     else go(sketch_wave_kernel<8, 19, 8>, 512u);
                 }
-                hipLaunchKernelGGL((sketch_fast_list_kernel<256, R0>), dim3(std::min(strips, 4096u)), dim3(256), 0, c->wstream, B, (const uint32_t *)B.fb_list, (const uint32_t *)B.fb_count);
+                if (B.A.G.a + 2 <= 16) hipLaunchKernelGGL((sketch_fast_list_kernel<256, R0>), dim3(std::min(strips, 4096u)), dim3(256), 0, c->wstream, B, (const uint32_t *)B.fb_list, (const uint32_t *)B.fb_count);
+                else hipLaunchKernelGGL((sketch_fast_list_kernel<256, R0, true>), dim3(std::min(strips, 4096u)), dim3(256), 0, c->wstream, B, (const uint32_t *)B.fb_list, (const uint32_t *)B.fb_count);
                 return;
             }
             const char *de = getenv("NTL_SKETCH_THRESH_DIRECT"); /* 1: the variant without staged keys for the large windows too (A/B) */
@@ -1635,7 +1638,7 @@ static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const nt
         if (cpw == 1.0) cpw = 10.0;
         /* a strip's expected 4096 cpw / w candidates must fit the list with room for their spread: 402 entries beside
            the staged keys (w >= 121 at 10 per window), 680 without them (sketch_thresh_kernel<.., DIRECT>: w >= 71) */
-        if (cpw > 0 && nt != 128 && w <= 255 && 4096.0 * cpw / w <= 580.0)
+        if (cpw > 0 && nt != 128 && G.a + 2 <= SK2_PAD && 4096.0 * cpw / w <= 580.0) /* (w > 255: sketch_wave_kernel only, wave_form) */
             B.thresh = (uint32_t)std::min(4294967295.0, 4294967296.0 * cpw / w);
         if (const char *e2 = getenv("NTL_SKETCH_ABLATE")) B.dbg = atoi(e2); /* tools/sketch_bench.py only: results are wrong */
         if (const char *e2 = getenv("NTL_SKETCH_FORCE_REDO")) B.force_redo = atoi(e2); /* tests: every strip takes both passes */

@@ -520,12 +520,12 @@ __global__ __launch_bounds__(NT) void sketch_fast_kernel(Sketch2Args B)
 /* The same pass over a list of strips: the ones sketch_thresh_kernel gave up (a window without a candidate, mostly).  What this
    pass cannot decide either goes on to B.redo_list, the exact pass's list.  A fixed grid walks the list, whose length is only
    known on the device. */
-template <int NT, int R0>
+template <int NT, int R0, bool BIG = false>
 __global__ __launch_bounds__(NT) void sketch_fast_list_kernel(Sketch2Args B, const uint32_t *__restrict__ list, const uint32_t *__restrict__ count)
 {
     const uint32_t n = *count;
     for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
-        sk2_fast_strip<NT, R0, false>(B, list[i]);
+        sk2_fast_strip<NT, R0, BIG>(B, list[i]); /* (BIG: windows of 256 .. 1135 k-mers, which sketch_wave_kernel takes since round 6) */
         __syncthreads(); /* the next strip's first writes to LDS behind this one's last reads */
     }
 }

@@ -238,6 +238,29 @@ def test_fast_window_pass_decides_random_sequence_alone(dev, monkeypatch):
         pc.check_sketch(dev, seqs, k, w)
 
 
+def test_wave_kernel_takes_the_large_windows(dev, monkeypatch):
+    """Round 6: windows of 256 .. 1135 k-mers (large-genome runs of ntLink use w = 500, 1000) go through
+    sketch_wave_kernel and per-strip lists like the windows up to 255 -- a window only enters that kernel's scans as a distance --, the
+    strips it gives up through the two-level form of the block-minima pass: the oracle's sketch on random sequence, on the fuzz
+    sequences (ties, N patterns, boundary lengths) and with every strip forced through all passes."""
+    import fuzz_cases
+    rng = np.random.default_rng(17)
+    seqs = [_rand_seq(rng, n) for n in (90000, 4200, 700000, 1300, 131, 5000, 2_000_000)]
+    for k, w in ((32, 256), (32, 500), (40, 1000), (24, 1135), (64, 300)):
+        st = {}
+        pc.check_sketch(dev, seqs, k, w, info=st)
+        assert st["from_lists"] and st["strips"] > 0 and st["redo_strips"] <= 1 and st["fallback_strips"] < 0.05 * st["strips"] + 3, (k, w, st)
+    for seed, k, w in ((1, 32, 500), (2, 21, 1000), (3, 24, 260)):
+        pc.check_sketch(dev, fuzz_cases.fuzz_sequences(seed), k, w)
+    monkeypatch.setenv("NTL_SKETCH_FORCE_REDO", "1")
+    pc.check_sketch(dev, seqs[:3], 32, 500)
+    monkeypatch.delenv("NTL_SKETCH_FORCE_REDO")
+    monkeypatch.setenv("NTL_SKETCH_WAVE", "0")  # without the wave kernel such windows take the block-minima pass and the bitmask, as before
+    st = {}
+    pc.check_sketch(dev, seqs[:3], 32, 500, info=st)
+    assert not st["from_lists"]
+
+
 def test_threshold_window_pass_random_sequence(dev, monkeypatch):
     """sketch_thresh_kernel (the default for 71 <= w <= 255): the oracle's sketch on random sequence; about N p e^(-w p) of
     the strips (N p candidates per strip) have a window without a candidate and are decided by the block-minima pass

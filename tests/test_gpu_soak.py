@@ -20,11 +20,12 @@ def _run(script, *args, timeout=900):
     return p.stdout
 
 
-@pytest.mark.parametrize("args", [("C3", 8, 1.5e9, 400), ("C5", 6, 1.5e9, 410), ("C3", 4, 1e9, 420, 32, 150)],
-                         ids=["C3_k32_w250", "C5_k24_w100", "C3_reads_k32_w150"])
+@pytest.mark.parametrize("args", [("C3", 8, 1.5e9, 400), ("C5", 6, 1.5e9, 410), ("C3", 4, 1e9, 420, 32, 150), ("C3", 3, 1e9, 430, 32, 500)],
+                         ids=["C3_k32_w250", "C5_k24_w100", "C3_reads_k32_w150", "C3_reads_k32_w500"])
 def test_sketch_volume_soak(args):
     """12 Gbases of C3 reads at k32 w250, 9 Gbases of C5 reads at k24 w100, 4 Gbases at k32 w150 -- the three shapes of
-    sketch_wave_kernel -- sketched on the device and by the oracle: every minimizer record equal."""
+    sketch_wave_kernel -- and 3 Gbases at k32 w500 (round 6: the large windows) sketched on the device and by the oracle: every minimizer
+    record equal."""
     out = _run("gpu_volume_soak.py", *args)
     assert "volume soak clean" in out, out[-2000:]
 

@@ -256,6 +256,16 @@ def test_sim_fast_window_pass_decides_random_sequence_alone(dev, monkeypatch):
     assert 0 < st["redo_strips"] < st["strips"]
 
 
+def test_sim_wave_kernel_takes_the_large_windows(dev):
+    """Windows of 256 .. 1135 k-mers through sketch_wave_kernel and the lists (round 6), under the mock."""
+    rng = np.random.default_rng(18)
+    seqs = [_rand_seq(rng, n) for n in (9000, 4200, 300, 1300, 14000)]
+    for k, w in ((32, 500), (24, 1000), (32, 256)):
+        st = {}
+        pc.check_sketch(dev, seqs, k, w, info=st)
+        assert st["from_lists"] and st["strips"] > 0, (k, w, st)
+
+
 def test_sim_fast_window_pass_hands_ties_to_the_exact_pass(dev, monkeypatch):
     """Identical k-mers inside one window (tandem repeats, homopolymers) tie on the 32-bit key: those strips must be
     detected and redone by the exact 64-bit pass; forcing every strip through both passes changes nothing."""
