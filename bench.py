@@ -37,7 +37,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 N_SIMD = 1024
-STAGES = ("sketch_meta", "sketch_mask", "sketch_redo", "sketch_emit", "probe", "map", "compact")
+STAGES = ("sketch_meta", "sketch_mask", "sketch_wave", "sketch_redo", "sketch_emit", "probe", "map", "compact")  # sketch_wave: the window kernel alone, inside sketch_mask
 
 
 def parse_args(argv=None):
@@ -346,13 +346,28 @@ def summarize(R, args, world, dev_name):
     nb = len(wl.read_batches)
 
     def window(prof, nsteps):
-        ms, n = prof["sketch_mask"]
+        # the dominant kernel's own launches (round 6: a span around sketch_wave_kernel alone; "sketch_mask" also holds the block-minima
+        # pass behind it, which is what rocprofv3's per-kernel average does not contain), or the window stage where that kernel does not run
+        ms, n = prof.get("sketch_wave", (0.0, 0))
+        if not n:
+            ms, n = prof["sketch_mask"]
         per_step = n / max(nsteps, 1)
         avg = ms / max(n, 1)
         bpl = read_bases / max(per_step, 1)
         return avg, bpl, n
 
     avg_pipe, bases_per_launch, n_pipe = window(R["prof"], steps)
+    if R["prof"].get("sketch_wave", (0.0, 0))[1]:
+        wv_ms, wv_n = R["prof"]["sketch_wave"]
+        mk_ms = R["prof"]["sketch_mask"][0]
+        per_cycle = ms_per_step * steps / max(wv_n, 1)
+        R["window_stream"] = {"what": "the window stream inside the timed steps, per sub-batch: a window kernel, then what stands between it and the next one "
+                                      "(the block-minima pass over the strips it gave up, the exact pass, the next sketch's preparation, launch gaps)",
+                              "cycle_ms": round(per_cycle, 4), "window_kernel_ms": round(wv_ms / max(wv_n, 1), 4),
+                              "between_window_kernels_ms": round(per_cycle - wv_ms / max(wv_n, 1), 4),
+                              "of_which_block_minima_pass_ms": round((mk_ms - wv_ms) / max(wv_n, 1), 4),
+                              "note": "the gap is where the other stream's map kernels run at their stand-alone speed: closing it (the fallback passes on MAIN, "
+                                      "profiles/HISTORY.md round 6) made every kernel shorter and the step longer"}
     if R["serial"]:
         avg_alone, _, n_alone = window(R["serial"]["prof"], R["serial"]["steps"])
     else:
@@ -391,7 +406,10 @@ def summarize(R, args, world, dev_name):
     # The headline figures (achieved, frac, avg_launch_ms) are those of the TIMED region -- the launches `value` is made of, where the kernel
     # shares the CUs with the previous sub-batch's lookup / map kernels on the other stream; `kernels_alone` holds the same kernel running
     # alone (the serial pass behind the timed region), which is what a rocprofv3 run with NTL_PIPELINE=0 sees.
-    roof = {"bound": "hbm", "kernel": pm.get("kernel", "sketch window kernel (read batches)"),
+    roof = {"bound": "valu", "bound_note": "what binds this kernel is VALU issue (integer rolling hash, no MFMA): `valu.frac` is the fraction of the SIMD cycles that "
+                                           "the irreducible rolling work accounts for; `achieved` / `peak` / `frac` stay the HBM figures of the bench contract "
+                                           "(algorithmic bytes / launch time / 8 TB/s), with `traffic` the counter bytes",
+            "kernel": pm.get("kernel", "sketch window kernel (read batches)"),
             "achieved": round(ach(avg_pipe), 2), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(ach(avg_pipe) / HBM_PEAK_GBS, 5), "traffic": pm.get("traffic"),
             "traffic_source": pm.get("traffic_source"),
@@ -408,6 +426,7 @@ def summarize(R, args, world, dev_name):
                            "achieved": round(whole_gbs, 1), "unit": "GB/s per GPU", "frac": round(whole_gbs / HBM_PEAK_GBS, 5)},
             "note": "integer/VALU-bound kernel (SURVEY 7): the 60 % HBM target of north_star is out of reach for a rolling hash (about 100 integer "
                     "operations per algorithmic byte); the roof that binds is VALU issue, in `valu`",
+            "window_stream": R.get("window_stream"),
             "valu": valu_roofline(dict(pm, strips_per_launch=(stats.get("strips") or 0) / max(nb, 1) or None,
                                        scan_rounds_per_strip=float(-(-int(4096 * 10 / w) // 64))), avg_alone, bases_per_launch)}
     if roof["valu"]:
@@ -465,6 +484,9 @@ def main():
             "per_rank_bases_per_step": [int(x) for x in R["per_rank_bases"]],
             "world_size": world, "rccl_ranks_seen": R["ranks_seen"], "ranks": R["ranks"],
             "sub_batches_per_rank": len(R["wl"].read_batches), "batch_bases": R["batch_bases"],
+            "scaling_note": ("this line is one of the driver's 1/2/4/8 runs" if world > 1 else
+                             "N = 1.  No 1 -> 8 GPU curve has been measured on hardware by the builder (no multi-GPU box in reach): other_workloads.C3_one_rank_of_8 "
+                             "is one rank's share on this GPU, profiles/r06_dist_host_scaling.json what 1 / 2 / 4 / 8 file-to-file ranks do to one host"),
         }
         if cores_mine:
             out["cores_per_rank"] = cores_mine
@@ -584,6 +606,19 @@ def dense_sketch_line(dev, k, w, bases=200_000_000, reps=5):
 
 
 VALU_FLOOR_PER_KMER = 9.0
+# the floor's instructions by issue class (profiles/valu_cycles.json): the rolling step of skw_step in the shipped ISA + one address operation
+VALU_FLOOR_CLASSES = (("v_alignbit_b32", 2), ("v_xor_b32", 2), ("v_lshrrev_b32", 1), ("v_add_u32", 2), ("vopc", 1), ("v_bfe_u32", 1))
+
+
+def valu_class_cycles(cls):
+    tab = getattr(valu_class_cycles, "tab", None)
+    if tab is None:
+        try:
+            tab = json.load(open(os.path.join(ROOT, "profiles", "valu_cycles.json")))["cycles"]
+        except (OSError, ValueError, KeyError):
+            tab = {}
+        valu_class_cycles.tab = tab
+    return float(tab.get(cls, 4.2))
 
 
 def window_lane_utilisation(read_lens, k, w):
@@ -639,11 +674,24 @@ def valu_roofline(pm, avg_launch_ms, bases_per_launch):
     priced = priced_cycles(pm, n)
     if meas and priced:
         clock = pm.get("clock_ghz") or 0.0
-        out.update({"measured_cycles_per_wave_instr": meas, "priced_cycles_per_wave_instr": priced["cycles"], "frac": round(priced["cycles"] / meas, 3),
+        # frac (round 6): the FLOOR's instructions at their calibrated issue cost / the SIMD cycles the launch took.  The
+        # floor per k-mer (VALU_FLOOR_CLASSES): what any rolling implementation of this key issues.  It can show waste; the figure that cannot
+        # -- the kernel's OWN mix priced against its own cycles, 1.0 by construction when the VALU pipe never idles -- is kept as
+        # `issue_slots_filled`, which only says that the pipe is full, not that it is full of useful work.
+        floor_cycles = sum(n_i * valu_class_cycles(cls) for cls, n_i in VALU_FLOOR_CLASSES)
+        useful = floor_cycles * (bases_per_launch / 64.0) / (meas * n)
+        out.update({"measured_cycles_per_wave_instr": meas, "priced_cycles_per_wave_instr": priced["cycles"],
+                    "frac": round(useful, 3),
+                    "frac_is": "floor instructions (VALU_FLOOR_CLASSES: 2 v_alignbit + 2 v_xor + v_lshrrev + 2 v_add + v_cmp + 1 address op per k-mer) x their "
+                               "calibrated issue cycles (profiles/valu_cycles.json) x k-mers per launch / 64, over the SIMD cycles of the launch "
+                               "(1024 SIMDs x GRBM_GUI_ACTIVE / 8 = measured cycles per wave-instruction x SQ_INSTS_VALU)",
+                    "floor_cycles_per_kmer_step": round(floor_cycles, 2),
+                    "issue_slots_filled": round(priced["cycles"] / meas, 3),
+                    "issue_slots_filled_is": "the kernel's own instruction mix at its calibrated cost / measured SIMD cycles per VALU wave-instruction: ~1 = the VALU "
+                                             "pipe is never idle; says nothing about how useful the instructions are (that is `frac` / `useful_frac`)",
                     "peak": round(N_SIMD * clock / priced["cycles"], 1), "clock_ghz": clock,
                     "priced_from": priced["how"], "isa_mix": pm.get("isa_mix"),
-                    "note": "frac = priced / measured SIMD cycles per VALU wave-instruction (no clamp); SQ_ACTIVE_INST_VALU is not used: in these "
-                            "counter files it equals SQ_INSTS_VALU"})
+                    "note": "SQ_ACTIVE_INST_VALU is not used: in these counter files it equals SQ_INSTS_VALU"})
     return out
 
 
@@ -846,6 +894,11 @@ def end_to_end(dev, wl, W, args):
         finally:
             os.chdir(cwd)
         out_bytes = sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d) if f.startswith("asm.fa."))
+        text_bytes = sum(os.path.getsize(os.path.join(d, f)) for f in files)
+        try:
+            rates = host_rates()
+        except Exception as exc:
+            rates = {"error": f"{type(exc).__name__}: {exc}"}
         gz = {}
         try:  # the forms reads really arrive in (ntLink:113-117,222: `gzip -cd -f FILES`): several .fq.gz files, one bgzip'd file
             gz = gz_forms(dev, d, files[0], W, cwd)
@@ -863,6 +916,15 @@ def end_to_end(dev, wl, W, args):
                 "one_time_costs_per_run": [x.get("one_time") for x in stats_all],
                 "text_formatted_on": "device (ntl_mapres_format)" if os.environ.get("NTL_DEVICE_TEXT", "1") != "0" else "host (ntl_write_verbose / ntl_write_paf)",
                 "compressed_inputs": gz,
+                "host_rates": rates,
+                "roofline": {"first_pass": e2e_roofline(rates, st["read_bases"], text_bytes, out_bytes, dt, cpu_budget()),
+                             "steady_state": e2e_roofline(rates, stats_all[best]["read_bases"], text_bytes, out_bytes, runs[best], cpu_budget()),
+                             "compressed": {nm: {"inflate_bound_s": round(2.0 * g["read_bases"] / (rates["inflate_GBps_per_core_zlib_of_sequence_text"] * 1e9 *
+                                                                                                    max(1, int(cpu_budget()[1] or cpu_budget()[0]))), 4),
+                                                 "measured_s": g["seconds"],
+                                                 "note": "FASTQ text = 2 bytes per base through inflate on every granted core (zlib's rate; the reader uses libdeflate "
+                                                         "where the box has it); one ordinary .gz member is ONE serial stream whatever inflates it"}
+                                            for nm, g in gz.items() if isinstance(g, dict) and "read_bases" in g and rates.get("inflate_GBps_per_core_zlib_of_sequence_text")}},
                 "host_cpu": dict(zip(("cpus_visible", "cpu_quota_cores"), cpu_budget())),
                 "reader": st.get("reader"),
                 "read_bases": st["read_bases"], "reads": st["reads"], "input": f"plain FASTA, {len(files)} read file(s), page cache ({d})",
@@ -874,6 +936,77 @@ def end_to_end(dev, wl, W, args):
                 "device_streams": int(os.environ.get("NTL_DEVICE_STREAMS", "2"))}
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+def host_rates():
+    """What the file-to-file path is made of besides kernels, measured here on the cores this process is granted: PCIe both ways
+    (1-GB page-locked torch tensors), the rate at which the granted cores move memory (numpy copies of 256-MB pieces on a thread per
+    core: the parser reads every text byte once and writes a quarter of it packed), zlib inflate per core."""
+    import threading
+    import zlib
+    import numpy as np
+    import torch
+    out = {}
+    try:
+        n = 1 << 30
+        h = torch.empty(n, dtype=torch.uint8).pin_memory()
+        g = torch.empty(n, dtype=torch.uint8, device="cuda")
+        for name, (dst, src) in (("h2d_GBps", (g, h)), ("d2h_GBps", (h, g))):
+            dst.copy_(src, non_blocking=True); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                dst.copy_(src, non_blocking=True)
+            torch.cuda.synchronize()
+            out[name] = round(3 * n / (time.perf_counter() - t0) / 1e9, 1)
+        del h, g
+    except Exception as exc:  # a rate that cannot be measured is left out, not guessed
+        out["pcie_error"] = f"{type(exc).__name__}: {exc}"
+    vis, quota = cpu_budget()
+    cores = max(1, int(quota or vis))
+    cores = min(cores, 64)
+    piece = 256 << 20
+    src = [np.ones(piece, np.uint8) for _ in range(cores)]
+    dst = [np.empty(piece, np.uint8) for _ in range(cores)]
+    def work(i):
+        for _ in range(4):
+            np.copyto(dst[i], src[i])
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+    t0 = time.perf_counter()
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    dt = time.perf_counter() - t0
+    out["host_copy_GBps_read_plus_write"] = round(2 * 4 * piece * cores / dt / 1e9, 1)
+    out["host_copy_threads"] = cores
+    del src, dst
+    text = (b"ACGTTGCA" * 8 + b"\n") * 200000
+    comp = zlib.compress(text, 1)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        zlib.decompress(comp)
+    out["inflate_GBps_per_core_zlib_of_sequence_text"] = round(5 * len(text) / (time.perf_counter() - t0) / 1e9, 2)
+    return out
+
+
+def e2e_roofline(rates, read_bases, text_bytes, out_bytes, seconds, cores):
+    """Lower bounds of a file-to-file pass from the byte counts and the measured rates: which resource would bind if everything else were
+    free, and how far the measured pass is from it."""
+    b = {}
+    if rates.get("host_copy_GBps_read_plus_write"):
+        # the parser reads the text and writes 2 bits per base; the emitters write the output text once more into the page cache
+        b["host_memory_s"] = round((text_bytes + 0.25 * read_bases + 2.0 * out_bytes) / (rates["host_copy_GBps_read_plus_write"] * 1e9), 4)
+    if rates.get("h2d_GBps"):
+        b["pcie_h2d_s"] = round(0.25 * read_bases / (rates["h2d_GBps"] * 1e9), 4)
+    if rates.get("d2h_GBps"):
+        b["pcie_d2h_s"] = round(out_bytes / (rates["d2h_GBps"] * 1e9), 4)
+    if not b:
+        return None
+    binds = max(b, key=b.get)
+    return {"bounds_s": b, "binds": binds, "measured_s": round(seconds, 3), "measured_over_bound": round(seconds / max(b[binds], 1e-9), 1),
+            "bytes": {"text_in": int(text_bytes), "packed_over_pcie": int(0.25 * read_bases), "text_out": int(out_bytes)},
+            "note": "host_memory_s prices every byte the host touches at the copy rate of the granted cores; the parser does more per byte than a copy "
+                    "(newline and header scan, 2-bit pack with pext), which is the factor above it"}
 
 
 def gz_forms(dev, d, fasta, W, cwd, max_bases=2_000_000_000):

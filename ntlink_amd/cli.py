@@ -171,6 +171,9 @@ def write_time_file(kv, command, wall_s, stats):
     for key in sorted(stats or {}):
         if key.startswith("t_") or key in ("read_bases", "reads", "read_minimizers", "index_hits", "index_size", "parsed_bytes",
                                            "parsed_bytes_per_rank", "pin_per_rank", "contigs_parsed_by_per_rank"):
+            if key == "t_stages_per_rank":  # (a JSON list, not a number of seconds)
+                lines.append(f"\tntlink_amd stage_seconds_per_rank: {stats[key]}")
+                continue
             lines.append(f"\tntlink_amd {key}: {stats[key]:.3f}" if isinstance(stats[key], float) else f"\tntlink_amd {key}: {stats[key]}")
     with open(f"{prefix}.n{kv['n']}.scaffold.dot.time", "w") as fh:
         fh.write("\n".join(lines) + "\n")

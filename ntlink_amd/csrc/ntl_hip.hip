@@ -1470,6 +1470,7 @@ static void launch_fast_r0(ntl_ctx *c, const Sketch2Args &B, unsigned strips)
                         wgs = 8u * ((per_xcd_chunks + per_wg - 1u) / per_wg);
                         Bq.chunk_budget = (uint32_t)budget;
                     }
+                    ProfSpan sp(c, "sketch_wave", SID_W); /* the window kernel alone (the span "sketch_mask" around this function also holds the block-minima pass) */
                     hipLaunchKernelGGL(kern, dim3(wgs), dim3(threads), 0, c->wstream, Bq);
                 };
                 if (per_strip <= 175.0) { /* w >= 235 at ten candidates per window */

@@ -11,6 +11,7 @@ Compute is on the GPU through ntlink_amd.capi (C ABI -> HIP kernels); this modul
 records between files and the device and runs the small CPU tail (pairing.py).
 """
 import datetime
+import json
 import os
 import sys
 import time
@@ -763,11 +764,13 @@ def run_pair(dev, target, reads, prefix=None, k=32, w=100, n=1, a=1, z=1000, f=1
                 for e in exts:
                     os.replace(prefix + e + ".assembling", prefix + e)
             mine = (out.tally.export(), {key: stats[key] for key in ("read_bases", "reads", "read_minimizers", "index_hits", "parsed_bytes")},
-                    ctg_share.get("contigs_parsed_by"))
+                    ctg_share.get("contigs_parsed_by"),
+                    {key: round(float(val), 3) for key, val in stats.items() if key.startswith("t_") and isinstance(val, (int, float))})
             parts = comm.gather(mine)  # pair-tally deltas and five counters per rank
             if root:
                 stats["parsed_bytes_per_rank"] = [p[1]["parsed_bytes"] for p in parts]
                 stats["contigs_parsed_by_per_rank"] = [p[2] for p in parts]  # (one parser per host: shared_contigs)
+                stats["t_stages_per_rank"] = json.dumps([p[3] for p in parts])  # every rank's stage seconds (tools/dist_host_scaling.py)
                 parts = [p[:2] for p in parts]
                 for exported, st in parts[1:]:
                     out.tally.merge(exported)

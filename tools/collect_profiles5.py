@@ -118,8 +118,12 @@ for workload in ("C3", "C5", "C2"):
                    simd_cycles_per_launch=int(simd_cycles), measured_cycles_per_wave_instr=round(simd_cycles / vi, 3),
                    salu_per_valu=round(avg("pmc_sq", "SQ_INSTS_SALU") / vi, 3), lds_per_valu=round(avg("pmc_sq", "SQ_INSTS_LDS") / vi, 3),
                    clock_ghz=round(cyc / dur, 3), profiled_launch_ms=round(dur / 1e6, 4),
+                   **({"strips_per_launch": round(bj["config"]["window_strips_per_step"] / max(bj.get("sub_batches_per_rank") or 1, 1), 1),
+                       "per_strip": {c[9:].lower(): round(avg("pmc_sq", c) / (bj["config"]["window_strips_per_step"] / max(bj.get("sub_batches_per_rank") or 1, 1)), 1)
+                                     for c in ("SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SALU")}}
+                      if bj.get("config", {}).get("window_strips_per_step") else {}),
                    wait_inst_any_over_wave_cycles=round(avg("pmc_sq", "SQ_WAIT_INST_ANY") / max(avg("pmc_sq", "SQ_WAVE_CYCLES"), 1), 3),
-                   isa_mix="profiles/r05_isa_mix.json",
+                   isa_mix=os.environ.get("NTL_ISA_MIX", "profiles/r06_isa_mix.json"),
                    valu_source=f"profiles/{tag}_pmc_summary_{workload}.json (pmc_sq pass): SQ_INSTS_VALU and GRBM_GUI_ACTIVE (/ 8 XCDs x 1024 SIMDs = SIMD cycles), "
                                f"average over the {n} read-batch launches (SQ_ACTIVE_INST_VALU equals SQ_INSTS_VALU in these files: it is not a busy-cycle count and is not used)")
     # the other big kernels of a step: bytes, VALU share, duration per launch

@@ -27,7 +27,7 @@ params = dict(k=k, z=1000, x=0.0, sensitive=W["sensitive"], repeat_filter=False)
 csk = dev.sketch(wl.contigs, k, w)
 ix = dev.index(csk, wl.ctg_len)
 dev.sync()
-STAGES = ("sketch_meta", "sketch_mask", "sketch_redo", "sketch_emit", "probe", "map", "compact")
+STAGES = ("sketch_meta", "sketch_mask", "sketch_wave", "sketch_redo", "sketch_emit", "probe", "map", "compact")
 
 
 def step():
