@@ -38,6 +38,10 @@ class Indexlr:
     """Iterates the records of a FASTA/FASTQ(.gz) file with their (k,w) minimizers, input order."""
 
     def __init__(self, seqfile, k, w, flags=IndexlrFlag.LONG_MODE, threads=1, verbose=False, device=None):
+        # the reference only ever passes LONG_MODE (bin/ntlink_patch_gaps.py:417-420); btllib's other modes (barcodes, Bloom-filter
+        # filtering, kept sequences, short-read mode) are not this path's and must not be taken for granted silently
+        if int(flags) != IndexlrFlag.LONG_MODE:
+            raise NotImplementedError(f"ntlink_amd.btllib.Indexlr supports flags=IndexlrFlag.LONG_MODE only (got {int(flags)})")
         from . import capi
         self._own = device is None
         self.dev = device if device is not None else capi.Device(0)

@@ -649,3 +649,11 @@ def test_native_pair_writers_report_io_errors(tmp_path):
         assert exc.value.errno == errno.ENOSPC and not os.path.exists(tmp_path / "g.dot")
     assert t.write(1, 1, str(tmp_path / "p.tsv"), str(tmp_path / "g2.dot")) == 1
     assert sorted(f for f in os.listdir(tmp_path) if not f.startswith("g.dot.tmp")) == ["g2.dot", "p.tsv"]
+
+
+def test_btllib_indexlr_refuses_the_modes_it_does_not_have():
+    """flags other than LONG_MODE raise instead of being ignored (no device needed: checked before one is opened)."""
+    import ntlink_amd.btllib as btllib
+    for flags in (btllib.IndexlrFlag.SHORT_MODE, btllib.IndexlrFlag.LONG_MODE | btllib.IndexlrFlag.BX, 0):
+        with pytest.raises(NotImplementedError):
+            btllib.Indexlr("x.fa", 20, 10, flags)
