@@ -31,6 +31,9 @@ dev.sketch(rb, k, w, index=ix, records=False).close()
 dev.sync()
 n_cu = 256
 for name, (wgs_per_cu, ilp, lds_read, lds_bytes) in [("none", (0, 1, 0, 0)),
+                                                     ("LDS-heavy, 8 waves", (1, 200, 1, 20000)), ("LDS-heavy, 16 waves", (2, 200, 1, 20000)), ("LDS-heavy, 24 waves", (3, 200, 1, 20000)),
+                                                     ("streaming global reads, 8 waves", (1, 300, 0, 0)), ("streaming global reads, 24 waves", (3, 300, 0, 0)),
+                                                     ("random 16-byte global reads, 8 waves", (1, 301, 0, 0)), ("random 16-byte global reads, 24 waves", (3, 301, 0, 0)),
                                                      ("24 waves, 40 KB of code", (3, 100, 1, 30000)), ("24 waves, 40 KB of code + global loads", (3, 101, 1, 30000)),
                                                      ("16 waves, 40 KB of code + global loads", (2, 101, 1, 30000)),
                                                      ("16 waves ilp1", (2, 1, 0, 1024)), ("16 waves ilp2", (2, 2, 0, 1024)), ("16 waves ilp4", (2, 4, 0, 1024)),
@@ -43,7 +46,7 @@ for name, (wgs_per_cu, ilp, lds_read, lds_bytes) in [("none", (0, 1, 0, 0)),
     t0 = time.perf_counter()
     for _ in range(a.reps):
         if wgs_per_cu:
-            iters = int(60000 / ilp) if ilp < 100 else 2000
+            iters = int(60000 / ilp) if ilp < 100 else (2000 if ilp < 200 else (40000 if ilp == 200 else 30000))
             assert hog.hog_start(wgs_per_cu * n_cu, iters, ilp, lds_read, lds_bytes) == 0
             time.sleep(0.002)
         sk = dev.sketch(rb, k, w, index=ix, records=False)
@@ -53,5 +56,6 @@ for name, (wgs_per_cu, ilp, lds_read, lds_bytes) in [("none", (0, 1, 0, 0)),
             hog_ms = float(hog.hog_wait())
     out = {nm: round(dev.prof_get(nm)[0] / a.reps, 3) for nm in ("sketch_wave", "sketch_mask", "sketch_emit")}
     dev.prof_enable(False)
-    print(json.dumps({"beside": name, "ms_per_launch": out, "hog_ms": hog_ms}), flush=True)
+    print(json.dumps({"beside": name, "ms_per_launch": out, "hog_ms": hog_ms,
+                      "hog_GBps": round(wgs_per_cu * n_cu * 512 * 16 * 30000 / (hog_ms * 1e-3) / 1e9) if hog_ms and ilp >= 300 else None}), flush=True)
 dev.close()

@@ -71,6 +71,43 @@ __global__ __launch_bounds__(512) void hog_big_kernel(uint32_t *out, int iters, 
     if ((hits ^ fx ^ ry) == 0x12345u) out[blockIdx.x] = hits;
 }
 
+/* LDS-heavy: per step three 8-byte LDS reads at lane-random offsets of a 4-KB area (bank conflicts, like the scans' and the lookup
+   tables' reads) and one sparse 4-byte write (two lanes in 64, like the candidate push), little VALU */
+__global__ __launch_bounds__(512) void hog_lds_kernel(uint32_t *out, int iters)
+{
+    extern __shared__ uint32_t s_dyn[];
+    __shared__ uint2 s_area[512 * 2];
+    for (int i = threadIdx.x; i < 1024; i += 512) s_area[i] = make_uint2(i * 2654435761u, i * 40503u + 77u);
+    if (threadIdx.x == 0) s_dyn[0] = 1u;
+    __syncthreads();
+    uint32_t x = threadIdx.x * 2246822519u + blockIdx.x, acc = 0;
+    uint32_t *const mine = (uint32_t *)&s_area[512 + (threadIdx.x & ~63)];
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint2 a = s_area[x & 511u], b = s_area[(x >> 9) & 511u], c = s_area[(x >> 18) & 511u];
+            x = (x * 1664525u + 1013904223u) ^ a.x ^ b.y ^ c.x;
+            acc += a.y ^ c.y;
+            if (((x >> 5) & 31u) == (threadIdx.x & 31u)) mine[threadIdx.x & 63] = x; /* two lanes of a wavefront */
+        }
+    }
+    if ((acc ^ x) == 0x12345u) out[blockIdx.x] = acc;
+}
+
+/* memory-heavy: every wavefront streams 16 bytes per lane per step out of a 1-GB array (coalesced) or gathers them from random lines */
+template <bool RANDOM>
+__global__ __launch_bounds__(512) void hog_mem_kernel(uint32_t *out, int iters, const uint4 *src, uint32_t nsrc)
+{
+    uint32_t at = (blockIdx.x * 512u + threadIdx.x) % nsrc, acc = 0, x = threadIdx.x * 2654435761u + blockIdx.x;
+    for (int it = 0; it < iters; it++) {
+        const uint4 v = src[at];
+        acc ^= v.x ^ v.w;
+        x = x * 1664525u + 1013904223u + v.y;
+        at = RANDOM ? (x % nsrc) : (at + 512u * 2048u) % nsrc;
+    }
+    if (acc == 0x12345u) out[blockIdx.x] = acc;
+}
+
 static hipStream_t g_stream;
 static hipEvent_t g_a, g_b;
 static uint32_t *g_out;
@@ -89,7 +126,10 @@ extern "C" int hog_start(int wgs, int iters, int ilp, int lds_read, int lds_byte
     hipEventRecord(g_a, g_stream);
     const dim3 grid(wgs), block(512);
 #define GO(I, L) hipLaunchKernelGGL((hog_kernel<I, L>), grid, block, (size_t)lds_bytes, g_stream, g_out, iters)
-    if (ilp == 100) hipLaunchKernelGGL((hog_big_kernel<false>), grid, block, (size_t)lds_bytes, g_stream, g_out, iters, (const uint4 *)g_src, g_nsrc);
+    if (ilp == 200) hipLaunchKernelGGL(hog_lds_kernel, grid, block, (size_t)lds_bytes, g_stream, g_out, iters);
+    else if (ilp == 300) hipLaunchKernelGGL((hog_mem_kernel<false>), grid, block, 0, g_stream, g_out, iters, (const uint4 *)g_src, g_nsrc);
+    else if (ilp == 301) hipLaunchKernelGGL((hog_mem_kernel<true>), grid, block, 0, g_stream, g_out, iters, (const uint4 *)g_src, g_nsrc);
+    else if (ilp == 100) hipLaunchKernelGGL((hog_big_kernel<false>), grid, block, (size_t)lds_bytes, g_stream, g_out, iters, (const uint4 *)g_src, g_nsrc);
     else if (ilp == 101) hipLaunchKernelGGL((hog_big_kernel<true>), grid, block, (size_t)lds_bytes, g_stream, g_out, iters, (const uint4 *)g_src, g_nsrc);
     else if (lds_read) { if (ilp >= 4) GO(4, true); else if (ilp == 2) GO(2, true); else GO(1, true); }
     else { if (ilp >= 4) GO(4, false); else if (ilp == 2) GO(2, false); else GO(1, false); }
