@@ -1288,9 +1288,7 @@ __device__ __forceinline__ SkwWords skw_words_load(const uint32_t *__restrict__ 
 /* A staged key carries the step it was made in in its six low bits: k' = (key & ~63) | t.  Two such words order their k-mers' hashes
    when they are more than SKW_NEAR apart: k'_j - k'_i > SKW_NEAR  =>  key_j - key_i > SKW_NEAR - 126 >= SK2_NEAR  =>  h0_i < h0_j
    ("exact" in the header of this file); closer pairs are the near ties that give a strip up -- 2^-23 per window instead of 2^-29. */
-#ifndef SKW_CHUNK
 #define SKW_CHUNK 4u /* strips a wavefront takes from its XCD's counter at a time */
-#endif
 #define SKW_NEAR 131u
 static_assert(SKW_NEAR >= 126u + SK2_NEAR, "see above");
 
