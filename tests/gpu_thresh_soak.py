@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised differential soak of the threshold window pass (sketch_wave_kernel / sketch_thresh_kernel + sketch_fast_list_kernel) on the GPU: product
-vs oracle over random k, w in 71..255, candidates per window, staged / direct list form, on adversarial and on long random
+vs oracle over random k, w in 71..255 and (round 6: the wave kernel's large windows) 256..1135, candidates per window, staged / direct list form, on adversarial and on long random
 sequences, for a given number of seconds.  Usage: tests/gpu_thresh_soak.py [seconds] [seed0]"""
 import os
 import sys
@@ -25,7 +25,7 @@ acgt = np.frombuffer(b"ACGT", np.uint8)
 while time.time() - t0 < budget:
     seed += 1
     k = int(rng.integers(5, 101))
-    w = int(rng.integers(71, 256))
+    w = int(rng.integers(71, 256)) if rng.integers(0, 4) else int(rng.integers(256, 1136))  # one configuration in four: a large window
     cpw = str(rng.choice(["10", "10", "6", "8", "13", "4"]))
     os.environ["NTL_SKETCH_THRESH"] = cpw
     os.environ["NTL_SKETCH_THRESH_DIRECT"] = str(int(rng.integers(0, 2)))
