@@ -13,6 +13,7 @@
 #include <chrono>
 #include <deque>
 #include <map>
+#include <unordered_map>
 #include <mutex>
 #include <memory>
 #include <string>
@@ -114,6 +115,11 @@ struct ntl_ctx {
     struct Slab { char *base; size_t size; size_t live; };
     std::vector<Slab> slabs;
     std::multimap<size_t, void *> slab_free;   /* dropped slab blocks by size */
+    std::unordered_map<void *, size_t> slab_size; /* every slab block's TRUE size (a reused block may be up to 25 % larger than what was asked for; round 6) */
+    /* slab blocks that were given back while work on them may still be queued: they join slab_free when the events recorded behind that
+       work have passed (polled by dev_alloc) -- no stream is waited for (round 6, ADVICE r5: dev_free used to synchronise all three) */
+    struct Limbo { void *p; size_t bytes; hipEvent_t ev[3]; };
+    std::deque<Limbo> slab_limbo;
     char *slab_cur = nullptr, *slab_end = nullptr;
     std::mutex slab_mu; /* (dev_free may be asked about another context's block: index_unref) */
     std::deque<CleanMask> masks;
@@ -318,24 +324,63 @@ static ntl_ctx::Slab *slab_of(ntl_ctx *c, const void *p)
 
 /* Gives a block of dev_alloc (of `bytes`, as asked for there) back.  A single block: hipFree, which waits for the device.  A slab
    block: the same wait -- whatever is still queued on the block has run -- and then onto the slabs' free list. */
+static void slab_limbo_poll(ntl_ctx *c, bool wait); /* (slab_mu held) */
+
 static void dev_free(ntl_ctx *c, void *p, size_t bytes)
 {
     if (!p) return;
-    {
-        std::lock_guard<std::mutex> g(c->slab_mu);
-        if (!slab_of(c, p)) { (void)hipFree(p); return; }
-    }
-    (void)sync_both(c);
+    (void)bytes;
     std::lock_guard<std::mutex> g(c->slab_mu);
     ntl_ctx::Slab *sl = slab_of(c, p);
-    if (sl && sl->live) sl->live--;
-    c->slab_free.insert({(bytes + 255) & ~(size_t)255, p});
+    if (!sl) { (void)hipFree(p); return; }
+    /* what is still queued on the block: an event behind each of the context's streams (made here, not taken from the context's event
+       list: this may be another context's thread, index_unref); no event to be had: the slow, safe way */
+    ntl_ctx::Limbo L;
+    L.p = p;
+    auto ts = c->slab_size.find(p);
+    L.bytes = ts != c->slab_size.end() ? ts->second : ((bytes + 255) & ~(size_t)255);
+    hipStream_t st[3] = {c->stream, c->wstream != c->stream ? c->wstream : nullptr,
+                         c->pstream != c->stream && c->pstream != c->wstream ? c->pstream : nullptr};
+    bool ok = true;
+    for (int i = 0; i < 3; i++) {
+        L.ev[i] = nullptr;
+        if (i && !st[i]) continue;
+        if (hipEventCreateWithFlags(&L.ev[i], hipEventDisableTiming) != hipSuccess || hipEventRecord(L.ev[i], st[i]) != hipSuccess) { ok = false; break; }
+    }
+    if (!ok) {
+        (void)hipGetLastError();
+        for (int i = 0; i < 3; i++) if (L.ev[i]) { (void)hipEventDestroy(L.ev[i]); L.ev[i] = nullptr; }
+        (void)sync_both(c);
+    }
+    if (sl->live) sl->live--;
+    c->slab_limbo.push_back(L);
+    slab_limbo_poll(c, false);
+}
+
+/* limbo blocks whose events have passed go onto the free list (wait: all of them, after waiting) */
+static void slab_limbo_poll(ntl_ctx *c, bool wait)
+{
+    for (auto it = c->slab_limbo.begin(); it != c->slab_limbo.end();) {
+        bool done = true;
+        for (int i = 0; i < 3 && done; i++)
+            if (it->ev[i]) {
+                hipError_t q = wait ? hipEventSynchronize(it->ev[i]) : hipEventQuery(it->ev[i]);
+                if (q == hipErrorNotReady) done = false;
+            }
+        if (!done) { ++it; continue; }
+        (void)hipGetLastError();
+        for (int i = 0; i < 3; i++) if (it->ev[i]) (void)hipEventDestroy(it->ev[i]);
+        c->slab_free.insert({it->bytes, it->p});
+        it = c->slab_limbo.erase(it);
+    }
+    (void)hipGetLastError(); /* (hipErrorNotReady is not an error) */
 }
 
 /* slabs without a live block go back to the driver (out of memory: dev_alloc); returns the bytes freed */
 static size_t slabs_trim(ntl_ctx *c)
 {
     std::lock_guard<std::mutex> g(c->slab_mu);
+    slab_limbo_poll(c, true); /* (memory has run out: wait for what is in limbo, its slabs may go) */
     size_t freed = 0;
     for (size_t i = 0; i < c->slabs.size();) {
         ntl_ctx::Slab sl = c->slabs[i];
@@ -343,6 +388,8 @@ static size_t slabs_trim(ntl_ctx *c)
         for (auto it = c->slab_free.begin(); it != c->slab_free.end();)
             it = ((char *)it->second >= sl.base && (char *)it->second < sl.base + sl.size) ? c->slab_free.erase(it) : std::next(it);
         if (c->slab_cur >= sl.base && c->slab_cur <= sl.base + sl.size) c->slab_cur = c->slab_end = nullptr;
+        for (auto it = c->slab_size.begin(); it != c->slab_size.end();)
+            it = ((char *)it->first >= sl.base && (char *)it->first < sl.base + sl.size) ? c->slab_size.erase(it) : std::next(it);
         (void)hipFree(sl.base);
         freed += sl.size;
         c->slabs.erase(c->slabs.begin() + (long)i);
@@ -375,8 +422,9 @@ static int dev_alloc(ntl_ctx *c, size_t bytes, void **out)
 #endif
     if (use_slabs && bytes <= NTL_SLAB_MAX_REQ) {
         const size_t need = (bytes + 255) & ~(size_t)255;
-        {   /* a dropped slab block of this size (dev_free has waited for whatever was queued on it) */
+        {   /* a dropped slab block of this size (whatever was queued on it has run: slab_limbo_poll) */
             std::lock_guard<std::mutex> g(c->slab_mu);
+            if (!c->slab_limbo.empty()) slab_limbo_poll(c, false);
             auto it = c->slab_free.lower_bound(need);
             if (it != c->slab_free.end() && it->first <= need + need / 4) {
                 *out = it->second;
@@ -394,7 +442,10 @@ static int dev_alloc(ntl_ctx *c, size_t bytes, void **out)
                 pe.launches++;
                 std::lock_guard<std::mutex> g(c->slab_mu);
                 /* what is left of the slab before it, as a free block (else it would be lost while one of its blocks lives) */
-                if (c->slab_cur && c->slab_end - c->slab_cur >= 256) c->slab_free.insert({(size_t)(c->slab_end - c->slab_cur) & ~(size_t)255, c->slab_cur});
+                if (c->slab_cur && c->slab_end - c->slab_cur >= 256) {
+                    c->slab_free.insert({(size_t)(c->slab_end - c->slab_cur) & ~(size_t)255, c->slab_cur});
+                    c->slab_size[c->slab_cur] = (size_t)(c->slab_end - c->slab_cur) & ~(size_t)255;
+                }
                 c->slabs.push_back({(char *)sl, NTL_SLAB_BYTES, 0});
                 c->slab_cur = (char *)sl; c->slab_end = (char *)sl + NTL_SLAB_BYTES;
             } else (void)hipGetLastError(); /* no room for a slab: single blocks as before */
@@ -402,6 +453,7 @@ static int dev_alloc(ntl_ctx *c, size_t bytes, void **out)
         if (c->slab_cur && (size_t)(c->slab_end - c->slab_cur) >= need) {
             std::lock_guard<std::mutex> g(c->slab_mu);
             *out = c->slab_cur;
+            c->slab_size[c->slab_cur] = need;
             if (ntl_ctx::Slab *sl = slab_of(c, c->slab_cur)) sl->live++;
             c->slab_cur += need;
             return NTL_OK;
@@ -667,6 +719,10 @@ extern "C" void ntl_ctx_destroy(ntl_ctx *c)
     (void)hipFree(c->g4);
     (void)hipFree(c->g8);
     for (auto &kv : c->g8k) (void)hipFree(kv.second);
+    {   /* (what dev_free left in limbo: its events go) */
+        std::lock_guard<std::mutex> g(c->slab_mu);
+        slab_limbo_poll(c, true);
+    }
     for (auto &sl : c->slabs) (void)hipFree(sl.base);
     c->slabs.clear();
     if (c->host_tmp) pin_free(c->host_tmp);
