@@ -1677,7 +1677,7 @@ static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const nt
     }
     if (ub_strips >= 0x7FFFFFFFull) return fail(c, NTL_EINVAL, "batch too large: too many strips");
     /* Which window pass, and what it writes.  32-bit fast pass + exact pass over what it flags; the exact pass alone for small windows
-       / huge k.  Where the fast pass is sketch_wave_kernel (94 <= w <= 255, k <= 64: every window ntLink is run with) the passes write
+       / huge k.  Where the fast pass is sketch_wave_kernel (94 <= w <= 1135, k <= 64: every window ntLink is run with) the passes write
        per-strip LISTS of minimizers (sketch_kernels.h, StripLists) and emit_list_kernel reads those; everywhere else, a bitmask of one
        bit per base and emit_kernel.  NTL_SKETCH_LISTS=0: the bitmask everywhere (A/B, tests). */
     bool fast = C == 16 && k <= 16 * SK2_QMAX && G.a + 2 <= SK2_PAD;

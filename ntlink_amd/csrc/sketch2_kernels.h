@@ -1248,7 +1248,10 @@ __global__ __launch_bounds__(NT) void sketch_thresh_kernel(Sketch2Args B)
  * Elements: local position p = 64 L + t of the strip is ordinal E0 + p; p = 0 belongs to the previous strip's windows only
  * and positions >= hi = min(4096, M - E0) lie behind the sequence: candidates found there are dropped when the list is made.
  * Gives the strip up (B.fb_list) when a lane stages more than S candidates, the list would hold more than 64 ROUNDS - 8, or the
- * scans say so (a window without a candidate, a near tie, a key within SKW_NEAR of the threshold).  Soaked against the oracle on
+ * scans say so (a window without a candidate, a near tie, a key within SKW_NEAR of the threshold).  Round 6: one pass over the list
+ * decides which candidates scan at all (below: "who has to scan"), and the window may be anything up to the block-minima pass's 1135
+ * k-mers -- it only enters the scans as a distance (the workgroup-per-strip passes' a + 2 <= 16 lanes is not this kernel's limit).
+ * Soaked against the oracle on
  * 24 Gbases and 985 random (k, w, candidates per window) configurations (profiles/r04s_*.log), and in every `pytest -m gpu` run
  * on 25 Gbases more (tests/test_gpu_soak.py).
  */
