@@ -35,6 +35,29 @@ def test_bench_line_on_the_simt_mock(tmp_path):
         assert key in out
     assert out["n_gpus"] == 1 and out["cpu_baseline"]["kind"] == "port" and "stages_s" in out["cpu_baseline"]
     assert out["config"]["index_size"] > 0 and out["config"]["mappings_hits_pafs_per_step"][0] > 0
+    # round 6: the roofline block says what binds, keeps the contract's HBM fields, and the line says that no scaling curve was measured
+    roof = out["roofline"]
+    assert roof["bound"] == "valu" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-4
+    assert "scaling_note" in out and "No 1 -> 8 GPU curve" in out["scaling_note"]
+
+
+def test_valu_roofline_fraction_is_priced_on_the_floor(monkeypatch):
+    """roofline.valu.frac = the floor's instructions at their calibrated issue cost / the SIMD cycles of the launch -- it must fall when
+    the kernel issues more instructions for the same bases, which the kernel's own mix priced against its own cycles
+    (issue_slots_filled) cannot show."""
+    sys.path.insert(0, ROOT)
+    import bench
+    floor = sum(n * bench.valu_class_cycles(c) for c, n in bench.VALU_FLOOR_CLASSES)
+    assert 27.0 < floor < 31.0 and sum(n for _, n in bench.VALU_FLOOR_CLASSES) == bench.VALU_FLOOR_PER_KMER
+    monkeypatch.setattr(bench, "priced_cycles", lambda pm, n: {"cycles": 3.3, "how": "test"})
+    bases = 3_900_000_000
+    lean = bench.valu_roofline({"valu_wave_instr_per_launch": 1.2e9, "measured_cycles_per_wave_instr": 3.3, "clock_ghz": 2.1}, 1.8, bases)
+    fat = bench.valu_roofline({"valu_wave_instr_per_launch": 2.4e9, "measured_cycles_per_wave_instr": 3.3, "clock_ghz": 2.1}, 3.6, bases)
+    assert abs(lean["frac"] - floor * (bases / 64) / (3.3 * 1.2e9)) < 1e-3
+    assert abs(fat["frac"] - lean["frac"] / 2) < 1e-3                      # twice the instructions for the same bases: half the fraction
+    assert lean["issue_slots_filled"] == fat["issue_slots_filled"] == 1.0  # ... which the self-priced figure does not see
+    assert abs(lean["useful_frac"] - 9.0 / (1.2e9 * 64 / bases)) < 1e-3
 
 
 def test_two_ranks_strong_scaling_line_on_the_simt_mock():
