@@ -216,6 +216,13 @@ __device__ __forceinline__ uint32_t ntl_le4_mask(uint32_t k0, uint32_t k1, uint3
     return acc;
 }
 
+/* At most 96 scalar registers for the kernels of the MAIN stream (round 6).  A SIMD holds 800 of them and a wavefront is given its
+   count rounded up to 16, plus 16 (MI355X_MICROARCH.md, residency): six window wavefronts (78 -> 96 each) leave 224, and with the 104-106
+   the lookup and map kernels took when left to themselves (-> 128) only ONE of their wavefronts fitted beside them on a SIMD -- a CU's
+   second lookup workgroup never became resident, which is why that kernel's time beside the window stage did not depend on how many
+   workgroups it was given (profiles/HISTORY.md, round 6).  With 96 (-> 112) two fit. */
+#define NTL_MAIN_STREAM_SGPRS __attribute__((amdgpu_num_sgpr(96)))
+
 /* Wavefront issue priority 0..3 (s_setprio).  The latency-bound kernels of the MAIN stream (index lookup, mapping, gathers) raise
    theirs: beside the window stage's resident, issue-bound wavefronts their few instructions between two memory round trips
    should not queue behind a stream of rolling steps. */

@@ -661,7 +661,7 @@ __device__ __forceinline__ int map_class_of(uint32_t nmx) { return nmx <= 256u ?
    at a time, votes which of them belong to its class and maps those one after the other.
    No list, no atomic; a class without reads costs one pass over the offsets. */
 template <int MAP_CAPH, int MAP_CAPR, int CLASS>
-__global__ __launch_bounds__(MAP_NT) void map_kernel(MapArgs A)
+__global__ __launch_bounds__(MAP_NT) NTL_MAIN_STREAM_SGPRS void map_kernel(MapArgs A)
 {
     NTL_PRIO_LATENCY_BOUND();
     __shared__ uint32_t s_h32[3][MAP_CAPH];
@@ -693,7 +693,7 @@ __global__ __launch_bounds__(MAP_NT) void map_kernel(MapArgs A)
 }
 
 /* the reads map_kernel could not stage in LDS, on their regions of the global scratch arrays */
-__global__ __launch_bounds__(MAP_NT) void map_overflow_kernel(MapArgs A)
+__global__ __launch_bounds__(MAP_NT) NTL_MAIN_STREAM_SGPRS void map_overflow_kernel(MapArgs A)
 {
     NTL_PRIO_LATENCY_BOUND();
     if (map_sketch_overflowed(A)) return;

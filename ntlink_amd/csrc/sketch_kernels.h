@@ -807,7 +807,7 @@ __global__ void mx_off_from_strips_kernel(const uint32_t *__restrict__ strip_fir
  * (lanes of one strip: consecutive words), the k-mer's hash from its bases, the record, the index lookup.
  */
 template <int PROBE, int U = 1>
-__global__ __launch_bounds__(EL_NT) void emit_list_kernel(EmitArgs A, EmitListArgs Q)
+__global__ __launch_bounds__(EL_NT) NTL_MAIN_STREAM_SGPRS void emit_list_kernel(EmitArgs A, EmitListArgs Q)
 {
     unsigned long long found = 0;
     __shared__ uint8_t s_sid[EL_CAP];

@@ -120,6 +120,7 @@ inline uint32_t ntl_le4_mask(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3,
     return 16u | (k3 <= lim ? 8u : 0u) | (k2 <= lim ? 4u : 0u) | (k1 <= lim ? 2u : 0u) | (k0 <= lim ? 1u : 0u);
 }
 #define NTL_PRIO_LATENCY_BOUND() ((void)0)
+#define NTL_MAIN_STREAM_SGPRS
 inline uint64_t ntl_load_u64_a1(const uint8_t *p) { uint64_t v; memcpy(&v, p, 8); return v; }
 inline uint32_t ntl_load_u32_a1(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; }
 inline void ntl_store_u64_a1(uint8_t *p, uint64_t v) { memcpy(p, &v, 8); }
