@@ -570,9 +570,10 @@ def pmc_summary(workload, scale, bases_per_launch):
 
 def dense_sketch_line(dev, k, w, bases=200_000_000, reps=5):
     """Sketch rate at the window sizes of the stages around `pair`: a minimizer every (w + 1) / 2 bases, so the records (16 B each) are most of
-    the bytes and the windows are too small for the threshold-sparsified pass (every k-mer would be a candidate): the exact 64-bit
-    window pass (sketch_mask_kernel, 4 k-mers per lane) + emit_kernel.  These stages sketch contig ends and read pieces -- megabases, not
-    the read set -- so the line is here for the record, not as a target."""
+    the bytes and the windows are too small for the threshold-sparsified pass (every k-mer would be a candidate).  Round 6:
+    sketch_small_kernel<W> (2 <= w <= 15: 16 k-mers per lane, the minima of a lane's windows in registers, exact 64-bit hashes; the
+    round-1 form -- four k-mers per lane, NTL_SKETCH_SMALL=0 -- made 226-238 Gbases/s in its window pass) + emit_kernel.  These stages
+    sketch contig ends and read pieces -- megabases, not the read set -- so the line is here for the record, not as a target."""
     import numpy as np
     b = dev.synth_genome(77, np.full(bases // 2_000_000, 2_000_000, np.uint32))
     try:
@@ -596,7 +597,9 @@ def dense_sketch_line(dev, k, w, bases=200_000_000, reps=5):
     win_ms = prof["sketch_mask"] + prof["sketch_redo"]
     return {"workload": f"{bases} bp of random sequence in 2-Mbp pieces, k={k} w={w}, one sketch call (records, no lookup)", "minimizers": int(n),
             "density": round(d, 4), "value": round(bases / dt / 1e9, 1), "unit": "Gbases/s", "ms_per_sketch": round(dt * 1e3, 3),
-            "records_G_per_s": round(n / dt / 1e9, 2), "stage_ms": prof, "window_pass": "per-strip lists" if from_lists else "bitmask (sketch_mask_kernel, exact 64-bit pass)",
+            "records_G_per_s": round(n / dt / 1e9, 2), "stage_ms": prof, "window_pass": "per-strip lists" if from_lists else ("bitmask (sketch_small_kernel, exact 64-bit pass, window minima in registers)"
+                                                                if 2 <= w <= 15 and os.environ.get("NTL_SKETCH_SMALL", "1") != "0" and not os.environ.get("NTL_SKETCH_C")
+                                                                else "bitmask (sketch_mask_kernel, exact 64-bit pass)"),
             "roofline": {"bound": "hbm", "bytes_per_base": round(bpb, 3), "formula": "0.25 + 16 d (packed bases in, 16-byte records out)",
                          "achieved": round(bpb * bases / (dt * 1e-0) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(bpb * bases / dt / 1e9 / HBM_PEAK_GBS, 4),

@@ -25,6 +25,7 @@
 #include "scan_kernels.h"
 #include "sketch_kernels.h"
 #include "sketch2_kernels.h"
+#include "sketch_small_kernels.h"
 #include "map_kernels.h"
 #include "pack_kernels.h"
 #include "synth_kernels.h"
@@ -1599,16 +1600,44 @@ static int mask_take(ntl_ctx *c, size_t bytes, int sid, CleanMask *out)
     return NTL_OK;
 }
 
+/* does the window pass of this window size run as sketch_small_kernel (2 <= w <= 15: the stages around `pair`)?  NTL_SKETCH_SMALL=0, or any
+   setting of the k-mers-per-lane knob: the round-1 forms with four / one k-mer per lane (A/B, tests).  Read per call. */
+static bool small_window_form(int w)
+{
+    if (w < 2 || w > 15 || getenv("NTL_SKETCH_C")) return false;
+    const char *e = getenv("NTL_SKETCH_SMALL");
+    return !e || atoi(e) != 0;
+}
+
+template <int W>
+static void launch_small_w(ntl_ctx *c, const SketchArgs &A, unsigned strips, bool multi)
+{
+    if (A.G.w == W) {
+        const dim3 grid((strips + 7u) & ~7u);
+        hipLaunchKernelGGL((sketch_small_kernel<W, false>), grid, dim3(256), 0, c->wstream, A);
+        if (multi) hipLaunchKernelGGL((sketch_small_kernel<W, true>), grid, dim3(256), 0, c->wstream, A);
+        return;
+    }
+    if constexpr (W < 15) launch_small_w<W + 1>(c, A, strips, multi);
+}
+
 /* geometry of the window pass for (k, w): k-mers per lane, lanes per strip */
 static int sketch_geometry(ntl_ctx *c, int k, int w, SketchGeom &G, int &C, int &nt)
 {
     if (k < 1 || k > 4096 || w < 1) return fail(c, NTL_EINVAL, "k must be in 1..4096 and w >= 1");
     C = w >= 16 ? 16 : (w >= 4 ? 4 : 1);
+    G.k = k; G.w = w;
+    if (small_window_form(w)) { /* sketch_small_kernel: 256 lanes x 16 k-mers, the minima of the 16 windows a lane starts in registers */
+        C = 16; nt = SK_NT;
+        G.a = 0; G.r0 = 0;
+        G.LW = nt - 1;          /* the last lane only supplies the w - 1 elements behind the last window */
+        G.NWO = G.LW * C - 1;
+        return NTL_OK;
+    }
     if (const char *e = getenv("NTL_SKETCH_C")) { /* tuning knob: k-mers per lane (16, 4, 1) */
         const int v = atoi(e);
         if ((v == 16 || v == 4 || v == 1) && w >= v) C = v;
     }
-    G.k = k; G.w = w;
     G.a = (w - C) / C; G.r0 = (w - C) % C;
     /* lanes per strip: 128-lane strips waste fewer lanes on the last strip of a ~10 kb read, 256-lane strips fewer on the halo
        (a+2 lanes) and fit eight workgroups of the 32-bit window pass on a CU.  Measured with that pass: 256 lanes +6 % at w=100
@@ -1680,7 +1709,8 @@ static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const nt
        / huge k.  Where the fast pass is sketch_wave_kernel (94 <= w <= 1135, k <= 64: every window ntLink is run with) the passes write
        per-strip LISTS of minimizers (sketch_kernels.h, StripLists) and emit_list_kernel reads those; everywhere else, a bitmask of one
        bit per base and emit_kernel.  NTL_SKETCH_LISTS=0: the bitmask everywhere (A/B, tests). */
-    bool fast = C == 16 && k <= 16 * SK2_QMAX && G.a + 2 <= SK2_PAD;
+    const bool small = small_window_form(w);
+    bool fast = C == 16 && k <= 16 * SK2_QMAX && G.a + 2 <= SK2_PAD && !small;
     if (const char *e = getenv("NTL_SKETCH_FAST")) fast = fast && atoi(e) != 0; /* 0: exact pass only (A/B, tests) */
     Sketch2Args B;
     memset(&B, 0, sizeof B);
@@ -1827,7 +1857,8 @@ static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const nt
             HIPCHK(c, hipMemcpyAsync(&((SketchSums *)s->slot)->redo_n, redo.p, 8, hipMemcpyDeviceToHost, ws));
         } else {
             ProfSpan sp(c, "sketch_mask", wsid);
-            if (C == 16) launch_mask<16>(c, A, (unsigned)ub_strips, true, b->any_multi, nt);
+            if (small) launch_small_w<2>(c, A, (unsigned)ub_strips, b->any_multi);
+            else if (C == 16) launch_mask<16>(c, A, (unsigned)ub_strips, true, b->any_multi, nt);
             else if (C == 4) launch_mask<4>(c, A, (unsigned)ub_strips, true, b->any_multi, nt);
             else launch_mask<1>(c, A, (unsigned)ub_strips, true, b->any_multi, nt);
             HIPCHK(c, hipGetLastError());
@@ -1899,7 +1930,10 @@ static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const nt
                grids (profiles/r04_share_sweep_C5.jsonl); the tag form (C3) is as fast uncapped (74.4-75.0 against 74.9-75.9) */
             /* emit_list_kernel (44 registers, 13 KB of LDS) would fill all 32 wavefront slots of a CU, and the window stage's resident
                workgroups of the next sub-batch then wait for them to drain (C3: 91 ms per step uncapped, 75.9 at two per CU) */
-            int per_cu = !c->pipelined ? 0 : (probe == 2 ? 3 : (lists ? 2 : 0));
+            /* beside the DENSE window shapes (w < 137: twelve window wavefronts per CU, launch_fast_r0) the tag form takes four: C2
+               0.890 -> 0.800 ms per step (0.806 at three, 0.815 uncapped; profiles/r07b_C2_share_sweep.txt) */
+            const bool dense_windows = fast && B.thresh && 4096.0 * (double)B.thresh / 4294967296.0 > 300.0;
+            int per_cu = !c->pipelined ? 0 : (probe == 2 ? 3 : (lists ? (dense_windows ? 4 : 2) : 0));
             if (const char *e = getenv("NTL_EMIT_WGS_PER_CU")) per_cu = atoi(e);
             const uint64_t cap = (uint64_t)per_cu * (uint64_t)c->n_cu;
             if (per_cu > 0 && cap >= 8 && cap < tiles) { egrid = (unsigned)cap; E.tile_next = tile_next.as<uint32_t>(); }

@@ -29,6 +29,36 @@ def check_sketch(dev, seqs, k, w, threads=0, info=None):
     return len(h)
 
 
+def small_window_sequences(seed=21, n_long=6, long_len=40000):
+    """Sequences for the small-window pass (sketch_small_kernel, 2 <= w <= 15): sequences of several strips (the wavefronts that lie
+    wholly inside a sequence take the path without per-window checks), strip-boundary lengths of ITS strips (4096 elements, 4079 own
+    windows), low complexity (equal hashes inside one window: the rightmost wins), N runs across strips."""
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+
+    def rnd(n):
+        return bytes(acgt[rng.integers(0, 4, n)])
+    out = [rnd(int(long_len + rng.integers(0, 5000))) for _ in range(n_long)]
+    out += [rnd(n) for n in (4079, 4080, 4081, 4093, 4094, 4095, 4096, 4097, 4110, 4111, 4112, 8158, 8159, 8160, 8175, 8190, 12240)]
+    out += [b"A" * 9000, b"AC" * 4500, b"AAC" * 3000, rnd(3000) + b"T" * 2500 + rnd(3000),
+            rnd(5000) + b"N" + rnd(4070) + b"NN" + rnd(13) + b"N" * 30 + rnd(9000) + b"N", b"N" * 17 + rnd(8200) + b"n" * 3 + rnd(40)]
+    return out
+
+
+def check_small_windows(dev, ws, ks=(15, 20, 33), seqs=None, fuzz_seeds=(4, 10)):
+    """sketch_small_kernel == oracle for every window size in ws (and the round-1 forms it replaced, NTL_SKETCH_SMALL=0, on one k)."""
+    import fuzz_cases
+    seqs = small_window_sequences() if seqs is None else seqs
+    fz = [q for sd in fuzz_seeds for q in fuzz_cases.fuzz_sequences(sd)]
+    n = 0
+    for w in ws:
+        for k in ks:
+            st = {}
+            n += check_sketch(dev, seqs + edge_sequences() + fz, k, w, info=st)
+            assert st["redo_strips"] == 0 and not st["from_lists"]
+    return n
+
+
 def near_tie_sequences(k, n_pairs, seed=11, pool=1 << 22, flank=30, third=False):
     """Sequences in which two DIFFERENT k-mers whose hashes agree in bits 33..63 (so the window pass's ring keys are within
     one of each other: it cannot order them) are the two smallest k-mers of one window: A + filler + B.  Found by brute force

@@ -49,6 +49,17 @@ def test_sketch_edge_cases(dev, k, w):
     pc.check_sketch(dev, pc.edge_sequences(), k, w)
 
 
+@pytest.mark.parametrize("ws", [(2, 3, 4), (5, 6, 7), (8, 9, 10), (11, 12, 13), (14, 15)], ids=lambda t: "w" + "_".join(map(str, t)))
+def test_small_window_pass(dev, ws, monkeypatch):
+    """Round 6: windows of 2 .. 15 k-mers -- the overlap stage's k15 w5 (ntLink:243-251) and the gap filler's
+    k20 w10 (bin/ntlink_patch_gaps.py:417-441) among them -- go through sketch_small_kernel<W> (16 k-mers per lane, window minima
+    in registers): every window size against the oracle on multi-strip sequences, its strips' boundary lengths, low complexity and
+    N runs; and the forms it replaced (four / one k-mer per lane) still agree."""
+    assert pc.check_small_windows(dev, ws) > 0
+    monkeypatch.setenv("NTL_SKETCH_SMALL", "0")
+    pc.check_small_windows(dev, ws[:1], ks=(20,))
+
+
 @pytest.mark.parametrize("k,w", [(12, 8), (20, 40), (5, 1)])
 def test_sketch_many_tiny_sequences(dev, k, w):
     """> 512 sequence starts per emit tile and several rounds of the workgroup-wide sequence search."""

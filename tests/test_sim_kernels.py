@@ -37,6 +37,13 @@ def test_sim_sketch_many_tiny_sequences(dev):
     pc.check_sketch(dev, pc.tiny_sequences(700), 12, 8)
 
 
+@pytest.mark.parametrize("w", [2, 5, 10, 15])
+def test_sim_small_window_pass(dev, w):
+    """sketch_small_kernel<W> (2 <= w <= 15, round 6) under the mock: strips of 4096 elements with 4079 own windows, ties, N runs."""
+    seqs = pc.small_window_sequences(n_long=1, long_len=9000)
+    assert pc.check_small_windows(dev, (w,), ks=(15, 33) if w == 5 else (20,), seqs=seqs, fuzz_seeds=(4,)) > 0
+
+
 def test_sim_sketch_reads_small_w(dev):
     reads = pc.fixture_seqs("long_reads_4_top5.fa")
     pc.check_sketch(dev, reads[:2], 15, 5)
