@@ -321,10 +321,43 @@ __attribute__((target("avx2,bmi2"))) static int ntl_pack32(const char *p, uint64
     *out = v;
     return 1;
 }
-static const bool g_have_pack32 = [] { return getenv("NTL_IO_NO_SIMD") == nullptr && __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2"); }();
+/* 64 bases per step where the CPU has AVX-512BW (the GPU boxes' EPYC 9575F; round 6): the four compares give the validity as one
+ * 64-bit mask; the codes -- bits 1-2 of every byte, G and T swapped back -- are folded pairwise by two multiply-adds (c0 + 4 c1 in
+ * sixteen bits, then w0 + 16 w1 in thirty-two: four bases per byte) and the low bytes of the sixteen dwords are the 128 packed bits. */
+__attribute__((target("avx512f,avx512bw"))) static int ntl_pack64(const char *p, uint64_t out[2])
+{
+    const __m512i x = _mm512_loadu_si512((const void *)p);
+    const __m512i u = _mm512_and_si512(x, _mm512_set1_epi8((char)0xDF));
+    const __mmask64 ok = _mm512_cmpeq_epi8_mask(u, _mm512_set1_epi8(0x41)) | _mm512_cmpeq_epi8_mask(u, _mm512_set1_epi8(0x43)) |
+                         _mm512_cmpeq_epi8_mask(u, _mm512_set1_epi8(0x47)) | _mm512_cmpeq_epi8_mask(u, _mm512_set1_epi8(0x54));
+    if (ok != ~(__mmask64)0) return 0;
+    __m512i v = _mm512_and_si512(_mm512_srli_epi16(x, 1), _mm512_set1_epi8(3));                  /* 0 1 3 2 */
+    v = _mm512_xor_si512(v, _mm512_and_si512(_mm512_srli_epi16(v, 1), _mm512_set1_epi8(1)));      /* 0 1 2 3 */
+    const __m512i w16 = _mm512_maddubs_epi16(v, _mm512_set1_epi16(0x0401));                       /* c0 + 4 c1 */
+    const __m512i w32 = _mm512_madd_epi16(w16, _mm512_set1_epi32(0x00100001));                    /* w0 + 16 w1 */
+    const __m128i r = _mm512_cvtepi32_epi8(w32);
+    _mm_storeu_si128((__m128i *)out, r);
+    return 1;
+}
+/* which packer steps this CPU has: 0 the 8-byte arithmetic only, 1 + AVX2 / BMI2 (32 bases), 2 + AVX-512BW (64 bases).  NTL_IO_SIMD=
+ * none | avx2 | avx512 caps it (tests, A/B; read where a parser range begins), NTL_IO_NO_SIMD = none. */
+static int ntl_pack_level()
+{
+    static const int hw = [] {
+        if (!(__builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2"))) return 0;
+        return __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") ? 2 : 1;
+    }();
+    if (getenv("NTL_IO_NO_SIMD")) return 0;
+    const char *e = getenv("NTL_IO_SIMD");
+    if (!e) return hw;
+    if (!strcmp(e, "none") || !strcmp(e, "0")) return 0;
+    if (!strcmp(e, "avx2")) return hw < 1 ? hw : 1;
+    return hw;
+}
 #else
 static int ntl_pack32(const char *, uint64_t *) { return 0; }
-static const bool g_have_pack32 = false;
+static int ntl_pack64(const char *, uint64_t *) { return 0; }
+static int ntl_pack_level() { return 0; }
 #endif
 
 struct PackSink {
@@ -336,9 +369,11 @@ struct PackSink {
     unsigned fill = 0;
     bool first_partial = false, in_run = false;
     uint64_t seq_nb0 = 0, run_nb0 = 0;
+    int simd = 0;
 
     void begin()
     {
+        simd = ntl_pack_level();
         const uint64_t g0 = NTL_PACK_LEAD + b0;
         widx = first_widx = g0 >> 4;
         fill = 2u * (unsigned)(g0 & 15u);
@@ -373,7 +408,19 @@ struct PackSink {
         const uint64_t K1 = 0x0101010101010101ull, K7F = 0x7F7F7F7F7F7F7F7Full, K80 = 0x8080808080808080ull;
         size_t k = 0;
         while (k < n) {
-            if (g_have_pack32 && n - k >= 32) {
+            if (simd >= 2 && n - k >= 64) {
+                uint64_t v128[2];
+                if (ntl_pack64(p + k, v128)) {
+                    if (!in_run) { in_run = true; run_nb0 = nb + k; }
+                    push(v128[0] & 0xFFFFFFFFull, 32);
+                    push(v128[0] >> 32, 32);
+                    push(v128[1] & 0xFFFFFFFFull, 32);
+                    push(v128[1] >> 32, 32);
+                    k += 64;
+                    continue;
+                }
+            }
+            if (simd >= 1 && n - k >= 32) {
                 uint64_t v64;
                 if (ntl_pack32(p + k, &v64)) {
                     if (!in_run) { in_run = true; run_nb0 = nb + k; }
@@ -1371,7 +1418,8 @@ struct SpanSink {
     unsigned fill = 0;
     bool in_run = false, overflow = false;
     uint64_t seq_nb0 = 0, run_nb0 = 0;
-    void begin() { widx = (NTL_PACK_LEAD + pos0) >> 4; fill = 0; } /* pos0 is a multiple of 16: whole words are this range's own */
+    int simd = 0;
+    void begin() { simd = ntl_pack_level(); widx = (NTL_PACK_LEAD + pos0) >> 4; fill = 0; } /* pos0 is a multiple of 16: whole words are this range's own */
     inline void push(uint64_t bits, unsigned nbits)
     {
         acc |= bits << fill;
@@ -1394,7 +1442,19 @@ struct SpanSink {
         const uint64_t K1 = 0x0101010101010101ull, K7F = 0x7F7F7F7F7F7F7F7Full, K80 = 0x8080808080808080ull;
         size_t k = 0;
         while (k < n) {
-            if (g_have_pack32 && n - k >= 32) {
+            if (simd >= 2 && n - k >= 64) {
+                uint64_t v128[2];
+                if (ntl_pack64(p + k, v128)) {
+                    if (!in_run) { in_run = true; run_nb0 = nb + k; }
+                    push(v128[0] & 0xFFFFFFFFull, 32);
+                    push(v128[0] >> 32, 32);
+                    push(v128[1] & 0xFFFFFFFFull, 32);
+                    push(v128[1] >> 32, 32);
+                    k += 64;
+                    continue;
+                }
+            }
+            if (simd >= 1 && n - k >= 32) {
                 uint64_t v64;
                 if (ntl_pack32(p + k, &v64)) {
                     if (!in_run) { in_run = true; run_nb0 = nb + k; }

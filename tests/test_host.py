@@ -473,10 +473,13 @@ def _expected_pack(buf, off):
     return words, np.array(srf, np.uint32), np.array(rst, np.uint32), np.array(rln, np.uint32)
 
 
-@pytest.mark.parametrize("threads,chunk", [("1", "1000000"), ("7", "900")])
-def test_parser_packs_bases_and_runs_like_the_device(tmp_path, monkeypatch, threads, chunk):
+@pytest.mark.parametrize("threads,chunk,simd", [("1", "1000000", None), ("7", "900", None), ("1", "1000000", "avx2"), ("3", "5000", "none")])
+def test_parser_packs_bases_and_runs_like_the_device(tmp_path, monkeypatch, threads, chunk, simd):
     """seqio.load(packed=True): 2-bit words and ACGT-run table made by the parser threads == what the device-side pack kernels
-    derive from the ASCII bytes (range cuts at any 2-bit offset, N / IUPAC / lower case, wrapped lines, empty records)."""
+    derive from the ASCII bytes (range cuts at any 2-bit offset, N / IUPAC / lower case, wrapped lines, empty records); with every
+    step width of the packer the CPU has (64 bases with AVX-512BW, 32 with AVX2 + BMI2, 8: NTL_IO_SIMD)."""
+    if simd:
+        monkeypatch.setenv("NTL_IO_SIMD", simd)
     rng = np.random.default_rng(int(threads))
     p = tmp_path / "x.fa"
     with open(p, "w") as fh:
