@@ -14,9 +14,10 @@
  *   1. a lane hashes its first k-mer from scratch and rolls 15 steps: 16 k-mers per from-scratch hash; the seed-table index of a
  *      step (leaving base + 4 x entering base) is a nibble of two words made once per lane;
  *   2. the first w - 1 hashes of every lane go through LDS to the lane on its left -- the only exchange, one barrier;
- *   3. the minima of the 16 windows that start in the lane's block, in REGISTERS, w known at compile time: a doubling table over the
- *      lane's 16 + w - 1 hashes (spans 1, 2, 4, 8: `X[i] = min(X[i], X[i + s])` in place), a window = the minimum of two spans that
- *      cover it; ties go to the right-hand operand (Indexlr keeps the rightmost of equal hashes -- identical k-mers in a window are
+ *   3. the minima of the 16 windows that start in the lane's block, in REGISTERS, w known at compile time: over the lane's 16 + w - 1
+ *      hashes the prefix and suffix minima of blocks of w elements (a window = the suffix of its block from its first element and
+ *      the prefix of the next block up to its last: 2.8 minima per window whatever w; w = 2: one pairwise minimum per element);
+ *      ties go to the right-hand operand (Indexlr keeps the rightmost of equal hashes -- identical k-mers in a window are
  *      common at these sizes); every entry carries its element number;
  *   4. a lane's windows set bits in a 31-bit word of its own, which goes into the strip's LDS bitmask with two atomics per LANE, and
  *      the strip's 128 words into the global bitmask as before.
@@ -35,11 +36,22 @@ __device__ __forceinline__ void small_min_right(uint64_t &ah, uint32_t &ap, cons
     ap = take ? bp : ap;
 }
 
+#ifndef NTL_SMALL_VH_FROM
+#define NTL_SMALL_VH_FROM 3 /* windows from this size on take their minima from block prefixes and suffixes (below) */
+#endif
+
 /* wavefronts per SIMD a window size is compiled for: 82 / 103 / 136 vector registers at w = 5 / 10 / 15 left to the compiler (5 / 4 / 3
    wavefronts); held to 6 wavefronts the smallest windows gain 7 % (window pass at w = 5: 654 -> 698 Gbases/s) and the others spill
    (w = 10: 587 -> 306; profiles/r07b_small_window_launch_bounds.txt) */
 template <int W>
-constexpr int small_waves_per_simd() { return W <= 5 ? 6 : 1; }
+constexpr int small_waves_per_simd()
+{
+#ifdef NTL_SMALL_WPE_ALL
+    return NTL_SMALL_WPE_ALL; /* experiments: tools/build_variant.py */
+#else
+    return W <= 5 ? 6 : 1;
+#endif
+}
 
 template <int W, bool MULTI>
 __global__ __launch_bounds__(256, (small_waves_per_simd<W>())) void sketch_small_kernel(SketchArgs A)
@@ -167,10 +179,34 @@ __global__ __launch_bounds__(256, (small_waves_per_simd<W>())) void sketch_small
 #pragma unroll
         for (int i = 0; i < N; i++) P[i] = H[i] == NTL_INF ? 31u : (uint32_t)i;
     }
+    /* w >= NTL_SMALL_VH_FROM: blocks of w elements; the minimum of every element's prefix of its block (left to right) and of its
+       suffix (right to left, in place).  A window that starts at element j of a block is that suffix at j and the prefix at
+       j + w - 1 in the next block (the suffix alone where it starts a block): about 2.8 minima per window whatever w -- 45 per lane
+       at w = 10 -- where the doubling table (spans 1, 2, 4, 8 in place, a window = the two spans of the largest power of two that
+       cover it) takes 3.3 (w = 5), 5 (w = 10: 80 per lane), 6 (w = 15).  w = 2: the doubling table (one level). */
+    constexpr bool VH = W >= NTL_SMALL_VH_FROM;
+    constexpr int NF = VH ? N : 1;
+    uint64_t Fh[NF];
+    uint32_t Fp[NF];
+    if constexpr (VH) {
 #pragma unroll
-    for (int s = 1; 2 * s <= W; s *= 2) {
+        for (int i = 0; i < N; i++) {
+            if (i % W == 0) { Fh[i] = H[i]; Fp[i] = P[i]; }
+            else {
+                const bool take = H[i] <= Fh[i - 1]; /* element i lies to the right of its prefix: a tie goes to it */
+                Fh[i] = take ? H[i] : Fh[i - 1];
+                Fp[i] = take ? P[i] : Fp[i - 1];
+            }
+        }
 #pragma unroll
-        for (int i = 0; i + s < N; i++) small_min_right(H[i], P[i], H[i + s], P[i + s]); /* in place: entry i + s still holds the span s */
+        for (int i = N - 2; i >= 0; i--)
+            if (i % W != W - 1) small_min_right(H[i], P[i], H[i + 1], P[i + 1]); /* entry i + 1 holds its suffix already */
+    } else {
+#pragma unroll
+        for (int s = 1; 2 * s <= W; s *= 2) {
+#pragma unroll
+            for (int i = 0; i + s < N; i++) small_min_right(H[i], P[i], H[i + s], P[i + s]); /* in place: entry i + s still holds the span s */
+        }
     }
     /* windows [s, s + w) in strip elements, s = 16 L + j: real where they start at a k-mer of the sequence (element 0 of a sequence's
        first strip is not one) and end inside it; the strip's own where s <= NWO (s = 0 is the previous strip's last window: the same
@@ -186,7 +222,9 @@ __global__ __launch_bounds__(256, (small_waves_per_simd<W>())) void sketch_small
         for (int j = 0; j < C; j++) {
             uint64_t mh = H[j];
             uint32_t mp = P[j];
-            if (W != P2) small_min_right(mh, mp, H[j + W - P2], P[j + W - P2]);
+            if constexpr (VH) {
+                if (j % W) small_min_right(mh, mp, Fh[VH ? j + W - 1 : 0], Fp[VH ? j + W - 1 : 0]);
+            } else if (W != P2) small_min_right(mh, mp, H[j + W - P2], P[j + W - P2]);
             if (all_inside) bits |= 1u << mp;
             else {
                 const int s = s0 + j;
