@@ -1952,7 +1952,9 @@ static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const nt
             else if (emit_u >= 2) hipLaunchKernelGGL((emit_list_kernel<2, 2>), dim3(egrid), dim3(EL_NT), 0, ms, E, Q);
             else hipLaunchKernelGGL((emit_list_kernel<2, 1>), dim3(egrid), dim3(EL_NT), 0, ms, E, Q);
         } else
-        if (probe == 0) hipLaunchKernelGGL((emit_kernel<0, 1>), dim3(egrid), dim3(EMIT_NT), 0, ms, E);
+        if (probe == 0 && (eu ? emit_u >= 4 : small)) hipLaunchKernelGGL((emit_kernel<0, 4>), dim3(egrid), dim3(EMIT_NT), 0, ms, E); /* dense sketches: four k-mers' loads in flight per thread */
+        else if (probe == 0 && emit_u >= 2) hipLaunchKernelGGL((emit_kernel<0, 2>), dim3(egrid), dim3(EMIT_NT), 0, ms, E);
+        else if (probe == 0) hipLaunchKernelGGL((emit_kernel<0, 1>), dim3(egrid), dim3(EMIT_NT), 0, ms, E);
         else if (probe == 1 && emit_u >= 2) hipLaunchKernelGGL((emit_kernel<1, 2>), dim3(egrid), dim3(EMIT_NT), 0, ms, E);
         else if (probe == 1) hipLaunchKernelGGL((emit_kernel<1, 1>), dim3(egrid), dim3(EMIT_NT), 0, ms, E);
         else if (emit_u >= 2) hipLaunchKernelGGL((emit_kernel<2, 2>), dim3(egrid), dim3(EMIT_NT), 0, ms, E);

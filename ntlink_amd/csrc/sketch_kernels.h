@@ -685,6 +685,10 @@ __global__ __launch_bounds__(EMIT_NT) void emit_kernel(EmitArgs A)
 #pragma unroll
         for (int i = 0; i < EMIT_WPT; i++) {
             uint32_t m = words[i];
+            const uint32_t pc = (uint32_t)__popc(m);
+            /* a word whose ranks all lie in another round is skipped whole: a dense sketch (w = 5: a third of all positions, eleven
+               rounds per tile) otherwise walks all of a thread's bits in every round */
+            if (r + pc <= r0 || r >= r0 + EMIT_CAP) { r += pc; continue; }
             while (m) {
                 const int b = __ffs(m) - 1;
                 m &= m - 1;
@@ -700,22 +704,28 @@ __global__ __launch_bounds__(EMIT_NT) void emit_kernel(EmitArgs A)
             uint64_t tt[U];
             MxRecord R[U];
             bool ok[U];
+            uint64_t gpv[U], fwd[U], rev[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const uint32_t i = i0 + (uint32_t)u * EMIT_NT;
                 const uint32_t ic = i < n ? i : i0; /* past the end: the first one again, result dropped */
-                const uint64_t gp = tile_w0 * 32 + s_list[ic];
+                gpv[u] = tile_w0 * 32 + s_list[ic];
+                ok[u] = i < n && tile_base + r0 + i < A.out_cap;
+            }
+            /* the base words of all U k-mers are asked for before any of them is hashed (hash_init_g4p_multi): a dense sketch -- the
+               small windows, a minimizer every three bases at w = 5 -- has nothing but these loads' latency between its barriers */
+            hash_init_g4p_multi<U>(A.packed, gpv, A.k, s_g4, s_g4r, s_seed, fwd, rev);
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint64_t gp = gpv[u];
                 const uint32_t sq = cached ? s_lo + seq_of_lds(base_lds, 0, s_hi - s_lo, gp) : seq_of(A.seq_base, s_lo, s_hi, gp);
                 const uint64_t sb = cached ? base_lds[sq - s_lo] : A.seq_base[sq];
-                uint64_t fwd, rev;
-                hash_init_g4p(A.packed, gp, A.k, s_g4, s_g4r, s_seed, fwd, rev);
-                uint64_t h = (fwd + rev) * A.mult;
+                uint64_t h = (fwd[u] + rev[u]) * A.mult;
                 h ^= h >> 27;
                 tt[u] = h;
                 R[u].hash = h;
                 R[u].pos = (uint32_t)(gp - sb);
-                R[u].meta = (sq << 1) | (fwd <= rev ? 1u : 0u);
-                ok[u] = i < n && tile_base + r0 + i < A.out_cap;
+                R[u].meta = (sq << 1) | (fwd[u] <= rev[u] ? 1u : 0u);
             }
             if (PROBE) {
                 IndexProbe<PROBE == 1> pr[U];
