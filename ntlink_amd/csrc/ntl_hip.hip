@@ -1621,6 +1621,10 @@ static void launch_small_w(ntl_ctx *c, const SketchArgs &A, unsigned strips, boo
     if constexpr (W < 15) launch_small_w<W + 1>(c, A, strips, multi);
 }
 
+#ifndef NTL_EMIT_DENSE_CAP
+#define NTL_EMIT_DENSE_CAP 8192 /* emit_kernel's positions per round for the dense sketches of the small windows (sketch_kernels.h) */
+#endif
+
 /* geometry of the window pass for (k, w): k-mers per lane, lanes per strip */
 static int sketch_geometry(ntl_ctx *c, int k, int w, SketchGeom &G, int &C, int &nt)
 {
@@ -1952,7 +1956,7 @@ static int sketch_enqueue(ntl_ctx *c, const ntl_batch *b, int k, int w, const nt
             else if (emit_u >= 2) hipLaunchKernelGGL((emit_list_kernel<2, 2>), dim3(egrid), dim3(EL_NT), 0, ms, E, Q);
             else hipLaunchKernelGGL((emit_list_kernel<2, 1>), dim3(egrid), dim3(EL_NT), 0, ms, E, Q);
         } else
-        if (probe == 0 && (eu ? emit_u >= 4 : small)) hipLaunchKernelGGL((emit_kernel<0, 4>), dim3(egrid), dim3(EMIT_NT), 0, ms, E); /* dense sketches: four k-mers' loads in flight per thread */
+        if (probe == 0 && (eu ? emit_u >= 4 : small)) hipLaunchKernelGGL((emit_kernel<0, 4, NTL_EMIT_DENSE_CAP>), dim3(egrid), dim3(EMIT_NT), 0, ms, E); /* dense sketches: rounds of 8192, four k-mers' loads in flight per thread */
         else if (probe == 0 && emit_u >= 2) hipLaunchKernelGGL((emit_kernel<0, 2>), dim3(egrid), dim3(EMIT_NT), 0, ms, E);
         else if (probe == 0) hipLaunchKernelGGL((emit_kernel<0, 1>), dim3(egrid), dim3(EMIT_NT), 0, ms, E);
         else if (probe == 1 && emit_u >= 2) hipLaunchKernelGGL((emit_kernel<1, 2>), dim3(egrid), dim3(EMIT_NT), 0, ms, E);

@@ -601,12 +601,15 @@ __device__ __forceinline__ uint32_t seq_of_lds(ntl_lds_cu64 *base, uint32_t lo, 
 }
 
 /* PROBE: 0 = records only, 1 = + index lookup through the slot tags, 2 = + index lookup on the slots directly (index_common.h) */
-template <int PROBE, int U = 1>
+/* CAP: positions staged per round.  A dense sketch (the small windows: up to a third of a tile's 65536 positions) is emitted in
+   rounds of 8192 -- between two rounds stand two barriers, and with 2048 per round a tile at w = 5 took eleven: emit 0.68 -> 0.53 ms
+   per 200 Mbp (profiles/HISTORY.md); everything else fits one round of EMIT_CAP and keeps the LDS for more resident workgroups */
+template <int PROBE, int U = 1, int CAP = EMIT_CAP>
 __global__ __launch_bounds__(EMIT_NT) void emit_kernel(EmitArgs A)
 {
     unsigned long long found = 0;
     __shared__ uint32_t s_tmp[EMIT_NT];
-    __shared__ uint16_t s_list[EMIT_CAP];
+    __shared__ uint16_t s_list[CAP];
     __shared__ uint16_t s_wrank[EMIT_TILE]; /* set bits of the tile before each of its words */
     __shared__ uint64_t s_seed[4][2];
     __shared__ uint64_t s_base[EMIT_SEQ_CAP];
@@ -680,7 +683,7 @@ __global__ __launch_bounds__(EMIT_NT) void emit_kernel(EmitArgs A)
             A.mx_off[s] = tile_base + s_wrank[wl] + (uint32_t)__popc(word & ((1u << b) - 1u));
         }
     }
-    for (uint32_t r0 = 0; r0 < total; r0 += EMIT_CAP) {
+    for (uint32_t r0 = 0; r0 < total; r0 += CAP) {
         uint32_t r = excl;
 #pragma unroll
         for (int i = 0; i < EMIT_WPT; i++) {
@@ -688,16 +691,16 @@ __global__ __launch_bounds__(EMIT_NT) void emit_kernel(EmitArgs A)
             const uint32_t pc = (uint32_t)__popc(m);
             /* a word whose ranks all lie in another round is skipped whole: a dense sketch (w = 5: a third of all positions, eleven
                rounds per tile) otherwise walks all of a thread's bits in every round */
-            if (r + pc <= r0 || r >= r0 + EMIT_CAP) { r += pc; continue; }
+            if (r + pc <= r0 || r >= r0 + CAP) { r += pc; continue; }
             while (m) {
                 const int b = __ffs(m) - 1;
                 m &= m - 1;
-                if (r >= r0 && r < r0 + EMIT_CAP) s_list[r - r0] = (uint16_t)((t * EMIT_WPT + i) * 32 + b);
+                if (r >= r0 && r < r0 + CAP) s_list[r - r0] = (uint16_t)((t * EMIT_WPT + i) * 32 + b);
                 r++;
             }
         }
         __syncthreads();
-        const uint32_t n = total - r0 < EMIT_CAP ? total - r0 : EMIT_CAP;
+        const uint32_t n = total - r0 < CAP ? total - r0 : CAP;
         /* U minimizers per thread and step, in straight-line code: their base-word loads, and then their first index loads, are
            in flight together (the kernel's time is the latency of these dependent random accesses, not its arithmetic) */
         for (uint32_t i0 = t; i0 < n; i0 += U * EMIT_NT) {
