@@ -11,3 +11,4 @@ timeout 1500 python tests/gpu_volume_soak.py C5 ${C5_BATCHES:-6} 1.5e9 620 2>&1 
 timeout 900 python tests/gpu_volume_soak.py C3 ${W500_BATCHES:-4} 1.5e9 640 32 500 2>&1 | tail -2 | tee gpurun_out/$TAG/volume_C3_w500.log
 timeout 900 python tests/gpu_map_soak.py C3 ${MAP_BATCHES:-6} 1e9 660 0 2>&1 | tail -2 | tee gpurun_out/$TAG/map_C3_for_map.log
 timeout 900 python tests/gpu_soak.py 2>&1 | tail -2 | tee gpurun_out/$TAG/gpu_soak.log
+timeout 900 python tests/gpu_small_soak.py ${SMALL_S:-240} 9500 2>&1 | tail -2 | tee gpurun_out/$TAG/small_soak.log
