@@ -40,9 +40,9 @@ __device__ __forceinline__ void small_min_right(uint64_t &ah, uint32_t &ap, cons
 #define NTL_SMALL_VH_FROM 3 /* windows from this size on take their minima from block prefixes and suffixes (below) */
 #endif
 
-/* wavefronts per SIMD a window size is compiled for: 82 / 103 / 136 vector registers at w = 5 / 10 / 15 left to the compiler (5 / 4 / 3
-   wavefronts); held to 6 wavefronts the smallest windows gain 7 % (window pass at w = 5: 654 -> 698 Gbases/s) and the others spill
-   (w = 10: 587 -> 306; profiles/r07b_small_window_launch_bounds.txt) */
+/* wavefronts per SIMD a window size is compiled for: 66 / 74 / 90 / 104 vector registers at w = 3 / 5 / 10 / 15 left to the compiler;
+   held to 6 wavefronts the smallest windows gain a few per cent and the larger ones spill (w = 10: 724 -> 621 Gbases/s, w = 12: 718 ->
+   413; profiles/r07g_small_window_launch_bounds_block_minima.txt, and r07b_* for the doubling-table form) */
 template <int W>
 constexpr int small_waves_per_simd()
 {
