@@ -113,6 +113,89 @@ def kernel_signature():
     return h.hexdigest()[:12]
 
 
+class DeviceStatePoller:
+    """Shader clock, socket power and junction temperature of this rank's GPU, sampled from the amdgpu hwmon files while the timed
+    steps run (a thread that reads three small sysfs files every 100 ms; nothing here can fail the bench: no hwmon, no field).
+    Why: the C3 step is instruction-bound and follows the shader clock, and the boxes differ in the clock they sustain under it --
+    on some the socket sits at a power limit through the steps (profiles/r07x_clocks_power_during_bench.txt: 2.13 GHz at 1.2 kW against
+    2.37 GHz in the lighter phases) -- so the line says which clock its number was measured at."""
+
+    def __init__(self, local_rank=0, period=0.1):
+        import glob
+        self.period, self.samples, self.thread, self.stop = period, [], None, False
+        dirs = []
+        for h in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            try:
+                if open(os.path.join(h, "freq1_label")).read().strip() == "sclk":
+                    dirs.append(h)
+            except OSError:
+                pass
+        # which of the node's cards is this process's GPU: the one at the PCI address the runtime reports; failing that, the card that
+        # draws the most power while the steps run (summary)
+        self.dirs, self.dir, self.which = dirs, None, None
+        try:
+            import torch
+            pr = torch.cuda.get_device_properties(torch.cuda.current_device())
+            addr = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{getattr(pr, 'pci_device_id', 0):02x}."
+            for h in dirs:
+                if os.path.basename(os.path.realpath(os.path.join(h, "..", ".."))).startswith(addr):
+                    self.dir, self.which = h, "the card at this device's PCI address " + addr + "0"
+        except Exception:
+            pass
+
+    def _read(self, name, scale, d=None):
+        try:
+            return int(open(os.path.join(d or self.dir, name)).read()) * scale
+        except (OSError, ValueError, TypeError):
+            return None
+
+    def sample(self):
+        out = []
+        for d in ([self.dir] if self.dir else self.dirs):
+            out.append((self._read("freq1_input", 1e-6, d), self._read("power1_input", 1e-6, d) or self._read("power1_average", 1e-6, d),
+                        self._read("temp2_input", 1e-3, d)))
+        return out
+
+    def _run(self):
+        while not self.stop:
+            self.samples.append(self.sample())
+            time.sleep(self.period)
+
+    def __enter__(self):
+        if self.dir or self.dirs:
+            import threading
+            self.idle = self.sample()
+            self.thread = threading.Thread(target=self._run, daemon=True)
+            self.thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.stop = True
+        if self.thread:
+            self.thread.join(timeout=1.0)
+        return False
+
+    def summary(self):
+        if not self.samples or not self.samples[0]:
+            return None
+        import statistics
+        cards = [self.dir] if self.dir else self.dirs
+        j, which = 0, self.which
+        if not self.dir:  # the busiest card
+            power = [statistics.median([x[i][1] or 0.0 for x in self.samples]) for i in range(len(cards))]
+            j = max(range(len(cards)), key=lambda i: power[i])
+            which = f"the card that drew the most power of the node's {len(cards)} (no PCI address from the runtime)"
+
+        def col(i):
+            v = [x[j][i] for x in self.samples if x[j][i] is not None]
+            return {"median": round(statistics.median(v), 1), "min": round(min(v), 1), "max": round(max(v), 1)} if v else None
+        return {"what": "this rank's GPU while the timed steps ran (amdgpu hwmon, one sample per 100 ms): the step is instruction-bound and follows "
+                        "the shader clock; where the socket power sits at a limit through the steps the clock is that limit's",
+                "samples": len(self.samples), "sclk_mhz": col(0), "socket_power_w": col(1), "junction_c": col(2),
+                "before_the_steps": {"sclk_mhz": self.idle[j][0], "socket_power_w": self.idle[j][1], "junction_c": self.idle[j][2]},
+                "power_cap_w": self._read("power1_cap", 1e-6, cards[j]), "source": cards[j], "picked": which}
+
+
 class Comm:
     """barrier / max / sum / gather over the ranks (RCCL on GPUs, gloo under the SIMT mock); a single process needs none"""
 
@@ -286,11 +369,13 @@ def run_workload(dev, comm, name, args, steps, warmup, rank, world, serial_steps
     for d in devs:
         d.prof_reset()
     comm.barrier(devs)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    comm.barrier(devs)  # ntl_ctx_sync: also where a failure of queued work nobody looked at is raised
-    elapsed = time.perf_counter() - t0
+    with DeviceStatePoller(int(os.environ.get("LOCAL_RANK", "0"))) as poller:
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        comm.barrier(devs)  # ntl_ctx_sync: also where a failure of queued work nobody looked at is raised
+        elapsed = time.perf_counter() - t0
+    device_state = poller.summary()
     prof = {nm: tuple(sum(x) for x in zip(*[d.prof_get(nm) for d in devs])) for nm in STAGES}
     if stats["read_mx"] is None:
         step(collect=True)
@@ -330,7 +415,7 @@ def run_workload(dev, comm, name, args, steps, warmup, rank, world, serial_steps
     return dict(name=name, W=W, wl=wl, ix=ix, csk=csk, params=params, stats=stats, gen_s=gen_s, contig_stage_ms=contig_stage_ms,
                 contig_prof=contig_prof, contig_mx=contig_mx, index_size=index_size, elapsed=elapsed_max, total_bases=total_bases,
                 prof=prof, serial=serial, pipelined=pipelined, per_rank_ms=per_rank_ms, per_rank_bases=per_rank_bases, steps=steps,
-                n_streams=n_streams, ranks_seen=ranks_seen, ranks=ranks, batch_bases=batch_bases)
+                n_streams=n_streams, ranks_seen=ranks_seen, ranks=ranks, batch_bases=batch_bases, device_state=device_state)
 
 
 def summarize(R, args, world, dev_name):
@@ -393,6 +478,7 @@ def summarize(R, args, world, dev_name):
            "contig_stage_kernels_ms": {nm: round(v[0], 3) for nm, v in R["contig_prof"].items() if v[1]},
            "value_incl_contig_stage_once": round(R["total_bases"] * steps / (R["elapsed"] + R["contig_stage_ms"] * 1e-3) / 1e9, 4),
            "timed_region_s": round(R["elapsed"], 3),
+           "device_state_during_timed_steps": R.get("device_state"),
            "pipeline": {"value_measured_with": mode, "host_waits_per_step": 0,
                         "bench_streams": R["n_streams"]},
            "stage_ms_per_step": {nm: round(v[0] / steps, 3) for nm, v in R["prof"].items()},

@@ -60,6 +60,32 @@ def test_valu_roofline_fraction_is_priced_on_the_floor(monkeypatch):
     assert abs(lean["useful_frac"] - 9.0 / (1.2e9 * 64 / bases)) < 1e-3
 
 
+def test_device_state_poller_reads_the_busiest_card(tmp_path, monkeypatch):
+    """config.device_state_during_timed_steps: shader clock / socket power / junction temperature from the amdgpu hwmon files while the
+    timed steps run (the step follows the clock, and the boxes differ in the clock they sustain).  No hwmon: no field, never an error;
+    no PCI address from the runtime: the card that draws the most power."""
+    import glob
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    with bench.DeviceStatePoller(0) as p:
+        pass
+    assert p.summary() is None or "sclk_mhz" in p.summary()  # (None here: no amdgpu hwmon in the CPU container)
+    dirs = []
+    for i, (mhz, watt) in enumerate(((2400, 290), (2130, 1190))):
+        d = tmp_path / f"card{i}" / "device" / "hwmon" / "hwmon0"
+        d.mkdir(parents=True)
+        for name, v in (("freq1_label", "sclk"), ("freq1_input", mhz * 10**6), ("power1_input", watt * 10**6), ("temp2_input", 58000), ("power1_cap", 1400 * 10**6)):
+            (d / name).write_text(f"{v}\n")
+        dirs.append(str(d))
+    monkeypatch.setattr(glob, "glob", lambda pat: dirs)
+    with bench.DeviceStatePoller(0, period=0.01) as p:
+        time.sleep(0.08)
+    st = p.summary()
+    assert st["samples"] >= 2 and st["source"] == dirs[1] and "most power" in st["picked"]
+    assert st["sclk_mhz"]["median"] == 2130.0 and st["socket_power_w"]["max"] == 1190.0 and st["junction_c"]["min"] == 58.0 and st["power_cap_w"] == 1400.0
+
+
 def test_two_ranks_strong_scaling_line_on_the_simt_mock():
     """`bench.py --gpus 2` (strong scaling is the default for N > 1: BASELINE.json configs[3]) end to end on CPU: the launcher starts two gloo ranks, each maps its half of the read
     set on the SIMT mock, rank 0 prints one line with n_gpus = 2, the max-over-ranks time and the summed bases."""
