@@ -166,6 +166,22 @@ def check_full_pipeline(dev, contigs, reads, k, w, **kw):
     return got
 
 
+def check_small_window_pipeline(dev, k, w, **kw):
+    """The whole path at a small window -- dense sketches (a minimizer every (w + 1) / 2 bases): sketch_small_kernel on both sides, the
+    index, and the mapping from all three forms of the read sketch (records, made for the index, record-less) against the oracle."""
+    from helpers import REF
+    contigs = fixture_seqs("scaffolds_4.fa")
+    reads = fixture_seqs("long_reads_4_top5.fa")
+    got = check_full_pipeline(dev, contigs, reads, k, w, **kw)
+    ctg_len = np.array([len(s) for s in contigs], np.uint32)
+    rlen = np.array([len(s) for s in reads], np.uint32)
+    for records in (True, False):
+        with dev.batch(contigs) as cb, dev.sketch(cb, k, w) as csk, dev.index(csk, ctg_len) as ix, dev.batch(reads) as rb, \
+                dev.sketch(rb, k, w, index=ix, records=records) as rsk, dev.map(ix, rsk, rlen, k=k, **kw) as res:
+            assert_same_records(res.download(), got)
+    return got
+
+
 def check_handles_outlive_their_inputs(dev, contigs, reads, k, w, n_live=700, tiny_len=None, **kw):
     """Two promises of the header's "Asynchrony" paragraph: (1) completed handles cost no page-locked slot -- more
     than the context's 512 slots' worth of completed sketches and map results stay alive side by side; (2) an index may be

@@ -60,6 +60,14 @@ def test_small_window_pass(dev, ws, monkeypatch):
     pc.check_small_windows(dev, ws[:1], ks=(20,))
 
 
+@pytest.mark.parametrize("k,w,flags", [(15, 5, {}), (32, 8, {}), (20, 10, {"sensitive": True}), (24, 3, {"repeat_filter": True})], ids=["k15w5", "k32w8", "k20w10s", "k24w3r"])
+def test_small_window_whole_path(dev, k, w, flags):
+    """Dense sketches through the whole path (sketch_small_kernel on contigs and reads, index, the three forms of the read sketch,
+    map: thousands of hits per read, the large staging classes and the overflow kernel) == oracle."""
+    got = pc.check_small_window_pipeline(dev, k, w, z=1000, **flags)
+    assert (len(got["maps"]) > 0) == (k != 15)  # (k15 w5 on this fixture: every read's hits are filtered out, on both sides)
+
+
 @pytest.mark.parametrize("k,w", [(12, 8), (20, 40), (5, 1)])
 def test_sketch_many_tiny_sequences(dev, k, w):
     """> 512 sequence starts per emit tile and several rounds of the workgroup-wide sequence search."""
